@@ -1,0 +1,183 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+P = (1 << 31) - 1
+HASH_STD, HASH_RAW0 = 0, 1
+FRI_ALPHA_PREV, FRI_ALPHA_FIRST = 0, 1
+
+u32p = C.POINTER(C.c_uint32)
+u32pp = C.POINTER(u32p)
+
+
+def build_oracle(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".h", ".cpp"))]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build_oracle()
+        L = C.CDLL(LIB_PATH)
+        L.orc_m31_mul.restype = C.c_uint32
+        L.orc_m31_add.restype = C.c_uint32
+        L.orc_m31_sub.restype = C.c_uint32
+        L.orc_m31_inv.restype = C.c_uint32
+        L.orc_m31_reduce.restype = C.c_uint32
+        L.orc_m31_reduce.argtypes = [C.c_uint64]
+        L.orc_bit_reverse_index.restype = C.c_uint32
+        L.orc_coset_index_to_circle_domain_index.restype = C.c_uint32
+        L.orc_eval_basis_at_m31_point.restype = C.c_uint32
+        L.orc_twiddles_new.restype = C.c_void_p
+        L.orc_twiddles_free.argtypes = [C.c_void_p]
+        L.orc_channel_new.restype = C.c_void_p
+        L.orc_channel_grind.restype = C.c_uint64
+        L.orc_channel_mix_u64.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_channel_verify_pow.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.orc_prove_synth.restype = u32p
+        L.orc_prove_synth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int,
+                                      C.POINTER(C.c_size_t)]
+        L.orc_verify_synth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_time_prove_synth.restype = C.c_double
+        L.orc_time_prove_synth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int]
+        L.orc_inter_seed_from.restype = C.c_uint64
+        L.orc_synth_tree_columns.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        L.orc_synth_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_blake2s.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ptr_array(arrs):
+    """uint32_t*[] from a list of contiguous uint32 numpy arrays."""
+    arr = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    return arr
+
+
+def u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def default_cfg(pow_bits=10, log_blowup=1, n_queries=3, log_last=0, hash_mode=HASH_STD, fri_alpha_mode=FRI_ALPHA_PREV,
+                log_constraint_degree=1):
+    return np.array([pow_bits, log_blowup, n_queries, log_last, hash_mode, fri_alpha_mode, log_constraint_degree],
+                    dtype=np.int32)
+
+
+def comps_array(comps):
+    """comps: list of (log_size, n_pre, n_main, n_inter)."""
+    return np.array(comps, dtype=np.int32).reshape(-1, 4).copy()
+
+
+class Twiddles:
+    def __init__(self, root_log):
+        self.root_log = root_log
+        self.h = C.c_void_p(lib().orc_twiddles_new(root_log))
+
+    def arrays(self):
+        n = 1 << self.root_log
+        tw, itw = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        lib().orc_twiddles_get(self.h, ptr(tw), ptr(itw))
+        return tw, itw
+
+    def interpolate(self, values):
+        v = u32(values).copy()
+        lib().orc_interpolate(self.h, ptr(v), int(np.log2(len(v))))
+        return v
+
+    def evaluate(self, coeffs, log_out):
+        c = u32(coeffs)
+        out = np.zeros(1 << log_out, np.uint32)
+        lib().orc_evaluate(self.h, ptr(c), int(np.log2(len(c))), ptr(out), log_out)
+        return out
+
+    def __del__(self):
+        try:
+            lib().orc_twiddles_free(self.h)
+        except Exception:
+            pass
+
+
+def finalize_column(nat):
+    nat = u32(nat)
+    out = np.zeros_like(nat)
+    lib().orc_finalize_column(ptr(nat), ptr(out), int(np.log2(len(nat))))
+    return out
+
+
+def eval_at_point(coeffs, pt8):
+    c = u32(coeffs)
+    out = np.zeros(4, np.uint32)
+    p = u32(pt8)
+    lib().orc_eval_at_point(ptr(c), int(np.log2(len(c))), ptr(p), ptr(out))
+    return out
+
+
+def merkle_commit(cols, mode=HASH_STD, want_layers=False):
+    cols = [u32(c) for c in cols]
+    logs = np.array([int(np.log2(len(c))) for c in cols], np.int32)
+    root = np.zeros(8, np.uint32)
+    layers = None
+    if want_layers:
+        mx = int(logs.max()) if len(cols) else 0
+        layers = np.zeros(8 * ((2 << mx) - 1), np.uint32)
+    lib().orc_merkle_commit(ptr_array(cols), ptr(logs), len(cols), mode, ptr(root), ptr(layers) if want_layers else None)
+    return (root, layers) if want_layers else root
+
+
+def synth_tree_columns(comps, tree, seed, inter_seed=0, threads=4):
+    comps = comps_array(comps)
+    outs = []
+    for (ls, a, b, c) in comps:
+        n = [a, b, c][tree]
+        outs += [np.zeros(1 << ls, np.uint32) for _ in range(n)]
+    lib().orc_synth_tree_columns(ptr(comps), len(comps), tree, seed, inter_seed, threads, ptr_array(outs))
+    return outs
+
+
+def prove_synth(comps, cfg, seed=1, ad=b"", threads=4):
+    comps = comps_array(comps)
+    n = C.c_size_t(0)
+    adb = (C.c_uint8 * max(1, len(ad)))(*ad)
+    p = lib().orc_prove_synth(ptr(comps), len(comps), ptr(cfg), seed, adb, len(ad), threads, C.byref(n))
+    if not p:
+        raise RuntimeError("oracle prove failed: " + lib().orc_last_error().decode())
+    words = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+    lib().orc_free(p)
+    return words
+
+
+def verify_synth(comps, cfg, words, ad=b""):
+    comps = comps_array(comps)
+    words = u32(words)
+    adb = (C.c_uint8 * max(1, len(ad)))(*ad)
+    rc = lib().orc_verify_synth(ptr(comps), len(comps), ptr(cfg), ptr(words), len(words), adb, len(ad))
+    return None if rc == 0 else lib().orc_last_error().decode()
+
+
+def time_prove_synth(comps, cfg, seed=1, threads=1):
+    comps = comps_array(comps)
+    return lib().orc_time_prove_synth(ptr(comps), len(comps), ptr(cfg), seed, threads)
