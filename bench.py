@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""bench.py — RISC-V cycles proved / s on the synthetic 2^22-row trace (BASELINE.json config #3).
+
+One "step" = one full prove of the synthetic machine (trace fill on device -> 3 tree commits
+(Circle-FFT LDE + Blake2s Merkle) -> composition -> tree 4 -> OODS -> DEEP quotients -> FRI -> PoW ->
+decommit -> proof bytes on the host), everything resident in HBM (the trace is generated on device).
+`value` = 2^log_n_rows * steps * n_gpus / seconds (max over ranks).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 22] [--no-cpu-baseline]
+For N > 1 it is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL); each rank proves its own trace (independent proofs — see DESIGN.md §multi-GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-rows", type=int, default=22)
+    ap.add_argument("--n-pre", type=int, default=27)      # reference column.rs:617-664 (18 + 9)
+    ap.add_argument("--n-main", type=int, default=347)    # reference column.rs:23-606
+    ap.add_argument("--n-inter", type=int, default=64)    # 16 logup columns x 4 base columns
+    ap.add_argument("--pow-bits", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log-rows", type=int, default=17)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libnexus_hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import nexus_zkvm_amd as nz
+    be = nz.HipBackend(local_rank)
+    comps = [(args.log_rows, args.n_pre, args.n_main, args.n_inter)]
+    cfg = nz.default_config(pow_bits=args.pow_bits)
+
+    def barrier():
+        be.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        be.prove(comps, cfg, seed=1000 + rank * 97 + w)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        be.prove(comps, cfg, seed=2000 + rank * 97 + s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # one extra instrumented step (outside the timed region) for the per-stage split and the FFT roofline:
+    # HIP events on the context's stream around every Circle-FFT pass sequence (nexus-zkvm_amd/csrc/ctx.hip KTimer)
+    words, stats = be.prove(comps, cfg, seed=4242 + rank, want_stats=True)
+    out = None
+    if rank == 0:
+        n_cycles = (1 << args.log_rows) * args.steps * world
+        lde_gbs = stats["lde_algorithmic_bytes"] / (stats["lde_kernel_ms"] * 1e-3) / 1e9 if stats["lde_kernel_ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "fft_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "RISC-V cycles proved/sec at log_n_rows=%d; achieved HBM GB/s on Circle-FFT" % args.log_rows,
+            "value": n_cycles / elapsed,
+            "unit": "cycles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (M31)",
+            "data": "synthetic",
+            "config": {"workload": "synthetic 2^%d-row trace, full prove (LDE+quotient+FRI+Merkle), %d preprocessed + %d main + %d interaction columns, blowup 2, %d queries, pow_bits %d"
+                       % (args.log_rows, args.n_pre, args.n_main, args.n_inter, cfg.n_queries, cfg.pow_bits),
+                       "log_n_rows": args.log_rows, "parallelism": "1 proof per GPU" if world > 1 else "1 GPU",
+                       "proof_words": int(len(words))},
+            "roofline": {"bound": "hbm", "achieved": lde_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "nx::fft_pass_kernel<INV> (Circle iFFT+FFT = LDE)",
+                         "algorithmic_bytes": stats["lde_algorithmic_bytes"], "kernel_ms": stats["lde_kernel_ms"]},
+            "stages_ms": {k: round(stats[k], 3) for k in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")},
+            "merkle": {"kernel_ms": stats["merkle_kernel_ms"], "algorithmic_bytes": stats["merkle_algorithmic_bytes"],
+                       "achieved_GBs": stats["merkle_algorithmic_bytes"] / (stats["merkle_kernel_ms"] * 1e-3) / 1e9 if stats["merkle_kernel_ms"] > 0 else 0.0},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            import oracle_lib as O   # checker / baseline only — never part of the measured GPU path
+            O.build_oracle()
+            cores = os.cpu_count() or 1
+            ccomps = [(args.cpu_log_rows, args.n_pre, args.n_main, args.n_inter)]
+            secs = O.time_prove_synth(ccomps, O.default_cfg(pow_bits=args.pow_bits), seed=7, threads=cores)
+            out["cpu_baseline"] = {"value": (1 << args.cpu_log_rows) / secs, "unit": "cycles/s", "cores": cores, "kind": "port",
+                                   "sample": "one full prove of the same machine at 2^%d rows (%.1f s) by the C++ oracle, %d threads; NOT Stwo SimdBackend"
+                                   % (args.cpu_log_rows, secs, cores)}
+        print(json.dumps(out), flush=True)
+    be.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,193 @@
+/*
+ * nexus_hip.h — C ABI of libnexus_hip.so, the MI355X (gfx950) backend for the Nexus zkVM
+ * commit-and-prove hot path.
+ *
+ * The reference (nexus-xyz/nexus-zkvm) has no FFI today: it instantiates Stwo's CPU `SimdBackend`
+ * directly (reference prover/src/machine.rs:16,186,203,286; prover2/machine/src/prove.rs:12,53,65,124).
+ * The drop-in boundary is therefore the family of Stwo backend traits the reference relies on; each
+ * entry point below names the trait method it replaces and the reference call site that reaches it.
+ * A Rust `HipBackend` shim that binds these symbols is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - All field data are canonical M31 values in [0, 2^31-1), one uint32_t each, little endian.
+ *    Secure-field (QM31) data are 4 coordinate words (a + bi) + (c + di)u  ->  {a, b, c, d};
+ *    secure *columns* are 4 separate coordinate columns (Stwo `SecureColumnByCoords`).
+ *  - Pointers named `d_*` / documented "device" are HIP device pointers (from nx_alloc, or any
+ *    hipMalloc'd / torch-allocated memory on the context's device).  Pointer *arrays* such as
+ *    `const uint32_t* const* cols` are HOST arrays holding device pointers.
+ *  - Every function returns NX_OK (0) or a negative error code; nx_last_error() gives the text.
+ *    Allocation failure is an error code, not a panic (reference: vec![] aborts, trace_builder.rs:29).
+ *  - A context is single-threaded at the protocol level like the reference's prover
+ *    (one &mut Blake2sChannel, machine.rs:197); all work is ordered on the context's HIP stream and
+ *    is asynchronous; only functions that return data to the host synchronise.
+ *  - Results are exact integers: bit-identical regardless of scheduling.
+ */
+#ifndef NEXUS_HIP_H
+#define NEXUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NX_OK 0
+#define NX_ERR_HIP (-1)       /* HIP runtime error (text in nx_last_error)                         */
+#define NX_ERR_ARG (-2)       /* invalid argument                                                   */
+#define NX_ERR_OOM (-3)       /* device or host allocation failed                                   */
+#define NX_ERR_PROTOCOL (-4)  /* ProvingError::ConstraintsNotSatisfied / FRI invalid degree         */
+#define NX_ERR_NO_DEVICE (-5) /* no gfx950 device visible — there is NO CPU fallback                */
+
+/* Merkle hash rule (unverifiable upstream detail kept switchable). */
+#define NX_HASH_BLAKE2S 0      /* standard Blake2s-256 of (left ‖ right ‖ column values)            */
+#define NX_HASH_BLAKE2S_RAW0 1 /* zero-state raw compression chaining, t = f = 0 (older Stwo)       */
+
+/* FRI circle-column folding alpha. */
+#define NX_FRI_ALPHA_PREV 0  /* fold circle columns with the previous layer's alpha (newer Stwo)    */
+#define NX_FRI_ALPHA_FIRST 1 /* fold all circle columns with the first alpha (older Stwo)           */
+
+typedef struct nx_ctx nx_ctx;
+typedef struct nx_twiddles nx_twiddles;
+typedef struct nx_tree nx_tree;
+
+/* ---------------------------------------------------------------- context ------------------- */
+int nx_ctx_create(int device, nx_ctx** out);
+void nx_ctx_destroy(nx_ctx* ctx);
+const char* nx_last_error(const nx_ctx* ctx); /* ctx may be NULL: last global error               */
+int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
+int nx_sync(nx_ctx* ctx);
+void* nx_ctx_stream(nx_ctx* ctx); /* hipStream_t the context launches on                       */
+const char* nx_version(void);
+
+/* ------------------------------------------- columns: Column / ColumnOps ------------------- */
+/* Column::zeros / from_iter / to_cpu (reference prover2/trace/src/builder.rs:103,
+ * prover2/trace/src/component.rs:40-44; BaseColumn in prover/src/trace/utils.rs:100). */
+int nx_alloc(nx_ctx* ctx, size_t n_words, uint32_t** d_out);
+int nx_free(nx_ctx* ctx, uint32_t* d_ptr);
+int nx_memset_zero(nx_ctx* ctx, uint32_t* d_ptr, size_t n_words);
+int nx_upload(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* h_src, size_t n_words);
+int nx_download(nx_ctx* ctx, uint32_t* h_dst, const uint32_t* d_src, size_t n_words);
+/* Gather scattered words: out[i] = d_ptrs[i][index[i]] (decommitment reads, MerkleProver::decommit). */
+int nx_gather(nx_ctx* ctx, const uint32_t* const* d_ptrs, const uint64_t* index, size_t n, uint32_t* h_out);
+
+/* K1 — ColumnOps<M31>::bit_reverse_column (reference prover/src/trace/utils.rs:101,
+ * prover2/trace/src/utils.rs:109).  In place. */
+int nx_bit_reverse(nx_ctx* ctx, uint32_t* d_col, uint32_t log_size);
+
+/* R3 — finalize_columns fused on device (reference prover/src/trace/utils.rs:94-106 +
+ * prover/src/trace/utils_external.rs:24-39): natural coset order -> bit-reversed circle-domain
+ * order, n_cols columns of 2^log_size words; src and dst must not alias. */
+int nx_finalize_columns(nx_ctx* ctx, const uint32_t* const* d_src_natural, uint32_t* const* d_dst,
+                        uint32_t n_cols, uint32_t log_size);
+/* Same, source on the host (the trace the AIR layer filled, TracesBuilder cols, trace_builder.rs:19-32). */
+int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst);
+
+/* ----------------------------------------------------- K2-K4, K7: PolyOps ------------------ */
+/* K2 — PolyOps::precompute_twiddles(CanonicCoset::new(log_half_coset + 1).half_coset())
+ * (reference prover/src/machine.rs:186-194, prover2/machine/src/prove.rs:53-57, verify.rs:121). */
+int nx_twiddles_create(nx_ctx* ctx, uint32_t log_half_coset, nx_twiddles** out);
+void nx_twiddles_destroy(nx_twiddles* tw);
+/* Test/debug access: copies the 2^log_half_coset forward and inverse twiddles to the host. */
+int nx_twiddles_download(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* h_tw, uint32_t* h_itw);
+
+/* K3 — PolyOps::interpolate_columns via TreeBuilder::extend_evals (reference
+ * prover/src/machine.rs:209,226,232,235,250,260).  In place: bit-reversed evaluations on
+ * CanonicCoset(log_size).circle_domain() -> coefficients. */
+int nx_interpolate_batch(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols,
+                         uint32_t log_size);
+/* K4 — PolyOps::evaluate_polynomials via TreeBuilder::commit -> CommitmentTreeProver::new
+ * (reference prover/src/machine.rs:228,237,263).  Coefficients (2^log_size) -> bit-reversed
+ * evaluations on CanonicCoset(log_size + log_expand).circle_domain(); out-of-place. */
+int nx_evaluate_batch(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_polys, uint32_t n_cols,
+                      uint32_t log_size, uint32_t log_expand, uint32_t* const* d_out);
+/* K3+K4 fused — what TreeBuilder::extend_evals followed by TreeBuilder::commit computes for one group of
+ * equally sized columns (reference prover/src/machine.rs:232-237): d_cols holds bit-reversed evaluations on
+ * entry and the coefficients on return; d_lde receives the evaluations on the blown-up domain.  Each column
+ * batch runs iFFT and FFT back to back so the coefficients stay on chip between the two transforms. */
+int nx_lde_batch(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size,
+                 uint32_t log_blowup, uint32_t* const* d_lde);
+/* K7 — PolyOps::eval_at_point (inside stwo::prover::prove, reference machine.rs:286):
+ * out[i] = polys[poly_idx[i]] evaluated at points[i] (8 words x‖y each), all polys of one log_size. */
+int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_size, const uint32_t* poly_idx,
+                      const uint32_t* h_points, uint32_t n_evals, uint32_t* h_out /* 4 words each */);
+
+/* ------------------------------------------- K5/K6: MerkleOps<Blake2sMerkleHasher> --------- */
+/* MerkleProver::commit -> MerkleOps::commit_on_layer per layer (reference machine.rs:228,237,263).
+ * Columns in commit order (stable-sorted by size inside); log_sizes are the column (LDE) sizes. */
+int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t* log_sizes, uint32_t n_cols,
+                     nx_tree** out);
+int nx_merkle_root(nx_ctx* ctx, const nx_tree* tree, uint8_t root[32]); /* roots(): machine.rs:411 */
+uint32_t nx_merkle_n_layers(const nx_tree* tree);
+/* Device pointer of layer k (2^k nodes x 8 words); layer 0 is the root. */
+const uint32_t* nx_merkle_layer(const nx_tree* tree, uint32_t k);
+void nx_tree_destroy(nx_tree* tree);
+
+/* ------------------------------------------------------------- K8: QuotientOps ------------- */
+/* QuotientOps::accumulate_quotients (inside prove).  One size group: n_cols columns of
+ * 2^log_size words; sample batches flattened: batch b has batch_counts[b] (column, value) pairs,
+ * column indices in col_idx, sampled values (4 words each) in values, point (8 words) in points.
+ * random_coeff is the DEEP alpha (4 words).  d_out4: 4 coordinate columns of 2^log_size words. */
+int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols,
+                            const uint32_t random_coeff[4], uint32_t n_batches, const uint32_t* points,
+                            const uint32_t* batch_counts, const uint32_t* col_idx, const uint32_t* values,
+                            uint32_t* const* d_out4);
+
+/* --------------------------------------------------------------- K9: FriOps ---------------- */
+/* FriOps::fold_circle_into_line: dst (line evaluation, 2^(src_log-1)) = dst*alpha^2 + fold(src). */
+int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4,
+                             const uint32_t* const* d_src4, uint32_t src_log, const uint32_t alpha[4]);
+/* FriOps::fold_line: src on the line domain half_odds(src_log + n_doublings) doubled n_doublings
+ * times (log size src_log) -> dst of log size src_log - 1. */
+int nx_fold_line(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log,
+                 uint32_t n_doublings, const uint32_t alpha[4], uint32_t* const* d_dst4);
+
+/* --------------------------------------------------------------- K10: GrindOps ------------- */
+/* GrindOps<Blake2sChannel>::grind: smallest nonce with >= pow_bits trailing zero bits of
+ * Blake2s(digest ‖ nonce_le64) read as a little-endian u128. */
+int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce);
+
+/* ------------------------------------------- synthetic machine (BASELINE configs #2-#4) ---- */
+/* The reference's AIR closures (MachineEval::evaluate, prover/src/components/mod.rs:48-56) are
+ * generic Rust and cannot cross a C ABI (last row).  For measurement the library
+ * carries the synthetic wide-Fibonacci-style machine of SURVEY.md §8(d): */
+typedef struct nx_component_spec {
+    uint32_t log_size, n_pre, n_main, n_inter;
+} nx_component_spec;
+
+typedef struct nx_pcs_config {
+    uint32_t pow_bits, log_blowup, n_queries, log_last_layer_degree_bound; /* PcsConfig / FriConfig */
+    uint32_t hash_mode, fri_alpha_mode;                                    /* switchable rules       */
+    uint32_t log_constraint_degree;                                        /* 1 or 2 (components/mod.rs:12) */
+} nx_pcs_config;
+
+typedef struct nx_prove_stats { /* milliseconds, device-synchronised stage boundaries */
+    double trace_gen, commit, composition, oods, quotients, fri, pow, decommit, total;
+    double lde_kernel_ms;        /* sum of Circle-FFT kernel time inside commits (HIP events)   */
+    uint64_t lde_algorithmic_bytes;
+    double merkle_kernel_ms;
+    uint64_t merkle_algorithmic_bytes;
+} nx_prove_stats;
+
+/* Fill tree `tree` (0 preprocessed / 1 main / 2 interaction) of the synthetic trace directly in
+ * bit-reversed circle-domain order: d_cols holds, component after component, n_* columns. */
+int nx_synth_fill_tree(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, uint32_t tree,
+                       uint64_t seed, uint64_t inter_seed, uint32_t* const* d_cols);
+
+/* Full prove of the synthetic machine: the orchestration of reference prover/src/machine.rs:184-296
+ * and stwo::prover::prove on device.  Returns a malloc'd proof in the flat "NXP1" u32 wire format
+ * (free with nx_free_host). stats may be NULL. */
+int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg,
+                   uint64_t seed, const uint8_t* ad, size_t ad_len, uint32_t** proof_words, size_t* n_words,
+                   nx_prove_stats* stats);
+void nx_free_host(void* p);
+
+/* Config #2: LDE + Blake2s commit of n_cols random columns of 2^log_size rows (already resident,
+ * bit-reversed evaluations, overwritten by their coefficients); d_lde receives the LDE columns. */
+int nx_lde_commit(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size,
+                  uint32_t log_blowup, uint32_t* const* d_lde, uint8_t root[32]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEXUS_HIP_H */

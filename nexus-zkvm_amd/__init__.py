@@ -1,0 +1,334 @@
+"""nexus_zkvm_amd — MI355X (gfx950) backend for the Nexus zkVM commit-and-prove hot path.
+
+Thin ctypes mirror of include/nexus_hip.h.  The names follow the Stwo backend traits the reference
+instantiates on `SimdBackend` (reference prover/src/machine.rs:16,186,203,286):
+`HipBackend.precompute_twiddles`, `.interpolate_columns`, `.evaluate_polynomials`, `.commit` (Merkle),
+`.eval_at_points`, `.accumulate_quotients`, `.fold_line`, `.fold_circle_into_line`, `.grind`, and the
+synthetic-machine `prove`.  There is NO CPU fallback: importing works without a GPU (so the symbol
+table can be checked), but creating a `HipBackend` raises if libnexus_hip.so or a gfx950 device is
+missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnexus_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nexus_hip.h")
+
+P = (1 << 31) - 1
+NX_OK = 0
+HASH_BLAKE2S, HASH_BLAKE2S_RAW0 = 0, 1
+FRI_ALPHA_PREV, FRI_ALPHA_FIRST = 0, 1
+
+
+class NexusHipError(RuntimeError):
+    pass
+
+
+class ComponentSpec(C.Structure):
+    _fields_ = [("log_size", C.c_uint32), ("n_pre", C.c_uint32), ("n_main", C.c_uint32), ("n_inter", C.c_uint32)]
+
+
+class PcsConfig(C.Structure):
+    _fields_ = [("pow_bits", C.c_uint32), ("log_blowup", C.c_uint32), ("n_queries", C.c_uint32),
+                ("log_last_layer_degree_bound", C.c_uint32), ("hash_mode", C.c_uint32), ("fri_alpha_mode", C.c_uint32),
+                ("log_constraint_degree", C.c_uint32)]
+
+
+class ProveStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")] + \
+               [("lde_kernel_ms", C.c_double), ("lde_algorithmic_bytes", C.c_uint64), ("merkle_kernel_ms", C.c_double),
+                ("merkle_algorithmic_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libnexus_hip.so (built in-tree by __graft_entry__.build / csrc/Makefile).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NexusHipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.nx_last_error.restype = C.c_char_p
+    L.nx_last_error.argtypes = [C.c_void_p]
+    L.nx_version.restype = C.c_char_p
+    L.nx_ctx_stream.restype = C.c_void_p
+    L.nx_merkle_layer.restype = C.c_void_p
+    L.nx_merkle_n_layers.restype = C.c_uint32
+    for name in ("nx_ctx_destroy", "nx_twiddles_destroy", "nx_tree_destroy", "nx_free_host"):
+        getattr(L, name).restype = None
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    """Function names declared in include/nexus_hip.h (used by the CPU test that the .so exports them all)."""
+    import re
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nx_[a-z0-9_]+)\s*\(", text)))
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def default_config(pow_bits=10, log_blowup=1, n_queries=3, log_last_layer_degree_bound=0, hash_mode=HASH_BLAKE2S,
+                   fri_alpha_mode=FRI_ALPHA_PREV, log_constraint_degree=1):
+    """PcsConfig::default() of the pinned Stwo is unverifiable here (pow_bits 5 or 10)."""
+    return PcsConfig(pow_bits, log_blowup, n_queries, log_last_layer_degree_bound, hash_mode, fri_alpha_mode, log_constraint_degree)
+
+
+class DeviceColumns:
+    """n_cols contiguous device columns of 2^log_size u32 words (a slab)."""
+
+    def __init__(self, backend, n_cols, log_size):
+        self.be, self.n_cols, self.log_size = backend, n_cols, log_size
+        self.ptr = C.c_void_p()
+        backend._chk(backend.L.nx_alloc(backend.ctx, C.c_size_t(max(1, n_cols << log_size)), C.byref(self.ptr)))
+
+    def col_ptrs(self):
+        stride = 4 << self.log_size
+        return (C.c_void_p * max(1, self.n_cols))(*[self.ptr.value + i * stride for i in range(self.n_cols)])
+
+    def upload(self, arr2d):
+        a = _u32(arr2d).reshape(self.n_cols, 1 << self.log_size)
+        self.be._chk(self.be.L.nx_upload(self.be.ctx, self.ptr, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
+        return self
+
+    def to_cpu(self):
+        out = np.empty((self.n_cols, 1 << self.log_size), np.uint32)
+        if out.size:
+            self.be._chk(self.be.L.nx_download(self.be.ctx, out.ctypes.data_as(C.c_void_p), self.ptr, C.c_size_t(out.size)))
+        return out
+
+    def free(self):
+        if self.ptr and self.ptr.value:
+            self.be.L.nx_free(self.be.ctx, self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Twiddles:
+    def __init__(self, backend, log_half_coset):
+        self.be, self.log_half = backend, log_half_coset
+        self.h = C.c_void_p()
+        backend._chk(backend.L.nx_twiddles_create(backend.ctx, log_half_coset, C.byref(self.h)))
+
+    def to_cpu(self):
+        n = 1 << self.log_half
+        tw, itw = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        self.be._chk(self.be.L.nx_twiddles_download(self.be.ctx, self.h, tw.ctypes.data_as(C.c_void_p), itw.ctypes.data_as(C.c_void_p)))
+        return tw, itw
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.be.L.nx_twiddles_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class MerkleTree:
+    def __init__(self, backend, handle):
+        self.be, self.h = backend, handle
+
+    def root(self):
+        out = np.empty(8, np.uint32)
+        self.be._chk(self.be.L.nx_merkle_root(self.be.ctx, self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def layer(self, k):
+        n = 8 << k
+        out = np.empty(n, np.uint32)
+        p = C.c_void_p(self.be.L.nx_merkle_layer(self.h, k))
+        self.be._chk(self.be.L.nx_download(self.be.ctx, out.ctypes.data_as(C.c_void_p), p, C.c_size_t(n)))
+        return out.reshape(-1, 8)
+
+    def n_layers(self):
+        return self.be.L.nx_merkle_n_layers(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.be.L.nx_tree_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class HipBackend:
+    """One context = one GPU = one prover transcript (the reference's single &mut channel)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.L.nx_ctx_create(int(device), C.byref(self.ctx))
+        if rc != NX_OK:
+            raise NexusHipError(f"nx_ctx_create failed ({rc}): {self.L.nx_last_error(None).decode()}")
+
+    def _chk(self, rc):
+        if rc != NX_OK:
+            raise NexusHipError(f"libnexus_hip error {rc}: {self.L.nx_last_error(self.ctx).decode()}")
+
+    def close(self):
+        if self.ctx:
+            self.L.nx_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def sync(self):
+        self._chk(self.L.nx_sync(self.ctx))
+
+    def set_hash_mode(self, mode):
+        self._chk(self.L.nx_ctx_set_hash_mode(self.ctx, mode))
+
+    # ---- Column ops ----
+    def columns(self, n_cols, log_size):
+        return DeviceColumns(self, n_cols, log_size)
+
+    def columns_from_host(self, arr2d):
+        a = _u32(arr2d)
+        if a.ndim == 1:
+            a = a[None, :]
+        return DeviceColumns(self, a.shape[0], int(np.log2(a.shape[1]))).upload(a)
+
+    def bit_reverse_column(self, cols, index=0):
+        p = C.c_void_p(cols.ptr.value + index * (4 << cols.log_size))
+        self._chk(self.L.nx_bit_reverse(self.ctx, p, cols.log_size))
+
+    def finalize_columns(self, natural):
+        """R3: natural coset order -> bit-reversed circle-domain order (reference trace/utils.rs:94-106)."""
+        out = DeviceColumns(self, natural.n_cols, natural.log_size)
+        self._chk(self.L.nx_finalize_columns(self.ctx, natural.col_ptrs(), out.col_ptrs(), natural.n_cols, natural.log_size))
+        return out
+
+    def upload_coset_order(self, host_col):
+        a = _u32(host_col)
+        out = DeviceColumns(self, 1, int(np.log2(a.size)))
+        self._chk(self.L.nx_upload_coset_order(self.ctx, a.ctypes.data_as(C.c_void_p), out.log_size, out.ptr))
+        return out
+
+    # ---- PolyOps ----
+    def precompute_twiddles(self, log_half_coset):
+        return Twiddles(self, log_half_coset)
+
+    def interpolate_columns(self, tw, cols):
+        self._chk(self.L.nx_interpolate_batch(self.ctx, tw.h, cols.col_ptrs(), cols.n_cols, cols.log_size))
+        return cols
+
+    def evaluate_polynomials(self, tw, polys, log_expand):
+        out = DeviceColumns(self, polys.n_cols, polys.log_size + log_expand)
+        self._chk(self.L.nx_evaluate_batch(self.ctx, tw.h, polys.col_ptrs(), polys.n_cols, polys.log_size, log_expand, out.col_ptrs()))
+        return out
+
+    def lde(self, tw, cols, log_blowup):
+        out = DeviceColumns(self, cols.n_cols, cols.log_size + log_blowup)
+        self._chk(self.L.nx_lde_batch(self.ctx, tw.h, cols.col_ptrs(), cols.n_cols, cols.log_size, log_blowup, out.col_ptrs()))
+        return out
+
+    def lde_commit(self, tw, cols, log_blowup):
+        out = DeviceColumns(self, cols.n_cols, cols.log_size + log_blowup)
+        root = np.empty(8, np.uint32)
+        self._chk(self.L.nx_lde_commit(self.ctx, tw.h, cols.col_ptrs(), cols.n_cols, cols.log_size, log_blowup, out.col_ptrs(),
+                                       root.ctypes.data_as(C.c_void_p)))
+        return out, root
+
+    def eval_at_points(self, polys, poly_idx, points):
+        idx = _u32(poly_idx)
+        pts = _u32(points).reshape(-1, 8)
+        out = np.empty((len(idx), 4), np.uint32)
+        self._chk(self.L.nx_eval_at_points(self.ctx, polys.col_ptrs(), polys.log_size, idx.ctypes.data_as(C.c_void_p),
+                                           pts.ctypes.data_as(C.c_void_p), len(idx), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- MerkleOps ----
+    def merkle_commit(self, column_sets):
+        """column_sets: list of DeviceColumns in commit order (mixed sizes allowed)."""
+        ptrs, logs = [], []
+        for cs in column_sets:
+            stride = 4 << cs.log_size
+            for i in range(cs.n_cols):
+                ptrs.append(cs.ptr.value + i * stride)
+                logs.append(cs.log_size)
+        arr = (C.c_void_p * max(1, len(ptrs)))(*ptrs)
+        lg = _u32(logs)
+        h = C.c_void_p()
+        self._chk(self.L.nx_merkle_commit(self.ctx, arr, lg.ctypes.data_as(C.c_void_p), len(ptrs), C.byref(h)))
+        return MerkleTree(self, h)
+
+    # ---- QuotientOps ----
+    def accumulate_quotients(self, cols, random_coeff, batches):
+        """batches: list of (point8, [(col_idx, value4), ...]).  Returns a 4-column DeviceColumns."""
+        out = DeviceColumns(self, 4, cols.log_size)
+        pts = _u32([b[0] for b in batches]).reshape(-1)
+        counts = _u32([len(b[1]) for b in batches])
+        cidx = _u32([cv[0] for b in batches for cv in b[1]])
+        vals = _u32([cv[1] for b in batches for cv in b[1]]).reshape(-1)
+        a = _u32(random_coeff)
+        self._chk(self.L.nx_accumulate_quotients(self.ctx, cols.log_size, cols.col_ptrs(), cols.n_cols, a.ctypes.data_as(C.c_void_p),
+                                                 len(batches), pts.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                                 cidx.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), out.col_ptrs()))
+        return out
+
+    # ---- FriOps ----
+    def fold_circle_into_line(self, tw, dst4, src4, alpha):
+        a = _u32(alpha)
+        self._chk(self.L.nx_fold_circle_into_line(self.ctx, tw.h, dst4.col_ptrs(), src4.col_ptrs(), src4.log_size, a.ctypes.data_as(C.c_void_p)))
+        return dst4
+
+    def fold_line(self, tw, src4, alpha, n_doublings=0):
+        out = DeviceColumns(self, 4, src4.log_size - 1)
+        a = _u32(alpha)
+        self._chk(self.L.nx_fold_line(self.ctx, tw.h, src4.col_ptrs(), src4.log_size, n_doublings, a.ctypes.data_as(C.c_void_p), out.col_ptrs()))
+        return out
+
+    # ---- GrindOps ----
+    def grind(self, digest_words, pow_bits):
+        d = _u32(digest_words)
+        nonce = C.c_uint64()
+        self._chk(self.L.nx_grind(self.ctx, d.ctypes.data_as(C.c_void_p), pow_bits, C.byref(nonce)))
+        return nonce.value
+
+    # ---- synthetic machine ----
+    @staticmethod
+    def _comps(comps):
+        return (ComponentSpec * len(comps))(*[ComponentSpec(*c) for c in comps])
+
+    def synth_fill_tree(self, comps, tree, seed, inter_seed=0):
+        sets = []
+        ptrs = []
+        for (ls, a, b, c) in comps:
+            n = [a, b, c][tree]
+            s = DeviceColumns(self, n, ls)
+            sets.append(s)
+            ptrs += [s.ptr.value + i * (4 << ls) for i in range(n)]
+        arr = (C.c_void_p * max(1, len(ptrs)))(*ptrs)
+        self._chk(self.L.nx_synth_fill_tree(self.ctx, self._comps(comps), len(comps), tree, C.c_uint64(seed), C.c_uint64(inter_seed), arr))
+        return sets
+
+    def prove(self, comps, cfg=None, seed=1, ad=b"", want_stats=False):
+        """nexus_vm_prover::prove analogue for the synthetic machine (reference prover/src/lib.rs:26-31)."""
+        cfg = cfg or default_config()
+        words, n = C.POINTER(C.c_uint32)(), C.c_size_t(0)
+        stats = ProveStats()
+        adb = (C.c_uint8 * max(1, len(ad)))(*ad)
+        self._chk(self.L.nx_prove_synth(self.ctx, self._comps(comps), len(comps), C.byref(cfg), C.c_uint64(seed), adb, C.c_size_t(len(ad)),
+                                        C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
+        out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
+        self.L.nx_free_host(words)
+        return (out, stats.as_dict()) if want_stats else out

@@ -1,0 +1,23 @@
+// Synthetic machine: shared host/device declarations (see air.hip).
+#pragma once
+#include "internal.h"
+
+namespace nx {
+
+constexpr uint32_t SYNTH_GROUP = 16;  // every 16 columns, two are free witness inputs
+
+inline bool synth_col_is_free(uint32_t k) { return (k % SYNTH_GROUP) < 2; }
+inline uint32_t synth_n_constraints(const nx_component_spec& c) {
+    uint32_t n = 2;
+    for (uint32_t k = 2; k < c.n_main; k++) if (!synth_col_is_free(k)) n++;
+    for (uint32_t k = 0; k < c.n_inter; k++) if (!synth_col_is_free(k)) n++;
+    return n;
+}
+
+int synth_constraints(nx_ctx* ctx, ColSet pre, ColSet mainc, ColSet inter, u32 n_main, u32 n_inter, int log_size, int e, const u32* d_pw,
+                      const u32* d_denom_inv, u32* const acc4[4]);
+int secure_accumulate(nx_ctx* ctx, u32* const dst4[4], const u32* const src4[4], u32 n);
+int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size, uint32_t log_expand, ColSet out);
+int merkle_layer(nx_ctx* ctx, ColSet cols, u32 n_cols, const u32* prev, u32* out, u32 log);
+
+}  // namespace nx

@@ -1,0 +1,156 @@
+// The synthetic wide-Fibonacci-style machine of SURVEY.md §8(d) on device: trace fill (written
+// directly in bit-reversed circle-domain order, i.e. reference prover/src/trace/utils.rs:94-106
+// fused away) and constraint-quotient evaluation on the evaluation domain (the device analogue of
+// stwo-constraint-framework FrameworkComponent::evaluate_constraint_quotients_on_domain, which the
+// reference reaches through MachineEval::evaluate, prover/src/components/mod.rs:39-57).
+#include "internal.h"
+#include "air.h"
+#include <algorithm>
+
+namespace nx {
+
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ u32 synth_rand(u64 seed, u32 tree, u32 comp, u32 col, u32 row) {
+    u64 x = splitmix64(seed ^ ((u64)tree << 60) ^ ((u64)comp << 52) ^ ((u64)col << 32) ^ (u64)row);
+    u32 v = (u32)(x >> 33);
+    return v == P ? 0 : v;
+}
+
+// One lane per output position i (bit-reversed circle-domain order) -> natural row -> all columns
+// of the requested tree of one component.  Writes are coalesced per column.
+__global__ __launch_bounds__(256) void synth_fill_kernel(ColSet cols, u32 log, u32 n_cols, u32 tree, u32 comp, u64 seed, u64 inter_seed) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 N = 1u << log;
+    if (i >= N) return;
+    u32 d = bitrev(i, log);
+    u32 row = d < N / 2 ? 2 * d : 2 * N - 1 - 2 * d;
+    if (tree == 0) {
+        for (u32 k = 0; k < n_cols; k++) {
+            u32 v;
+            if (k == 0) v = row == 0;
+            else if (k == 1) v = row == N - 1;
+            else v = m_reduce64((u64)row * (u64)(k + 1) + 7ull * k);
+            cols.col(k)[i] = v;
+        }
+    } else if (tree == 1) {
+        u32 s0 = synth_rand(seed, 1, comp, 0, 0xFFFFFFFFu), s1 = synth_rand(seed, 1, comp, 1, 0xFFFFFFFFu);
+        u32 a = m_add(s0, row);
+        u32 tri = (u32)((((u64)row * (u64)(row ? row - 1 : 0)) / 2) % P);
+        u32 b = m_add(m_add(s1, m_mul(row, s0)), tri);
+        cols.col(0)[i] = a;
+        if (n_cols > 1) cols.col(1)[i] = b;
+        for (u32 k = 2; k < n_cols; k++) {
+            u32 v = (k % SYNTH_GROUP) < 2 ? synth_rand(seed, 1, comp, k, row) : m_add(m_sqr(b), m_sqr(a));
+            cols.col(k)[i] = v;
+            a = b; b = v;
+        }
+    } else {
+        u32 a = 0, b = 0;
+        for (u32 k = 0; k < n_cols; k++) {
+            u32 v = (k % SYNTH_GROUP) < 2 ? synth_rand(inter_seed, 2, comp, k, row) : m_add(m_sqr(b), m_sqr(a));
+            cols.col(k)[i] = v;
+            a = b; b = v;
+        }
+    }
+}
+
+// Constraint quotients of one component on its evaluation domain (log size e = log_size + d).
+// Constraints, in declaration order (same as oracle/air.h):
+//   (main0' - main0 - 1)(1 - is_last), (main1' - main1 - main0)(1 - is_last),
+//   main_k - main_{k-1}^2 - main_{k-2}^2  for k >= 2 with k % 16 >= 2,   likewise for the interaction tree.
+// row_res = Σ_j pw[j] * C_j(row);  acc[row] += row_res * denom_inv[row >> log_size].
+__global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColSet mainc, ColSet inter, u32 n_main, u32 n_inter, int log_size, int e,
+                                                                const u32* __restrict__ pw /*QM31 per constraint*/,
+                                                                const u32* __restrict__ denom_inv, u32* a0, u32* a1, u32* a2, u32* a3) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (1u << e)) return;
+    // row `offset` = +1 trace step away (stwo-constraint-framework offset_bit_reversed_circle_domain_index)
+    u32 rn;
+    {
+        u32 idx = bitrev(r, e), half = 1u << (e - 1), step = 1u << (e - log_size - 1);
+        if (idx < half) idx = (idx + step) & (half - 1);
+        else idx = ((idx - half - step) & (half - 1)) + half;
+        rn = bitrev(idx, e);
+    }
+    u32 not_last = m_sub(1, pre.col(1)[r]);
+    u32 m0 = mainc.col(0)[r], m1 = mainc.col(1)[r];
+    u32 m0n = mainc.col(0)[rn], m1n = mainc.col(1)[rn];
+    u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    u32 j = 0;
+#define ACC(val)                                                           \
+    {                                                                      \
+        u32 v__ = (val);                                                   \
+        r0 = m_add(r0, m_mul(pw[4 * j], v__)); r1 = m_add(r1, m_mul(pw[4 * j + 1], v__)); \
+        r2 = m_add(r2, m_mul(pw[4 * j + 2], v__)); r3 = m_add(r3, m_mul(pw[4 * j + 3], v__)); \
+        j++;                                                               \
+    }
+    ACC(m_mul(m_sub(m_sub(m0n, m0), 1), not_last));
+    ACC(m_mul(m_sub(m_sub(m1n, m1), m0), not_last));
+    u32 a = m0, b = m1;
+    for (u32 k = 2; k < n_main; k++) {
+        u32 v = mainc.col(k)[r];
+        if ((k % SYNTH_GROUP) >= 2) ACC(m_sub(m_sub(v, m_sqr(b)), m_sqr(a)));
+        a = b; b = v;
+    }
+    a = 0; b = 0;
+    for (u32 k = 0; k < n_inter; k++) {
+        u32 v = inter.col(k)[r];
+        if ((k % SYNTH_GROUP) >= 2) ACC(m_sub(m_sub(v, m_sqr(b)), m_sqr(a)));
+        a = b; b = v;
+    }
+#undef ACC
+    u32 di = denom_inv[r >> log_size];
+    a0[r] = m_add(a0[r], m_mul(r0, di)); a1[r] = m_add(a1[r], m_mul(r1, di));
+    a2[r] = m_add(a2[r], m_mul(r2, di)); a3[r] = m_add(a3[r], m_mul(r3, di));
+}
+
+// dst[k][i] += src[k][i]  (AccumulationOps::accumulate)
+__global__ void secure_accumulate_kernel(u32* d0, u32* d1, u32* d2, u32* d3, const u32* s0, const u32* s1, const u32* s2, const u32* s3, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    d0[i] = m_add(d0[i], s0[i]); d1[i] = m_add(d1[i], s1[i]); d2[i] = m_add(d2[i], s2[i]); d3[i] = m_add(d3[i], s3[i]);
+}
+
+int synth_constraints(nx_ctx* ctx, ColSet pre, ColSet mainc, ColSet inter, u32 n_main, u32 n_inter, int log_size, int e, const u32* d_pw,
+                      const u32* d_denom_inv, u32* const acc4[4]) {
+    u32 n = 1u << e;
+    hipLaunchKernelGGL(synth_constraints_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pre, mainc, inter, n_main, n_inter, log_size, e,
+                       d_pw, d_denom_inv, acc4[0], acc4[1], acc4[2], acc4[3]);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+int secure_accumulate(nx_ctx* ctx, u32* const dst4[4], const u32* const src4[4], u32 n) {
+    hipLaunchKernelGGL(secure_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dst4[0], dst4[1], dst4[2], dst4[3], src4[0], src4[1],
+                       src4[2], src4[3], n);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" int nx_synth_fill_tree(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, uint32_t tree, uint64_t seed, uint64_t inter_seed,
+                                  uint32_t* const* d_cols) {
+    if (tree > 2) return set_err(ctx, NX_ERR_ARG, "nx_synth_fill_tree: tree must be 0, 1 or 2");
+    size_t first = 0;
+    for (uint32_t ci = 0; ci < n_comps; ci++) {
+        const nx_component_spec& c = comps[ci];
+        if (c.n_pre < 2 || c.n_main < 2 || c.log_size < 1 || c.log_size > 28) return set_err(ctx, NX_ERR_ARG, "synthetic component needs n_pre >= 2, n_main >= 2, 1 <= log_size <= 28");
+        uint32_t n = tree == 0 ? c.n_pre : tree == 1 ? c.n_main : c.n_inter;
+        if (n) {
+            ColSet cs; NX_TRY(make_colset(ctx, d_cols + first, n, &cs));
+            uint32_t N = 1u << c.log_size;
+            hipLaunchKernelGGL(synth_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, cs, c.log_size, n, tree, ci, seed, inter_seed);
+            NX_LAUNCH_CHECK(ctx);
+        }
+        first += n;
+    }
+    return NX_OK;
+}

@@ -1,0 +1,189 @@
+// Context, device memory, staging ring, gather, timing.  Part of libnexus_hip.so (gfx950 only).
+#include "internal.h"
+#include <string.h>
+#include <stdlib.h>
+
+namespace nx {
+
+thread_local std::string g_last_error;
+
+int set_err(nx_ctx* ctx, int code, const std::string& msg) {
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+    return code;
+}
+int hip_fail(nx_ctx* ctx, hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return set_err(ctx, e == hipErrorOutOfMemory ? NX_ERR_OOM : NX_ERR_HIP, buf);
+}
+
+int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out) {
+    size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > ctx->scratch_size) return set_err(ctx, NX_ERR_ARG, "stage: request larger than scratch ring");
+    if (ctx->scratch_off + need > ctx->scratch_size) {
+        // wrap: make sure every earlier consumer of the ring has finished
+        NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->scratch_off = 0;
+    }
+    memcpy(ctx->h_scratch + ctx->scratch_off, h_src, bytes);
+    NX_HIP(ctx, hipMemcpyAsync(ctx->d_scratch + ctx->scratch_off, ctx->h_scratch + ctx->scratch_off, bytes,
+                               hipMemcpyHostToDevice, ctx->stream));
+    *d_out = ctx->d_scratch + ctx->scratch_off;
+    ctx->scratch_off += need;
+    return NX_OK;
+}
+
+int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out) {
+    out->base = nullptr; out->stride = 0; out->table = nullptr;
+    if (n == 0) return NX_OK;
+    out->base = (uint32_t*)h_ptrs[0];
+    if (n == 1) return NX_OK;
+    bool uniform = h_ptrs[1] > h_ptrs[0];
+    uint64_t stride = uniform ? (uint64_t)(h_ptrs[1] - h_ptrs[0]) : 0;
+    for (uint32_t i = 2; uniform && i < n; i++)
+        if (h_ptrs[i] != h_ptrs[0] + (uint64_t)i * stride) uniform = false;
+    if (uniform) { out->stride = stride; return NX_OK; }
+    void* d = nullptr;
+    NX_TRY(stage(ctx, h_ptrs, (size_t)n * sizeof(uint32_t*), &d));
+    out->table = (uint32_t* const*)d;
+    return NX_OK;
+}
+
+static hipEvent_t get_event(nx_ctx* ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+KTimer::KTimer(nx_ctx* c, int kind, uint64_t bytes) : ctx(c), idx(-1) {
+    if (!c->timing) return;
+    nx_ctx::Span s; s.e0 = get_event(c); s.e1 = get_event(c); s.kind = kind;
+    (void)hipEventRecord(s.e0, c->stream);
+    c->kind_bytes[kind] += bytes;
+    idx = (int)c->spans.size();
+    c->spans.push_back(s);
+}
+KTimer::~KTimer() { if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].e1, ctx->stream); }
+void timing_flush(nx_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->spans) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, s.e0, s.e1);
+        ctx->kind_ms[s.kind] += ms;
+        ctx->event_pool.push_back(s.e0); ctx->event_pool.push_back(s.e1);
+    }
+    ctx->spans.clear();
+}
+void timing_reset(nx_ctx* ctx) {
+    timing_flush(ctx);
+    for (int i = 0; i < 4; i++) { ctx->kind_ms[i] = 0; ctx->kind_bytes[i] = 0; }
+}
+
+__global__ void gather_kernel(const uint32_t* const* ptrs, const uint64_t* index, size_t n, uint32_t* out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ptrs[i][index[i]];
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+const char* nx_version(void) { return "nexus_hip 0.1 (gfx950)"; }
+
+const char* nx_last_error(const nx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int nx_ctx_create(int device, nx_ctx** out) {
+    if (!out) return set_err(nullptr, NX_ERR_ARG, "nx_ctx_create: out is NULL");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_err(nullptr, NX_ERR_NO_DEVICE, "nx_ctx_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= count) return set_err(nullptr, NX_ERR_ARG, "nx_ctx_create: bad device index");
+    hipDeviceProp_t prop;
+    NX_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return set_err(nullptr, NX_ERR_NO_DEVICE, std::string("nx_ctx_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    NX_HIP(nullptr, hipSetDevice(device));
+    nx_ctx* c = new nx_ctx();
+    c->device = device; c->hash_mode = NX_HASH_BLAKE2S; c->timing = false;
+    c->scratch_size = 16u << 20; c->scratch_off = 0; c->d_scratch = nullptr; c->h_scratch = nullptr;
+    for (int i = 0; i < 4; i++) { c->kind_ms[i] = 0; c->kind_bytes[i] = 0; }
+    NX_HIP(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    NX_HIP(nullptr, hipMalloc((void**)&c->d_scratch, c->scratch_size));
+    NX_HIP(nullptr, hipHostMalloc((void**)&c->h_scratch, c->scratch_size, hipHostMallocDefault));
+    *out = c;
+    return NX_OK;
+}
+
+void nx_ctx_destroy(nx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    timing_flush(ctx);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode) {
+    if (mode != NX_HASH_BLAKE2S && mode != NX_HASH_BLAKE2S_RAW0) return set_err(ctx, NX_ERR_ARG, "bad hash mode");
+    ctx->hash_mode = mode;
+    return NX_OK;
+}
+
+int nx_sync(nx_ctx* ctx) { NX_HIP(ctx, hipStreamSynchronize(ctx->stream)); return NX_OK; }
+void* nx_ctx_stream(nx_ctx* ctx) { return (void*)ctx->stream; }
+
+int nx_alloc(nx_ctx* ctx, size_t n_words, uint32_t** d_out) {
+    *d_out = nullptr;
+    if (n_words == 0) n_words = 1;
+    NX_HIP(ctx, hipMalloc((void**)d_out, n_words * 4));
+    return NX_OK;
+}
+int nx_free(nx_ctx* ctx, uint32_t* d_ptr) {
+    if (!d_ptr) return NX_OK;
+    NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    NX_HIP(ctx, hipFree(d_ptr));
+    return NX_OK;
+}
+int nx_memset_zero(nx_ctx* ctx, uint32_t* d_ptr, size_t n_words) {
+    NX_HIP(ctx, hipMemsetAsync(d_ptr, 0, n_words * 4, ctx->stream));
+    return NX_OK;
+}
+int nx_upload(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* h_src, size_t n_words) {
+    NX_HIP(ctx, hipMemcpyAsync(d_dst, h_src, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    NX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_src may be pageable and reused by the caller
+    return NX_OK;
+}
+int nx_download(nx_ctx* ctx, uint32_t* h_dst, const uint32_t* d_src, size_t n_words) {
+    NX_HIP(ctx, hipMemcpyAsync(h_dst, d_src, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NX_OK;
+}
+
+int nx_gather(nx_ctx* ctx, const uint32_t* const* d_ptrs, const uint64_t* index, size_t n, uint32_t* h_out) {
+    if (n == 0) return NX_OK;
+    uint8_t* d = nullptr;
+    size_t bytes = n * (8 + 8 + 4);
+    NX_HIP(ctx, hipMalloc((void**)&d, bytes));
+    const uint32_t** dp = (const uint32_t**)d;
+    uint64_t* di = (uint64_t*)(d + n * 8);
+    uint32_t* dout = (uint32_t*)(d + n * 16);
+    hipError_t e = hipMemcpyAsync(dp, d_ptrs, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(di, index, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dp, di, n, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out, dout, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "nx_gather", __FILE__, __LINE__);
+    return NX_OK;
+}
+
+void nx_free_host(void* p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,451 @@
+// Circle FFT / iFFT over M31 for gfx950 (K1-K4 of SURVEY.md §8(a)).
+//
+// Replaces Stwo `PolyOps::{precompute_twiddles, interpolate_columns, evaluate_polynomials}` and
+// `ColumnOps::bit_reverse_column`, reached from reference prover/src/machine.rs:186,209-263 and
+// prover/src/trace/utils.rs:94-106.
+//
+// Design (MI355X-first, not a port of Stwo's u32x16 SIMD loops):
+//  * A transform of 2^n points is split into 2-3 *passes*; a pass owns a contiguous range of
+//    butterfly layers [lo, hi) and processes tiles that hold every index bit of that range plus B
+//    low bits, so each global access is a >=2^B*4-byte contiguous run (coalesced 64-128 B segments).
+//  * Inside a pass the tile lives in LDS (padded 1 word per 16 against bank conflicts); each lane
+//    pulls 16 values into VGPRs and runs 4 butterfly layers in registers (radix-16) between LDS
+//    round trips, so LDS traffic is ~1/4 of a layer-per-sync schedule.
+//  * Mersenne reduction stays in registers (field.cuh); all stores are canonical.
+//  * Columns are processed in small batches through *all* passes before the next batch starts, so a
+//    batch's inter-pass traffic stays resident in the 256 MB Infinity Cache instead of going to HBM.
+//  * The zero-extension of the LDE ("extend") is folded into the first evaluate pass: source words
+//    at index >= 2^log_in read as zero, nothing is materialised.
+#include "internal.h"
+#include <stdlib.h>
+#include <algorithm>
+
+namespace nx {
+
+// ------------------------------------------------------------------ twiddles (K2) -----------
+__global__ void twiddle_kernel(u32* tw, u32* itw, int h) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 total = 1u << h;
+    if (p >= total) return;
+    u32 q = total - p;
+    u32 val;
+    if (q == 1) {
+        val = 1;  // padding element
+    } else {
+        int m = 31 - __clz(q - 1);          // this layer holds 2^m twiddles
+        int l = h - 1 - m;                  // doubling depth
+        u32 k = (2u << m) - q;              // index within the layer
+        u32 init = (1u << (31 - h - 2)) << l, step = (1u << (31 - h)) << l;
+        u32 idx = (init + step * bitrev(k, m)) & 0x7fffffffu;
+        val = pt_from_index(idx).x;
+    }
+    tw[p] = val;
+    itw[p] = m_inv(val);
+}
+
+// ------------------------------------------------------------------ FFT passes (K3/K4) ------
+struct FftPass {
+    ColSet src, dst;
+    const u32* tw;   // forward or inverse twiddle buffer, 2^tw_log words
+    u32 tw_log;
+    int n;           // log size of the transform
+    int log_in;      // source holds 2^log_in words; higher indices read as zero
+    int lo, hi;      // butterfly layers [lo, hi)
+    int B;           // low contiguous index bits carried by a tile (0 when lo == 0)
+    u32 scale;       // multiply outputs by this on store (0: no scaling)
+    u32 n_cols;
+};
+
+__device__ __forceinline__ u32 lds_pad(u32 t) { return t + (t >> 4); }
+
+__device__ __forceinline__ u32 line_tw(const FftPass& a, int layer, u32 h) {
+    return a.tw[(1u << a.tw_log) - (1u << (a.n - layer)) + h];
+}
+// circle-layer twiddle h, derived from the first line layer: [x, y] -> [y, -y, -x, x]
+__device__ __forceinline__ u32 circle_tw(const FftPass& a, u32 h) {
+    u32 c = h >> 2;
+    u32 x = line_tw(a, 1, 2 * c), y = line_tw(a, 1, 2 * c + 1);
+    u32 sel = h & 3;
+    u32 v = (sel & 2) ? x : y;
+    return (sel == 1 || sel == 2) ? m_neg(v) : v;
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void radix_round(u32* lds, const FftPass& a, int j, u32 tile_base, int s) {
+    const int bp = a.B + j;
+    const u32 n_items = (1u << s) >> R;
+    const u32 maskB = (1u << a.B) - 1;
+    const int l0 = a.lo + j;
+    for (u32 w = threadIdx.x; w < n_items; w += blockDim.x) {
+        u32 wl = w & ((1u << bp) - 1), wh = w >> bp;
+        u32 t0 = (wh << (bp + R)) | wl;
+        u32 v[1 << R];
+#pragma unroll
+        for (int e = 0; e < (1 << R); e++) v[e] = lds[lds_pad(t0 + ((u32)e << bp))];
+        u32 g0 = tile_base + ((t0 >> a.B) << a.lo) + (t0 & maskB);
+#pragma unroll
+        for (int qq = 0; qq < R; qq++) {
+            const int q = INV ? qq : R - 1 - qq;
+            const int layer = l0 + q;
+            u32 hbase = g0 >> (layer + 1);
+#pragma unroll
+            for (int e = 0; e < (1 << R); e++) {
+                if (e & (1 << q)) continue;
+                u32 h = hbase + ((u32)e >> (q + 1));
+                u32 t = layer == 0 ? circle_tw(a, h) : line_tw(a, layer, h);
+                u32 x0 = v[e], x1 = v[e | (1 << q)];
+                if (INV) { v[e] = m_add(x0, x1); v[e | (1 << q)] = m_mul(m_sub(x0, x1), t); }
+                else { u32 m = m_mul(x1, t); v[e] = m_add(x0, m); v[e | (1 << q)] = m_sub(x0, m); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < (1 << R); e++) lds[lds_pad(t0 + ((u32)e << bp))] = v[e];
+    }
+    __syncthreads();
+}
+
+template <bool INV>
+__global__ void fft_pass_kernel(FftPass a) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int K = a.hi - a.lo, s = a.B + K;
+    const u32 S = 1u << s;
+    const u32 col = blockIdx.x % a.n_cols, tile = blockIdx.x / a.n_cols;
+    const int lb = a.lo - a.B;  // bits of the low-block part of the tile id
+    const u32 lowblock = tile & ((1u << lb) - 1), high = tile >> lb;
+    const u32 tile_base = (high << a.hi) | (lowblock << a.B);
+    const u32 maskB = (1u << a.B) - 1;
+    const u32* __restrict__ src = a.src.col(col);
+    u32* __restrict__ dst = a.dst.col(col);
+    const u32 in_limit = 1u << a.log_in;
+
+    // ---- global -> LDS, 16-byte accesses (a tile row of 2^B words is contiguous; B>=2 or lo==0) ----
+    for (u32 t = threadIdx.x * 4; t < S; t += blockDim.x * 4) {
+        u32 g = tile_base + ((t >> a.B) << a.lo) + (t & maskB);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g + 3 < in_limit) v = *reinterpret_cast<const uint4*>(src + g);
+        else if (g < in_limit) { v.x = src[g]; if (g + 1 < in_limit) v.y = src[g + 1]; if (g + 2 < in_limit) v.z = src[g + 2]; }
+        u32 p = lds_pad(t);
+        lds[p] = v.x; lds[p + 1] = v.y; lds[p + 2] = v.z; lds[p + 3] = v.w;
+    }
+    __syncthreads();
+
+    // ---- butterfly rounds: up to 4 layers per LDS round trip ----
+    if (INV) {
+        int j = 0;
+        while (K - j >= 4) { radix_round<4, true>(lds, a, j, tile_base, s); j += 4; }
+        if (K - j == 3) radix_round<3, true>(lds, a, j, tile_base, s);
+        else if (K - j == 2) radix_round<2, true>(lds, a, j, tile_base, s);
+        else if (K - j == 1) radix_round<1, true>(lds, a, j, tile_base, s);
+    } else {
+        int j = K;
+        while (j >= 4) { j -= 4; radix_round<4, false>(lds, a, j, tile_base, s); }
+        if (j == 3) radix_round<3, false>(lds, a, 0, tile_base, s);
+        else if (j == 2) radix_round<2, false>(lds, a, 0, tile_base, s);
+        else if (j == 1) radix_round<1, false>(lds, a, 0, tile_base, s);
+    }
+
+    // ---- LDS -> global ----
+    for (u32 t = threadIdx.x * 4; t < S; t += blockDim.x * 4) {
+        u32 g = tile_base + ((t >> a.B) << a.lo) + (t & maskB);
+        u32 p = lds_pad(t);
+        uint4 v = make_uint4(lds[p], lds[p + 1], lds[p + 2], lds[p + 3]);
+        if (a.scale) { v.x = m_mul(v.x, a.scale); v.y = m_mul(v.y, a.scale); v.z = m_mul(v.z, a.scale); v.w = m_mul(v.w, a.scale); }
+        *reinterpret_cast<uint4*>(dst + g) = v;
+    }
+}
+
+// n = 1, 2 (Stwo special-cases them too: prover/backend/cpu/circle.rs interpolate/evaluate)
+__global__ void fft_tiny_kernel(ColSet src, ColSet dst, u32 n_cols, int n, int log_in, bool inv) {
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    const u32* s = src.col(c); u32* d = dst.col(c);
+    u32 v[4];
+    for (int i = 0; i < (1 << n); i++) v[i] = i < (1 << log_in) ? s[i] : 0;
+    Pt p0 = pt_from_index(half_odds_index(n - 1, 0));
+    if (n == 1) {
+        if (inv) { u32 a = v[0], b = v[1]; u32 hi = m_inv(2); v[0] = m_mul(m_add(a, b), hi); v[1] = m_mul(m_mul(m_sub(a, b), m_inv(p0.y)), hi); }
+        else { u32 m = m_mul(v[1], p0.y); u32 a = v[0]; v[0] = m_add(a, m); v[1] = m_sub(a, m); }
+    } else {
+        if (inv) {
+            u32 xi = m_inv(p0.x), yi = m_inv(p0.y), qi = m_inv(4);
+            u32 a0 = m_add(v[0], v[1]), a1 = m_mul(m_sub(v[0], v[1]), yi);
+            u32 a2 = m_add(v[2], v[3]), a3 = m_mul(m_sub(v[2], v[3]), m_neg(yi));
+            v[0] = m_mul(m_add(a0, a2), qi); v[2] = m_mul(m_mul(m_sub(a0, a2), xi), qi);
+            v[1] = m_mul(m_add(a1, a3), qi); v[3] = m_mul(m_mul(m_sub(a1, a3), xi), qi);
+        } else {
+            u32 m = m_mul(v[2], p0.x); u32 b0 = m_add(v[0], m), b2 = m_sub(v[0], m);
+            m = m_mul(v[3], p0.x); u32 b1 = m_add(v[1], m), b3 = m_sub(v[1], m);
+            m = m_mul(b1, p0.y); v[0] = m_add(b0, m); v[1] = m_sub(b0, m);
+            m = m_mul(b3, m_neg(p0.y)); v[2] = m_add(b2, m); v[3] = m_sub(b2, m);
+        }
+    }
+    for (int i = 0; i < (1 << n); i++) d[i] = v[i];
+}
+
+// ---- planning ----
+struct FftTune { int smax, bmax, threads, batch_cols; };
+static FftTune g_tune = {13, 5, 256, 8};
+static bool g_tune_init = false;
+static void tune_init() {
+    if (g_tune_init) return;
+    g_tune_init = true;
+    if (const char* e = getenv("NX_FFT_SMAX")) g_tune.smax = atoi(e);
+    if (const char* e = getenv("NX_FFT_B")) g_tune.bmax = atoi(e);
+    if (const char* e = getenv("NX_FFT_THREADS")) g_tune.threads = atoi(e);
+    if (const char* e = getenv("NX_FFT_BATCH")) g_tune.batch_cols = atoi(e);
+    g_tune.smax = std::max(6, std::min(g_tune.smax, 15));
+    g_tune.bmax = std::max(2, std::min(g_tune.bmax, 6));
+    if (g_tune.threads != 128 && g_tune.threads != 256 && g_tune.threads != 512 && g_tune.threads != 1024) g_tune.threads = 256;
+    g_tune.batch_cols = std::max(1, g_tune.batch_cols);
+}
+
+struct PassPlan { int lo, hi, B; };
+static int rounds_of(int k) { return (k + 3) / 4; }
+// Layer ranges in ascending order; the first holds layers [0, s0) as a contiguous tile, later passes
+// hold k <= smax - bmax layers plus bmax low bits.  Fewest passes first (each pass is one HBM/MALL
+// round trip), then fewest LDS rounds (4 layers per round), then the largest first tile.
+static std::vector<PassPlan> plan_passes(int n) {
+    tune_init();
+    std::vector<PassPlan> p;
+    if (n <= g_tune.smax) { p.push_back({0, n, 0}); return p; }
+    int kmax = g_tune.smax - g_tune.bmax;
+    int extra = (n - g_tune.smax + kmax - 1) / kmax;
+    // choose s0 in [max(bmax, n - extra*kmax), smax]; split the rest as evenly as the round count allows
+    int best_s0 = -1, best_rounds = 1 << 30;
+    std::vector<int> best_ks;
+    for (int s0 = g_tune.smax; s0 >= std::max(g_tune.bmax, n - extra * kmax); s0--) {
+        int rest = n - s0;
+        // greedy: fill passes with multiples of 4 where possible
+        std::vector<int> ks(extra, 0);
+        int left = rest;
+        for (int i = 0; i < extra; i++) {
+            int remaining_passes = extra - i - 1;
+            int k = std::min(kmax, left - remaining_passes);          // leave >= 1 layer for each later pass
+            int need_min = left - remaining_passes * kmax;            // later passes cannot absorb more
+            int k4 = (k / 4) * 4;
+            if (k4 >= std::max(1, need_min) && k4 > 0) k = k4;
+            ks[i] = k; left -= k;
+        }
+        if (left != 0) continue;
+        int r = rounds_of(s0);
+        for (int k : ks) r += rounds_of(k);
+        if (r < best_rounds) { best_rounds = r; best_s0 = s0; best_ks = ks; }
+    }
+    p.push_back({0, best_s0, 0});
+    int lo = best_s0;
+    for (int k : best_ks) {
+        // tile >= 2^11 words where the layer count is small: longer contiguous runs, fewer tiny blocks
+        int B = std::min(lo, std::max(g_tune.bmax, std::min(11, g_tune.smax) - k));
+        p.push_back({lo, lo + k, B}); lo += k;
+    }
+    return p;
+}
+
+static int launch_pass(nx_ctx* ctx, bool inv, const FftPass& a) {
+    int s = a.B + (a.hi - a.lo);
+    u32 tiles = 1u << (a.n - s);
+    size_t lds_bytes = (((size_t)1 << s) + ((size_t)1 << s >> 4) + 4) * 4;
+    int threads = std::min<int>(g_tune.threads, std::max(64, (1 << s) / 4));
+    dim3 grid(tiles * a.n_cols), block(threads);
+    if (lds_bytes > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
+    if (inv) hipLaunchKernelGGL(fft_pass_kernel<true>, grid, block, lds_bytes, ctx->stream, a);
+    else hipLaunchKernelGGL(fft_pass_kernel<false>, grid, block, lds_bytes, ctx->stream, a);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+static ColSet sub_colset(const ColSet& c, u32 first) {
+    ColSet r = c;
+    if (c.table) r.table = c.table + first; else r.base = c.base + (uint64_t)first * c.stride;
+    return r;
+}
+
+static int check_tw(nx_ctx* ctx, const nx_twiddles* tw, int n) {
+    if (!tw) return set_err(ctx, NX_ERR_ARG, "twiddles are NULL");
+    if (n < 1 || n - 1 > (int)tw->log_half) return set_err(ctx, NX_ERR_ARG, "domain larger than the twiddle tree (or log_size < 1)");
+    return NX_OK;
+}
+
+static int interpolate_cols(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_cols, int n) {
+    if (n <= 2) {
+        hipLaunchKernelGGL(fft_tiny_kernel, dim3((n_cols + 63) / 64), dim3(64), 0, ctx->stream, cols, cols, n_cols, n, n, true);
+        NX_LAUNCH_CHECK(ctx);
+        return NX_OK;
+    }
+    std::vector<PassPlan> plan = plan_passes(n);
+    u32 scale = m_inv(1u << n);
+    for (size_t i = 0; i < plan.size(); i++) {
+        FftPass a; a.src = cols; a.dst = cols; a.tw = tw->d_itw; a.tw_log = tw->log_half; a.n = n; a.log_in = n;
+        a.lo = plan[i].lo; a.hi = plan[i].hi; a.B = plan[i].B; a.scale = i + 1 == plan.size() ? scale : 0; a.n_cols = n_cols;
+        NX_TRY(launch_pass(ctx, true, a));
+    }
+    return NX_OK;
+}
+
+static int evaluate_cols(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n_cols, int log_in, int n, ColSet out) {
+    if (n <= 2) {
+        hipLaunchKernelGGL(fft_tiny_kernel, dim3((n_cols + 63) / 64), dim3(64), 0, ctx->stream, polys, out, n_cols, n, log_in, false);
+        NX_LAUNCH_CHECK(ctx);
+        return NX_OK;
+    }
+    std::vector<PassPlan> plan = plan_passes(n);
+    for (size_t k = plan.size(); k-- > 0;) {
+        bool first = k + 1 == plan.size();
+        FftPass a; a.src = first ? polys : out; a.dst = out; a.tw = tw->d_tw; a.tw_log = tw->log_half; a.n = n;
+        a.log_in = first ? log_in : n; a.lo = plan[k].lo; a.hi = plan[k].hi; a.B = plan[k].B; a.scale = 0; a.n_cols = n_cols;
+        NX_TRY(launch_pass(ctx, false, a));
+    }
+    return NX_OK;
+}
+
+int fft_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size) {
+    NX_TRY(check_tw(ctx, tw, (int)log_size));
+    tune_init();
+    KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * 8ull << log_size);
+    for (u32 c0 = 0; c0 < n_cols; c0 += g_tune.batch_cols) {
+        u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
+        NX_TRY(interpolate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size));
+    }
+    return NX_OK;
+}
+
+int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_cols, uint32_t log_size, uint32_t log_expand, ColSet out) {
+    int n = (int)(log_size + log_expand);
+    NX_TRY(check_tw(ctx, tw, n));
+    tune_init();
+    KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * ((4ull << log_size) + (4ull << n)));
+    for (u32 c0 = 0; c0 < n_cols; c0 += g_tune.batch_cols) {
+        u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
+        NX_TRY(evaluate_cols(ctx, tw, sub_colset(polys, c0), nb, (int)log_size, n, sub_colset(out, c0)));
+    }
+    return NX_OK;
+}
+
+// iFFT + LDE per column batch (coefficients stay cache-resident between the two transforms).
+int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size, uint32_t log_expand, ColSet out) {
+    int n = (int)(log_size + log_expand);
+    NX_TRY(check_tw(ctx, tw, n));
+    tune_init();
+    // algorithmic bytes: read N evals, write N coeffs, write M = 2^n LDE words
+    KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * ((8ull << log_size) + (4ull << n)));
+    for (u32 c0 = 0; c0 < n_cols; c0 += g_tune.batch_cols) {
+        u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
+        NX_TRY(interpolate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size));
+        NX_TRY(evaluate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, n, sub_colset(out, c0)));
+    }
+    return NX_OK;
+}
+
+// ------------------------------------------------------------------ permutations (K1, R3) ---
+__global__ void bit_reverse_kernel(u32* col, int log) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << log)) return;
+    u32 j = bitrev(i, log);
+    if (i < j) { u32 a = col[i], b = col[j]; col[i] = b; col[j] = a; }
+}
+
+// out[i] = natural[ coset_index( bitrev(i) ) ]: natural coset order -> bit-reversed circle-domain order
+__device__ __forceinline__ u32 natural_index_of(u32 i, int log) {
+    u32 N = 1u << log, d = bitrev(i, log);
+    return d < N / 2 ? 2 * d : 2 * N - 1 - 2 * d;
+}
+__global__ void finalize_kernel(ColSet src, ColSet dst, u32 n_cols, int log) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = blockIdx.y;
+    if (i >= (1u << log) || c >= n_cols) return;
+    dst.col(c)[i] = src.col(c)[natural_index_of(i, log)];
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+int nx_twiddles_create(nx_ctx* ctx, uint32_t log_half_coset, nx_twiddles** out) {
+    if (!ctx || !out) return set_err(ctx, NX_ERR_ARG, "nx_twiddles_create: NULL argument");
+    if (log_half_coset < 1 || log_half_coset > 28) return set_err(ctx, NX_ERR_ARG, "nx_twiddles_create: log_half_coset out of range [1,28]");
+    nx_twiddles* t = new nx_twiddles();
+    t->ctx = ctx; t->log_half = log_half_coset; t->d_tw = nullptr; t->d_itw = nullptr;
+    size_t bytes = (size_t)4 << log_half_coset;
+    hipError_t e = hipMalloc((void**)&t->d_tw, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->d_itw, bytes);
+    if (e != hipSuccess) { if (t->d_tw) (void)hipFree(t->d_tw); delete t; return hip_fail(ctx, e, "hipMalloc(twiddles)", __FILE__, __LINE__); }
+    u32 total = 1u << log_half_coset;
+    hipLaunchKernelGGL(twiddle_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, t->d_tw, t->d_itw, (int)log_half_coset);
+    e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipFree(t->d_tw); (void)hipFree(t->d_itw); delete t; return hip_fail(ctx, e, "twiddle_kernel", __FILE__, __LINE__); }
+    *out = t;
+    return NX_OK;
+}
+
+void nx_twiddles_destroy(nx_twiddles* tw) {
+    if (!tw) return;
+    (void)hipStreamSynchronize(tw->ctx->stream);
+    (void)hipFree(tw->d_tw); (void)hipFree(tw->d_itw);
+    delete tw;
+}
+
+int nx_twiddles_download(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* h_tw, uint32_t* h_itw) {
+    NX_TRY(nx_download(ctx, h_tw, tw->d_tw, (size_t)1 << tw->log_half));
+    return nx_download(ctx, h_itw, tw->d_itw, (size_t)1 << tw->log_half);
+}
+
+int nx_interpolate_batch(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size) {
+    if (n_cols == 0) return NX_OK;
+    ColSet cs; NX_TRY(make_colset(ctx, d_cols, n_cols, &cs));
+    return fft_interpolate(ctx, tw, cs, n_cols, log_size);
+}
+
+int nx_evaluate_batch(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_polys, uint32_t n_cols, uint32_t log_size,
+                      uint32_t log_expand, uint32_t* const* d_out) {
+    if (n_cols == 0) return NX_OK;
+    ColSet p, o;
+    NX_TRY(make_colset(ctx, d_polys, n_cols, &p));
+    NX_TRY(make_colset(ctx, d_out, n_cols, &o));
+    return fft_evaluate(ctx, tw, p, n_cols, log_size, log_expand, o);
+}
+
+int nx_bit_reverse(nx_ctx* ctx, uint32_t* d_col, uint32_t log_size) {
+    u32 n = 1u << log_size;
+    hipLaunchKernelGGL(bit_reverse_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_col, (int)log_size);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+int nx_finalize_columns(nx_ctx* ctx, const uint32_t* const* d_src_natural, uint32_t* const* d_dst, uint32_t n_cols, uint32_t log_size) {
+    if (n_cols == 0) return NX_OK;
+    if (log_size < 1) return set_err(ctx, NX_ERR_ARG, "nx_finalize_columns: log_size < 1");
+    ColSet s, d;
+    NX_TRY(make_colset(ctx, d_src_natural, n_cols, &s));
+    NX_TRY(make_colset(ctx, d_dst, n_cols, &d));
+    u32 n = 1u << log_size;
+    for (u32 c0 = 0; c0 < n_cols; c0 += 32768) {
+        u32 nb = std::min<u32>(32768, n_cols - c0);
+        hipLaunchKernelGGL(finalize_kernel, dim3((n + 255) / 256, nb), dim3(256), 0, ctx->stream, sub_colset(s, c0), sub_colset(d, c0), nb, (int)log_size);
+        NX_LAUNCH_CHECK(ctx);
+    }
+    return NX_OK;
+}
+
+int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst) {
+    uint32_t* d_tmp = nullptr;
+    size_t n = (size_t)1 << log_size;
+    NX_HIP(ctx, hipMalloc((void**)&d_tmp, n * 4));
+    hipError_t e = hipMemcpyAsync(d_tmp, h_natural, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    int rc = NX_OK;
+    if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemcpyAsync", __FILE__, __LINE__);
+    if (rc == NX_OK) { const uint32_t* sp = d_tmp; uint32_t* dp = d_dst; rc = nx_finalize_columns(ctx, &sp, &dp, 1, log_size); }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_tmp);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// M31 / CM31 / QM31 arithmetic and the circle group for gfx950 kernels and the host driver.
+// Field tower as restated by the reference's own spec (specification/zkvm-spec-3.0.pdf §3.1):
+// M31 = F_p, p = 2^31-1; CM31 = M31[i]/(i^2+1); QM31 = CM31[u]/(u^2-2-i).
+// All values are canonical ([0, p)) on every load and store: committed columns are hashed as raw
+// u32 words, so `p` (== 0) must never be emitted (SURVEY.md §7 "Canonical representatives").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NX_HD __host__ __device__ __forceinline__
+
+namespace nx {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr u32 P = 0x7fffffffu;
+
+// In-register Mersenne reduction: every op is a handful of 32-bit VALU instructions; `min` on the
+// wrapped difference replaces compare+select.
+NX_HD u32 umin32(u32 a, u32 b) { return a < b ? a : b; }
+NX_HD u32 m_add(u32 a, u32 b) { u32 s = a + b; return umin32(s, s - P); }
+NX_HD u32 m_sub(u32 a, u32 b) { u32 d = a - b; return umin32(d, d + P); }
+NX_HD u32 m_neg(u32 a) { return a ? P - a : 0; }
+NX_HD u32 m_mul(u32 a, u32 b) {
+    u64 p = (u64)a * (u64)b;                 // v_mul_lo_u32 + v_mul_hi_u32
+    u32 lo = (u32)p & P, hi = (u32)(p >> 31);
+    u32 s = lo + hi;                          // < 2p
+    return umin32(s, s - P);
+}
+NX_HD u32 m_sqr(u32 a) { return m_mul(a, a); }
+NX_HD u32 m_reduce64(u64 x) {  // x < p^2
+    return (u32)((((((x >> 31) + x + 1) >> 31) + x)) & P);
+}
+NX_HD u32 m_pow(u32 a, u32 e) {
+    u32 r = 1;
+    while (e) { if (e & 1) r = m_mul(r, a); a = m_sqr(a); e >>= 1; }
+    return r;
+}
+NX_HD u32 m_inv(u32 a) { return m_pow(a, P - 2); }
+NX_HD u32 m_double_x(u32 x) { u32 s = m_sqr(x); return m_sub(m_add(s, s), 1); }
+
+struct CM31 { u32 a, b; };
+NX_HD CM31 cm(u32 a, u32 b) { CM31 r; r.a = a; r.b = b; return r; }
+NX_HD CM31 c_add(CM31 x, CM31 y) { return cm(m_add(x.a, y.a), m_add(x.b, y.b)); }
+NX_HD CM31 c_sub(CM31 x, CM31 y) { return cm(m_sub(x.a, y.a), m_sub(x.b, y.b)); }
+NX_HD CM31 c_neg(CM31 x) { return cm(m_neg(x.a), m_neg(x.b)); }
+NX_HD CM31 c_mul(CM31 x, CM31 y) {
+    return cm(m_sub(m_mul(x.a, y.a), m_mul(x.b, y.b)), m_add(m_mul(x.a, y.b), m_mul(x.b, y.a)));
+}
+NX_HD CM31 c_mul_m(CM31 x, u32 s) { return cm(m_mul(x.a, s), m_mul(x.b, s)); }
+NX_HD CM31 c_mul_R(CM31 x) { return cm(m_sub(m_add(x.a, x.a), x.b), m_add(m_add(x.b, x.b), x.a)); }  // * (2+i)
+NX_HD CM31 c_inv(CM31 x) {
+    u32 d = m_inv(m_add(m_sqr(x.a), m_sqr(x.b)));
+    return cm(m_mul(x.a, d), m_mul(m_neg(x.b), d));
+}
+
+struct QM31 { CM31 a, b; };
+NX_HD QM31 qm(u32 a, u32 b, u32 c, u32 d) { QM31 r; r.a = cm(a, b); r.b = cm(c, d); return r; }
+NX_HD QM31 q_from_m(u32 a) { return qm(a, 0, 0, 0); }
+NX_HD QM31 q_zero() { return qm(0, 0, 0, 0); }
+NX_HD QM31 q_one() { return qm(1, 0, 0, 0); }
+NX_HD QM31 q_add(QM31 x, QM31 y) { QM31 r; r.a = c_add(x.a, y.a); r.b = c_add(x.b, y.b); return r; }
+NX_HD QM31 q_sub(QM31 x, QM31 y) { QM31 r; r.a = c_sub(x.a, y.a); r.b = c_sub(x.b, y.b); return r; }
+NX_HD QM31 q_neg(QM31 x) { QM31 r; r.a = c_neg(x.a); r.b = c_neg(x.b); return r; }
+NX_HD QM31 q_mul(QM31 x, QM31 y) {
+    QM31 r;
+    r.a = c_add(c_mul(x.a, y.a), c_mul_R(c_mul(x.b, y.b)));
+    r.b = c_add(c_mul(x.a, y.b), c_mul(x.b, y.a));
+    return r;
+}
+NX_HD QM31 q_sqr(QM31 x) { return q_mul(x, x); }
+NX_HD QM31 q_mul_m(QM31 x, u32 s) { QM31 r; r.a = c_mul_m(x.a, s); r.b = c_mul_m(x.b, s); return r; }
+NX_HD QM31 q_mul_c(QM31 x, CM31 s) { QM31 r; r.a = c_mul(x.a, s); r.b = c_mul(x.b, s); return r; }
+NX_HD QM31 q_conj(QM31 x) { QM31 r; r.a = x.a; r.b = c_neg(x.b); return r; }
+NX_HD QM31 q_inv(QM31 x) {
+    CM31 b2 = c_mul(x.b, x.b);
+    CM31 denom = c_sub(c_mul(x.a, x.a), c_mul_R(b2));
+    CM31 di = c_inv(denom);
+    QM31 r; r.a = c_mul(x.a, di); r.b = c_mul(c_neg(x.b), di);
+    return r;
+}
+NX_HD bool q_eq(QM31 x, QM31 y) { return x.a.a == y.a.a && x.a.b == y.a.b && x.b.a == y.b.a && x.b.b == y.b.b; }
+NX_HD bool q_is_zero(QM31 x) { return !(x.a.a | x.a.b | x.b.a | x.b.b); }
+NX_HD QM31 q_double_x(QM31 x) { QM31 s = q_sqr(x); return q_sub(q_add(s, s), q_one()); }
+NX_HD void q_store(u32* o, QM31 x) { o[0] = x.a.a; o[1] = x.a.b; o[2] = x.b.a; o[3] = x.b.b; }
+NX_HD QM31 q_load(const u32* i) { return qm(i[0], i[1], i[2], i[3]); }
+NX_HD QM31 q_pow(QM31 a, u64 e) {
+    QM31 r = q_one();
+    while (e) { if (e & 1) r = q_mul(r, a); a = q_sqr(a); e >>= 1; }
+    return r;
+}
+
+// ---- circle group (generator (2, 1268011823), order 2^31) ----
+struct Pt { u32 x, y; };
+NX_HD Pt pt_add(Pt p, Pt q) {
+    Pt r;
+    r.x = m_sub(m_mul(p.x, q.x), m_mul(p.y, q.y));
+    r.y = m_add(m_mul(p.x, q.y), m_mul(p.y, q.x));
+    return r;
+}
+NX_HD Pt pt_from_index(u32 idx) {
+    Pt res; res.x = 1; res.y = 0;
+    Pt cur; cur.x = 2; cur.y = 1268011823u;
+    idx &= 0x7fffffffu;
+    while (idx) { if (idx & 1) res = pt_add(res, cur); cur = pt_add(cur, cur); idx >>= 1; }
+    return res;
+}
+struct QPt { QM31 x, y; };
+NX_HD QPt qpt_add(QPt p, QPt q) {
+    QPt r;
+    r.x = q_sub(q_mul(p.x, q.x), q_mul(p.y, q.y));
+    r.y = q_add(q_mul(p.x, q.y), q_mul(p.y, q.x));
+    return r;
+}
+
+// index of Coset::half_odds(log).at(i) and of CanonicCoset(log).circle_domain().at(i)
+NX_HD u32 half_odds_index(int log, u32 i) { return ((1u << (31 - log - 2)) + (i << (31 - log))) & 0x7fffffffu; }
+NX_HD u32 circle_domain_index(int log, u32 i) {
+    u32 half = 1u << (log - 1);
+    if (i < half) return half_odds_index(log - 1, i);
+    return (0u - half_odds_index(log - 1, i - half)) & 0x7fffffffu;
+}
+NX_HD u32 bitrev(u32 i, int log) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return log ? (__brev(i) >> (32 - log)) : i;
+#else
+    u32 r = 0;
+    for (int k = 0; k < log; k++) r |= ((i >> k) & 1u) << (log - 1 - k);
+    return r;
+#endif
+}
+
+}  // namespace nx

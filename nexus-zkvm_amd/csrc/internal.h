@@ -1,0 +1,89 @@
+// Internal declarations shared by the translation units of libnexus_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/nexus_hip.h"
+#include "field.cuh"
+
+struct nx_ctx {
+    int device;
+    hipStream_t stream;
+    int hash_mode;
+    std::string err;
+    // small device scratch for pointer tables / constants (ring, stream ordered)
+    uint8_t* d_scratch;
+    size_t scratch_size, scratch_off;
+    uint8_t* h_scratch;  // pinned mirror of the ring
+    // kernel timing (HIP events on ctx->stream), resolved lazily by nx::timing_flush
+    bool timing;
+    struct Span { hipEvent_t e0, e1; int kind; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    double kind_ms[4];
+    uint64_t kind_bytes[4];
+};
+enum { NX_T_LDE = 0, NX_T_MERKLE = 1, NX_T_QUOT = 2, NX_T_OTHER = 3 };
+
+struct nx_twiddles {
+    nx_ctx* ctx;
+    uint32_t log_half;  // root half coset log size; buffers hold 2^log_half words
+    uint32_t* d_tw;
+    uint32_t* d_itw;
+};
+
+struct nx_tree {
+    nx_ctx* ctx;
+    std::vector<uint32_t*> layers;  // layers[k]: 2^k nodes x 8 words, device
+};
+
+namespace nx {
+
+extern thread_local std::string g_last_error;
+
+int set_err(nx_ctx* ctx, int code, const std::string& msg);
+int hip_fail(nx_ctx* ctx, hipError_t e, const char* what, const char* file, int line);
+
+#define NX_HIP(ctx, call)                                                         \
+    do {                                                                          \
+        hipError_t e__ = (call);                                                  \
+        if (e__ != hipSuccess) return nx::hip_fail((ctx), e__, #call, __FILE__, __LINE__); \
+    } while (0)
+#define NX_TRY(call)                  \
+    do {                              \
+        int rc__ = (call);            \
+        if (rc__ != NX_OK) return rc__; \
+    } while (0)
+#define NX_LAUNCH_CHECK(ctx) NX_HIP(ctx, hipGetLastError())
+
+// A set of equally sized columns: either base + c*stride (words) or a device pointer table.
+struct ColSet {
+    uint32_t* base;
+    uint64_t stride;
+    uint32_t* const* table;  // device memory, may be null
+    __device__ __forceinline__ uint32_t* col(uint32_t c) const { return table ? table[c] : base + (uint64_t)c * stride; }
+};
+
+// Builds a ColSet from a host array of device pointers: constant stride is detected, otherwise the
+// table is staged into the context's device scratch ring (stream-ordered).
+int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out);
+// Stage arbitrary bytes into device scratch; returns device pointer (valid until the ring wraps).
+int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out);
+
+// Event-pair span on ctx->stream, recorded only when ctx->timing is on; resolved by timing_flush.
+struct KTimer {
+    nx_ctx* ctx; int idx;
+    KTimer(nx_ctx* c, int kind, uint64_t algorithmic_bytes);
+    ~KTimer();
+};
+void timing_flush(nx_ctx* ctx);  // synchronises the stream and folds spans into kind_ms[]
+void timing_reset(nx_ctx* ctx);
+
+// ---- kernels' host-side launchers (device pointers; all stream-ordered on ctx->stream) ----
+int fft_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size);
+int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_cols, uint32_t log_size,
+                 uint32_t log_expand, ColSet out);
+
+}  // namespace nx

@@ -1,0 +1,220 @@
+// Blake2s mixed-degree Merkle commitment and proof-of-work grinding for gfx950 (K5, K10).
+//
+// Replaces Stwo `MerkleOps<Blake2sMerkleHasher>::commit_on_layer` (driven by MerkleProver::commit,
+// reached from reference prover/src/machine.rs:228,237,263 and, on the verifier side,
+// machine.rs:363-417) and `GrindOps<Blake2sChannel>::grind`.
+//
+// Design: one lane per tree node; a node's message is streamed 16 columns (one 64-byte Blake2s
+// block) at a time — for each column the 64 lanes of a wave read 64 consecutive rows, a 256-byte
+// coalesced access — with the 8-word chaining state and the 16-word block in VGPRs, the 10 rounds
+// fully unrolled with compile-time message schedule (rotates lower to v_alignbit_b32).  The kernel
+// is VALU-issue bound (≈1000 integer ops per block), not HBM bound.
+#include "internal.h"
+#include <algorithm>
+#include <numeric>
+#include <string.h>
+
+namespace nx {
+
+__device__ __constant__ const u32 B2S_IV_D[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                                  0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+
+__device__ __forceinline__ u32 rotr(u32 x, int r) { return __builtin_amdgcn_alignbit(x, x, r); }
+
+#define B2S_G(a, b, c, d, x, y)                         \
+    a = a + b + (x); d = rotr(d ^ a, 16);               \
+    c = c + d;       b = rotr(b ^ c, 12);               \
+    a = a + b + (y); d = rotr(d ^ a, 8);                \
+    c = c + d;       b = rotr(b ^ c, 7);
+
+#define B2S_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    B2S_G(v0, v4, v8, v12, m[s0], m[s1]);   B2S_G(v1, v5, v9, v13, m[s2], m[s3]);       \
+    B2S_G(v2, v6, v10, v14, m[s4], m[s5]);  B2S_G(v3, v7, v11, v15, m[s6], m[s7]);      \
+    B2S_G(v0, v5, v10, v15, m[s8], m[s9]);  B2S_G(v1, v6, v11, v12, m[s10], m[s11]);    \
+    B2S_G(v2, v7, v8, v13, m[s12], m[s13]); B2S_G(v3, v4, v9, v14, m[s14], m[s15]);
+
+__device__ __forceinline__ void b2s_compress(u32 h[8], const u32 m[16], u32 t0, u32 f0) {
+    u32 v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+    u32 v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
+    u32 v12 = 0x510E527Fu ^ t0, v13 = 0x9B05688Cu, v14 = 0x1F83D9ABu ^ f0, v15 = 0x5BE0CD19u;
+    B2S_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B2S_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    B2S_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    B2S_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    B2S_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    B2S_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    B2S_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    B2S_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    B2S_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    B2S_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+    h[0] ^= v0 ^ v8;  h[1] ^= v1 ^ v9;  h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11;
+    h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
+}
+
+// One Merkle layer: node i = H(prev[2i] ‖ prev[2i+1] ‖ col_0[i] ‖ col_1[i] ‖ ...).
+//   MODE 0: standard Blake2s-256 (byte counter, final-block flag, IV ^ parameter block)
+//   MODE 1: zero-state raw compression chaining, t = f = 0, zero-padded 64-byte blocks
+template <int MODE>
+__global__ __launch_bounds__(256) void merkle_layer_kernel(ColSet cols, u32 n_cols, const u32* __restrict__ prev,
+                                                           u32* __restrict__ out, u32 n_nodes) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    u32 h[8];
+    if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) h[k] = B2S_IV_D[k];
+        h[0] ^= 0x01010020u;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) h[k] = 0;
+    }
+    const u32 total_bytes = (prev ? 64u : 0u) + 4u * n_cols;
+    u32 m[16];
+    u32 t = 0;
+    if (prev) {
+        const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
+        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+        m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+        t = 64;
+        if (MODE == 0) b2s_compress(h, m, t, n_cols == 0 ? 0xFFFFFFFFu : 0u);
+        else b2s_compress(h, m, 0, 0);
+    } else if (MODE == 0 && n_cols == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = 0;
+        b2s_compress(h, m, 0, 0xFFFFFFFFu);  // Blake2s of the empty message
+    }
+    for (u32 c0 = 0; c0 < n_cols; c0 += 16) {
+        if (c0 + 16 <= n_cols) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) m[k] = cols.col(c0 + k)[i];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols.col(c0 + k)[i] : 0u;
+        }
+        bool last = c0 + 16 >= n_cols;
+        if (MODE == 0) { t = last ? total_bytes : t + 64; b2s_compress(h, m, t, last ? 0xFFFFFFFFu : 0u); }
+        else b2s_compress(h, m, 0, 0);
+    }
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// GrindOps: nonce = base + thread; H(digest ‖ nonce_le64) is a single final 40-byte block.
+__global__ void grind_kernel(const u32* __restrict__ digest, u32 pow_bits, u64 base, unsigned long long* result) {
+    u64 nonce = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 h[8], m[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { h[k] = B2S_IV_D[k]; m[k] = digest[k]; }
+    h[0] ^= 0x01010020u;
+    m[8] = (u32)nonce; m[9] = (u32)(nonce >> 32);
+#pragma unroll
+    for (int k = 10; k < 16; k++) m[k] = 0;
+    b2s_compress(h, m, 40, 0xFFFFFFFFu);
+    u32 tz;
+    if (h[0]) tz = __ffs(h[0]) - 1;
+    else if (h[1]) tz = 32 + __ffs(h[1]) - 1;
+    else if (h[2]) tz = 64 + __ffs(h[2]) - 1;
+    else if (h[3]) tz = 96 + __ffs(h[3]) - 1;
+    else tz = 128;
+    if (tz >= pow_bits) atomicMin(result, (unsigned long long)nonce);
+}
+
+int merkle_layer(nx_ctx* ctx, ColSet cols, u32 n_cols, const u32* prev, u32* out, u32 log) {
+    u32 n = 1u << log;
+    dim3 grid((n + 255) / 256), block(256);
+    if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_layer_kernel<0>, grid, block, 0, ctx->stream, cols, n_cols, prev, out, n);
+    else hipLaunchKernelGGL(merkle_layer_kernel<1>, grid, block, 0, ctx->stream, cols, n_cols, prev, out, n);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t* log_sizes, uint32_t n_cols, nx_tree** out) {
+    if (!ctx || !out) return set_err(ctx, NX_ERR_ARG, "nx_merkle_commit: NULL argument");
+    // stable sort by size, descending (MerkleProver::commit)
+    std::vector<uint32_t> order(n_cols);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return log_sizes[a] > log_sizes[b]; });
+    uint32_t max_log = n_cols ? log_sizes[order[0]] : 0;
+    if (max_log > 30) return set_err(ctx, NX_ERR_ARG, "nx_merkle_commit: column too large");
+    std::vector<const uint32_t*> sorted(n_cols);
+    for (uint32_t i = 0; i < n_cols; i++) sorted[i] = d_cols[order[i]];
+
+    nx_tree* t = new nx_tree();
+    t->ctx = ctx;
+    uint32_t* buf = nullptr;
+    size_t total_nodes = ((size_t)2 << max_log) - 1;
+    hipError_t e = hipMalloc((void**)&buf, total_nodes * 32);
+    if (e != hipSuccess) { delete t; return hip_fail(ctx, e, "hipMalloc(merkle layers)", __FILE__, __LINE__); }
+    // layers[k] at node offset 2^k - 1 (root first) inside one allocation
+    t->layers.resize(max_log + 1);
+    for (uint32_t k = 0; k <= max_log; k++) t->layers[k] = buf + (((size_t)1 << k) - 1) * 8;
+
+    uint64_t alg_bytes = 0;
+    for (uint32_t i = 0; i < n_cols; i++) alg_bytes += 4ull << log_sizes[i];
+    alg_bytes += (128ull << max_log);  // 32 B written per leaf + ~96 B per leaf for all inner layers
+    KTimer timer(ctx, NX_T_MERKLE, alg_bytes);
+
+    size_t ci = 0;
+    int rc = NX_OK;
+    for (int log = (int)max_log; log >= 0 && rc == NX_OK; log--) {
+        size_t c0 = ci;
+        while (ci < n_cols && log_sizes[order[ci]] == (uint32_t)log) ci++;
+        ColSet cs;
+        rc = make_colset(ctx, (const uint32_t* const*)(sorted.data() + c0), (uint32_t)(ci - c0), &cs);
+        if (rc != NX_OK) break;
+        const uint32_t* prev = (uint32_t)log < max_log ? t->layers[log + 1] : nullptr;
+        rc = merkle_layer(ctx, cs, (uint32_t)(ci - c0), prev, t->layers[log], (uint32_t)log);
+    }
+    if (rc != NX_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(buf); delete t; return rc; }
+    *out = t;
+    return NX_OK;
+}
+
+int nx_merkle_root(nx_ctx* ctx, const nx_tree* tree, uint8_t root[32]) {
+    return nx_download(ctx, (uint32_t*)root, tree->layers[0], 8);
+}
+uint32_t nx_merkle_n_layers(const nx_tree* tree) { return (uint32_t)tree->layers.size(); }
+const uint32_t* nx_merkle_layer(const nx_tree* tree, uint32_t k) { return k < tree->layers.size() ? tree->layers[k] : nullptr; }
+
+void nx_tree_destroy(nx_tree* tree) {
+    if (!tree) return;
+    (void)hipStreamSynchronize(tree->ctx->stream);
+    if (!tree->layers.empty()) (void)hipFree(tree->layers[0]);
+    delete tree;
+}
+
+int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce) {
+    if (pow_bits > 64) return set_err(ctx, NX_ERR_ARG, "nx_grind: pow_bits > 64");
+    struct { uint32_t d[8]; unsigned long long res; } h;
+    memcpy(h.d, digest, 32);
+    h.res = ~0ull;
+    uint8_t* d = nullptr;
+    NX_HIP(ctx, hipMalloc((void**)&d, sizeof h));
+    hipError_t e = hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream);
+    const uint64_t batch = 1ull << 22;
+    uint64_t base = 0;
+    unsigned long long res = ~0ull;
+    while (e == hipSuccess) {
+        hipLaunchKernelGGL(grind_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx->stream, (const u32*)d, pow_bits, base,
+                           (unsigned long long*)(d + 32));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&res, d + 32, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (res != ~0ull) break;
+        base += batch;
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "nx_grind", __FILE__, __LINE__);
+    *nonce = res;
+    return NX_OK;
+}
+
+}  // extern "C"

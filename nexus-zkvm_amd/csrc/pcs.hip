@@ -1,0 +1,307 @@
+// OODS evaluation, DEEP quotients and FRI folds for gfx950 (K7, K8, K9 of SURVEY.md §8(a)).
+//
+// Replaces Stwo `PolyOps::eval_at_point`, `QuotientOps::accumulate_quotients` and
+// `FriOps::{fold_line, fold_circle_into_line}` — all reached from `stwo::prover::prove`
+// (reference prover/src/machine.rs:286-290, prover2/machine/src/prove.rs:124-128).
+// All three are streaming kernels bounded by HBM bandwidth (one pass over the data they touch).
+#include "internal.h"
+#include <algorithm>
+#include <map>
+#include <string.h>
+
+namespace nx {
+
+// ------------------------------------------------------------------ K7: eval_at_point -------
+// f(p) = Σ_j c_j · basis_j(p), basis_j = Π_k factor_k^{bit_k(j)} with factors [y, x, π(x), π²(x), ...].
+// Split j = (j_hi, j_lo): basis_j = T_hi[j_hi] · T_lo[j_lo].  A lane owns a fixed set of j_lo and
+// walks j_hi, so T_hi[j_hi] is wave-uniform (scalar registers) and every coefficient costs one
+// M31 x QM31 multiply-add; T_lo is applied once per lane at the end.
+constexpr int EVAL_LOG_LO = 11;
+constexpr int EVAL_THREADS = 256;
+constexpr int EVAL_KL = (1 << EVAL_LOG_LO) / EVAL_THREADS;  // j_lo values per lane
+
+__global__ __launch_bounds__(EVAL_THREADS) void eval_at_point_kernel(ColSet polys, int log, const u32* __restrict__ t_lo /*4 x 2^L*/,
+                                                                     const u32* __restrict__ t_hi /*4 x n_hi, AoS*/, u32 hi_per_block,
+                                                                     u32* __restrict__ partial /*[poly][chunk][4]*/, u32 n_chunks) {
+    const int L = log < EVAL_LOG_LO ? log : EVAL_LOG_LO;
+    const u32 n_lo = 1u << L, n_hi = 1u << (log - L);
+    const u32 poly = blockIdx.y, chunk = blockIdx.x;
+    const u32* __restrict__ c = polys.col(poly);
+    QM31 acc[EVAL_KL];
+#pragma unroll
+    for (int k = 0; k < EVAL_KL; k++) acc[k] = q_zero();
+    u32 h0 = chunk * hi_per_block, h1 = min(n_hi, h0 + hi_per_block);
+    for (u32 jh = h0; jh < h1; jh++) {
+        QM31 th = q_load(t_hi + 4 * jh);  // uniform
+        const u32* row = c + ((size_t)jh << L);
+#pragma unroll
+        for (int k = 0; k < EVAL_KL; k++) {
+            u32 jl = threadIdx.x + k * EVAL_THREADS;
+            if (jl < n_lo) acc[k] = q_add(acc[k], q_mul_m(th, row[jl]));
+        }
+    }
+    QM31 tot = q_zero();
+#pragma unroll
+    for (int k = 0; k < EVAL_KL; k++) {
+        u32 jl = threadIdx.x + k * EVAL_THREADS;
+        if (jl < n_lo) tot = q_add(tot, q_mul(acc[k], qm(t_lo[jl], t_lo[n_lo + jl], t_lo[2 * n_lo + jl], t_lo[3 * n_lo + jl])));
+    }
+    // block reduction (wave shuffle then LDS)
+    __shared__ u32 red[EVAL_THREADS / 64][4];
+    u32 w[4] = {tot.a.a, tot.a.b, tot.b.a, tot.b.b};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        for (int off = 32; off > 0; off >>= 1) w[q] = m_add(w[q], __shfl_down(w[q], off, 64));
+    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 4; q++) red[threadIdx.x >> 6][q] = w[q];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        u32 s = 0;
+        for (int k = 0; k < EVAL_THREADS / 64; k++) s = m_add(s, red[k][threadIdx.x]);
+        partial[((size_t)poly * n_chunks + chunk) * 4 + threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------ K8: DEEP quotients ------
+struct QBatchDev {       // one ColumnSampleBatch, device-resident description
+    u32 first, count;    // range in the flattened (col_idx, c) arrays
+    u32 prx[2], pry[2], pix[2], piy[2];  // CM31 parts of the sample point
+    u32 sum_a[4], sum_b[4];              // Σ alpha^k a_k , Σ alpha^k b_k   (QM31)
+    u32 coeff[4];                        // alpha^{count}
+};
+
+__global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, const QBatchDev* __restrict__ batches, u32 n_batches,
+                                                       const u32* __restrict__ col_idx, const u32* __restrict__ cks /*4 per entry*/,
+                                                       u32* __restrict__ o0, u32* __restrict__ o1, u32* __restrict__ o2, u32* __restrict__ o3) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (1u << log)) return;
+    Pt dp = pt_from_index(circle_domain_index(log, bitrev(r, log)));
+    QM31 acc = q_zero();
+    for (u32 b = 0; b < n_batches; b++) {
+        const QBatchDev& B = batches[b];
+        // numerator: Σ_k c_k f_k(d) - (d.y Σ a_k + Σ b_k)
+        u32 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        const u32 end = B.first + B.count;
+        for (u32 k = B.first; k < end; k++) {
+            u32 f = cols.col(col_idx[k])[r];
+            n0 = m_add(n0, m_mul(cks[4 * k], f));
+            n1 = m_add(n1, m_mul(cks[4 * k + 1], f));
+            n2 = m_add(n2, m_mul(cks[4 * k + 2], f));
+            n3 = m_add(n3, m_mul(cks[4 * k + 3], f));
+        }
+        QM31 num = q_sub(qm(n0, n1, n2, n3), q_add(q_mul_m(q_load(B.sum_a), dp.y), q_load(B.sum_b)));
+        // denominator (CM31): (Re p.x - d.x) Im p.y - (Re p.y - d.y) Im p.x
+        CM31 den = c_sub(c_mul(c_sub(cm(B.prx[0], B.prx[1]), cm(dp.x, 0)), cm(B.piy[0], B.piy[1])),
+                         c_mul(c_sub(cm(B.pry[0], B.pry[1]), cm(dp.y, 0)), cm(B.pix[0], B.pix[1])));
+        acc = q_add(q_mul(acc, q_load(B.coeff)), q_mul_c(num, c_inv(den)));
+    }
+    o0[r] = acc.a.a; o1[r] = acc.a.b; o2[r] = acc.b.a; o3[r] = acc.b.b;
+}
+
+// ------------------------------------------------------------------ K9: FRI folds -----------
+__device__ __forceinline__ u32 tw_at(const u32* tw, u32 tw_log, int n, int layer, u32 h) {
+    return tw[(1u << tw_log) - (1u << (n - layer)) + h];
+}
+// 1/y of CanonicCoset(L).circle_domain().at(bitrev_L(2i)) == circle-layer inverse twiddle i of a size-2^L domain
+__device__ __forceinline__ u32 circle_itw(const u32* itw, u32 tw_log, int L, u32 h) {
+    if (L == 1) return m_inv(pt_from_index(half_odds_index(0, 0)).y);
+    if (L == 2) { Pt p = pt_from_index(half_odds_index(1, 0)); u32 yi = m_inv(p.y); return h ? m_neg(yi) : yi; }
+    u32 c = h >> 2;
+    u32 x = tw_at(itw, tw_log, L, 1, 2 * c), y = tw_at(itw, tw_log, L, 1, 2 * c + 1);
+    u32 sel = h & 3;
+    u32 v = (sel & 2) ? x : y;
+    return (sel == 1 || sel == 2) ? m_neg(v) : v;
+}
+
+struct Sec4 { u32* c[4]; };
+struct Sec4C { const u32* c[4]; };
+
+__global__ void fold_circle_kernel(Sec4 dst, Sec4C src, int L, const u32* __restrict__ itw, u32 tw_log, QM31 alpha, QM31 alpha_sq) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (L - 1))) return;
+    u32 yi = circle_itw(itw, tw_log, L, i);
+    QM31 f0, f1;
+    {
+        uint2 a = *reinterpret_cast<const uint2*>(src.c[0] + 2 * i), b = *reinterpret_cast<const uint2*>(src.c[1] + 2 * i);
+        uint2 c = *reinterpret_cast<const uint2*>(src.c[2] + 2 * i), d = *reinterpret_cast<const uint2*>(src.c[3] + 2 * i);
+        f0 = qm(a.x, b.x, c.x, d.x); f1 = qm(a.y, b.y, c.y, d.y);
+    }
+    QM31 s = q_add(f0, f1), t = q_mul_m(q_sub(f0, f1), yi);   // ibutterfly
+    QM31 fp = q_add(q_mul(alpha, t), s);
+    QM31 d = qm(dst.c[0][i], dst.c[1][i], dst.c[2][i], dst.c[3][i]);
+    d = q_add(q_mul(d, alpha_sq), fp);
+    dst.c[0][i] = d.a.a; dst.c[1][i] = d.a.b; dst.c[2][i] = d.b.a; dst.c[3][i] = d.b.b;
+}
+
+// line domain of log size L is Coset::half_odds(L); 1/x at bitrev_L(2i) is itwiddle layer (H-L), entry i
+__global__ void fold_line_kernel(Sec4 dst, Sec4C src, int L, const u32* __restrict__ itw, u32 tw_log, QM31 alpha) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (L - 1))) return;
+    u32 xi = itw[(1u << tw_log) - (1u << L) + i];
+    uint2 a = *reinterpret_cast<const uint2*>(src.c[0] + 2 * i), b = *reinterpret_cast<const uint2*>(src.c[1] + 2 * i);
+    uint2 c = *reinterpret_cast<const uint2*>(src.c[2] + 2 * i), d = *reinterpret_cast<const uint2*>(src.c[3] + 2 * i);
+    QM31 f0 = qm(a.x, b.x, c.x, d.x), f1 = qm(a.y, b.y, c.y, d.y);
+    QM31 s = q_add(f0, f1), t = q_mul_m(q_sub(f0, f1), xi);
+    QM31 o = q_add(s, q_mul(alpha, t));
+    dst.c[0][i] = o.a.a; dst.c[1][i] = o.a.b; dst.c[2][i] = o.b.a; dst.c[3][i] = o.b.b;
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_size, const uint32_t* poly_idx,
+                      const uint32_t* h_points, uint32_t n_evals, uint32_t* h_out) {
+    if (n_evals == 0) return NX_OK;
+    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_eval_at_points: log_size too large");
+    const int n = (int)log_size;
+    // group by distinct point (insertion order)
+    std::vector<std::vector<uint32_t>> groups;
+    std::vector<const uint32_t*> gpts;
+    for (uint32_t i = 0; i < n_evals; i++) {
+        size_t g = 0;
+        for (; g < gpts.size(); g++) if (!memcmp(gpts[g], h_points + 8 * i, 32)) break;
+        if (g == gpts.size()) { gpts.push_back(h_points + 8 * i); groups.emplace_back(); }
+        groups[g].push_back(i);
+    }
+    const int L = std::min(n, EVAL_LOG_LO);
+    const uint32_t n_lo = 1u << L, n_hi = 1u << (n - L);
+    for (size_t g = 0; g < groups.size(); g++) {
+        QPt p; p.x = q_load(gpts[g]); p.y = q_load(gpts[g] + 4);
+        // factors for bit k of j: [y, x, pi(x), pi^2(x), ...]
+        std::vector<QM31> f(n);
+        if (n > 0) f[0] = p.y;
+        { QM31 x = p.x; for (int k = 1; k < n; k++) { f[k] = x; x = q_double_x(x); } }
+        std::vector<uint32_t> tlo(4 * (size_t)n_lo), thi(4 * (size_t)n_hi);
+        {
+            std::vector<QM31> t(n_lo); t[0] = q_one();
+            for (int k = 0; k < L; k++) for (uint32_t j = 0; j < (1u << k); j++) t[j + (1u << k)] = q_mul(t[j], f[k]);
+            for (uint32_t j = 0; j < n_lo; j++) { tlo[j] = t[j].a.a; tlo[n_lo + j] = t[j].a.b; tlo[2 * n_lo + j] = t[j].b.a; tlo[3 * n_lo + j] = t[j].b.b; }
+            std::vector<QM31> u(n_hi); u[0] = q_one();
+            for (int k = L; k < n; k++) for (uint32_t j = 0; j < (1u << (k - L)); j++) u[j + (1u << (k - L))] = q_mul(u[j], f[k]);
+            for (uint32_t j = 0; j < n_hi; j++) q_store(&thi[4 * j], u[j]);
+        }
+        const uint32_t np = (uint32_t)groups[g].size();
+        std::vector<const uint32_t*> sel(np);
+        for (uint32_t i = 0; i < np; i++) sel[i] = d_polys[poly_idx[groups[g][i]]];
+        uint32_t hi_per_block = std::max<uint32_t>(1, std::min<uint32_t>(n_hi, 128));
+        uint32_t n_chunks = (n_hi + hi_per_block - 1) / hi_per_block;
+        // device buffers: tables + partials (+ pointer table when needed)
+        uint32_t *d_lo = nullptr, *d_hi = nullptr, *d_part = nullptr;
+        uint32_t* const* d_tab = nullptr;
+        size_t part_words = (size_t)np * n_chunks * 4;
+        uint8_t* blob = nullptr;
+        size_t bytes = tlo.size() * 4 + thi.size() * 4 + part_words * 4 + (size_t)np * 8;
+        NX_HIP(ctx, hipMalloc((void**)&blob, bytes));
+        d_lo = (uint32_t*)blob; d_hi = d_lo + tlo.size(); d_part = d_hi + thi.size();
+        d_tab = (uint32_t* const*)(blob + (tlo.size() + thi.size() + part_words) * 4);
+        hipError_t e = hipMemcpyAsync(d_lo, tlo.data(), tlo.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_hi, thi.data(), thi.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync((void*)d_tab, sel.data(), (size_t)np * 8, hipMemcpyHostToDevice, ctx->stream);
+        std::vector<uint32_t> part(part_words);
+        if (e == hipSuccess) {
+            ColSet cs; cs.base = nullptr; cs.stride = 0; cs.table = d_tab;
+            for (uint32_t p0 = 0; p0 < np && e == hipSuccess; p0 += 32768) {
+                uint32_t nb = std::min<uint32_t>(32768, np - p0);
+                ColSet sub = cs; sub.table = d_tab + p0;
+                hipLaunchKernelGGL(eval_at_point_kernel, dim3(n_chunks, nb), dim3(EVAL_THREADS), 0, ctx->stream, sub, n, d_lo, d_hi,
+                                   hi_per_block, d_part + (size_t)p0 * n_chunks * 4, n_chunks);
+                e = hipGetLastError();
+            }
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_part, part_words * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(blob);
+        if (e != hipSuccess) return hip_fail(ctx, e, "nx_eval_at_points", __FILE__, __LINE__);
+        for (uint32_t i = 0; i < np; i++) {
+            uint32_t s[4] = {0, 0, 0, 0};
+            for (uint32_t c = 0; c < n_chunks; c++) for (int q = 0; q < 4; q++) s[q] = m_add(s[q], part[((size_t)i * n_chunks + c) * 4 + q]);
+            memcpy(h_out + 4 * (size_t)groups[g][i], s, 16);
+        }
+    }
+    return NX_OK;
+}
+
+int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
+                            uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
+                            const uint32_t* values, uint32_t* const* d_out4) {
+    if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: bad log_size");
+    QM31 alpha = q_load(random_coeff);
+    size_t total = 0;
+    for (uint32_t b = 0; b < n_batches; b++) total += batch_counts[b];
+    std::vector<QBatchDev> hb(n_batches);
+    std::vector<uint32_t> cks(4 * total);
+    size_t k = 0;
+    for (uint32_t b = 0; b < n_batches; b++) {
+        QBatchDev& B = hb[b];
+        QPt p; p.x = q_load(points + 8 * b); p.y = q_load(points + 8 * b + 4);
+        B.first = (uint32_t)k; B.count = batch_counts[b];
+        B.prx[0] = p.x.a.a; B.prx[1] = p.x.a.b; B.pix[0] = p.x.b.a; B.pix[1] = p.x.b.b;
+        B.pry[0] = p.y.a.a; B.pry[1] = p.y.a.b; B.piy[0] = p.y.b.a; B.piy[1] = p.y.b.b;
+        QM31 a_pow = q_one(), sa = q_zero(), sb = q_zero();
+        QM31 c0 = q_sub(q_conj(p.y), p.y);  // conj(p.y) - p.y
+        for (uint32_t j = 0; j < batch_counts[b]; j++, k++) {
+            if (col_idx[k] >= n_cols) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: column index out of range");
+            a_pow = q_mul(a_pow, alpha);
+            QM31 v = q_load(values + 4 * k);
+            QM31 a = q_sub(q_conj(v), v);
+            QM31 bb = q_sub(q_mul(v, c0), q_mul(a, p.y));
+            sa = q_add(sa, q_mul(a_pow, a));
+            sb = q_add(sb, q_mul(a_pow, bb));
+            q_store(&cks[4 * k], q_mul(a_pow, c0));
+        }
+        q_store(B.sum_a, sa); q_store(B.sum_b, sb); q_store(B.coeff, a_pow);
+    }
+    // stage descriptors (persist until the kernel ran: own allocation, freed after sync-free enqueue via stream callback-less pattern)
+    uint8_t* blob = nullptr;
+    size_t bytes_b = hb.size() * sizeof(QBatchDev), bytes_i = total * 4, bytes_c = cks.size() * 4, bytes_t = (size_t)n_cols * 8;
+    size_t off_i = (bytes_b + 15) & ~(size_t)15, off_c = off_i + ((bytes_i + 15) & ~(size_t)15), off_t = off_c + ((bytes_c + 15) & ~(size_t)15);
+    NX_HIP(ctx, hipMalloc((void**)&blob, off_t + bytes_t + 16));
+    hipError_t e = hipMemcpyAsync(blob, hb.data(), bytes_b, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(blob + off_i, col_idx, bytes_i, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(blob + off_c, cks.data(), bytes_c, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_cols) e = hipMemcpyAsync(blob + off_t, d_cols, bytes_t, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        ColSet cs; cs.base = nullptr; cs.stride = 0; cs.table = (uint32_t* const*)(blob + off_t);
+        uint64_t alg = ((uint64_t)n_cols * 4 + 16) << log_size;
+        KTimer timer(ctx, NX_T_QUOT, alg);
+        uint32_t n = 1u << log_size;
+        hipLaunchKernelGGL(quotient_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
+                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+        e = hipGetLastError();
+    }
+    // the pageable host vectors above die at return: wait for the copies (kernel completion is not required for them,
+    // but the blob must outlive the kernel, so synchronise before freeing it)
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(blob);
+    if (e != hipSuccess) return hip_fail(ctx, e, "nx_accumulate_quotients", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_accumulate_quotients(sync)", __FILE__, __LINE__);
+    return NX_OK;
+}
+
+int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log,
+                             const uint32_t alpha[4]) {
+    if (src_log < 1 || (src_log >= 3 && src_log - 1 > tw->log_half)) return set_err(ctx, NX_ERR_ARG, "nx_fold_circle_into_line: bad log");
+    Sec4 d; Sec4C s;
+    for (int q = 0; q < 4; q++) { d.c[q] = d_dst4[q]; s.c[q] = d_src4[q]; }
+    QM31 a = q_load(alpha);
+    uint32_t n = 1u << (src_log - 1);
+    hipLaunchKernelGGL(fold_circle_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, tw->d_itw, tw->log_half, a, q_sqr(a));
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+int nx_fold_line(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, uint32_t n_doublings, const uint32_t alpha[4],
+                 uint32_t* const* d_dst4) {
+    (void)n_doublings;  // half_odds(k).double() == half_odds(k-1): the domain of log size L is always half_odds(L)
+    if (src_log < 1 || src_log > tw->log_half) return set_err(ctx, NX_ERR_ARG, "nx_fold_line: domain not covered by the twiddle tree");
+    Sec4 d; Sec4C s;
+    for (int q = 0; q < 4; q++) { d.c[q] = d_dst4[q]; s.c[q] = d_src4[q]; }
+    uint32_t n = 1u << (src_log - 1);
+    hipLaunchKernelGGL(fold_line_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, tw->d_itw, tw->log_half, q_load(alpha));
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,678 @@
+// Host driver of the device prover: the C++ mirror of the Stwo objects the reference instantiates
+//   CommitmentSchemeProver / TreeBuilder   (reference prover/src/machine.rs:202-263)
+//   stwo::prover::prove                     (reference prover/src/machine.rs:286-290)
+//   FriProver, prove_values, decommit       (inside prove)
+// written against the C ABI of include/nexus_hip.h (plus the synthetic machine's own kernels), so
+// that everything a Rust `HipBackend` shim needs is exercised through the same entry points.
+// The reference's toolchain (Rust nightly) is absent from this image, hence C++ (task rule ②).
+#include "internal.h"
+#include "air.h"
+#include "host/channel.h"
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <set>
+#include <string.h>
+#include <stdlib.h>
+
+namespace nxhip {
+
+using namespace nx;
+
+#define H_TRY(call) do { int rc__ = (call); if (rc__ != NX_OK) return rc__; } while (0)
+
+struct DevBuf {  // owned device allocation
+    nx_ctx* ctx = nullptr; uint32_t* p = nullptr; size_t words = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept { ctx = o.ctx; p = o.p; words = o.words; o.p = nullptr; }
+    DevBuf& operator=(DevBuf&& o) noexcept { release(); ctx = o.ctx; p = o.p; words = o.words; o.p = nullptr; return *this; }
+    int alloc(nx_ctx* c, size_t w) { release(); ctx = c; words = w; return nx_alloc(c, w, &p); }
+    void release() { if (p) { (void)nx_free(ctx, p); p = nullptr; } }
+    ~DevBuf() { release(); }
+};
+
+struct ColumnRef { uint32_t* ptr; uint32_t log; };
+
+struct PcsConfig { uint32_t pow_bits, log_blowup, n_queries, log_last_layer_degree_bound, fri_alpha_mode, log_constraint_degree; };
+
+struct MerkleDecommitment { std::vector<Blake2sHash> hash_witness; std::vector<uint32_t> column_witness; };
+
+// ---------------------------------------------------------------- MerkleProver::decommit ------
+// The walk depends only on the query positions and the layer structure, so it first records which
+// words are needed, fetches them with ONE gather (nx_gather) and then distributes them.
+static int merkle_decommit(nx_ctx* ctx, const nx_tree* tree, const std::map<uint32_t, std::vector<size_t>>& queries_per_log,
+                           std::vector<ColumnRef> cols, std::vector<uint32_t>* queried_values, MerkleDecommitment* d) {
+    std::stable_sort(cols.begin(), cols.end(), [](const ColumnRef& a, const ColumnRef& b) { return a.log > b.log; });
+    std::vector<const uint32_t*> ptrs; std::vector<uint64_t> idx; std::vector<uint8_t> kind;  // 0 hash word, 1 queried, 2 column witness
+    size_t ci = 0;
+    std::vector<size_t> last;
+    uint32_t n_layers = nx_merkle_n_layers(tree);
+    for (int log = (int)n_layers - 1; log >= 0; log--) {
+        std::vector<const uint32_t*> lc;
+        while (ci < cols.size() && cols[ci].log == (uint32_t)log) lc.push_back(cols[ci++].ptr);
+        const uint32_t* prev = (uint32_t)(log + 1) < n_layers ? nx_merkle_layer(tree, log + 1) : nullptr;
+        static const std::vector<size_t> none;
+        auto it = queries_per_log.find((uint32_t)log);
+        const std::vector<size_t>& lq = it == queries_per_log.end() ? none : it->second;
+        size_t pi = 0, qi = 0;
+        std::vector<size_t> total;
+        while (pi < last.size() || qi < lq.size()) {
+            size_t node;
+            if (pi < last.size() && qi < lq.size()) node = std::min(last[pi] / 2, lq[qi]);
+            else if (pi < last.size()) node = last[pi] / 2;
+            else node = lq[qi];
+            if (prev) {
+                for (size_t child = 2 * node; child <= 2 * node + 1; child++) {
+                    if (pi < last.size() && last[pi] == child) { pi++; continue; }
+                    for (int w = 0; w < 8; w++) { ptrs.push_back(prev); idx.push_back(child * 8 + w); kind.push_back(0); }
+                }
+            }
+            uint8_t k = 2;
+            if (qi < lq.size() && lq[qi] == node) { qi++; k = 1; }
+            for (auto c : lc) { ptrs.push_back(c); idx.push_back(node); kind.push_back(k); }
+            total.push_back(node);
+        }
+        last.swap(total);
+    }
+    std::vector<uint32_t> vals(ptrs.size());
+    H_TRY(nx_gather(ctx, ptrs.data(), idx.data(), ptrs.size(), vals.data()));
+    Blake2sHash cur; int hw = 0;
+    for (size_t i = 0; i < vals.size(); i++) {
+        if (kind[i] == 0) { cur.w[hw++] = vals[i]; if (hw == 8) { d->hash_witness.push_back(cur); hw = 0; } }
+        else if (kind[i] == 1) { if (queried_values) queried_values->push_back(vals[i]); }
+        else d->column_witness.push_back(vals[i]);
+    }
+    return NX_OK;
+}
+
+// ---------------------------------------------------------------- commitment scheme ----------
+struct CommitmentTreeProver {
+    std::vector<ColumnRef> polys;  // coefficients, commit order
+    std::vector<ColumnRef> evals;  // LDE (log = poly log + log_blowup)
+    std::vector<DevBuf> bufs;
+    nx_tree* merkle = nullptr;
+    Blake2sHash root;
+    CommitmentTreeProver() {}
+    CommitmentTreeProver(CommitmentTreeProver&& o) noexcept
+        : polys(std::move(o.polys)), evals(std::move(o.evals)), bufs(std::move(o.bufs)), merkle(o.merkle), root(o.root) { o.merkle = nullptr; }
+    CommitmentTreeProver(const CommitmentTreeProver&) = delete;
+    ~CommitmentTreeProver() { if (merkle) nx_tree_destroy(merkle); }
+};
+
+class CommitmentSchemeProver;
+
+// TreeBuilder::{extend_evals, extend_polys, commit}
+class TreeBuilder {
+    struct Group { DevBuf slab; uint32_t n_cols, log; bool is_evals; };
+    CommitmentSchemeProver& cs;
+    std::vector<Group> groups;
+  public:
+    explicit TreeBuilder(CommitmentSchemeProver& c) : cs(c) {}
+    // slab: n_cols contiguous columns of 2^log words (bit-reversed evaluations on CanonicCoset(log).circle_domain())
+    void extend_evals(DevBuf&& slab, uint32_t n_cols, uint32_t log) { Group g; g.slab = std::move(slab); g.n_cols = n_cols; g.log = log; g.is_evals = true; groups.push_back(std::move(g)); }
+    void extend_polys(DevBuf&& slab, uint32_t n_cols, uint32_t log) { Group g; g.slab = std::move(slab); g.n_cols = n_cols; g.log = log; g.is_evals = false; groups.push_back(std::move(g)); }
+    int commit(Blake2sChannel& channel);
+};
+
+class CommitmentSchemeProver {
+  public:
+    nx_ctx* ctx; const nx_twiddles* tw; PcsConfig cfg;
+    std::vector<CommitmentTreeProver> trees;
+    CommitmentSchemeProver(nx_ctx* c, const nx_twiddles* t, PcsConfig f) : ctx(c), tw(t), cfg(f) {}
+    TreeBuilder tree_builder() { return TreeBuilder(*this); }
+};
+
+static std::vector<uint32_t*> col_ptrs(uint32_t* base, uint32_t n, uint32_t log) {
+    std::vector<uint32_t*> v(n);
+    for (uint32_t i = 0; i < n; i++) v[i] = base + ((size_t)i << log);
+    return v;
+}
+
+int TreeBuilder::commit(Blake2sChannel& channel) {
+    nx_ctx* ctx = cs.ctx;
+    CommitmentTreeProver t;
+    for (auto& g : groups) {
+        uint32_t el = g.log + cs.cfg.log_blowup;
+        DevBuf lde;
+        if (g.n_cols) {
+            H_TRY(lde.alloc(ctx, (size_t)g.n_cols << el));
+            auto in = col_ptrs(g.slab.p, g.n_cols, g.log), out = col_ptrs(lde.p, g.n_cols, el);
+            if (g.is_evals) H_TRY(nx_lde_batch(ctx, cs.tw, in.data(), g.n_cols, g.log, cs.cfg.log_blowup, out.data()));   // K3 + K4
+            else H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)in.data(), g.n_cols, g.log, cs.cfg.log_blowup, out.data()));  // K4
+            for (uint32_t i = 0; i < g.n_cols; i++) { t.polys.push_back({in[i], g.log}); t.evals.push_back({out[i], el}); }
+        }
+        t.bufs.push_back(std::move(g.slab));
+        t.bufs.push_back(std::move(lde));
+    }
+    std::vector<const uint32_t*> cp; std::vector<uint32_t> logs;
+    for (auto& e : t.evals) { cp.push_back(e.ptr); logs.push_back(e.log); }
+    H_TRY(nx_merkle_commit(ctx, cp.data(), logs.data(), (uint32_t)cp.size(), &t.merkle));   // K5
+    H_TRY(nx_merkle_root(ctx, t.merkle, (uint8_t*)t.root.w));
+    channel.mix_root(t.root);                                                                // K6
+    cs.trees.push_back(std::move(t));
+    groups.clear();
+    return NX_OK;
+}
+
+// ---------------------------------------------------------------- FRI ------------------------
+struct SecureColumn {  // SecureColumnByCoords on device
+    DevBuf buf; uint32_t log = 0; uint32_t* c[4] = {nullptr, nullptr, nullptr, nullptr};
+    int alloc(nx_ctx* ctx, uint32_t l) { log = l; H_TRY(buf.alloc(ctx, (size_t)4 << l)); for (int k = 0; k < 4; k++) c[k] = buf.p + ((size_t)k << l); return NX_OK; }
+};
+struct FriLayer { SecureColumn eval; nx_tree* merkle = nullptr; Blake2sHash root; };
+struct FriLayerProof { std::vector<QM31> fri_witness; MerkleDecommitment decommitment; Blake2sHash commitment; };
+
+struct Proof {
+    std::vector<Blake2sHash> commitments;
+    std::vector<std::vector<std::vector<QM31>>> sampled_values;
+    std::vector<MerkleDecommitment> decommitments;
+    std::vector<std::vector<uint32_t>> queried_values;
+    uint64_t proof_of_work = 0;
+    FriLayerProof first_layer;
+    std::vector<FriLayerProof> inner_layers;
+    std::vector<QM31> last_layer_poly;
+};
+
+static std::vector<size_t> queries_fold(const std::vector<size_t>& q, uint32_t n_folds) {
+    std::vector<size_t> r;
+    for (size_t p : q) { size_t f = p >> n_folds; if (r.empty() || r.back() != f) r.push_back(f); }
+    return r;
+}
+
+class FriProver {
+  public:
+    nx_ctx* ctx; const nx_twiddles* tw; PcsConfig cfg;
+    std::vector<SecureColumn> columns;  // first layer, decreasing size
+    nx_tree* first_merkle = nullptr; Blake2sHash first_root;
+    std::vector<FriLayer> inner;
+    std::vector<QM31> last_layer_poly;
+    FriProver(nx_ctx* c, const nx_twiddles* t, PcsConfig f) : ctx(c), tw(t), cfg(f) {}
+    ~FriProver() { if (first_merkle) nx_tree_destroy(first_merkle); for (auto& l : inner) if (l.merkle) nx_tree_destroy(l.merkle); }
+
+    static int commit_secure(nx_ctx* ctx, const std::vector<const SecureColumn*>& cols, nx_tree** tree, Blake2sHash* root) {
+        std::vector<const uint32_t*> p; std::vector<uint32_t> logs;
+        for (auto s : cols) for (int k = 0; k < 4; k++) { p.push_back(s->c[k]); logs.push_back(s->log); }
+        H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), (uint32_t)p.size(), tree));
+        return nx_merkle_root(ctx, *tree, (uint8_t*)root->w);
+    }
+
+    // FriProver::commit
+    int commit(Blake2sChannel& channel, std::vector<SecureColumn>&& cols) {
+        columns = std::move(cols);
+        if (columns.empty()) return set_err(ctx, NX_ERR_ARG, "fri: no columns");
+        { std::vector<const SecureColumn*> p; for (auto& c : columns) p.push_back(&c); H_TRY(commit_secure(ctx, p, &first_merkle, &first_root)); }
+        channel.mix_root(first_root);
+        QM31 folding_alpha = channel.draw_secure_felt();
+        const QM31 first_alpha = folding_alpha;
+        uint32_t layer_log = columns[0].log - 1;
+        SecureColumn layer; H_TRY(layer.alloc(ctx, layer_log));
+        H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
+        const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
+        size_t ci = 0; uint32_t n_doublings = 0;
+        while (layer_log > last_log) {
+            while (ci < columns.size() && columns[ci].log - 1 == layer_log) {
+                QM31 a = cfg.fri_alpha_mode == NX_FRI_ALPHA_PREV ? folding_alpha : first_alpha;
+                uint32_t aw[4]; q_store(aw, a);
+                H_TRY(nx_fold_circle_into_line(ctx, tw, layer.c, (const uint32_t* const*)columns[ci].c, columns[ci].log, aw));
+                ci++;
+            }
+            FriLayer L; L.eval = std::move(layer);
+            for (int k = 0; k < 4; k++) L.eval.c[k] = L.eval.buf.p + ((size_t)k << layer_log);
+            { std::vector<const SecureColumn*> p{&L.eval}; H_TRY(commit_secure(ctx, p, &L.merkle, &L.root)); }
+            channel.mix_root(L.root);
+            folding_alpha = channel.draw_secure_felt();
+            SecureColumn next; H_TRY(next.alloc(ctx, layer_log - 1));
+            uint32_t aw[4]; q_store(aw, folding_alpha);
+            H_TRY(nx_fold_line(ctx, tw, (const uint32_t* const*)L.eval.c, layer_log, n_doublings, aw, next.c));
+            inner.push_back(std::move(L));
+            // moved FriLayer: fix coordinate pointers (buffer address is unchanged by the move)
+            layer = std::move(next);
+            for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << (layer_log - 1));
+            layer_log--; n_doublings++;
+        }
+        if (ci != columns.size()) return set_err(ctx, NX_ERR_PROTOCOL, "fri: first-layer columns not consumed (column smaller than the last layer)");
+        // commit_last_layer: tiny — interpolate the line evaluation on the host
+        size_t n = (size_t)1 << layer_log;
+        std::vector<uint32_t> h(4 * n);
+        H_TRY(nx_download(ctx, h.data(), layer.buf.p, 4 * n));
+        std::vector<QM31> v(n);
+        for (size_t i = 0; i < n; i++) v[i] = qm(h[i], h[n + i], h[2 * n + i], h[3 * n + i]);
+        // LineEvaluation::interpolate (bit_reverse, line_ifft, scale) then into_ordered_coefficients
+        for (size_t i = 0; i < n; i++) { size_t j = bitrev((u32)i, (int)layer_log); if (i < j) std::swap(v[i], v[j]); }
+        {
+            int dl = (int)layer_log;  // current line domain: half_odds(dl)
+            while (dl > 0) {
+                size_t ds = (size_t)1 << dl;
+                for (size_t c0 = 0; c0 < n; c0 += ds)
+                    for (size_t i = 0; i < ds / 2; i++) {
+                        u32 x = pt_from_index(half_odds_index(dl, (u32)i)).x;
+                        QM31 a = v[c0 + i], b = v[c0 + ds / 2 + i];
+                        v[c0 + i] = q_add(a, b); v[c0 + ds / 2 + i] = q_mul_m(q_sub(a, b), m_inv(x));
+                    }
+                dl--;
+            }
+        }
+        u32 len_inv = m_inv((u32)n);
+        for (auto& x : v) x = q_mul_m(x, len_inv);
+        for (size_t i = 0; i < n; i++) { size_t j = bitrev((u32)i, (int)layer_log); if (i < j) std::swap(v[i], v[j]); }
+        size_t bound = (size_t)1 << cfg.log_last_layer_degree_bound;
+        for (size_t i = bound; i < n; i++) if (!q_is_zero(v[i])) return set_err(ctx, NX_ERR_PROTOCOL, "fri: invalid degree in the last layer");
+        v.resize(bound);
+        channel.mix_felts(v);
+        last_layer_poly = v;
+        return NX_OK;
+    }
+
+    // compute_decommitment_positions_and_witness_evals: positions now, witness values gathered later
+    static void decommit_positions(const std::vector<size_t>& queries, std::vector<size_t>* positions, std::vector<size_t>* witness_pos) {
+        size_t i = 0;
+        while (i < queries.size()) {
+            size_t j = i;
+            while (j < queries.size() && (queries[j] >> 1) == (queries[i] >> 1)) j++;
+            size_t start = (queries[i] >> 1) << 1, qi = i;
+            for (size_t pos = start; pos < start + 2; pos++) {
+                positions->push_back(pos);
+                if (qi < j && queries[qi] == pos) { qi++; continue; }
+                witness_pos->push_back(pos);
+            }
+            i = j;
+        }
+    }
+    int gather_secure(const SecureColumn& col, const std::vector<size_t>& pos, std::vector<QM31>* out) {
+        std::vector<const uint32_t*> p; std::vector<uint64_t> idx;
+        for (size_t q : pos) for (int k = 0; k < 4; k++) { p.push_back(col.c[k]); idx.push_back(q); }
+        std::vector<uint32_t> v(p.size());
+        H_TRY(nx_gather(ctx, p.data(), idx.data(), p.size(), v.data()));
+        for (size_t i = 0; i < pos.size(); i++) out->push_back(qm(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]));
+        return NX_OK;
+    }
+
+    // FriProver::decommit
+    int decommit(Blake2sChannel& channel, Proof* proof, std::map<uint32_t, std::vector<size_t>>* query_positions_per_log) {
+        uint32_t max_log = columns[0].log;
+        // Queries::generate
+        std::vector<size_t> queries;
+        {
+            std::set<size_t> q; uint32_t cnt = 0; size_t mask = ((size_t)1 << max_log) - 1; bool done = false;
+            while (!done) {
+                uint32_t w[8]; channel.draw_u32s(w);
+                for (int i = 0; i < 8 && !done; i++) { q.insert((size_t)w[i] & mask); if (++cnt == cfg.n_queries) done = true; }
+            }
+            queries.assign(q.begin(), q.end());
+        }
+        for (auto& c : columns) (*query_positions_per_log)[c.log] = queries_fold(queries, max_log - c.log);
+        {   // first layer
+            std::map<uint32_t, std::vector<size_t>> pos_by_log;
+            std::vector<ColumnRef> refs;
+            for (auto& c : columns) {
+                std::vector<size_t> pos, wpos;
+                decommit_positions(queries_fold(queries, max_log - c.log), &pos, &wpos);
+                H_TRY(gather_secure(c, wpos, &proof->first_layer.fri_witness));
+                pos_by_log[c.log] = pos;
+                for (int k = 0; k < 4; k++) refs.push_back({c.c[k], c.log});
+            }
+            H_TRY(merkle_decommit(ctx, first_merkle, pos_by_log, refs, nullptr, &proof->first_layer.decommitment));
+            proof->first_layer.commitment = first_root;
+        }
+        std::vector<size_t> lq = queries_fold(queries, 1);
+        for (auto& L : inner) {
+            FriLayerProof lp;
+            std::vector<size_t> pos, wpos;
+            decommit_positions(lq, &pos, &wpos);
+            H_TRY(gather_secure(L.eval, wpos, &lp.fri_witness));
+            std::map<uint32_t, std::vector<size_t>> pos_by_log; pos_by_log[L.eval.log] = pos;
+            std::vector<ColumnRef> refs; for (int k = 0; k < 4; k++) refs.push_back({L.eval.c[k], L.eval.log});
+            H_TRY(merkle_decommit(ctx, L.merkle, pos_by_log, refs, nullptr, &lp.decommitment));
+            lp.commitment = L.root;
+            proof->inner_layers.push_back(std::move(lp));
+            lq = queries_fold(lq, 1);
+        }
+        proof->last_layer_poly = last_layer_poly;
+        return NX_OK;
+    }
+};
+
+// ---------------------------------------------------------------- proof wire format ("NXP1") --
+static void ser_hash(std::vector<uint32_t>& o, const Blake2sHash& h) { o.insert(o.end(), h.w, h.w + 8); }
+static void ser_q(std::vector<uint32_t>& o, QM31 q) { uint32_t w[4]; q_store(w, q); o.insert(o.end(), w, w + 4); }
+static void ser_decommit(std::vector<uint32_t>& o, const MerkleDecommitment& d) {
+    o.push_back((uint32_t)d.hash_witness.size()); for (auto& h : d.hash_witness) ser_hash(o, h);
+    o.push_back((uint32_t)d.column_witness.size()); o.insert(o.end(), d.column_witness.begin(), d.column_witness.end());
+}
+static void ser_fri_layer(std::vector<uint32_t>& o, const FriLayerProof& l) {
+    o.push_back((uint32_t)l.fri_witness.size()); for (auto& q : l.fri_witness) ser_q(o, q);
+    ser_decommit(o, l.decommitment); ser_hash(o, l.commitment);
+}
+static std::vector<uint32_t> serialize(const Proof& p, const PcsConfig& cfg) {
+    std::vector<uint32_t> o;
+    o.push_back(0x3150584Eu);  // "NXP1"
+    o.push_back(cfg.pow_bits); o.push_back(cfg.log_blowup); o.push_back(cfg.n_queries); o.push_back(cfg.log_last_layer_degree_bound);
+    o.push_back((uint32_t)p.commitments.size());
+    for (auto& h : p.commitments) ser_hash(o, h);
+    for (auto& t : p.sampled_values) { o.push_back((uint32_t)t.size()); for (auto& c : t) { o.push_back((uint32_t)c.size()); for (auto& q : c) ser_q(o, q); } }
+    for (auto& d : p.decommitments) ser_decommit(o, d);
+    for (auto& v : p.queried_values) { o.push_back((uint32_t)v.size()); o.insert(o.end(), v.begin(), v.end()); }
+    o.push_back((uint32_t)p.proof_of_work); o.push_back((uint32_t)(p.proof_of_work >> 32));
+    ser_fri_layer(o, p.first_layer);
+    o.push_back((uint32_t)p.inner_layers.size());
+    for (auto& l : p.inner_layers) ser_fri_layer(o, l);
+    o.push_back((uint32_t)p.last_layer_poly.size());
+    for (auto& q : p.last_layer_poly) ser_q(o, q);
+    return o;
+}
+
+// ---------------------------------------------------------------- synthetic machine ----------
+struct Loc { size_t pre0, main0, inter0; };
+
+static QPt get_random_point(Blake2sChannel& ch) {  // CirclePoint::get_random_point
+    QM31 t = ch.draw_secure_felt(), t2 = q_sqr(t);
+    QM31 inv = q_inv(q_add(t2, q_one()));
+    QPt p; p.x = q_mul(q_sub(q_one(), t2), inv); p.y = q_mul(q_add(t, t), inv);
+    return p;
+}
+static QM31 coset_vanishing_q(uint32_t n, QPt p) { QM31 x = p.x; for (uint32_t i = 1; i < n; i++) x = q_double_x(x); return x; }
+
+// ComponentProvers::compute_composition_polynomial for the synthetic machine.
+static int compute_composition(CommitmentSchemeProver& cs, const nx_component_spec* comps, uint32_t n_comps, const std::vector<Loc>& locs,
+                               QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) {
+    nx_ctx* ctx = cs.ctx;
+    const uint32_t lcd = cs.cfg.log_constraint_degree, blow = cs.cfg.log_blowup;
+    size_t total = 0;
+    for (uint32_t i = 0; i < n_comps; i++) total += synth_n_constraints(comps[i]);
+    std::vector<QM31> powers(total);
+    { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
+    std::map<uint32_t, SecureColumn> sub;  // evaluation-domain log size -> accumulation
+    size_t remaining = total;
+    for (uint32_t ci = 0; ci < n_comps; ci++) {
+        const nx_component_spec& c = comps[ci];
+        const uint32_t e = c.log_size + lcd;
+        const size_t nc = synth_n_constraints(c);
+        std::vector<uint32_t> pw(4 * nc);  // this component takes the LAST nc remaining powers, reversed
+        for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[remaining - 1 - j]);
+        remaining -= nc;
+        void* d_pw = nullptr; H_TRY(stage(ctx, pw.data(), pw.size() * 4, &d_pw));
+        // denominators: 1 / coset_vanishing(trace coset, eval_domain.at(i)), bit-reversed over log_expand bits
+        const uint32_t log_expand = e - c.log_size;
+        std::vector<uint32_t> den((size_t)1 << log_expand);
+        for (uint32_t i = 0; i < den.size(); i++) {
+            u32 x = pt_from_index(circle_domain_index((int)e, i)).x;
+            for (uint32_t k = 1; k < c.log_size; k++) x = m_double_x(x);
+            den[bitrev(i, (int)log_expand)] = m_inv(x);
+        }
+        void* d_den = nullptr; H_TRY(stage(ctx, den.data(), den.size() * 4, &d_den));
+        // trace on the evaluation domain
+        ColSet pre, mainc, inter;
+        DevBuf ext;
+        auto slab_set = [](uint32_t* base, uint32_t log) { ColSet s; s.base = base; s.stride = (uint64_t)1 << log; s.table = nullptr; return s; };
+        if (e == c.log_size + blow) {
+            pre = slab_set(cs.trees[0].evals[locs[ci].pre0].ptr, e);
+            mainc = slab_set(cs.trees[1].evals[locs[ci].main0].ptr, e);
+            inter = slab_set(c.n_inter ? cs.trees[2].evals[locs[ci].inter0].ptr : nullptr, e);
+        } else {  // "need_to_extend": re-evaluate the polynomials on the constraint domain
+            uint32_t ncols = c.n_pre + c.n_main + c.n_inter;
+            H_TRY(ext.alloc(ctx, (size_t)ncols << e));
+            std::vector<const uint32_t*> src;
+            for (uint32_t k = 0; k < c.n_pre; k++) src.push_back(cs.trees[0].polys[locs[ci].pre0 + k].ptr);
+            for (uint32_t k = 0; k < c.n_main; k++) src.push_back(cs.trees[1].polys[locs[ci].main0 + k].ptr);
+            for (uint32_t k = 0; k < c.n_inter; k++) src.push_back(cs.trees[2].polys[locs[ci].inter0 + k].ptr);
+            auto dst = col_ptrs(ext.p, ncols, e);
+            H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), ncols, c.log_size, e - c.log_size, dst.data()));
+            pre = slab_set(ext.p, e);
+            mainc = slab_set(ext.p + ((size_t)c.n_pre << e), e);
+            inter = slab_set(ext.p + ((size_t)(c.n_pre + c.n_main) << e), e);
+        }
+        if (!sub.count(e)) { H_TRY(sub[e].alloc(ctx, e)); H_TRY(nx_memset_zero(ctx, sub[e].buf.p, sub[e].buf.words)); }
+        H_TRY(synth_constraints(ctx, pre, mainc, inter, c.n_main, c.n_inter, (int)c.log_size, (int)e, (const u32*)d_pw, (const u32*)d_den, sub[e].c));
+    }
+    // DomainEvaluationAccumulator::finalize — ascending size: lift the running polynomial, add, interpolate
+    DevBuf cur; uint32_t cur_log = 0; bool have = false;
+    for (auto& kv : sub) {
+        uint32_t log = kv.first; SecureColumn& values = kv.second;
+        if (have) {
+            DevBuf lifted; H_TRY(lifted.alloc(ctx, (size_t)4 << log));
+            auto src = col_ptrs(cur.p, 4, cur_log), dst = col_ptrs(lifted.p, 4, log);
+            H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)src.data(), 4, cur_log, log - cur_log, dst.data()));
+            const u32* s4[4] = {dst[0], dst[1], dst[2], dst[3]};
+            H_TRY(secure_accumulate(ctx, values.c, s4, 1u << log));
+            H_TRY(nx_sync(ctx));
+        }
+        H_TRY(nx_interpolate_batch(ctx, cs.tw, values.c, 4, log));
+        cur = std::move(values.buf); cur_log = log; have = true;
+    }
+    *out_polys = std::move(cur); *out_log = cur_log;
+    return NX_OK;
+}
+
+// eval_composition_polynomial_at_point (the prover's OODS sanity check, stwo prover/mod.rs::prove)
+static QM31 eval_composition_at_point(const nx_component_spec* comps, uint32_t n_comps, const std::vector<Loc>& locs, QPt point,
+                                      const std::vector<std::vector<std::vector<QM31>>>& sv, QM31 random_coeff) {
+    QM31 acc = q_zero();
+    for (uint32_t ci = 0; ci < n_comps; ci++) {
+        const nx_component_spec& c = comps[ci];
+        QM31 di = q_inv(coset_vanishing_q(c.log_size, point));
+        auto add = [&](QM31 v) { acc = q_add(q_mul(acc, random_coeff), q_mul(di, v)); };
+        auto M = [&](uint32_t k, int s = 0) { return sv[1][locs[ci].main0 + k][s]; };
+        auto I = [&](uint32_t k) { return sv[2][locs[ci].inter0 + k][0]; };
+        QM31 not_last = q_sub(q_one(), sv[0][locs[ci].pre0 + 1][0]);
+        add(q_mul(q_sub(q_sub(M(0, 1), M(0)), q_one()), not_last));
+        add(q_mul(q_sub(q_sub(M(1, 1), M(1)), M(0)), not_last));
+        for (uint32_t k = 2; k < c.n_main; k++) if (!synth_col_is_free(k)) add(q_sub(q_sub(M(k), q_sqr(M(k - 1))), q_sqr(M(k - 2))));
+        for (uint32_t k = 0; k < c.n_inter; k++) if (!synth_col_is_free(k)) add(q_sub(q_sub(I(k), q_sqr(I(k - 1))), q_sqr(I(k - 2))));
+    }
+    return acc;
+}
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
+                       size_t ad_len, std::vector<uint32_t>* words, nx_prove_stats* st) {
+    PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
+    if (n_comps == 0) return set_err(ctx, NX_ERR_ARG, "prove: no components");
+    if (cfg.log_blowup < 1 || cfg.log_constraint_degree < 1 || cfg.log_constraint_degree > 2) return set_err(ctx, NX_ERR_ARG, "prove: log_blowup >= 1 and log_constraint_degree in {1,2} required");
+    H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
+    uint32_t max_log = 0;
+    std::vector<Loc> locs; { size_t a = 0, b = 0, c = 0; for (uint32_t i = 0; i < n_comps; i++) { locs.push_back({a, b, c}); a += comps[i].n_pre; b += comps[i].n_main; c += comps[i].n_inter; max_log = std::max(max_log, comps[i].log_size); } }
+    const bool timed = st != nullptr;
+    nx_prove_stats local_stats;
+    if (!st) st = &local_stats;
+    memset(st, 0, sizeof *st);
+    if (timed) { ctx->timing = true; timing_reset(ctx); }
+    double t_start = 0, t0 = 0;
+    auto lap = [&](double* slot) { if (!timed) return; (void)nx_sync(ctx); double t = now_ms(); *slot += t - t0; t0 = t; };
+    if (timed) { (void)nx_sync(ctx); t_start = t0 = now_ms(); }
+
+    // machine.rs:184-194 — twiddles for CanonicCoset(max_log + LOG_CONSTRAINT_DEGREE + log_blowup).half_coset
+    nx_twiddles* tw = nullptr;
+    H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));
+    struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
+    Blake2sChannel channel;
+    for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
+    CommitmentSchemeProver cs(ctx, tw, cfg);                                          // machine.rs:202-203
+    for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
+    lap(&st->commit);
+
+    auto fill_and_commit = [&](uint32_t tree, uint64_t inter_seed) -> int {
+        TreeBuilder tb = cs.tree_builder();
+        std::vector<uint32_t*> all;
+        std::vector<DevBuf> slabs(n_comps);
+        for (uint32_t i = 0; i < n_comps; i++) {
+            uint32_t n = tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter;
+            if (n) H_TRY(slabs[i].alloc(ctx, (size_t)n << comps[i].log_size));
+            auto p = col_ptrs(slabs[i].p, n, comps[i].log_size);
+            all.insert(all.end(), p.begin(), p.end());
+        }
+        H_TRY(nx_synth_fill_tree(ctx, comps, n_comps, tree, seed, inter_seed, all.data()));
+        lap(&st->trace_gen);
+        for (uint32_t i = 0; i < n_comps; i++) {
+            uint32_t n = tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter;
+            tb.extend_evals(std::move(slabs[i]), n, comps[i].log_size);
+        }
+        H_TRY(tb.commit(channel));
+        lap(&st->commit);
+        return NX_OK;
+    };
+    H_TRY(fill_and_commit(0, 0));                                                     // machine.rs:208-228
+    H_TRY(fill_and_commit(1, 0));                                                     // machine.rs:230-237
+    QM31 z = channel.draw_secure_felt();                                              // machine.rs:239-240 (lookup elements)
+    uint64_t inter_seed = ((u64)z.a.a << 32) ^ (u64)z.a.b ^ ((u64)z.b.a << 16) ^ ((u64)z.b.b << 48);
+    channel.mix_felts(std::vector<QM31>(n_comps, q_zero()));                          // machine.rs:262 (claimed sums)
+    H_TRY(fill_and_commit(2, inter_seed));                                            // machine.rs:249-263
+
+    // ---------------- stwo::prover::prove ----------------
+    QM31 random_coeff = channel.draw_secure_felt();
+    DevBuf comp_polys; uint32_t clog = 0;
+    H_TRY(compute_composition(cs, comps, n_comps, locs, random_coeff, &comp_polys, &clog));
+    lap(&st->composition);
+    { TreeBuilder tb = cs.tree_builder(); tb.extend_polys(std::move(comp_polys), 4, clog); H_TRY(tb.commit(channel)); }
+    lap(&st->commit);
+    QPt oods = get_random_point(channel);
+
+    // mask points: tree -> column -> points
+    std::vector<std::vector<std::vector<QPt>>> points(4);
+    for (uint32_t i = 0; i < n_comps; i++) {
+        QPt step; { Pt s = pt_from_index(1u << (31 - comps[i].log_size)); step.x = q_from_m(s.x); step.y = q_from_m(s.y); }
+        for (uint32_t k = 0; k < comps[i].n_pre; k++) points[0].push_back({oods});
+        for (uint32_t k = 0; k < comps[i].n_main; k++) { if (k < 2) points[1].push_back({oods, qpt_add(oods, step)}); else points[1].push_back({oods}); }
+        for (uint32_t k = 0; k < comps[i].n_inter; k++) points[2].push_back({oods});
+    }
+    for (int k = 0; k < 4; k++) points[3].push_back({oods});
+
+    // ---------------- prove_values ----------------
+    Proof proof;
+    proof.sampled_values.resize(4);
+    for (int t = 0; t < 4; t++) {
+        auto& tr = cs.trees[t];
+        proof.sampled_values[t].resize(tr.polys.size());
+        std::map<uint32_t, std::vector<uint32_t>> by_log;  // poly log -> column indices
+        for (uint32_t c = 0; c < tr.polys.size(); c++) by_log[tr.polys[c].log].push_back(c);
+        for (auto& kv : by_log) {
+            std::vector<const uint32_t*> pp; std::vector<uint32_t> pidx, pts; std::vector<std::pair<uint32_t, uint32_t>> where;
+            for (uint32_t li = 0; li < kv.second.size(); li++) {
+                uint32_t c = kv.second[li];
+                pp.push_back(tr.polys[c].ptr);
+                for (uint32_t s = 0; s < points[t][c].size(); s++) {
+                    pidx.push_back(li);
+                    uint32_t w[8]; q_store(w, points[t][c][s].x); q_store(w + 4, points[t][c][s].y);
+                    pts.insert(pts.end(), w, w + 8);
+                    where.push_back({c, s});
+                }
+                proof.sampled_values[t][c].resize(points[t][c].size());
+            }
+            std::vector<uint32_t> out(4 * pidx.size());
+            H_TRY(nx_eval_at_points(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), out.data()));   // K7
+            for (size_t i = 0; i < where.size(); i++) proof.sampled_values[t][where[i].first][where[i].second] = q_load(&out[4 * i]);
+        }
+    }
+    { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); channel.mix_felts(flat); }
+    lap(&st->oods);
+    QM31 q_coeff = channel.draw_secure_felt();
+    // compute_fri_quotients: all columns flattened, stable-sorted by LDE size (descending), grouped by size
+    struct Flat { const uint32_t* ptr; uint32_t log; int t; uint32_t c; };
+    std::vector<Flat> all;
+    for (int t = 0; t < 4; t++) for (uint32_t c = 0; c < cs.trees[t].evals.size(); c++) all.push_back({cs.trees[t].evals[c].ptr, cs.trees[t].evals[c].log, t, c});
+    std::stable_sort(all.begin(), all.end(), [](const Flat& a, const Flat& b) { return a.log > b.log; });
+    std::vector<SecureColumn> quotients;
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i; while (j < all.size() && all[j].log == all[i].log) j++;
+        // ColumnSampleBatch::new_vec — group by point, insertion ordered
+        std::vector<QPt> bpts; std::vector<std::vector<std::pair<uint32_t, QM31>>> bcols;
+        std::vector<const uint32_t*> gcols;
+        for (size_t k = i; k < j; k++) {
+            gcols.push_back(all[k].ptr);
+            const auto& ps = points[all[k].t][all[k].c];
+            for (size_t s = 0; s < ps.size(); s++) {
+                size_t b = 0;
+                for (; b < bpts.size(); b++) if (q_eq(bpts[b].x, ps[s].x) && q_eq(bpts[b].y, ps[s].y)) break;
+                if (b == bpts.size()) { bpts.push_back(ps[s]); bcols.emplace_back(); }
+                bcols[b].push_back({(uint32_t)(k - i), proof.sampled_values[all[k].t][all[k].c][s]});
+            }
+        }
+        std::vector<uint32_t> fpts, counts, cidx, vals;
+        for (size_t b = 0; b < bpts.size(); b++) {
+            uint32_t w[8]; q_store(w, bpts[b].x); q_store(w + 4, bpts[b].y); fpts.insert(fpts.end(), w, w + 8);
+            counts.push_back((uint32_t)bcols[b].size());
+            for (auto& cv : bcols[b]) { cidx.push_back(cv.first); uint32_t q[4]; q_store(q, cv.second); vals.insert(vals.end(), q, q + 4); }
+        }
+        SecureColumn qc; H_TRY(qc.alloc(ctx, all[i].log));
+        uint32_t aw[4]; q_store(aw, q_coeff);
+        H_TRY(nx_accumulate_quotients(ctx, all[i].log, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(),
+                                      cidx.data(), vals.data(), qc.c));                                                              // K8
+        quotients.push_back(std::move(qc));
+        for (int k = 0; k < 4; k++) quotients.back().c[k] = quotients.back().buf.p + ((size_t)k << quotients.back().log);
+        i = j;
+    }
+    lap(&st->quotients);
+    FriProver fri(ctx, tw, cfg);
+    H_TRY(fri.commit(channel, std::move(quotients)));                                                                                 // K9
+    lap(&st->fri);
+    H_TRY(nx_grind(ctx, (const uint8_t*)channel.digest.w, cfg.pow_bits, &proof.proof_of_work));                                       // K10
+    channel.mix_u64(proof.proof_of_work);
+    lap(&st->pow);
+    std::map<uint32_t, std::vector<size_t>> qpos;
+    H_TRY(fri.decommit(channel, &proof, &qpos));
+    proof.decommitments.resize(4); proof.queried_values.resize(4);
+    for (int t = 0; t < 4; t++) {
+        H_TRY(merkle_decommit(ctx, cs.trees[t].merkle, qpos, cs.trees[t].evals, &proof.queried_values[t], &proof.decommitments[t]));
+        proof.commitments.push_back(cs.trees[t].root);
+    }
+    lap(&st->decommit);
+    // ProvingError::ConstraintsNotSatisfied sanity check
+    QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
+    QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
+    if (!q_eq(lhs, eval_composition_at_point(comps, n_comps, locs, oods, proof.sampled_values, random_coeff)))
+        return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
+    *words = serialize(proof, cfg);
+    if (timed) {
+        (void)nx_sync(ctx);
+        st->total = now_ms() - t_start;
+        timing_flush(ctx);
+        st->lde_kernel_ms = ctx->kind_ms[NX_T_LDE]; st->lde_algorithmic_bytes = ctx->kind_bytes[NX_T_LDE];
+        st->merkle_kernel_ms = ctx->kind_ms[NX_T_MERKLE]; st->merkle_algorithmic_bytes = ctx->kind_bytes[NX_T_MERKLE];
+        ctx->timing = false;
+    }
+    return NX_OK;
+}
+
+}  // namespace nxhip
+
+using namespace nx;
+
+extern "C" {
+
+int nx_lde_batch(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size, uint32_t log_blowup,
+                 uint32_t* const* d_lde) {
+    if (n_cols == 0) return NX_OK;
+    ColSet c, o;
+    NX_TRY(make_colset(ctx, d_cols, n_cols, &c));
+    NX_TRY(make_colset(ctx, d_lde, n_cols, &o));
+    return fft_lde(ctx, tw, c, n_cols, log_size, log_blowup, o);
+}
+
+int nx_lde_commit(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size, uint32_t log_blowup,
+                  uint32_t* const* d_lde, uint8_t root[32]) {
+    NX_TRY(nx_lde_batch(ctx, tw, d_cols, n_cols, log_size, log_blowup, d_lde));
+    std::vector<uint32_t> logs(n_cols, log_size + log_blowup);
+    nx_tree* t = nullptr;
+    NX_TRY(nx_merkle_commit(ctx, (const uint32_t* const*)d_lde, logs.data(), n_cols, &t));
+    int rc = nx_merkle_root(ctx, t, root);
+    nx_tree_destroy(t);
+    return rc;
+}
+
+int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
+                   size_t ad_len, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth: NULL argument");
+    std::vector<uint32_t> w;
+    int rc = nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, &w, stats);
+    ctx->timing = false;
+    if (rc != NX_OK) return rc;
+    uint32_t* out = (uint32_t*)malloc(w.size() * 4);
+    if (!out) return set_err(ctx, NX_ERR_OOM, "nx_prove_synth: malloc failed");
+    memcpy(out, w.data(), w.size() * 4);
+    *proof_words = out; *n_words = w.size();
+    return NX_OK;
+}
+
+}  // extern "C"
