@@ -80,14 +80,15 @@ __global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColS
     u32 not_last = m_sub(1, pre.col(1)[r]);
     u32 m0 = mainc.col(0)[r], m1 = mainc.col(1)[r];
     u32 m0n = mainc.col(0)[rn], m1n = mainc.col(1)[rn];
-    u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // lazy 64-bit accumulation, folded every 4 constraints
     u32 j = 0;
 #define ACC(val)                                                           \
     {                                                                      \
         u32 v__ = (val);                                                   \
-        r0 = m_add(r0, m_mul(pw[4 * j], v__)); r1 = m_add(r1, m_mul(pw[4 * j + 1], v__)); \
-        r2 = m_add(r2, m_mul(pw[4 * j + 2], v__)); r3 = m_add(r3, m_mul(pw[4 * j + 3], v__)); \
+        r0 = acc_mad(r0, pw[4 * j], v__); r1 = acc_mad(r1, pw[4 * j + 1], v__); \
+        r2 = acc_mad(r2, pw[4 * j + 2], v__); r3 = acc_mad(r3, pw[4 * j + 3], v__); \
         j++;                                                               \
+        if ((j & 3) == 0) { r0 = acc_fold(r0); r1 = acc_fold(r1); r2 = acc_fold(r2); r3 = acc_fold(r3); } \
     }
     ACC(m_mul(m_sub(m_sub(m0n, m0), 1), not_last));
     ACC(m_mul(m_sub(m_sub(m1n, m1), m0), not_last));
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColS
     }
 #undef ACC
     u32 di = denom_inv[r >> log_size];
-    a0[r] = m_add(a0[r], m_mul(r0, di)); a1[r] = m_add(a1[r], m_mul(r1, di));
-    a2[r] = m_add(a2[r], m_mul(r2, di)); a3[r] = m_add(a3[r], m_mul(r3, di));
+    a0[r] = m_add(a0[r], m_mul(acc_final(r0), di)); a1[r] = m_add(a1[r], m_mul(acc_final(r1), di));
+    a2[r] = m_add(a2[r], m_mul(acc_final(r2), di)); a3[r] = m_add(a3[r], m_mul(acc_final(r3), di));
 }
 
 // dst[k][i] += src[k][i]  (AccumulationOps::accumulate)

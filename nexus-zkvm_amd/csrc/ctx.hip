@@ -50,6 +50,40 @@ int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* 
     return NX_OK;
 }
 
+int dev_alloc(nx_ctx* ctx, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 4;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = ctx->free_blocks.find(bytes);
+    if (it != ctx->free_blocks.end()) {
+        *out = it->second; ctx->free_blocks.erase(it); ctx->cached_bytes -= bytes;
+        ctx->live_blocks[*out] = bytes;
+        return NX_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {  // give cached blocks back to the driver and retry once
+        (void)hipGetLastError();
+        dev_cache_release(ctx);
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess) { *out = nullptr; return hip_fail(ctx, e, "hipMalloc", __FILE__, __LINE__); }
+    ctx->live_blocks[*out] = bytes;
+    return NX_OK;
+}
+void dev_free(nx_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx->live_blocks.find(p);
+    if (it == ctx->live_blocks.end()) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(p); return; }  // foreign pointer
+    ctx->free_blocks.insert({it->second, p});
+    ctx->cached_bytes += it->second;
+    ctx->live_blocks.erase(it);
+    if (ctx->cached_bytes > ((size_t)96 << 30)) dev_cache_release(ctx);  // keep the cache bounded
+}
+void dev_cache_release(nx_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+    ctx->free_blocks.clear(); ctx->cached_bytes = 0;
+}
+
 static hipEvent_t get_event(nx_ctx* ctx) {
     if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -106,7 +140,7 @@ int nx_ctx_create(int device, nx_ctx** out) {
     NX_HIP(nullptr, hipSetDevice(device));
     nx_ctx* c = new nx_ctx();
     c->device = device; c->hash_mode = NX_HASH_BLAKE2S; c->timing = false;
-    c->scratch_size = 16u << 20; c->scratch_off = 0; c->d_scratch = nullptr; c->h_scratch = nullptr;
+    c->scratch_size = 16u << 20; c->scratch_off = 0; c->d_scratch = nullptr; c->h_scratch = nullptr; c->cached_bytes = 0;
     for (int i = 0; i < 4; i++) { c->kind_ms[i] = 0; c->kind_bytes[i] = 0; }
     NX_HIP(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     NX_HIP(nullptr, hipMalloc((void**)&c->d_scratch, c->scratch_size));
@@ -121,6 +155,8 @@ void nx_ctx_destroy(nx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     timing_flush(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    dev_cache_release(ctx);
+    for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     (void)hipStreamDestroy(ctx->stream);
@@ -138,14 +174,10 @@ void* nx_ctx_stream(nx_ctx* ctx) { return (void*)ctx->stream; }
 
 int nx_alloc(nx_ctx* ctx, size_t n_words, uint32_t** d_out) {
     *d_out = nullptr;
-    if (n_words == 0) n_words = 1;
-    NX_HIP(ctx, hipMalloc((void**)d_out, n_words * 4));
-    return NX_OK;
+    return dev_alloc(ctx, n_words * 4, (void**)d_out);
 }
 int nx_free(nx_ctx* ctx, uint32_t* d_ptr) {
-    if (!d_ptr) return NX_OK;
-    NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    NX_HIP(ctx, hipFree(d_ptr));
+    dev_free(ctx, d_ptr);
     return NX_OK;
 }
 int nx_memset_zero(nx_ctx* ctx, uint32_t* d_ptr, size_t n_words) {
@@ -167,7 +199,7 @@ int nx_gather(nx_ctx* ctx, const uint32_t* const* d_ptrs, const uint64_t* index,
     if (n == 0) return NX_OK;
     uint8_t* d = nullptr;
     size_t bytes = n * (8 + 8 + 4);
-    NX_HIP(ctx, hipMalloc((void**)&d, bytes));
+    NX_TRY(dev_alloc(ctx, bytes, (void**)&d));
     const uint32_t** dp = (const uint32_t**)d;
     uint64_t* di = (uint64_t*)(d + n * 8);
     uint32_t* dout = (uint32_t*)(d + n * 16);
@@ -179,7 +211,7 @@ int nx_gather(nx_ctx* ctx, const uint32_t* const* d_ptrs, const uint64_t* index,
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_out, dout, n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    dev_free(ctx, d);
     if (e != hipSuccess) return hip_fail(ctx, e, "nx_gather", __FILE__, __LINE__);
     return NX_OK;
 }

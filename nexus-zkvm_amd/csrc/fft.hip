@@ -58,53 +58,102 @@ struct FftPass {
 
 __device__ __forceinline__ u32 lds_pad(u32 t) { return t + (t >> 4); }
 
-__device__ __forceinline__ u32 line_tw(const FftPass& a, int layer, u32 h) {
-    return a.tw[(1u << a.tw_log) - (1u << (a.n - layer)) + h];
-}
-// circle-layer twiddle h, derived from the first line layer: [x, y] -> [y, -y, -x, x]
-__device__ __forceinline__ u32 circle_tw(const FftPass& a, u32 h) {
-    u32 c = h >> 2;
-    u32 x = line_tw(a, 1, 2 * c), y = line_tw(a, 1, 2 * c + 1);
-    u32 sel = h & 3;
-    u32 v = (sel & 2) ? x : y;
-    return (sel == 1 || sel == 2) ? m_neg(v) : v;
+// butterfly / inverse butterfly with the twiddle's sign folded into the output wiring (no negation op)
+template <bool INV>
+__device__ __forceinline__ void bfly(u32& x0, u32& x1, u32 t, bool neg) {
+    if (INV) {
+        u32 s = m_add(x0, x1);
+        u32 d = neg ? m_sub(x1, x0) : m_sub(x0, x1);
+        x0 = s; x1 = m_mul(d, t);
+    } else {
+        u32 m = m_mul(x1, t);
+        u32 a = m_add(x0, m), b = m_sub(x0, m);
+        x0 = neg ? b : a; x1 = neg ? a : b;
+    }
 }
 
-template <int R, bool INV>
+template <int CNT>
+__device__ __forceinline__ void load_tw(const u32* __restrict__ p, u32* dst) {
+    if (CNT == 8) {
+        uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+    } else if (CNT == 4) {
+        uint4 a = *reinterpret_cast<const uint4*>(p);
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+    } else if (CNT == 2) {
+        uint2 a = *reinterpret_cast<const uint2*>(p);
+        dst[0] = a.x; dst[1] = a.y;
+    } else {
+        dst[0] = p[0];
+    }
+}
+
+// loads the twiddles of layers Q..R-1 of a lane's block (compile-time recursion: counts are template constants)
+template <int R, int Q, bool CIRCLE>
+__device__ __forceinline__ void load_round_tw(const u32* const __restrict__* twl, u32 g0, int l0, u32* tw) {
+    if constexpr (Q < R) {
+        if constexpr (!(CIRCLE && Q == 0))
+            load_tw<(1 << (R - 1 - Q))>(twl[Q] + (g0 >> (l0 + Q + 1)), tw + ((1 << R) - (1 << (R - Q))));
+        load_round_tw<R, Q + 1, CIRCLE>(twl, g0, l0, tw);
+    }
+}
+
+// One LDS round trip: every lane owns 2^R tile elements that differ in R consecutive layer bits and runs those
+// R butterfly layers in registers.  Twiddles of layer q are 2^(R-1-q) consecutive, aligned words -> one vector
+// load per layer.  CIRCLE: the round's first layer is the circle layer, whose twiddles are derived from the
+// next (first line) layer's values as [x, y] -> [y, -y, -x, x].
+template <int R, bool INV, bool CIRCLE>
 __device__ __forceinline__ void radix_round(u32* lds, const FftPass& a, int j, u32 tile_base, int s) {
-    const int bp = a.B + j;
+    static_assert(!CIRCLE || R >= 3, "circle rounds need the pair (x, y) of the first line layer");
+    const int bp = a.B + j;  // 0 or >= 4 (rounds start at multiples of 4; B is 0 or >= 5)
+    const u32 estride = bp ? ((1u << bp) + ((1u << bp) >> 4)) : 1u;  // padded distance between a lane's elements
     const u32 n_items = (1u << s) >> R;
     const u32 maskB = (1u << a.B) - 1;
     const int l0 = a.lo + j;
+    const u32* __restrict__ twl[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) twl[q] = a.tw + ((1u << a.tw_log) - (1u << (a.n - (l0 + q))));
     for (u32 w = threadIdx.x; w < n_items; w += blockDim.x) {
-        u32 wl = w & ((1u << bp) - 1), wh = w >> bp;
-        u32 t0 = (wh << (bp + R)) | wl;
+        const u32 wl = w & ((1u << bp) - 1), wh = w >> bp;
+        const u32 t0 = (wh << (bp + R)) | wl;
+        const u32 p0 = lds_pad(t0);
         u32 v[1 << R];
 #pragma unroll
-        for (int e = 0; e < (1 << R); e++) v[e] = lds[lds_pad(t0 + ((u32)e << bp))];
-        u32 g0 = tile_base + ((t0 >> a.B) << a.lo) + (t0 & maskB);
+        for (int e = 0; e < (1 << R); e++) v[e] = lds[p0 + e * estride];
+        const u32 g0 = tile_base + ((t0 >> a.B) << a.lo) + (t0 & maskB);
+        u32 tw[(1 << R)];  // layer q at offset 2^R - 2^(R-q), 2^(R-1-q) entries
+        load_round_tw<R, 0, CIRCLE>(twl, g0, l0, tw);
 #pragma unroll
         for (int qq = 0; qq < R; qq++) {
             const int q = INV ? qq : R - 1 - qq;
-            const int layer = l0 + q;
-            u32 hbase = g0 >> (layer + 1);
 #pragma unroll
             for (int e = 0; e < (1 << R); e++) {
                 if (e & (1 << q)) continue;
-                u32 h = hbase + ((u32)e >> (q + 1));
-                u32 t = layer == 0 ? circle_tw(a, h) : line_tw(a, layer, h);
-                u32 x0 = v[e], x1 = v[e | (1 << q)];
-                if (INV) { v[e] = m_add(x0, x1); v[e | (1 << q)] = m_mul(m_sub(x0, x1), t); }
-                else { u32 m = m_mul(x1, t); v[e] = m_add(x0, m); v[e | (1 << q)] = m_sub(x0, m); }
+                const int h = e >> (q + 1);  // pair index within the lane's block
+                if (CIRCLE && q == 0) {
+                    const int c = h >> 2, sel = h & 3;
+                    const u32 t = tw[((1 << R) - (1 << (R - 1))) + 2 * c + ((sel & 2) ? 0 : 1)];  // x for sel 2,3; y for sel 0,1
+                    bfly<INV>(v[e], v[e | 1], t, sel == 1 || sel == 2);
+                } else {
+                    bfly<INV>(v[e], v[e | (1 << q)], tw[((1 << R) - (1 << (R - q))) + h], false);
+                }
             }
         }
 #pragma unroll
-        for (int e = 0; e < (1 << R); e++) lds[lds_pad(t0 + ((u32)e << bp))] = v[e];
+        for (int e = 0; e < (1 << R); e++) lds[p0 + e * estride] = v[e];
     }
     __syncthreads();
 }
 
-template <bool INV>
+template <bool INV, bool FIRST>
+__device__ __forceinline__ void remainder_round(u32* lds, const FftPass& a, int rem, int j, bool circle, u32 tile_base, int s) {
+    if (rem == 3) { if (FIRST && circle) radix_round<3, INV, true>(lds, a, j, tile_base, s); else radix_round<3, INV, false>(lds, a, j, tile_base, s); }
+    else if (rem == 2) radix_round<2, INV, false>(lds, a, j, tile_base, s);
+    else if (rem == 1) radix_round<1, INV, false>(lds, a, j, tile_base, s);
+}
+
+// FIRST: the pass that holds layers [0, s0) as a contiguous tile (lo == 0, B == 0) and therefore the circle layer.
+template <bool INV, bool FIRST>
 __global__ void fft_pass_kernel(FftPass a) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int K = a.hi - a.lo, s = a.B + K;
@@ -129,19 +178,20 @@ __global__ void fft_pass_kernel(FftPass a) {
     }
     __syncthreads();
 
-    // ---- butterfly rounds: up to 4 layers per LDS round trip ----
+    // ---- butterfly rounds: 4 layers per LDS round trip, rounds start at layer offsets that are multiples of 4 ----
+    const int nfull = K >> 2, rem = K & 3;
     if (INV) {
-        int j = 0;
-        while (K - j >= 4) { radix_round<4, true>(lds, a, j, tile_base, s); j += 4; }
-        if (K - j == 3) radix_round<3, true>(lds, a, j, tile_base, s);
-        else if (K - j == 2) radix_round<2, true>(lds, a, j, tile_base, s);
-        else if (K - j == 1) radix_round<1, true>(lds, a, j, tile_base, s);
+        for (int i = 0; i < nfull; i++) {
+            if (FIRST && i == 0) radix_round<4, true, true>(lds, a, 0, tile_base, s);
+            else radix_round<4, true, false>(lds, a, 4 * i, tile_base, s);
+        }
+        if (rem) remainder_round<true, FIRST>(lds, a, rem, 4 * nfull, nfull == 0, tile_base, s);
     } else {
-        int j = K;
-        while (j >= 4) { j -= 4; radix_round<4, false>(lds, a, j, tile_base, s); }
-        if (j == 3) radix_round<3, false>(lds, a, 0, tile_base, s);
-        else if (j == 2) radix_round<2, false>(lds, a, 0, tile_base, s);
-        else if (j == 1) radix_round<1, false>(lds, a, 0, tile_base, s);
+        if (rem) remainder_round<false, FIRST>(lds, a, rem, 4 * nfull, nfull == 0, tile_base, s);
+        for (int i = nfull - 1; i >= 0; i--) {
+            if (FIRST && i == 0) radix_round<4, false, true>(lds, a, 0, tile_base, s);
+            else radix_round<4, false, false>(lds, a, 4 * i, tile_base, s);
+        }
     }
 
     // ---- LDS -> global ----
@@ -247,16 +297,21 @@ static int launch_pass(nx_ctx* ctx, bool inv, const FftPass& a) {
     size_t lds_bytes = (((size_t)1 << s) + ((size_t)1 << s >> 4) + 4) * 4;
     int threads = std::min<int>(g_tune.threads, std::max(64, (1 << s) / 4));
     dim3 grid(tiles * a.n_cols), block(threads);
+    const bool first = a.lo == 0;
     if (lds_bytes > 48 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
     }
-    if (inv) hipLaunchKernelGGL(fft_pass_kernel<true>, grid, block, lds_bytes, ctx->stream, a);
-    else hipLaunchKernelGGL(fft_pass_kernel<false>, grid, block, lds_bytes, ctx->stream, a);
+    if (inv && first) hipLaunchKernelGGL((fft_pass_kernel<true, true>), grid, block, lds_bytes, ctx->stream, a);
+    else if (inv) hipLaunchKernelGGL((fft_pass_kernel<true, false>), grid, block, lds_bytes, ctx->stream, a);
+    else if (first) hipLaunchKernelGGL((fft_pass_kernel<false, true>), grid, block, lds_bytes, ctx->stream, a);
+    else hipLaunchKernelGGL((fft_pass_kernel<false, false>), grid, block, lds_bytes, ctx->stream, a);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
@@ -375,21 +430,21 @@ int nx_twiddles_create(nx_ctx* ctx, uint32_t log_half_coset, nx_twiddles** out) 
     nx_twiddles* t = new nx_twiddles();
     t->ctx = ctx; t->log_half = log_half_coset; t->d_tw = nullptr; t->d_itw = nullptr;
     size_t bytes = (size_t)4 << log_half_coset;
-    hipError_t e = hipMalloc((void**)&t->d_tw, bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&t->d_itw, bytes);
-    if (e != hipSuccess) { if (t->d_tw) (void)hipFree(t->d_tw); delete t; return hip_fail(ctx, e, "hipMalloc(twiddles)", __FILE__, __LINE__); }
+    int rc0 = dev_alloc(ctx, bytes, (void**)&t->d_tw);
+    if (rc0 == NX_OK) rc0 = dev_alloc(ctx, bytes, (void**)&t->d_itw);
+    if (rc0 != NX_OK) { dev_free(ctx, t->d_tw); delete t; return rc0; }
+    hipError_t e;
     u32 total = 1u << log_half_coset;
     hipLaunchKernelGGL(twiddle_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, t->d_tw, t->d_itw, (int)log_half_coset);
     e = hipGetLastError();
-    if (e != hipSuccess) { (void)hipFree(t->d_tw); (void)hipFree(t->d_itw); delete t; return hip_fail(ctx, e, "twiddle_kernel", __FILE__, __LINE__); }
+    if (e != hipSuccess) { dev_free(ctx, t->d_tw); dev_free(ctx, t->d_itw); delete t; return hip_fail(ctx, e, "twiddle_kernel", __FILE__, __LINE__); }
     *out = t;
     return NX_OK;
 }
 
 void nx_twiddles_destroy(nx_twiddles* tw) {
     if (!tw) return;
-    (void)hipStreamSynchronize(tw->ctx->stream);
-    (void)hipFree(tw->d_tw); (void)hipFree(tw->d_itw);
+    dev_free(tw->ctx, tw->d_tw); dev_free(tw->ctx, tw->d_itw);
     delete tw;
 }
 
@@ -438,13 +493,13 @@ int nx_finalize_columns(nx_ctx* ctx, const uint32_t* const* d_src_natural, uint3
 int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst) {
     uint32_t* d_tmp = nullptr;
     size_t n = (size_t)1 << log_size;
-    NX_HIP(ctx, hipMalloc((void**)&d_tmp, n * 4));
+    NX_TRY(dev_alloc(ctx, n * 4, (void**)&d_tmp));
     hipError_t e = hipMemcpyAsync(d_tmp, h_natural, n * 4, hipMemcpyHostToDevice, ctx->stream);
     int rc = NX_OK;
     if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemcpyAsync", __FILE__, __LINE__);
     if (rc == NX_OK) { const uint32_t* sp = d_tmp; uint32_t* dp = d_dst; rc = nx_finalize_columns(ctx, &sp, &dp, 1, log_size); }
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_tmp);
+    dev_free(ctx, d_tmp);
     return rc;
 }
 

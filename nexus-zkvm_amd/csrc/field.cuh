@@ -40,6 +40,17 @@ NX_HD u32 m_pow(u32 a, u32 e) {
 NX_HD u32 m_inv(u32 a) { return m_pow(a, P - 2); }
 NX_HD u32 m_double_x(u32 x) { u32 s = m_sqr(x); return m_sub(m_add(s, s), 1); }
 
+// Lazy dot-product accumulation: products of canonical values are added as raw 64-bit integers
+// (one v_mad_u64_u32 each); acc_fold() brings the sum back below 2^34 and must run at least every
+// 4 products (4*(p-1)^2 + 2^33 + 2^31 < 2^64).  acc_final() returns the canonical residue.
+NX_HD u64 acc_mad(u64 acc, u32 a, u32 b) { return acc + (u64)a * (u64)b; }
+NX_HD u64 acc_fold(u64 x) { return (x & (u64)P) + (x >> 31); }
+NX_HD u32 acc_final(u64 x) {
+    x = acc_fold(x);                       // < 2^34
+    u32 s = ((u32)x & P) + (u32)(x >> 31); // < 2^31 + 8
+    return umin32(s, s - P);
+}
+
 struct CM31 { u32 a, b; };
 NX_HD CM31 cm(u32 a, u32 b) { CM31 r; r.a = a; r.b = b; return r; }
 NX_HD CM31 c_add(CM31 x, CM31 y) { return cm(m_add(x.a, y.a), m_add(x.b, y.b)); }

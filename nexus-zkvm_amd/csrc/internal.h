@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string>
 #include <vector>
+#include <map>
 #include "../../include/nexus_hip.h"
 #include "field.cuh"
 
@@ -17,6 +18,11 @@ struct nx_ctx {
     uint8_t* d_scratch;
     size_t scratch_size, scratch_off;
     uint8_t* h_scratch;  // pinned mirror of the ring
+    // caching allocator: freed device blocks are kept by exact size and handed back to later nx_alloc calls
+    // (a prove repeats the same slab sizes); reuse is safe because all work is ordered on ctx->stream.
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    size_t cached_bytes;
     // kernel timing (HIP events on ctx->stream), resolved lazily by nx::timing_flush
     bool timing;
     struct Span { hipEvent_t e0, e1; int kind; };
@@ -71,6 +77,10 @@ struct ColSet {
 int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out);
 // Stage arbitrary bytes into device scratch; returns device pointer (valid until the ring wraps).
 int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out);
+// cached device allocation (bytes); dev_free returns the block to the cache (no device sync)
+int dev_alloc(nx_ctx* ctx, size_t bytes, void** out);
+void dev_free(nx_ctx* ctx, void* p);
+void dev_cache_release(nx_ctx* ctx);
 
 // Event-pair span on ctx->stream, recorded only when ctx->timing is on; resolved by timing_flush.
 struct KTimer {

@@ -84,21 +84,57 @@ __global__ __launch_bounds__(256) void merkle_layer_kernel(ColSet cols, u32 n_co
         for (int k = 0; k < 16; k++) m[k] = 0;
         b2s_compress(h, m, 0, 0xFFFFFFFFu);  // Blake2s of the empty message
     }
-    for (u32 c0 = 0; c0 < n_cols; c0 += 16) {
+    // stream the columns 16 at a time, double-buffered: the 16 loads of chunk k+1 are in flight while the
+    // ~1000 VALU ops of chunk k's compression run
+    u32 nx_[16];
+    auto load_chunk = [&](u32 c0, u32* dst) {
         if (c0 + 16 <= n_cols) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) m[k] = cols.col(c0 + k)[i];
+            for (int k = 0; k < 16; k++) dst[k] = cols.col(c0 + k)[i];
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) m[k] = (c0 + k < n_cols) ? cols.col(c0 + k)[i] : 0u;
+            for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? cols.col(c0 + k)[i] : 0u;
         }
+    };
+    if (n_cols) load_chunk(0, nx_);
+    for (u32 c0 = 0; c0 < n_cols; c0 += 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = nx_[k];
         bool last = c0 + 16 >= n_cols;
+        if (!last) load_chunk(c0 + 16, nx_);
         if (MODE == 0) { t = last ? total_bytes : t + 64; b2s_compress(h, m, t, last ? 0xFFFFFFFFu : 0u); }
         else b2s_compress(h, m, 0, 0);
     }
     uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
     o[0] = make_uint4(h[0], h[1], h[2], h[3]);
     o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// Top of the tree in ONE launch: layers `top`..0 (2^top <= 1024 nodes) when no columns are injected there.
+// `base` is the start of the tree allocation (layer k at node offset 2^k - 1).
+template <int MODE>
+__global__ __launch_bounds__(1024) void merkle_top_kernel(u32* __restrict__ base, int top) {
+    for (int log = top; log >= 0; log--) {
+        u32 i = threadIdx.x;
+        if (i < (1u << log)) {
+            const u32* prev = base + (((size_t)2 << log) - 1) * 8;
+            u32* out = base + (((size_t)1 << log) - 1) * 8;
+            u32 h[8], m[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) h[k] = MODE == 0 ? B2S_IV_D[k] : 0u;
+            if (MODE == 0) h[0] ^= 0x01010020u;
+            const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
+            uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+            m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+            if (MODE == 0) b2s_compress(h, m, 64, 0xFFFFFFFFu); else b2s_compress(h, m, 0, 0);
+            uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+            o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // GrindOps: nonce = base + thread; H(digest ‖ nonce_le64) is a single final 40-byte block.
@@ -151,8 +187,7 @@ int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t*
     t->ctx = ctx;
     uint32_t* buf = nullptr;
     size_t total_nodes = ((size_t)2 << max_log) - 1;
-    hipError_t e = hipMalloc((void**)&buf, total_nodes * 32);
-    if (e != hipSuccess) { delete t; return hip_fail(ctx, e, "hipMalloc(merkle layers)", __FILE__, __LINE__); }
+    { int rc0 = dev_alloc(ctx, total_nodes * 32, (void**)&buf); if (rc0 != NX_OK) { delete t; return rc0; } }
     // layers[k] at node offset 2^k - 1 (root first) inside one allocation
     t->layers.resize(max_log + 1);
     for (uint32_t k = 0; k <= max_log; k++) t->layers[k] = buf + (((size_t)1 << k) - 1) * 8;
@@ -164,7 +199,17 @@ int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t*
 
     size_t ci = 0;
     int rc = NX_OK;
+    // layers at or below `top_fused` hold no columns and have <= 1024 nodes: one launch for all of them
+    int smallest_col_log = n_cols ? (int)log_sizes[order[n_cols - 1]] : 0;
+    int top_fused = std::min(10, std::min((int)max_log - 1, smallest_col_log - 1));
     for (int log = (int)max_log; log >= 0 && rc == NX_OK; log--) {
+        if (log == top_fused && log >= 1) {
+            if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_top_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
+            else hipLaunchKernelGGL(merkle_top_kernel<1>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) rc = hip_fail(ctx, le, "merkle_top_kernel", __FILE__, __LINE__);
+            break;
+        }
         size_t c0 = ci;
         while (ci < n_cols && log_sizes[order[ci]] == (uint32_t)log) ci++;
         ColSet cs;
@@ -173,7 +218,7 @@ int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t*
         const uint32_t* prev = (uint32_t)log < max_log ? t->layers[log + 1] : nullptr;
         rc = merkle_layer(ctx, cs, (uint32_t)(ci - c0), prev, t->layers[log], (uint32_t)log);
     }
-    if (rc != NX_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(buf); delete t; return rc; }
+    if (rc != NX_OK) { dev_free(ctx, buf); delete t; return rc; }
     *out = t;
     return NX_OK;
 }
@@ -186,8 +231,7 @@ const uint32_t* nx_merkle_layer(const nx_tree* tree, uint32_t k) { return k < tr
 
 void nx_tree_destroy(nx_tree* tree) {
     if (!tree) return;
-    (void)hipStreamSynchronize(tree->ctx->stream);
-    if (!tree->layers.empty()) (void)hipFree(tree->layers[0]);
+    if (!tree->layers.empty()) dev_free(tree->ctx, tree->layers[0]);
     delete tree;
 }
 
@@ -197,7 +241,7 @@ int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t*
     memcpy(h.d, digest, 32);
     h.res = ~0ull;
     uint8_t* d = nullptr;
-    NX_HIP(ctx, hipMalloc((void**)&d, sizeof h));
+    NX_TRY(dev_alloc(ctx, sizeof h, (void**)&d));
     hipError_t e = hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream);
     const uint64_t batch = 1ull << 22;
     uint64_t base = 0;
@@ -211,7 +255,8 @@ int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t*
         if (res != ~0ull) break;
         base += batch;
     }
-    (void)hipFree(d);
+    (void)hipStreamSynchronize(ctx->stream);
+    dev_free(ctx, d);
     if (e != hipSuccess) return hip_fail(ctx, e, "nx_grind", __FILE__, __LINE__);
     *nonce = res;
     return NX_OK;

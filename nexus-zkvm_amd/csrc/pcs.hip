@@ -16,7 +16,7 @@ namespace nx {
 // Split j = (j_hi, j_lo): basis_j = T_hi[j_hi] · T_lo[j_lo].  A lane owns a fixed set of j_lo and
 // walks j_hi, so T_hi[j_hi] is wave-uniform (scalar registers) and every coefficient costs one
 // M31 x QM31 multiply-add; T_lo is applied once per lane at the end.
-constexpr int EVAL_LOG_LO = 11;
+constexpr int EVAL_LOG_LO = 10;
 constexpr int EVAL_THREADS = 256;
 constexpr int EVAL_KL = (1 << EVAL_LOG_LO) / EVAL_THREADS;  // j_lo values per lane
 
@@ -27,24 +27,33 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_at_point_kernel(ColSet poly
     const u32 n_lo = 1u << L, n_hi = 1u << (log - L);
     const u32 poly = blockIdx.y, chunk = blockIdx.x;
     const u32* __restrict__ c = polys.col(poly);
-    QM31 acc[EVAL_KL];
+    u64 acc[EVAL_KL][4];
 #pragma unroll
-    for (int k = 0; k < EVAL_KL; k++) acc[k] = q_zero();
+    for (int k = 0; k < EVAL_KL; k++) for (int q = 0; q < 4; q++) acc[k][q] = 0;
     u32 h0 = chunk * hi_per_block, h1 = min(n_hi, h0 + hi_per_block);
+    u32 pending = 0;
     for (u32 jh = h0; jh < h1; jh++) {
-        QM31 th = q_load(t_hi + 4 * jh);  // uniform
+        const u32 th0 = t_hi[4 * jh], th1 = t_hi[4 * jh + 1], th2 = t_hi[4 * jh + 2], th3 = t_hi[4 * jh + 3];  // wave-uniform
         const u32* row = c + ((size_t)jh << L);
 #pragma unroll
         for (int k = 0; k < EVAL_KL; k++) {
             u32 jl = threadIdx.x + k * EVAL_THREADS;
-            if (jl < n_lo) acc[k] = q_add(acc[k], q_mul_m(th, row[jl]));
+            u32 cv = jl < n_lo ? row[jl] : 0u;
+            acc[k][0] = acc_mad(acc[k][0], th0, cv); acc[k][1] = acc_mad(acc[k][1], th1, cv);
+            acc[k][2] = acc_mad(acc[k][2], th2, cv); acc[k][3] = acc_mad(acc[k][3], th3, cv);
+        }
+        if (++pending == 4) {
+            pending = 0;
+#pragma unroll
+            for (int k = 0; k < EVAL_KL; k++) for (int q = 0; q < 4; q++) acc[k][q] = acc_fold(acc[k][q]);
         }
     }
     QM31 tot = q_zero();
 #pragma unroll
     for (int k = 0; k < EVAL_KL; k++) {
         u32 jl = threadIdx.x + k * EVAL_THREADS;
-        if (jl < n_lo) tot = q_add(tot, q_mul(acc[k], qm(t_lo[jl], t_lo[n_lo + jl], t_lo[2 * n_lo + jl], t_lo[3 * n_lo + jl])));
+        QM31 a = qm(acc_final(acc[k][0]), acc_final(acc[k][1]), acc_final(acc[k][2]), acc_final(acc[k][3]));
+        if (jl < n_lo) tot = q_add(tot, q_mul(a, qm(t_lo[jl], t_lo[n_lo + jl], t_lo[2 * n_lo + jl], t_lo[3 * n_lo + jl])));
     }
     // block reduction (wave shuffle then LDS)
     __shared__ u32 red[EVAL_THREADS / 64][4];
@@ -79,16 +88,24 @@ __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, con
     for (u32 b = 0; b < n_batches; b++) {
         const QBatchDev& B = batches[b];
         // numerator: Σ_k c_k f_k(d) - (d.y Σ a_k + Σ b_k)
-        u32 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
         const u32 end = B.first + B.count;
-        for (u32 k = B.first; k < end; k++) {
-            u32 f = cols.col(col_idx[k])[r];
-            n0 = m_add(n0, m_mul(cks[4 * k], f));
-            n1 = m_add(n1, m_mul(cks[4 * k + 1], f));
-            n2 = m_add(n2, m_mul(cks[4 * k + 2], f));
-            n3 = m_add(n3, m_mul(cks[4 * k + 3], f));
+        u32 k = B.first;
+        for (; k + 4 <= end; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                u32 f = cols.col(col_idx[k + u])[r];
+                n0 = acc_mad(n0, cks[4 * (k + u)], f); n1 = acc_mad(n1, cks[4 * (k + u) + 1], f);
+                n2 = acc_mad(n2, cks[4 * (k + u) + 2], f); n3 = acc_mad(n3, cks[4 * (k + u) + 3], f);
+            }
+            n0 = acc_fold(n0); n1 = acc_fold(n1); n2 = acc_fold(n2); n3 = acc_fold(n3);
         }
-        QM31 num = q_sub(qm(n0, n1, n2, n3), q_add(q_mul_m(q_load(B.sum_a), dp.y), q_load(B.sum_b)));
+        for (; k < end; k++) {
+            u32 f = cols.col(col_idx[k])[r];
+            n0 = acc_mad(n0, cks[4 * k], f); n1 = acc_mad(n1, cks[4 * k + 1], f);
+            n2 = acc_mad(n2, cks[4 * k + 2], f); n3 = acc_mad(n3, cks[4 * k + 3], f);
+        }
+        QM31 num = q_sub(qm(acc_final(n0), acc_final(n1), acc_final(n2), acc_final(n3)), q_add(q_mul_m(q_load(B.sum_a), dp.y), q_load(B.sum_b)));
         // denominator (CM31): (Re p.x - d.x) Im p.y - (Re p.y - d.y) Im p.x
         CM31 den = c_sub(c_mul(c_sub(cm(B.prx[0], B.prx[1]), cm(dp.x, 0)), cm(B.piy[0], B.piy[1])),
                          c_mul(c_sub(cm(B.pry[0], B.pry[1]), cm(dp.y, 0)), cm(B.pix[0], B.pix[1])));
@@ -193,7 +210,7 @@ int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_
         size_t part_words = (size_t)np * n_chunks * 4;
         uint8_t* blob = nullptr;
         size_t bytes = tlo.size() * 4 + thi.size() * 4 + part_words * 4 + (size_t)np * 8;
-        NX_HIP(ctx, hipMalloc((void**)&blob, bytes));
+        NX_TRY(dev_alloc(ctx, bytes, (void**)&blob));
         d_lo = (uint32_t*)blob; d_hi = d_lo + tlo.size(); d_part = d_hi + thi.size();
         d_tab = (uint32_t* const*)(blob + (tlo.size() + thi.size() + part_words) * 4);
         hipError_t e = hipMemcpyAsync(d_lo, tlo.data(), tlo.size() * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -212,7 +229,7 @@ int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_
         }
         if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_part, part_words * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(blob);
+        dev_free(ctx, blob);
         if (e != hipSuccess) return hip_fail(ctx, e, "nx_eval_at_points", __FILE__, __LINE__);
         for (uint32_t i = 0; i < np; i++) {
             uint32_t s[4] = {0, 0, 0, 0};
@@ -257,7 +274,7 @@ int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* cons
     uint8_t* blob = nullptr;
     size_t bytes_b = hb.size() * sizeof(QBatchDev), bytes_i = total * 4, bytes_c = cks.size() * 4, bytes_t = (size_t)n_cols * 8;
     size_t off_i = (bytes_b + 15) & ~(size_t)15, off_c = off_i + ((bytes_i + 15) & ~(size_t)15), off_t = off_c + ((bytes_c + 15) & ~(size_t)15);
-    NX_HIP(ctx, hipMalloc((void**)&blob, off_t + bytes_t + 16));
+    NX_TRY(dev_alloc(ctx, off_t + bytes_t + 16, (void**)&blob));
     hipError_t e = hipMemcpyAsync(blob, hb.data(), bytes_b, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && total) e = hipMemcpyAsync(blob + off_i, col_idx, bytes_i, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && total) e = hipMemcpyAsync(blob + off_c, cks.data(), bytes_c, hipMemcpyHostToDevice, ctx->stream);
@@ -274,7 +291,7 @@ int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* cons
     // the pageable host vectors above die at return: wait for the copies (kernel completion is not required for them,
     // but the blob must outlive the kernel, so synchronise before freeing it)
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(blob);
+    dev_free(ctx, blob);
     if (e != hipSuccess) return hip_fail(ctx, e, "nx_accumulate_quotients", __FILE__, __LINE__);
     if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_accumulate_quotients(sync)", __FILE__, __LINE__);
     return NX_OK;
