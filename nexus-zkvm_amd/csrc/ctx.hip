@@ -111,6 +111,26 @@ void timing_reset(nx_ctx* ctx) {
     for (int i = 0; i < 4; i++) { ctx->kind_ms[i] = 0; ctx->kind_bytes[i] = 0; }
 }
 
+int streams_fork(nx_ctx* ctx, int n_streams) {
+    if (n_streams <= 1) return NX_OK;
+    NX_HIP(ctx, hipEventRecord(ctx->fork_ev, ctx->stream));
+    for (int i = 0; i + 1 < n_streams && i < 3; i++) NX_HIP(ctx, hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0));
+    return NX_OK;
+}
+void streams_pick(nx_ctx* ctx, int batch_index, int n_streams) {
+    int k = n_streams <= 1 ? 0 : batch_index % (n_streams > 4 ? 4 : n_streams);
+    ctx->cur = k == 0 ? ctx->stream : ctx->side[k - 1];
+}
+int streams_join(nx_ctx* ctx, int n_streams) {
+    ctx->cur = ctx->stream;
+    if (n_streams <= 1) return NX_OK;
+    for (int i = 0; i + 1 < n_streams && i < 3; i++) {
+        NX_HIP(ctx, hipEventRecord(ctx->join_ev[i], ctx->side[i]));
+        NX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->join_ev[i], 0));
+    }
+    return NX_OK;
+}
+
 __global__ void gather_kernel(const uint32_t* const* ptrs, const uint64_t* index, size_t n, uint32_t* out) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = ptrs[i][index[i]];
@@ -139,10 +159,16 @@ int nx_ctx_create(int device, nx_ctx** out) {
         return set_err(nullptr, NX_ERR_NO_DEVICE, std::string("nx_ctx_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     NX_HIP(nullptr, hipSetDevice(device));
     nx_ctx* c = new nx_ctx();
-    c->device = device; c->hash_mode = NX_HASH_BLAKE2S; c->timing = false;
+    c->device = device; c->hash_mode = NX_HASH_BLAKE2S; c->timing = false; c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->scratch_size = 16u << 20; c->scratch_off = 0; c->d_scratch = nullptr; c->h_scratch = nullptr; c->cached_bytes = 0;
     for (int i = 0; i < 4; i++) { c->kind_ms[i] = 0; c->kind_bytes[i] = 0; }
     NX_HIP(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->cur = c->stream;
+    NX_HIP(nullptr, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) {
+        NX_HIP(nullptr, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        NX_HIP(nullptr, hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
+    }
     NX_HIP(nullptr, hipMalloc((void**)&c->d_scratch, c->scratch_size));
     NX_HIP(nullptr, hipHostMalloc((void**)&c->h_scratch, c->scratch_size, hipHostMallocDefault));
     *out = c;
@@ -159,6 +185,8 @@ void nx_ctx_destroy(nx_ctx* ctx) {
     for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(ctx->side[i]); (void)hipEventDestroy(ctx->join_ev[i]); }
+    (void)hipEventDestroy(ctx->fork_ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

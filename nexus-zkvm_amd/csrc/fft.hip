@@ -233,8 +233,8 @@ __global__ void fft_tiny_kernel(ColSet src, ColSet dst, u32 n_cols, int n, int l
 }
 
 // ---- planning ----
-struct FftTune { int smax, bmax, threads, batch_cols; };
-static FftTune g_tune = {13, 5, 256, 8};
+struct FftTune { int smax, bmax, threads, batch_cols, legacy, streams; };
+static FftTune g_tune = {13, 5, 256, 4, 0, 4};
 static bool g_tune_init = false;
 static void tune_init() {
     if (g_tune_init) return;
@@ -243,6 +243,8 @@ static void tune_init() {
     if (const char* e = getenv("NX_FFT_B")) g_tune.bmax = atoi(e);
     if (const char* e = getenv("NX_FFT_THREADS")) g_tune.threads = atoi(e);
     if (const char* e = getenv("NX_FFT_BATCH")) g_tune.batch_cols = atoi(e);
+    if (const char* e = getenv("NX_FFT_LEGACY")) g_tune.legacy = atoi(e);
+    if (const char* e = getenv("NX_FFT_STREAMS")) g_tune.streams = std::max(1, std::min(4, atoi(e)));
     g_tune.smax = std::max(6, std::min(g_tune.smax, 15));
     g_tune.bmax = std::max(2, std::min(g_tune.bmax, 6));
     if (g_tune.threads != 128 && g_tune.threads != 256 && g_tune.threads != 512 && g_tune.threads != 1024) g_tune.threads = 256;
@@ -308,10 +310,10 @@ static int launch_pass(nx_ctx* ctx, bool inv, const FftPass& a) {
             attr_set = true;
         }
     }
-    if (inv && first) hipLaunchKernelGGL((fft_pass_kernel<true, true>), grid, block, lds_bytes, ctx->stream, a);
-    else if (inv) hipLaunchKernelGGL((fft_pass_kernel<true, false>), grid, block, lds_bytes, ctx->stream, a);
-    else if (first) hipLaunchKernelGGL((fft_pass_kernel<false, true>), grid, block, lds_bytes, ctx->stream, a);
-    else hipLaunchKernelGGL((fft_pass_kernel<false, false>), grid, block, lds_bytes, ctx->stream, a);
+    if (inv && first) hipLaunchKernelGGL((fft_pass_kernel<true, true>), grid, block, lds_bytes, ctx->cur, a);
+    else if (inv) hipLaunchKernelGGL((fft_pass_kernel<true, false>), grid, block, lds_bytes, ctx->cur, a);
+    else if (first) hipLaunchKernelGGL((fft_pass_kernel<false, true>), grid, block, lds_bytes, ctx->cur, a);
+    else hipLaunchKernelGGL((fft_pass_kernel<false, false>), grid, block, lds_bytes, ctx->cur, a);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
@@ -329,8 +331,9 @@ static int check_tw(nx_ctx* ctx, const nx_twiddles* tw, int n) {
 }
 
 static int interpolate_cols(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_cols, int n) {
+    if (n >= 13 && !g_tune.legacy) return fft13_interpolate(ctx, tw, cols, n_cols, n);
     if (n <= 2) {
-        hipLaunchKernelGGL(fft_tiny_kernel, dim3((n_cols + 63) / 64), dim3(64), 0, ctx->stream, cols, cols, n_cols, n, n, true);
+        hipLaunchKernelGGL(fft_tiny_kernel, dim3((n_cols + 63) / 64), dim3(64), 0, ctx->cur, cols, cols, n_cols, n, n, true);
         NX_LAUNCH_CHECK(ctx);
         return NX_OK;
     }
@@ -345,8 +348,9 @@ static int interpolate_cols(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32
 }
 
 static int evaluate_cols(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n_cols, int log_in, int n, ColSet out) {
+    if (log_in >= 13 && !g_tune.legacy) return fft13_evaluate(ctx, tw, polys, n_cols, log_in, n, out);
     if (n <= 2) {
-        hipLaunchKernelGGL(fft_tiny_kernel, dim3((n_cols + 63) / 64), dim3(64), 0, ctx->stream, polys, out, n_cols, n, log_in, false);
+        hipLaunchKernelGGL(fft_tiny_kernel, dim3((n_cols + 63) / 64), dim3(64), 0, ctx->cur, polys, out, n_cols, n, log_in, false);
         NX_LAUNCH_CHECK(ctx);
         return NX_OK;
     }
@@ -364,11 +368,16 @@ int fft_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_
     NX_TRY(check_tw(ctx, tw, (int)log_size));
     tune_init();
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * 8ull << log_size);
-    for (u32 c0 = 0; c0 < n_cols; c0 += g_tune.batch_cols) {
+    const int ns = n_cols > (u32)g_tune.batch_cols ? g_tune.streams : 1;
+    NX_TRY(streams_fork(ctx, ns));
+    int rc = NX_OK;
+    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += g_tune.batch_cols, bi++) {
         u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
-        NX_TRY(interpolate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size));
+        streams_pick(ctx, (int)bi, ns);
+        rc = interpolate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size);
     }
-    return NX_OK;
+    int rj = streams_join(ctx, ns);
+    return rc != NX_OK ? rc : rj;
 }
 
 int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_cols, uint32_t log_size, uint32_t log_expand, ColSet out) {
@@ -376,11 +385,16 @@ int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_co
     NX_TRY(check_tw(ctx, tw, n));
     tune_init();
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * ((4ull << log_size) + (4ull << n)));
-    for (u32 c0 = 0; c0 < n_cols; c0 += g_tune.batch_cols) {
+    const int ns = n_cols > (u32)g_tune.batch_cols ? g_tune.streams : 1;
+    NX_TRY(streams_fork(ctx, ns));
+    int rc = NX_OK;
+    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += g_tune.batch_cols, bi++) {
         u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
-        NX_TRY(evaluate_cols(ctx, tw, sub_colset(polys, c0), nb, (int)log_size, n, sub_colset(out, c0)));
+        streams_pick(ctx, (int)bi, ns);
+        rc = evaluate_cols(ctx, tw, sub_colset(polys, c0), nb, (int)log_size, n, sub_colset(out, c0));
     }
-    return NX_OK;
+    int rj = streams_join(ctx, ns);
+    return rc != NX_OK ? rc : rj;
 }
 
 // iFFT + LDE per column batch (coefficients stay cache-resident between the two transforms).
@@ -390,12 +404,17 @@ int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, ui
     tune_init();
     // algorithmic bytes: read N evals, write N coeffs, write M = 2^n LDE words
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * ((8ull << log_size) + (4ull << n)));
-    for (u32 c0 = 0; c0 < n_cols; c0 += g_tune.batch_cols) {
+    const int ns = n_cols > (u32)g_tune.batch_cols ? g_tune.streams : 1;
+    NX_TRY(streams_fork(ctx, ns));
+    int rc = NX_OK;
+    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += g_tune.batch_cols, bi++) {
         u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
-        NX_TRY(interpolate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size));
-        NX_TRY(evaluate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, n, sub_colset(out, c0)));
+        streams_pick(ctx, (int)bi, ns);
+        rc = interpolate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size);
+        if (rc == NX_OK) rc = evaluate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, n, sub_colset(out, c0));
     }
-    return NX_OK;
+    int rj = streams_join(ctx, ns);
+    return rc != NX_OK ? rc : rj;
 }
 
 // ------------------------------------------------------------------ permutations (K1, R3) ---

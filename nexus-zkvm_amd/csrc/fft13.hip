@@ -1,0 +1,426 @@
+// Circle FFT / iFFT passes for transforms of >= 2^13 points: the fast path of K3/K4.
+//
+// Same math as fft.hip (Stwo CpuBackend circle.rs butterflies, bit-reversed order), different schedule:
+//  * a pass owns 13 index bits: K butterfly layers [lo, lo+K) plus B = 13-K low bits that only make
+//    the global accesses contiguous (runs of 2^B words, B = 0 for the pass that holds layers [0,13)).
+//    2^22 points = 2 passes (13 + 9 layers); each pass is one HBM round trip.
+//  * a block transforms the same 2^13-row tile of CB columns (1 or 2): with CB = 2 the LDS tile holds
+//    (col0, col1) pairs, every LDS access is 64-bit, twiddles and index arithmetic are paid once per pair.
+//  * RB layers per LDS round trip (radix-2^RB in registers, RB = 3 or 4); the pass's top layer is fused
+//    into the global<->LDS staging (its twiddle is uniform over the tile).
+//  * the twiddles of a round are requested one round ahead, so a round waits on LDS only.
+//  * the trivial top layers of an LDE (inputs that are zero by construction) are not computed: the
+//    coefficient tile is replicated, each replica runs the remaining layers with its own twiddles.
+//  * blockIdx -> (tile, column group) keeps all column groups of a tile on one XCD (same twiddles,
+//    neighbouring runs of the same cache lines) — for speed only, correctness never depends on it.
+#include "internal.h"
+#include <algorithm>
+#include <stdlib.h>
+
+namespace nx {
+
+constexpr int T13_S = 13;
+constexpr u32 T13_ROWS = 1u << T13_S;
+constexpr u32 T13_HALF = T13_ROWS / 2;
+
+struct Pass13 {
+    ColSet src, dst;
+    const u32* tw;   // forward or inverse twiddle buffer (2^tw_log words)
+    u32 tw_log;
+    int n;           // log size of the whole transform (index space of dst)
+    int log_in;      // src holds 2^log_in words; dst index bits >= log_in select a replica
+    int lo, K, B;    // layers [lo, lo+K), K + B == 13
+    u32 scale;       // inverse passes: multiply the outputs by this (0 = none)
+    u32 n_cols, n_groups, tiles;
+};
+
+template <int CB> struct alignas(4 * CB) Row { u32 c[CB]; };
+
+__device__ __forceinline__ u32 pad13(u32 t) { return t + (t >> 4); }
+
+// t2 = 2 * twiddle (doubled once per lane after the load, see field.cuh m_mul_dbl)
+template <bool INV>
+__device__ __forceinline__ void bfly13(u32& x0, u32& x1, u32 t2, bool neg) {
+    if (INV) {
+        u32 s = m_add(x0, x1);
+        u32 d = neg ? m_sub(x1, x0) : m_sub(x0, x1);
+        x0 = s; x1 = m_mul_dbl(d, t2);
+    } else {
+        u32 m = m_mul_dbl(x1, t2);
+        u32 a = m_add(x0, m), b = m_sub(x0, m);
+        x0 = neg ? b : a; x1 = neg ? a : b;
+    }
+}
+
+template <int CNT>
+__device__ __forceinline__ void load_tw13(const u32* __restrict__ p, u32* dst) {
+    if constexpr (CNT == 8) {
+        uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+    } else if constexpr (CNT == 4) {
+        uint4 a = *reinterpret_cast<const uint4*>(p);
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+    } else if constexpr (CNT == 2) {
+        uint2 a = *reinterpret_cast<const uint2*>(p);
+        dst[0] = a.x; dst[1] = a.y;
+    } else {
+        dst[0] = p[0];
+    }
+}
+
+// twiddles of layers l0+Q .. l0+R-1 for the 2^R rows starting at global index g0: layer q at tw[2^R - 2^(R-q)], 2^(R-1-q) words
+template <int R, int Q, bool CIRCLE>
+__device__ __forceinline__ void load_round_tw13(const u32* const __restrict__* twl, u32 g0, int l0, u32* tw) {
+    if constexpr (Q < R) {
+        if constexpr (!(CIRCLE && Q == 0))
+            load_tw13<(1 << (R - 1 - Q))>(twl[Q] + (g0 >> (l0 + Q + 1)), tw + ((1 << R) - (1 << (R - Q))));
+        load_round_tw13<R, Q + 1, CIRCLE>(twl, g0, l0, tw);
+    }
+}
+
+// the R butterfly layers of 2^R rows held in registers; CIRCLE: layer 0 is the circle layer, its twiddles are
+// derived from the first line layer's (x, y) pairs as [y, -y, -x, x]
+template <int R, int CB, bool INV, bool CIRCLE>
+__device__ __forceinline__ void butterflies(Row<CB>* v, const u32* tw) {
+    static_assert(!CIRCLE || R >= 3, "circle rounds need the (x, y) pair of the first line layer");
+#pragma unroll
+    for (int qq = 0; qq < R; qq++) {
+        const int q = INV ? qq : R - 1 - qq;
+#pragma unroll
+        for (int e = 0; e < (1 << R); e++) {
+            if (e & (1 << q)) continue;
+            const int h = e >> (q + 1);
+            if (CIRCLE && q == 0) {
+                const int c = h >> 2, sel = h & 3;
+                const u32 t = tw[((1 << R) - (1 << (R - 1))) + 2 * c + ((sel & 2) ? 0 : 1)];
+                const bool neg = sel == 1 || sel == 2;
+#pragma unroll
+                for (int k = 0; k < CB; k++) bfly13<INV>(v[e].c[k], v[e | 1].c[k], t, neg);
+            } else {
+                const u32 t = tw[((1 << R) - (1 << (R - q))) + h];
+#pragma unroll
+                for (int k = 0; k < CB; k++) bfly13<INV>(v[e].c[k], v[e | (1 << q)].c[k], t, false);
+            }
+        }
+    }
+}
+
+// twiddle request for the full round at tile bit `bp`, for the 2^RB rows this lane owns
+template <int RB, bool CIRCLE>
+__device__ __forceinline__ void tw_request(const Pass13& a, int bp, u32 tile_base, u32* tw) {
+    const u32 w = threadIdx.x;
+    const u32 wl = w & ((1u << bp) - 1), wh = w >> bp;
+    const u32 t0 = (wh << (bp + RB)) | wl;
+    const u32 g0 = tile_base + ((t0 >> a.B) << a.lo) + (t0 & ((1u << a.B) - 1));
+    const int l0 = a.lo + (bp - a.B);
+    const u32* __restrict__ twl[RB];
+#pragma unroll
+    for (int q = 0; q < RB; q++) twl[q] = a.tw + ((1u << a.tw_log) - (1u << (a.n - (l0 + q))));
+    load_round_tw13<RB, 0, CIRCLE>(twl, g0, l0, tw);
+#pragma unroll
+    for (int k = CIRCLE ? (1 << (RB - 1)) : 0; k < (1 << RB) - 1; k++) tw[k] <<= 1;
+}
+
+// One full LDS round trip (every lane owns 2^RB rows): tile bits [bp, bp+RB), twiddles already in registers.
+template <int RB, int CB, bool INV, bool CIRCLE>
+__device__ __forceinline__ void round_full(Row<CB>* lds, int bp, const u32* tw) {
+    const u32 w = threadIdx.x;
+    const u32 wl = w & ((1u << bp) - 1), wh = w >> bp;
+    const u32 t0 = (wh << (bp + RB)) | wl;
+    Row<CB> v[1 << RB];
+    if (bp == 0 || bp >= 4) {   // the padding is linear in the row step
+        const u32 estride = bp ? ((1u << bp) + ((1u << bp) >> 4)) : 1u;
+        const u32 p0 = pad13(t0);
+#pragma unroll
+        for (int e = 0; e < (1 << RB); e++) v[e] = lds[p0 + e * estride];
+        butterflies<RB, CB, INV, CIRCLE>(v, tw);
+#pragma unroll
+        for (int e = 0; e < (1 << RB); e++) lds[p0 + e * estride] = v[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < (1 << RB); e++) v[e] = lds[pad13(t0 + ((u32)e << bp))];
+        butterflies<RB, CB, INV, CIRCLE>(v, tw);
+#pragma unroll
+        for (int e = 0; e < (1 << RB); e++) lds[pad13(t0 + ((u32)e << bp))] = v[e];
+    }
+}
+
+// Remainder round (R < RB layers at the bottom of a non-FIRST pass, bp >= 4): several row groups per lane.
+template <int R, int CB, int NT, bool INV>
+__device__ __forceinline__ void round_rem(Row<CB>* lds, const Pass13& a, int bp, u32 tile_base) {
+    constexpr u32 NBLK = T13_ROWS >> R;
+    const u32 estride = (1u << bp) + ((1u << bp) >> 4);
+    const u32 maskB = (1u << a.B) - 1;
+    const int l0 = a.lo + (bp - a.B);
+    const u32* __restrict__ twl[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) twl[q] = a.tw + ((1u << a.tw_log) - (1u << (a.n - (l0 + q))));
+#pragma unroll 1
+    for (u32 w = threadIdx.x; w < NBLK; w += NT) {
+        const u32 wl = w & ((1u << bp) - 1), wh = w >> bp;
+        const u32 t0 = (wh << (bp + R)) | wl;
+        const u32 p0 = pad13(t0);
+        Row<CB> v[1 << R];
+#pragma unroll
+        for (int e = 0; e < (1 << R); e++) v[e] = lds[p0 + e * estride];
+        const u32 g0 = tile_base + ((t0 >> a.B) << a.lo) + (t0 & maskB);
+        u32 tw[1 << R];
+        load_round_tw13<R, 0, false>(twl, g0, l0, tw);
+#pragma unroll
+        for (int k = 0; k < (1 << R) - 1; k++) tw[k] <<= 1;
+        butterflies<R, CB, INV, false>(v, tw);
+#pragma unroll
+        for (int e = 0; e < (1 << R); e++) lds[p0 + e * estride] = v[e];
+    }
+}
+
+template <int RB, int CB, int NT, bool INV>
+__device__ __forceinline__ void rem_round13(Row<CB>* lds, const Pass13& a, int rem, int bp, u32 tile_base) {
+    if (rem == 3) { if constexpr (RB > 3) round_rem<3, CB, NT, INV>(lds, a, bp, tile_base); }
+    else if (rem == 2) round_rem<2, CB, NT, INV>(lds, a, bp, tile_base);
+    else if (rem == 1) round_rem<1, CB, NT, INV>(lds, a, bp, tile_base);
+    __syncthreads();
+}
+
+__device__ __forceinline__ u32 get4(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// FIRST: the pass that owns layers [0, 13) on a contiguous tile (lo == 0, B == 0), including the circle layer.
+// One block = one (tile, group of CB columns), 2^(13-RB) lanes.
+template <bool INV, bool FIRST, int CB, int RB>
+__global__ __launch_bounds__(T13_ROWS >> RB) void fft13_kernel(Pass13 a) {
+    constexpr int NT = T13_ROWS >> RB;
+    constexpr int MAXR = (T13_S - 1 + RB - 1) / RB;       // full rounds in a 13-layer pass
+    extern __shared__ __attribute__((aligned(16))) u32 lds13[];
+    Row<CB>* lds = reinterpret_cast<Row<CB>*>(lds13);
+    u32 tile, grp;
+    {
+        const u32 b = blockIdx.x;
+        if (a.tiles >= 8) { const u32 xcd = b & 7, y = b >> 3; grp = y % a.n_groups; tile = xcd * (a.tiles >> 3) + y / a.n_groups; }
+        else { grp = b % a.n_groups; tile = b / a.n_groups; }
+    }
+    const u32* __restrict__ s[CB];
+    u32* __restrict__ d[CB];
+    bool live[CB];
+#pragma unroll
+    for (int k = 0; k < CB; k++) {
+        const u32 c = min(grp * CB + k, a.n_cols - 1);
+        live[k] = grp * CB + k < a.n_cols;
+        s[k] = a.src.col(c); d[k] = a.dst.col(c);
+    }
+
+    const int B = FIRST ? 0 : a.B, lo = FIRST ? 0 : a.lo, K = FIRST ? T13_S : a.K;
+    const int lb = lo - B;
+    const u32 lowblock = tile & ((1u << lb) - 1), high = tile >> lb;
+    const u32 tile_base = (high << (lo + K)) | (lowblock << B);
+    const u32 src_base = tile_base & ((1u << a.log_in) - 1);
+    const u32 maskB = (1u << B) - 1;
+    auto goff = [&](u32 t) -> u32 { return FIRST ? t : (((t >> B) << lo) + (t & maskB)); };
+
+    // full rounds sit at tile bits bp(i) = B + rem + RB i, i < nfull; the remainder round (K-1 mod RB layers) at bit B
+    const int K1 = K - 1, nfull = K1 / RB, rem = K1 % RB;
+    auto bp_of = [&](int i) -> int { return B + rem + RB * i; };
+    u32 twA[1 << RB], twB[1 << RB];
+    if (nfull) {
+        const int i0 = INV ? 0 : nfull - 1;
+        if (FIRST && i0 == 0) tw_request<RB, true>(a, 0, tile_base, twA); else tw_request<RB, false>(a, bp_of(i0), tile_base, twA);
+    }
+    // the pass's top layer (tile bit 12): one twiddle for the whole tile
+    const int le = lo + K - 1;
+    const u32 te = a.tw[((1u << a.tw_log) - (1u << (a.n - le))) + high], te2 = te << 1;
+
+    if (INV) {
+#pragma unroll
+        for (int it = 0; it < (int)(T13_ROWS / 4) / NT; it++) {
+            const u32 t = (threadIdx.x + it * NT) * 4;
+            const u32 g = src_base + goff(t);
+            uint4 x[CB];
+#pragma unroll
+            for (int k = 0; k < CB; k++) x[k] = *reinterpret_cast<const uint4*>(s[k] + g);
+            const u32 p = pad13(t);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Row<CB> r;
+#pragma unroll
+                for (int k = 0; k < CB; k++) r.c[k] = get4(x[k], i);
+                lds[p + i] = r;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < (int)(T13_HALF / 4) / NT; it++) {
+            const u32 t = (threadIdx.x + it * NT) * 4;
+            const u32 ga = src_base + goff(t), gb = src_base + goff(t + T13_HALF);
+            uint4 xa[CB], xb[CB];
+#pragma unroll
+            for (int k = 0; k < CB; k++) { xa[k] = *reinterpret_cast<const uint4*>(s[k] + ga); xb[k] = *reinterpret_cast<const uint4*>(s[k] + gb); }
+            const u32 pa = pad13(t), pb = pad13(t + T13_HALF);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Row<CB> ra, rb;
+#pragma unroll
+                for (int k = 0; k < CB; k++) {
+                    u32 u = get4(xa[k], i), w = get4(xb[k], i);
+                    bfly13<false>(u, w, te2, false);
+                    ra.c[k] = u; rb.c[k] = w;
+                }
+                lds[pa + i] = ra;
+                lds[pb + i] = rb;
+            }
+        }
+    }
+    __syncthreads();
+
+    // step j of the round sequence uses twiddle registers (j even ? twA : twB) and requests step j+1's into the other set
+    if (INV) {
+        if (rem) rem_round13<RB, CB, NT, true>(lds, a, rem, B, tile_base);
+#pragma unroll
+        for (int j = 0; j < MAXR; j++) {
+            if (j < nfull) {
+                u32* cur = (j & 1) ? twB : twA;
+                u32* nxt = (j & 1) ? twA : twB;
+                if (j + 1 < nfull) tw_request<RB, false>(a, bp_of(j + 1), tile_base, nxt);
+                __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of this round's butterflies
+                if (FIRST && j == 0) round_full<RB, CB, true, true>(lds, 0, cur); else round_full<RB, CB, true, false>(lds, bp_of(j), cur);
+                __syncthreads();
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < MAXR; j++) {
+            if (j < nfull) {
+                const int i = nfull - 1 - j;
+                u32* cur = (j & 1) ? twB : twA;
+                u32* nxt = (j & 1) ? twA : twB;
+                if (i > 0) { if (FIRST && i == 1) tw_request<RB, true>(a, 0, tile_base, nxt); else tw_request<RB, false>(a, bp_of(i - 1), tile_base, nxt); }
+                __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of this round's butterflies
+                if (FIRST && i == 0) round_full<RB, CB, false, true>(lds, 0, cur); else round_full<RB, CB, false, false>(lds, bp_of(i), cur);
+                __syncthreads();
+            }
+        }
+        if (rem) rem_round13<RB, CB, NT, false>(lds, a, rem, B, tile_base);
+    }
+
+    if (INV) {
+        // top layer fused into the store; the 1/N scale rides on it (one multiply per output instead of two)
+        const u32 sc2 = a.scale << 1, tes2 = (a.scale ? m_mul(te, a.scale) : te) << 1;
+#pragma unroll
+        for (int it = 0; it < (int)(T13_HALF / 4) / NT; it++) {
+            const u32 t = (threadIdx.x + it * NT) * 4;
+            const u32 pa = pad13(t), pb = pad13(t + T13_HALF);
+            u32 oa[CB][4], ob[CB][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const Row<CB> x = lds[pa + i], y = lds[pb + i];
+#pragma unroll
+                for (int k = 0; k < CB; k++) {
+                    const u32 sm = m_add(x.c[k], y.c[k]), df = m_sub(x.c[k], y.c[k]);
+                    oa[k][i] = sc2 ? m_mul_dbl(sm, sc2) : sm; ob[k][i] = m_mul_dbl(df, tes2);
+                }
+            }
+            const u32 ga = tile_base + goff(t), gb = tile_base + goff(t + T13_HALF);
+#pragma unroll
+            for (int k = 0; k < CB; k++) {
+                if (live[k]) {
+                    *reinterpret_cast<uint4*>(d[k] + ga) = make_uint4(oa[k][0], oa[k][1], oa[k][2], oa[k][3]);
+                    *reinterpret_cast<uint4*>(d[k] + gb) = make_uint4(ob[k][0], ob[k][1], ob[k][2], ob[k][3]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < (int)(T13_ROWS / 4) / NT; it++) {
+            const u32 t = (threadIdx.x + it * NT) * 4;
+            const u32 p = pad13(t);
+            const Row<CB> x0 = lds[p], x1 = lds[p + 1], x2 = lds[p + 2], x3 = lds[p + 3];
+            const u32 g = tile_base + goff(t);
+#pragma unroll
+            for (int k = 0; k < CB; k++)
+                if (live[k]) *reinterpret_cast<uint4*>(d[k] + g) = make_uint4(x0.c[k], x1.c[k], x2.c[k], x3.c[k]);
+        }
+    }
+}
+
+// ---- planning: layers [0, m) -> the FIRST pass [0, 13) plus passes of <= 9 layers (runs of >= 16 words) ----
+struct Plan13 { int lo, K, B; };
+static std::vector<Plan13> plan13(int m) {
+    std::vector<Plan13> p;
+    p.push_back({0, T13_S, 0});
+    int rest = m - T13_S;
+    if (rest <= 0) return p;
+    int nhi = (rest + 8) / 9, lo = T13_S;
+    for (int i = 0; i < nhi; i++) {
+        int k = rest / nhi + (i < rest % nhi ? 1 : 0);
+        p.push_back({lo, k, T13_S - k});
+        lo += k;
+    }
+    return p;
+}
+
+struct Shape13 { int cb, rb; };
+static Shape13 g_shape = {2, 4};
+static bool g_shape_init = false;
+static void shape_init() {
+    if (g_shape_init) return;
+    g_shape_init = true;
+    if (const char* e = getenv("NX_FFT_CB")) g_shape.cb = atoi(e) == 1 ? 1 : 2;
+    if (const char* e = getenv("NX_FFT_RB")) g_shape.rb = atoi(e) == 3 ? 3 : 4;
+}
+
+template <bool INV, bool FIRST, int CB, int RB>
+static int launch13_t(nx_ctx* ctx, const Pass13& a) {
+    static bool attr_set = false;
+    const size_t lds_bytes = ((size_t)T13_ROWS + (T13_ROWS >> 4)) * 4 * CB;
+    if (!attr_set) {
+        NX_HIP(ctx, hipFuncSetAttribute((const void*)fft13_kernel<INV, FIRST, CB, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid(a.tiles * a.n_groups), block(T13_ROWS >> RB);
+    hipLaunchKernelGGL((fft13_kernel<INV, FIRST, CB, RB>), grid, block, lds_bytes, ctx->cur, a);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+template <int CB, int RB>
+static int launch13_s(nx_ctx* ctx, bool inv, bool first, const Pass13& a) {
+    if (inv && first) return launch13_t<true, true, CB, RB>(ctx, a);
+    if (inv) return launch13_t<true, false, CB, RB>(ctx, a);
+    if (first) return launch13_t<false, true, CB, RB>(ctx, a);
+    return launch13_t<false, false, CB, RB>(ctx, a);
+}
+
+static int launch13(nx_ctx* ctx, bool inv, bool first, Pass13 a) {
+    shape_init();
+    const int cb = a.n_cols == 1 ? 1 : g_shape.cb;
+    a.n_groups = (a.n_cols + cb - 1) / cb;
+    if (cb == 2 && g_shape.rb == 4) return launch13_s<2, 4>(ctx, inv, first, a);
+    if (cb == 2) return launch13_s<2, 3>(ctx, inv, first, a);
+    if (g_shape.rb == 4) return launch13_s<1, 4>(ctx, inv, first, a);
+    return launch13_s<1, 3>(ctx, inv, first, a);
+}
+
+// in-place iFFT of n_cols columns of 2^n words (n >= 13)
+int fft13_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_cols, int n) {
+    std::vector<Plan13> plan = plan13(n);
+    for (size_t i = 0; i < plan.size(); i++) {
+        Pass13 a; a.src = cols; a.dst = cols; a.tw = tw->d_itw; a.tw_log = tw->log_half; a.n = n; a.log_in = n;
+        a.lo = plan[i].lo; a.K = plan[i].K; a.B = plan[i].B; a.scale = i + 1 == plan.size() ? m_inv(1u << n) : 0;
+        a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S);
+        NX_TRY(launch13(ctx, true, i == 0, a));
+    }
+    return NX_OK;
+}
+
+// FFT of 2^log_in coefficients per column onto 2^n points (n >= log_in >= 13); out may alias polys when n == log_in
+int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n_cols, int log_in, int n, ColSet out) {
+    std::vector<Plan13> plan = plan13(log_in);
+    for (size_t k = plan.size(); k-- > 0;) {
+        const bool top = k + 1 == plan.size();
+        Pass13 a; a.src = top ? polys : out; a.dst = out; a.tw = tw->d_tw; a.tw_log = tw->log_half; a.n = n; a.log_in = top ? log_in : n;
+        a.lo = plan[k].lo; a.K = plan[k].K; a.B = plan[k].B; a.scale = 0;
+        a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S);
+        NX_TRY(launch13(ctx, false, k == 0, a));
+    }
+    return NX_OK;
+}
+
+}  // namespace nx

@@ -16,18 +16,22 @@ typedef uint64_t u64;
 
 constexpr u32 P = 0x7fffffffu;
 
-// In-register Mersenne reduction: every op is a handful of 32-bit VALU instructions; `min` on the
-// wrapped difference replaces compare+select.
+// In-register Mersenne reduction.  Instruction choice is measured (tools/ubench/valu_asm.hip, bfly_rates.hip):
+// on gfx950 v_add/v_sub/v_and/v_lshr/v_cndmask issue in ~2 cycles per wave, v_min_u32, v_alignbit and every
+// multiply in ~4, v_mad_u64_u32 in ~5.  So the conditional subtract is carry + select (v_sub_co, v_cndmask),
+// not subtract + v_min, and a product is split at bit 31 by multiplying with the DOUBLED factor:
+// a * (2b) = hi * 2^32 + 2 * lo  with  a*b = hi * 2^31 + lo  (1.5x the butterfly rate of and/alignbit/min).
 NX_HD u32 umin32(u32 a, u32 b) { return a < b ? a : b; }
-NX_HD u32 m_add(u32 a, u32 b) { u32 s = a + b; return umin32(s, s - P); }
-NX_HD u32 m_sub(u32 a, u32 b) { u32 d = a - b; return umin32(d, d + P); }
+NX_HD u32 m_csub(u32 s) { u32 d; bool borrow = __builtin_usub_overflow(s, P, &d); return borrow ? s : d; }  // s < 2p
+NX_HD u32 m_add(u32 a, u32 b) { return m_csub(a + b); }
+NX_HD u32 m_sub(u32 a, u32 b) { u32 d; bool borrow = __builtin_usub_overflow(a, b, &d); return borrow ? d + P : d; }
 NX_HD u32 m_neg(u32 a) { return a ? P - a : 0; }
-NX_HD u32 m_mul(u32 a, u32 b) {
-    u64 p = (u64)a * (u64)b;                 // v_mul_lo_u32 + v_mul_hi_u32
-    u32 lo = (u32)p & P, hi = (u32)(p >> 31);
-    u32 s = lo + hi;                          // < 2p
-    return umin32(s, s - P);
+// b2 = 2*b for a canonical b (e.g. a twiddle doubled once and reused)
+NX_HD u32 m_mul_dbl(u32 a, u32 b2) {
+    u64 p = (u64)a * (u64)b2;                 // v_mad_u64_u32
+    return m_csub((u32)(p >> 32) + ((u32)p >> 1));
 }
+NX_HD u32 m_mul(u32 a, u32 b) { return m_mul_dbl(a, b << 1); }
 NX_HD u32 m_sqr(u32 a) { return m_mul(a, a); }
 NX_HD u32 m_reduce64(u64 x) {  // x < p^2
     return (u32)((((((x >> 31) + x + 1) >> 31) + x)) & P);
@@ -48,7 +52,7 @@ NX_HD u64 acc_fold(u64 x) { return (x & (u64)P) + (x >> 31); }
 NX_HD u32 acc_final(u64 x) {
     x = acc_fold(x);                       // < 2^34
     u32 s = ((u32)x & P) + (u32)(x >> 31); // < 2^31 + 8
-    return umin32(s, s - P);
+    return m_csub(s);
 }
 
 struct CM31 { u32 a, b; };

@@ -12,7 +12,13 @@
 struct nx_ctx {
     int device;
     hipStream_t stream;
+    // FFT column batches are spread over the main stream and these side streams (fork/join with events) so that
+    // one batch's memory-heavy pass overlaps another batch's butterfly-heavy pass and launch tails are filled
+    hipStream_t side[3];
+    hipEvent_t fork_ev, join_ev[3];
+    hipStream_t cur;   // stream the FFT launchers enqueue on (== stream outside a forked region)
     int hash_mode;
+    int n_cus;       // compute units of the device
     std::string err;
     // small device scratch for pointer tables / constants (ring, stream ordered)
     uint8_t* d_scratch;
@@ -95,5 +101,14 @@ void timing_reset(nx_ctx* ctx);
 int fft_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size);
 int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_cols, uint32_t log_size,
                  uint32_t log_expand, ColSet out);
+
+// fork/join of the side streams around a loop over independent column batches
+int streams_fork(nx_ctx* ctx, int n_streams);
+void streams_pick(nx_ctx* ctx, int batch_index, int n_streams);
+int streams_join(nx_ctx* ctx, int n_streams);
+
+// fast path for transforms of >= 2^13 points (fft13.hip)
+int fft13_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n);
+int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_cols, int log_in, int n, ColSet out);
 
 }  // namespace nx

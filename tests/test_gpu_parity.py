@@ -65,6 +65,30 @@ def test_interpolate_evaluate_match_oracle(be, oracle, log):
         lde.free()
 
 
+@pytest.mark.parametrize("log", [21, 22, 23])
+def test_large_transforms_match_oracle_and_roundtrip(be, oracle, log):
+    """2-pass (13+8, 13+9 layers) and 3-pass (13+5+5) schedules of the wide kernel: one column against the oracle,
+    the others through interpolate∘evaluate = id and LDE-restricted-to-the-trace-domain properties."""
+    n_cols = 3
+    tw = be.precompute_twiddles(log + 1)
+    otw = oracle.Twiddles(log + 1)
+    vals = rand_cols(900 + log, n_cols, log)
+    cols = be.columns_from_host(vals)
+    be.interpolate_columns(tw, cols)
+    coeffs = cols.to_cpu()
+    assert np.array_equal(coeffs[2], otw.interpolate(vals[2]))
+    back = be.evaluate_polynomials(tw, cols, 0)
+    assert np.array_equal(back.to_cpu(), vals)
+    back.free()
+    lde = be.evaluate_polynomials(tw, cols, 1)
+    got = lde.to_cpu()
+    assert got.max() < P
+    assert np.array_equal(got[1], otw.evaluate(coeffs[1], log + 1))
+    be.interpolate_columns(tw, lde)
+    c2 = lde.to_cpu()
+    assert np.array_equal(c2[:, :1 << log], coeffs) and not c2[:, 1 << log:].any()
+
+
 def test_lde_fused_and_pointer_table_path(be, oracle):
     """nx_lde_batch == interpolate+evaluate; columns that are not a uniform slab take the table path."""
     log, n_cols = 10, 7
