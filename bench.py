@@ -87,11 +87,16 @@ def main():
     if rank == 0:
         n_cycles = (1 << args.log_rows) * args.steps * world
         lde_gbs = stats["lde_algorithmic_bytes"] / (stats["lde_kernel_ms"] * 1e-3) / 1e9 if stats["lde_kernel_ms"] > 0 else 0.0
+        # HBM bytes of the same LDE work from the PMC passes of tools/pmc_traffic.py (FETCH_SIZE x2 + WRITE_SIZE, calibrated
+        # on a known copy as MI355X_MICROARCH.md prescribes), measured per column at the same log size and scaled to this
+        # prove's column count; null when the committed measurement is for another size
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "fft_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("algorithmic_bytes_per_column") == float(16 << args.log_rows):
+                    traffic = tj["hbm_bytes_per_column"] * (stats["lde_algorithmic_bytes"] / float(16 << args.log_rows))
             except Exception:
                 traffic = None
         out = {
@@ -112,7 +117,7 @@ def main():
                        "log_n_rows": args.log_rows, "parallelism": "1 proof per GPU" if world > 1 else "1 GPU",
                        "proof_words": int(len(words))},
             "roofline": {"bound": "hbm", "achieved": lde_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "nx::fft_pass_kernel<INV> (Circle iFFT+FFT = LDE)",
+                         "traffic": traffic, "kernel": "nx::fft13_kernel<INV, FIRST, 2, 4> (Circle iFFT+FFT = LDE, all passes of one prove)",
                          "algorithmic_bytes": stats["lde_algorithmic_bytes"], "kernel_ms": stats["lde_kernel_ms"]},
             "stages_ms": {k: round(stats[k], 3) for k in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")},
             "merkle": {"kernel_ms": stats["merkle_kernel_ms"], "algorithmic_bytes": stats["merkle_algorithmic_bytes"],

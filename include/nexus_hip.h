@@ -68,6 +68,9 @@ int nx_free(nx_ctx* ctx, uint32_t* d_ptr);
 int nx_memset_zero(nx_ctx* ctx, uint32_t* d_ptr, size_t n_words);
 int nx_upload(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* h_src, size_t n_words);
 int nx_download(nx_ctx* ctx, uint32_t* h_dst, const uint32_t* d_src, size_t n_words);
+/* Column::clone on device (the reference clones whole traces before committing them: prover/src/machine.rs:210-214,232;
+ * prover2/trace/src/component.rs:75).  Stream-ordered; src and dst must not overlap. */
+int nx_copy(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words);
 /* Gather scattered words: out[i] = d_ptrs[i][index[i]] (decommitment reads, MerkleProver::decommit). */
 int nx_gather(nx_ctx* ctx, const uint32_t* const* d_ptrs, const uint64_t* index, size_t n, uint32_t* h_out);
 

@@ -198,6 +198,12 @@ class HipBackend:
         self._chk(self.L.nx_ctx_set_hash_mode(self.ctx, mode))
 
     # ---- Column ops ----
+    def clone_columns(self, cols):
+        """Column::clone on device (nx_copy)."""
+        out = DeviceColumns(self, cols.n_cols, cols.log_size)
+        self._chk(self.L.nx_copy(self.ctx, out.ptr, cols.ptr, C.c_size_t(cols.n_cols << cols.log_size)))
+        return out
+
     def columns(self, n_cols, log_size):
         return DeviceColumns(self, n_cols, log_size)
 

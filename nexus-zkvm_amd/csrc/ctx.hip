@@ -2,6 +2,7 @@
 #include "internal.h"
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
 
 namespace nx {
 
@@ -131,6 +132,11 @@ int streams_join(nx_ctx* ctx, int n_streams) {
     return NX_OK;
 }
 
+// 16 bytes per lane, grid-stride: the plain streaming pattern (also the calibration kernel of tools/pmc_traffic.py)
+__global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 __global__ void gather_kernel(const uint32_t* const* ptrs, const uint64_t* index, size_t n, uint32_t* out) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = ptrs[i][index[i]];
@@ -220,6 +226,19 @@ int nx_upload(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* h_src, size_t n_word
 int nx_download(nx_ctx* ctx, uint32_t* h_dst, const uint32_t* d_src, size_t n_words) {
     NX_HIP(ctx, hipMemcpyAsync(h_dst, d_src, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NX_OK;
+}
+
+int nx_copy(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words) {
+    if (n_words == 0) return NX_OK;
+    if ((n_words & 3) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_src & 15)) {
+        NX_HIP(ctx, hipMemcpyAsync(d_dst, d_src, n_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return NX_OK;
+    }
+    size_t n4 = n_words / 4;
+    unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, (size_t)ctx->n_cus * 16);
+    hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)d_dst, (const uint4*)d_src, n4);
+    NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
 
