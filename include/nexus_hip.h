@@ -126,6 +126,21 @@ uint32_t nx_merkle_n_layers(const nx_tree* tree);
 const uint32_t* nx_merkle_layer(const nx_tree* tree, uint32_t k);
 void nx_tree_destroy(nx_tree* tree);
 
+/* Column-sharded commitment (BASELINE config #4).  A tree leaf is one sequential Blake2s chain
+ * over ALL columns of the tree (16 columns = one 64-byte block), so column shards of one tree are chained:
+ * the GPU that owns columns [col_offset, col_offset + n_cols) of a layer with total_cols columns continues the
+ * 8-word chaining state of rows [row_begin, row_begin + n_rows) received from the previous GPU (d_state_in == NULL
+ * for the shard that starts at column 0) and hands its state on; col_offset must be a multiple of 16.  The shard
+ * that holds the last column applies the hash finalisation, so its d_state_out rows are the leaf digests.
+ * d_state_in / d_state_out: n_rows x 8 words, indexed by row - row_begin (may alias).  d_cols: full columns
+ * of 2^log_size words. */
+int nx_merkle_leaf_chain(nx_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size,
+                         uint32_t col_offset, uint32_t total_cols, const uint32_t* d_state_in, uint32_t* d_state_out,
+                         uint64_t row_begin, uint64_t n_rows);
+/* MerkleProver over already hashed leaves: builds the inner layers above 2^log_size leaf digests (8 words each,
+ * copied in) — the part of a sharded commit the last GPU of the chain runs before broadcasting the root. */
+int nx_merkle_from_leaves(nx_ctx* ctx, const uint32_t* d_leaf_digests, uint32_t log_size, nx_tree** out);
+
 /* ------------------------------------------------------------- K8: QuotientOps ------------- */
 /* QuotientOps::accumulate_quotients (inside prove).  One size group: n_cols columns of
  * 2^log_size words; sample batches flattened: batch b has batch_counts[b] (column, value) pairs,

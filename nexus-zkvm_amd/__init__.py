@@ -113,7 +113,8 @@ class DeviceColumns:
 
     def free(self):
         if self.ptr and self.ptr.value:
-            self.be.L.nx_free(self.be.ctx, self.ptr)
+            if self.be.ctx:   # after HipBackend.close() the context (and every allocation it cached) is gone
+                self.be.L.nx_free(self.be.ctx, self.ptr)
             self.ptr = C.c_void_p()
 
     def __del__(self):
@@ -138,7 +139,8 @@ class Twiddles:
     def __del__(self):
         try:
             if self.h:
-                self.be.L.nx_twiddles_destroy(self.h)
+                if self.be.ctx:
+                    self.be.L.nx_twiddles_destroy(self.h)
                 self.h = None
         except Exception:
             pass
@@ -166,7 +168,8 @@ class MerkleTree:
     def __del__(self):
         try:
             if self.h:
-                self.be.L.nx_tree_destroy(self.h)
+                if self.be.ctx:
+                    self.be.L.nx_tree_destroy(self.h)
                 self.h = None
         except Exception:
             pass
@@ -275,6 +278,21 @@ class HipBackend:
         lg = _u32(logs)
         h = C.c_void_p()
         self._chk(self.L.nx_merkle_commit(self.ctx, arr, lg.ctypes.data_as(C.c_void_p), len(ptrs), C.byref(h)))
+        return MerkleTree(self, h)
+
+    def merkle_leaf_chain(self, cols, col_offset, total_cols, state_in_ptr, state_out_ptr, row_begin=0, n_rows=None):
+        """One column shard of a leaf layer (nx_merkle_leaf_chain): cols are this shard's columns (a DeviceColumns),
+        state pointers are raw device addresses (ints) of n_rows x 8 words; state_in_ptr is None for the shard at column 0."""
+        if n_rows is None:
+            n_rows = (1 << cols.log_size) - row_begin
+        self._chk(self.L.nx_merkle_leaf_chain(self.ctx, cols.col_ptrs(), cols.n_cols, cols.log_size, col_offset, total_cols,
+                                              C.c_void_p(state_in_ptr) if state_in_ptr else None, C.c_void_p(state_out_ptr),
+                                              C.c_uint64(row_begin), C.c_uint64(n_rows)))
+
+    def merkle_from_leaves(self, leaf_ptr, log_size):
+        """Inner layers above 2^log_size leaf digests at device address leaf_ptr (nx_merkle_from_leaves)."""
+        h = C.c_void_p()
+        self._chk(self.L.nx_merkle_from_leaves(self.ctx, C.c_void_p(leaf_ptr), log_size, C.byref(h)))
         return MerkleTree(self, h)
 
     # ---- QuotientOps ----

@@ -110,6 +110,57 @@ __global__ __launch_bounds__(256) void merkle_layer_kernel(ColSet cols, u32 n_co
     o[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 
+
+// One column shard of a leaf layer: continue (or start) the per-row chaining state over this shard's columns.
+// `first`: the shard starts at column 0 (state = IV); `last`: it holds the layer's last column (finalisation).
+template <int MODE>
+__global__ __launch_bounds__(256) void merkle_leaf_chain_kernel(ColSet cols, u32 n_cols, u32 col_offset, u32 total_cols,
+                                                                const u32* __restrict__ state_in, u32* __restrict__ state_out,
+                                                                u64 row_begin, u64 n_rows) {
+    const u64 r = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const u64 i = row_begin + r;
+    const bool last_shard = col_offset + n_cols == total_cols;
+    u32 h[8];
+    if (state_in) {
+        const uint4* p = reinterpret_cast<const uint4*>(state_in + r * 8);
+        uint4 a = p[0], b = p[1];
+        h[0] = a.x; h[1] = a.y; h[2] = a.z; h[3] = a.w; h[4] = b.x; h[5] = b.y; h[6] = b.z; h[7] = b.w;
+    } else if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) h[k] = B2S_IV_D[k];
+        h[0] ^= 0x01010020u;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) h[k] = 0;
+    }
+    const u32 total_bytes = 4u * total_cols;
+    u32 t = 4u * col_offset;   // bytes hashed by the previous shards
+    u32 m[16], nx_[16];
+    auto load_chunk = [&](u32 c0, u32* dst) {
+        if (c0 + 16 <= n_cols) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = cols.col(c0 + k)[i];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? cols.col(c0 + k)[i] : 0u;
+        }
+    };
+    if (n_cols) load_chunk(0, nx_);
+    for (u32 c0 = 0; c0 < n_cols; c0 += 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = nx_[k];
+        const bool last_chunk = c0 + 16 >= n_cols;
+        if (!last_chunk) load_chunk(c0 + 16, nx_);
+        const bool fin = last_chunk && last_shard;
+        if (MODE == 0) { t = fin ? total_bytes : t + 64; b2s_compress(h, m, t, fin ? 0xFFFFFFFFu : 0u); }
+        else b2s_compress(h, m, 0, 0);
+    }
+    uint4* o = reinterpret_cast<uint4*>(state_out + r * 8);
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
 // Top of the tree in ONE launch: layers `top`..0 (2^top <= 1024 nodes) when no columns are injected there.
 // `base` is the start of the tree allocation (layer k at node offset 2^k - 1).
 template <int MODE>
@@ -217,6 +268,56 @@ int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t*
         if (rc != NX_OK) break;
         const uint32_t* prev = (uint32_t)log < max_log ? t->layers[log + 1] : nullptr;
         rc = merkle_layer(ctx, cs, (uint32_t)(ci - c0), prev, t->layers[log], (uint32_t)log);
+    }
+    if (rc != NX_OK) { dev_free(ctx, buf); delete t; return rc; }
+    *out = t;
+    return NX_OK;
+}
+
+
+int nx_merkle_leaf_chain(nx_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size, uint32_t col_offset,
+                         uint32_t total_cols, const uint32_t* d_state_in, uint32_t* d_state_out, uint64_t row_begin, uint64_t n_rows) {
+    if (!ctx || !d_state_out || (n_cols && !d_cols)) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: NULL argument");
+    if (n_cols == 0 || col_offset + (uint64_t)n_cols > total_cols) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: empty shard or column range outside the layer");
+    if (col_offset % 16) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: col_offset must be a multiple of 16 (one Blake2s block)");
+    if (col_offset + n_cols != total_cols && n_cols % 16) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: an inner shard must hold a multiple of 16 columns");
+    if ((col_offset == 0) != (d_state_in == nullptr)) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: d_state_in must be NULL exactly for the shard at column 0");
+    if (log_size > 30 || row_begin + n_rows > ((uint64_t)1 << log_size)) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: row range outside the column");
+    if (n_rows == 0) return NX_OK;
+    ColSet cs; NX_TRY(make_colset(ctx, d_cols, n_cols, &cs));
+    KTimer timer(ctx, NX_T_MERKLE, n_rows * (4ull * n_cols + 64));
+    dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
+    if (ctx->hash_mode == NX_HASH_BLAKE2S)
+        hipLaunchKernelGGL(merkle_leaf_chain_kernel<0>, grid, block, 0, ctx->stream, cs, n_cols, col_offset, total_cols, d_state_in, d_state_out, row_begin, n_rows);
+    else
+        hipLaunchKernelGGL(merkle_leaf_chain_kernel<1>, grid, block, 0, ctx->stream, cs, n_cols, col_offset, total_cols, d_state_in, d_state_out, row_begin, n_rows);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+int nx_merkle_from_leaves(nx_ctx* ctx, const uint32_t* d_leaf_digests, uint32_t log_size, nx_tree** out) {
+    if (!ctx || !out || !d_leaf_digests) return set_err(ctx, NX_ERR_ARG, "nx_merkle_from_leaves: NULL argument");
+    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_merkle_from_leaves: layer too large");
+    nx_tree* t = new nx_tree();
+    t->ctx = ctx;
+    uint32_t* buf = nullptr;
+    size_t total_nodes = ((size_t)2 << log_size) - 1;
+    { int rc0 = dev_alloc(ctx, total_nodes * 32, (void**)&buf); if (rc0 != NX_OK) { delete t; return rc0; } }
+    t->layers.resize(log_size + 1);
+    for (uint32_t k = 0; k <= log_size; k++) t->layers[k] = buf + (((size_t)1 << k) - 1) * 8;
+    int rc = nx_copy(ctx, t->layers[log_size], d_leaf_digests, (size_t)8 << log_size);
+    KTimer timer(ctx, NX_T_MERKLE, (uint64_t)96 << log_size);
+    const int top_fused = std::min(10, (int)log_size - 1);
+    ColSet none; none.base = nullptr; none.stride = 0; none.table = nullptr;
+    for (int log = (int)log_size - 1; log >= 0 && rc == NX_OK; log--) {
+        if (log == top_fused && log >= 1) {
+            if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_top_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
+            else hipLaunchKernelGGL(merkle_top_kernel<1>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) rc = hip_fail(ctx, le, "merkle_top_kernel", __FILE__, __LINE__);
+            break;
+        }
+        rc = merkle_layer(ctx, none, 0, t->layers[log + 1], t->layers[log], (uint32_t)log);
     }
     if (rc != NX_OK) { dev_free(ctx, buf); delete t; return rc; }
     *out = t;

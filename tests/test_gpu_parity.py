@@ -318,3 +318,35 @@ def test_large_prove_accepted_by_oracle_verifier(be, nz, oracle):
     w2[len(w) // 2] ^= 4
     assert oracle.verify_synth(comps, ocfg, w2) is not None
     assert stats["total"] > 0 and stats["lde_kernel_ms"] > 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sharded_leaf_chain_equals_single_commit(be, mode):
+    """SURVEY §8(e) / config #4 building blocks on one GPU: the columns of a tree are cut into 16-aligned shards (as
+    nexus_zkvm_amd.sharded.plan_column_shards would for 3 ranks), each shard continues the chaining state of the
+    previous one over row chunks, the last one finalises; leaves and root must equal nx_merkle_commit of all columns."""
+    from nexus_zkvm_amd.sharded import plan_column_shards
+    be.set_hash_mode(mode)
+    try:
+        for n_cols, log in ((40, 9), (33, 7), (16, 6), (347, 8)):
+            vals = rand_cols(n_cols * 7 + log, n_cols, log)
+            full = be.columns_from_host(vals)
+            tree = be.merkle_commit([full])
+            shards = [s for s in plan_column_shards(n_cols, 3) if s[1] > s[0]]
+            n_rows = 1 << log
+            state = be.columns(8, log)            # n_rows x 8 words
+            bounds = [0, n_rows // 3, n_rows]
+            for si, (lo, hi) in enumerate(shards):
+                part = be.columns_from_host(vals[lo:hi])
+                for rb, re in zip(bounds, bounds[1:]):
+                    sp = state.ptr.value + rb * 32
+                    be.merkle_leaf_chain(part, lo, n_cols, sp if si else None, sp, rb, re - rb)
+            be.sync()
+            leaves = state.to_cpu().reshape(-1, 8)
+            assert np.array_equal(leaves, tree.layer(log)), (mode, n_cols, log)
+            t2 = be.merkle_from_leaves(state.ptr.value, log)
+            assert np.array_equal(t2.root(), tree.root())
+            for k in range(log):
+                assert np.array_equal(t2.layer(k), tree.layer(k))
+    finally:
+        be.set_hash_mode(0)
