@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnexus_hip.so")
+LIB_PATH = os.environ.get("NX_LIB") or os.path.join(_HERE, "libnexus_hip.so")   # NX_LIB: A/B builds for tools/ only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nexus_hip.h")
 
 P = (1 << 31) - 1

@@ -25,6 +25,8 @@ int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out) {
     if (ctx->scratch_off + need > ctx->scratch_size) {
         // wrap: make sure every earlier consumer of the ring has finished
         NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream));
+        for (int i = 0; i < 3; i++) NX_HIP(ctx, hipStreamSynchronize(ctx->side[i]));
         ctx->scratch_off = 0;
     }
     memcpy(ctx->h_scratch + ctx->scratch_off, h_src, bytes);
@@ -89,17 +91,18 @@ static hipEvent_t get_event(nx_ctx* ctx) {
     if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-KTimer::KTimer(nx_ctx* c, int kind, uint64_t bytes) : ctx(c), idx(-1) {
+KTimer::KTimer(nx_ctx* c, int kind, uint64_t bytes, hipStream_t on_stream) : ctx(c), idx(-1), stream(on_stream ? on_stream : c->stream) {
     if (!c->timing) return;
     nx_ctx::Span s; s.e0 = get_event(c); s.e1 = get_event(c); s.kind = kind;
-    (void)hipEventRecord(s.e0, c->stream);
+    (void)hipEventRecord(s.e0, stream);
     c->kind_bytes[kind] += bytes;
     idx = (int)c->spans.size();
     c->spans.push_back(s);
 }
-KTimer::~KTimer() { if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].e1, ctx->stream); }
+KTimer::~KTimer() { if (idx >= 0) (void)hipEventRecord(ctx->spans[idx].e1, stream); }
 void timing_flush(nx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->hash_stream);
     for (auto& s : ctx->spans) {
         float ms = 0; (void)hipEventElapsedTime(&ms, s.e0, s.e1);
         ctx->kind_ms[s.kind] += ms;
@@ -170,6 +173,8 @@ int nx_ctx_create(int device, nx_ctx** out) {
     for (int i = 0; i < 4; i++) { c->kind_ms[i] = 0; c->kind_bytes[i] = 0; }
     NX_HIP(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->cur = c->stream;
+    NX_HIP(nullptr, hipStreamCreateWithFlags(&c->hash_stream, hipStreamNonBlocking));
+    NX_HIP(nullptr, hipEventCreateWithFlags(&c->hash_ev, hipEventDisableTiming));
     NX_HIP(nullptr, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     for (int i = 0; i < 3; i++) {
         NX_HIP(nullptr, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
@@ -193,6 +198,7 @@ void nx_ctx_destroy(nx_ctx* ctx) {
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
     for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(ctx->side[i]); (void)hipEventDestroy(ctx->join_ev[i]); }
     (void)hipEventDestroy(ctx->fork_ev);
+    (void)hipStreamDestroy(ctx->hash_stream); (void)hipEventDestroy(ctx->hash_ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -203,7 +209,7 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode) {
     return NX_OK;
 }
 
-int nx_sync(nx_ctx* ctx) { NX_HIP(ctx, hipStreamSynchronize(ctx->stream)); return NX_OK; }
+int nx_sync(nx_ctx* ctx) { NX_HIP(ctx, hipStreamSynchronize(ctx->stream)); NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream)); return NX_OK; }
 void* nx_ctx_stream(nx_ctx* ctx) { return (void*)ctx->stream; }
 
 int nx_alloc(nx_ctx* ctx, size_t n_words, uint32_t** d_out) {

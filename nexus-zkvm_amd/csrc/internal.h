@@ -17,6 +17,8 @@ struct nx_ctx {
     hipStream_t side[3];
     hipEvent_t fork_ev, join_ev[3];
     hipStream_t cur;   // stream the FFT launchers enqueue on (== stream outside a forked region)
+    hipStream_t hash_stream;   // leaf hashing of finished column groups runs here, next to the LDE of the next group
+    hipEvent_t hash_ev;
     int hash_mode;
     int n_cus;       // compute units of the device
     std::string err;
@@ -90,8 +92,8 @@ void dev_cache_release(nx_ctx* ctx);
 
 // Event-pair span on ctx->stream, recorded only when ctx->timing is on; resolved by timing_flush.
 struct KTimer {
-    nx_ctx* ctx; int idx;
-    KTimer(nx_ctx* c, int kind, uint64_t algorithmic_bytes);
+    nx_ctx* ctx; int idx; hipStream_t stream;
+    KTimer(nx_ctx* c, int kind, uint64_t algorithmic_bytes, hipStream_t on_stream = nullptr);
     ~KTimer();
 };
 void timing_flush(nx_ctx* ctx);  // synchronises the stream and folds spans into kind_ms[]
@@ -101,6 +103,20 @@ void timing_reset(nx_ctx* ctx);
 int fft_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size);
 int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_cols, uint32_t log_size,
                  uint32_t log_expand, ColSet out);
+
+// Pipelined tree build (merkle.hip): the leaf layer is a per-row Blake2s chain over the largest columns in commit order,
+// so finished column groups can be absorbed (on ctx->hash_stream) while the main stream already transforms the next group.
+struct TreePipe {
+    nx_tree* tree = nullptr;
+    uint32_t max_log = 0, total_leaf_cols = 0, absorbed = 0;
+    std::vector<const uint32_t*> pending;   // columns handed in but not yet hashed (kept until a 16-column block is complete)
+    bool any_launch = false;
+};
+int tree_pipe_begin(nx_ctx* ctx, uint32_t max_log, uint32_t total_leaf_cols, TreePipe* tp);
+int tree_pipe_absorb(nx_ctx* ctx, TreePipe* tp, const uint32_t* const* d_cols, uint32_t n_cols, bool flush);
+// smaller columns (log < max_log) in commit order with their sizes; hands the finished tree to *out
+int tree_pipe_finish(nx_ctx* ctx, TreePipe* tp, const uint32_t* const* d_small_cols, const uint32_t* small_logs, uint32_t n_small, nx_tree** out);
+int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size, uint32_t log_expand, ColSet out);
 
 // fork/join of the side streams around a loop over independent column batches
 int streams_fork(nx_ctx* ctx, int n_streams);

@@ -21,6 +21,8 @@ __device__ __constant__ const u32 B2S_IV_D[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6
 
 __device__ __forceinline__ u32 rotr(u32 x, int r) { return __builtin_amdgcn_alignbit(x, x, r); }
 
+// a + b + x stays one v_add3_u32: splitting it into two v_add_u32 wins 7 % in a register-only loop
+// (tools/ubench/b2s_rates.hip) but loses 14 % in the real leaf kernel (A/B on the same box, 2.31 vs 2.67 ms / 128 columns).
 #define B2S_G(a, b, c, d, x, y)                         \
     a = a + b + (x); d = rotr(d ^ a, 16);               \
     c = c + d;       b = rotr(b ^ c, 12);               \
@@ -208,6 +210,98 @@ __global__ void grind_kernel(const u32* __restrict__ digest, u32 pow_bits, u64 b
     if (tz >= pow_bits) atomicMin(result, (unsigned long long)nonce);
 }
 
+int merkle_layer(nx_ctx* ctx, ColSet cols, u32 n_cols, const u32* prev, u32* out, u32 log);
+
+int leaf_chain_launch(nx_ctx* ctx, hipStream_t stream, ColSet cs, u32 n_cols, u32 col_offset, u32 total_cols, const u32* state_in, u32* state_out,
+                      u64 row_begin, u64 n_rows) {
+    KTimer timer(ctx, NX_T_MERKLE, n_rows * (4ull * n_cols + 64), stream);
+    dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
+    if (ctx->hash_mode == NX_HASH_BLAKE2S)
+        hipLaunchKernelGGL(merkle_leaf_chain_kernel<0>, grid, block, 0, stream, cs, n_cols, col_offset, total_cols, state_in, state_out, row_begin, n_rows);
+    else
+        hipLaunchKernelGGL(merkle_leaf_chain_kernel<1>, grid, block, 0, stream, cs, n_cols, col_offset, total_cols, state_in, state_out, row_begin, n_rows);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+// inner layers [max_log-1 .. 0] above an already hashed layer max_log; `sorted`/`logs`: the smaller columns, size-descending
+static int build_inner_layers(nx_ctx* ctx, nx_tree* t, uint32_t max_log, const std::vector<const uint32_t*>& sorted, const std::vector<uint32_t>& logs) {
+    uint32_t* buf = t->layers[0];
+    size_t ci = 0;
+    const size_t n = sorted.size();
+    int smallest_col_log = n ? (int)logs[n - 1] : (int)max_log;
+    int top_fused = std::min(10, std::min((int)max_log - 1, smallest_col_log - 1));
+    for (int log = (int)max_log - 1; log >= 0; log--) {
+        if (log == top_fused && log >= 1) {
+            if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_top_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
+            else hipLaunchKernelGGL(merkle_top_kernel<1>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
+            NX_LAUNCH_CHECK(ctx);
+            break;
+        }
+        size_t c0 = ci;
+        while (ci < n && logs[ci] == (uint32_t)log) ci++;
+        ColSet cs;
+        NX_TRY(make_colset(ctx, (const uint32_t* const*)(sorted.data() + c0), (uint32_t)(ci - c0), &cs));
+        NX_TRY(merkle_layer(ctx, cs, (uint32_t)(ci - c0), t->layers[log + 1], t->layers[log], (uint32_t)log));
+    }
+    return NX_OK;
+}
+
+int tree_pipe_begin(nx_ctx* ctx, uint32_t max_log, uint32_t total_leaf_cols, TreePipe* tp) {
+    if (max_log > 30 || total_leaf_cols == 0) return set_err(ctx, NX_ERR_ARG, "tree_pipe_begin: bad shape");
+    nx_tree* t = new nx_tree();
+    t->ctx = ctx;
+    uint32_t* buf = nullptr;
+    size_t total_nodes = ((size_t)2 << max_log) - 1;
+    { int rc0 = dev_alloc(ctx, total_nodes * 32, (void**)&buf); if (rc0 != NX_OK) { delete t; return rc0; } }
+    t->layers.resize(max_log + 1);
+    for (uint32_t k = 0; k <= max_log; k++) t->layers[k] = buf + (((size_t)1 << k) - 1) * 8;
+    tp->tree = t; tp->max_log = max_log; tp->total_leaf_cols = total_leaf_cols; tp->absorbed = 0; tp->pending.clear(); tp->any_launch = false;
+    return NX_OK;
+}
+
+// Hash every complete 16-column block handed in so far (all of them when `flush`): ordered after the work already on the
+// main stream (the LDE that produced the columns), executed on the hash stream.
+int tree_pipe_absorb(nx_ctx* ctx, TreePipe* tp, const uint32_t* const* d_cols, uint32_t n_cols, bool flush) {
+    for (uint32_t i = 0; i < n_cols; i++) tp->pending.push_back(d_cols[i]);
+    if (tp->absorbed + tp->pending.size() > tp->total_leaf_cols) return set_err(ctx, NX_ERR_ARG, "tree_pipe_absorb: more columns than announced");
+    const bool is_end = tp->absorbed + tp->pending.size() == tp->total_leaf_cols;
+    size_t take = (flush || is_end) && is_end ? tp->pending.size() : (tp->pending.size() / 16) * 16;
+    if (take == 0) return NX_OK;
+    ColSet cs; NX_TRY(make_colset(ctx, tp->pending.data(), (uint32_t)take, &cs));   // pointer table staged on the main stream
+    NX_HIP(ctx, hipEventRecord(ctx->hash_ev, ctx->stream));
+    NX_HIP(ctx, hipStreamWaitEvent(ctx->hash_stream, ctx->hash_ev, 0));
+    u32* leaves = tp->tree->layers[tp->max_log];
+    NX_TRY(leaf_chain_launch(ctx, ctx->hash_stream, cs, (u32)take, tp->absorbed, tp->total_leaf_cols, tp->absorbed ? leaves : nullptr, leaves, 0,
+                             (u64)1 << tp->max_log));
+    tp->absorbed += (uint32_t)take;
+    tp->pending.erase(tp->pending.begin(), tp->pending.begin() + take);
+    tp->any_launch = true;
+    return NX_OK;
+}
+
+int tree_pipe_finish(nx_ctx* ctx, TreePipe* tp, const uint32_t* const* d_small_cols, const uint32_t* small_logs, uint32_t n_small, nx_tree** out) {
+    int rc = tree_pipe_absorb(ctx, tp, nullptr, 0, true);
+    if (rc == NX_OK && tp->absorbed != tp->total_leaf_cols) rc = set_err(ctx, NX_ERR_ARG, "tree_pipe_finish: fewer leaf columns than announced");
+    if (rc == NX_OK) {
+        hipError_t e = hipEventRecord(ctx->hash_ev, ctx->hash_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->hash_ev, 0);
+        if (e != hipSuccess) rc = hip_fail(ctx, e, "tree_pipe_finish", __FILE__, __LINE__);
+    }
+    if (rc == NX_OK) {
+        std::vector<uint32_t> order(n_small);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return small_logs[a] > small_logs[b]; });
+        std::vector<const uint32_t*> sorted(n_small); std::vector<uint32_t> logs(n_small);
+        for (uint32_t i = 0; i < n_small; i++) { sorted[i] = d_small_cols[order[i]]; logs[i] = small_logs[order[i]]; }
+        KTimer timer(ctx, NX_T_MERKLE, (uint64_t)96 << tp->max_log);
+        rc = build_inner_layers(ctx, tp->tree, tp->max_log, sorted, logs);
+    }
+    if (rc != NX_OK) { (void)hipStreamSynchronize(ctx->hash_stream); nx_tree_destroy(tp->tree); tp->tree = nullptr; return rc; }
+    *out = tp->tree; tp->tree = nullptr;
+    return NX_OK;
+}
+
 int merkle_layer(nx_ctx* ctx, ColSet cols, u32 n_cols, const u32* prev, u32* out, u32 log) {
     u32 n = 1u << log;
     dim3 grid((n + 255) / 256), block(256);
@@ -285,14 +379,7 @@ int nx_merkle_leaf_chain(nx_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_
     if (log_size > 30 || row_begin + n_rows > ((uint64_t)1 << log_size)) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: row range outside the column");
     if (n_rows == 0) return NX_OK;
     ColSet cs; NX_TRY(make_colset(ctx, d_cols, n_cols, &cs));
-    KTimer timer(ctx, NX_T_MERKLE, n_rows * (4ull * n_cols + 64));
-    dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
-    if (ctx->hash_mode == NX_HASH_BLAKE2S)
-        hipLaunchKernelGGL(merkle_leaf_chain_kernel<0>, grid, block, 0, ctx->stream, cs, n_cols, col_offset, total_cols, d_state_in, d_state_out, row_begin, n_rows);
-    else
-        hipLaunchKernelGGL(merkle_leaf_chain_kernel<1>, grid, block, 0, ctx->stream, cs, n_cols, col_offset, total_cols, d_state_in, d_state_out, row_begin, n_rows);
-    NX_LAUNCH_CHECK(ctx);
-    return NX_OK;
+    return leaf_chain_launch(ctx, ctx->stream, cs, n_cols, col_offset, total_cols, d_state_in, d_state_out, row_begin, n_rows);
 }
 
 int nx_merkle_from_leaves(nx_ctx* ctx, const uint32_t* d_leaf_digests, uint32_t log_size, nx_tree** out) {

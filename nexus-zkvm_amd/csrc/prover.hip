@@ -130,25 +130,51 @@ static std::vector<uint32_t*> col_ptrs(uint32_t* base, uint32_t n, uint32_t log)
     return v;
 }
 
+// TreeBuilder::commit = CommitmentTreeProver::new (LDE of every polynomial) + MerkleProver::commit.  The leaf layer is one
+// Blake2s chain per row over the largest columns in commit order, so it is built incrementally: as soon as a group of
+// columns is extended, its 16-column blocks are absorbed on the hash stream while the main stream already extends the next
+// group (tree_pipe_* in merkle.hip).  Hashing is VALU-bound, the Circle FFT mostly waits on memory: they overlap well.
+static uint32_t pipe_group_cols() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("NX_PIPE_COLS"); v = e ? atoi(e) : 0; if (v < 16) v = 1 << 30; v = (v / 16) * 16; }
+    return (uint32_t)v;
+}
+
 int TreeBuilder::commit(Blake2sChannel& channel) {
     nx_ctx* ctx = cs.ctx;
     CommitmentTreeProver t;
+    uint32_t max_el = 0, total_leaf_cols = 0;
+    for (auto& g : groups) if (g.n_cols) max_el = std::max(max_el, g.log + cs.cfg.log_blowup);
+    for (auto& g : groups) if (g.n_cols && g.log + cs.cfg.log_blowup == max_el) total_leaf_cols += g.n_cols;
+    TreePipe tp;
+    struct PipeGuard { nx_ctx* c; TreePipe* p; ~PipeGuard() { if (p->tree) { (void)nx_sync(c); nx_tree_destroy(p->tree); p->tree = nullptr; } } } guard{ctx, &tp};
+    if (total_leaf_cols) H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp));
+    std::vector<const uint32_t*> small_cols; std::vector<uint32_t> small_logs;
+    const uint32_t G = pipe_group_cols();
     for (auto& g : groups) {
         uint32_t el = g.log + cs.cfg.log_blowup;
         DevBuf lde;
         if (g.n_cols) {
             H_TRY(lde.alloc(ctx, (size_t)g.n_cols << el));
             auto in = col_ptrs(g.slab.p, g.n_cols, g.log), out = col_ptrs(lde.p, g.n_cols, el);
-            if (g.is_evals) H_TRY(nx_lde_batch(ctx, cs.tw, in.data(), g.n_cols, g.log, cs.cfg.log_blowup, out.data()));   // K3 + K4
-            else H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)in.data(), g.n_cols, g.log, cs.cfg.log_blowup, out.data()));  // K4
-            for (uint32_t i = 0; i < g.n_cols; i++) { t.polys.push_back({in[i], g.log}); t.evals.push_back({out[i], el}); }
+            const bool leaf = el == max_el;
+            const uint32_t step = leaf ? G : g.n_cols;
+            for (uint32_t c0 = 0; c0 < g.n_cols; c0 += step) {
+                const uint32_t nb = std::min(step, g.n_cols - c0);
+                if (g.is_evals) H_TRY(nx_lde_batch(ctx, cs.tw, in.data() + c0, nb, g.log, cs.cfg.log_blowup, out.data() + c0));   // K3 + K4
+                else H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)in.data() + c0, nb, g.log, cs.cfg.log_blowup, out.data() + c0));  // K4
+                if (leaf) H_TRY(tree_pipe_absorb(ctx, &tp, (const uint32_t* const*)out.data() + c0, nb, false));                   // K5, leaf layer
+            }
+            for (uint32_t i = 0; i < g.n_cols; i++) {
+                t.polys.push_back({in[i], g.log}); t.evals.push_back({out[i], el});
+                if (!leaf) { small_cols.push_back(out[i]); small_logs.push_back(el); }
+            }
         }
         t.bufs.push_back(std::move(g.slab));
         t.bufs.push_back(std::move(lde));
     }
-    std::vector<const uint32_t*> cp; std::vector<uint32_t> logs;
-    for (auto& e : t.evals) { cp.push_back(e.ptr); logs.push_back(e.log); }
-    H_TRY(nx_merkle_commit(ctx, cp.data(), logs.data(), (uint32_t)cp.size(), &t.merkle));   // K5
+    if (total_leaf_cols) H_TRY(tree_pipe_finish(ctx, &tp, small_cols.data(), small_logs.data(), (uint32_t)small_cols.size(), &t.merkle));   // K5, inner layers
+    else H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &t.merkle));
     H_TRY(nx_merkle_root(ctx, t.merkle, (uint8_t*)t.root.w));
     channel.mix_root(t.root);                                                                // K6
     cs.trees.push_back(std::move(t));
