@@ -32,6 +32,7 @@ struct Pass13 {
     int lo, K, B;    // layers [lo, lo+K), K + B == 13
     u32 scale;       // inverse passes: multiply the outputs by this (0 = none)
     u32 n_cols, n_groups, tiles;
+    u32 rep_log;     // log2 of the replica count of this pass's source tiles (LDE top pass), else 0
 };
 
 template <int CB> struct alignas(4 * CB) Row { u32 c[CB]; };
@@ -195,8 +196,14 @@ __global__ __launch_bounds__(T13_ROWS >> RB) void fft13_kernel(Pass13 a) {
     u32 tile, grp;
     {
         const u32 b = blockIdx.x;
-        if (a.tiles >= 8) { const u32 xcd = b & 7, y = b >> 3; grp = y % a.n_groups; tile = xcd * (a.tiles >> 3) + y / a.n_groups; }
-        else { grp = b % a.n_groups; tile = b / a.n_groups; }
+        const u32 src_tiles = a.tiles >> a.rep_log;
+        if (src_tiles >= 8) {
+            // XCD x owns source tiles [x, x+1) * src_tiles/8; the replicas of a source tile and its column groups run back to
+            // back on that XCD, so the tile's coefficients and twiddles are fetched into one L2 once
+            const u32 xcd = b & 7, y = b >> 3, idx = y / a.n_groups;
+            grp = y % a.n_groups;
+            tile = ((idx & ((1u << a.rep_log) - 1)) * src_tiles) + xcd * (src_tiles >> 3) + (idx >> a.rep_log);
+        } else { grp = b % a.n_groups; tile = b / a.n_groups; }
     }
     const u32* __restrict__ s[CB];
     u32* __restrict__ d[CB];
@@ -404,7 +411,7 @@ int fft13_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_col
     for (size_t i = 0; i < plan.size(); i++) {
         Pass13 a; a.src = cols; a.dst = cols; a.tw = tw->d_itw; a.tw_log = tw->log_half; a.n = n; a.log_in = n;
         a.lo = plan[i].lo; a.K = plan[i].K; a.B = plan[i].B; a.scale = i + 1 == plan.size() ? m_inv(1u << n) : 0;
-        a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S);
+        a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S); a.rep_log = 0;
         NX_TRY(launch13(ctx, true, i == 0, a));
     }
     return NX_OK;
@@ -417,7 +424,7 @@ int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n_cols,
         const bool top = k + 1 == plan.size();
         Pass13 a; a.src = top ? polys : out; a.dst = out; a.tw = tw->d_tw; a.tw_log = tw->log_half; a.n = n; a.log_in = top ? log_in : n;
         a.lo = plan[k].lo; a.K = plan[k].K; a.B = plan[k].B; a.scale = 0;
-        a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S);
+        a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S); a.rep_log = top ? (u32)(n - log_in) : 0;
         NX_TRY(launch13(ctx, false, k == 0, a));
     }
     return NX_OK;

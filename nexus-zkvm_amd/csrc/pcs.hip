@@ -91,6 +91,17 @@ __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, con
         u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
         const u32 end = B.first + B.count;
         u32 k = B.first;
+        for (; k + 8 <= end; k += 8) {   // 8 column reads in flight per lane
+            u32 f[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) f[u] = cols.col(col_idx[k + u])[r];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                n0 = acc_mad(n0, cks[4 * (k + u)], f[u]); n1 = acc_mad(n1, cks[4 * (k + u) + 1], f[u]);
+                n2 = acc_mad(n2, cks[4 * (k + u) + 2], f[u]); n3 = acc_mad(n3, cks[4 * (k + u) + 3], f[u]);
+                if ((u & 3) == 3) { n0 = acc_fold(n0); n1 = acc_fold(n1); n2 = acc_fold(n2); n3 = acc_fold(n3); }
+            }
+        }
         for (; k + 4 <= end; k += 4) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {

@@ -40,12 +40,20 @@ struct PcsConfig { uint32_t pow_bits, log_blowup, n_queries, log_last_layer_degr
 struct MerkleDecommitment { std::vector<Blake2sHash> hash_witness; std::vector<uint32_t> column_witness; };
 
 // ---------------------------------------------------------------- MerkleProver::decommit ------
-// The walk depends only on the query positions and the layer structure, so it first records which
-// words are needed, fetches them with ONE gather (nx_gather) and then distributes them.
-static int merkle_decommit(nx_ctx* ctx, const nx_tree* tree, const std::map<uint32_t, std::vector<size_t>>& queries_per_log,
-                           std::vector<ColumnRef> cols, std::vector<uint32_t>* queried_values, MerkleDecommitment* d) {
+// Every word a decommitment needs depends only on the query positions and the layer structure, so all decommitments of a
+// proof (4 trees + every FRI layer + the FRI witness values) first record their reads in one GatherBatch, ONE nx_gather
+// fetches them (one kernel, one device->host copy, one synchronisation), then each plan picks its words up.
+struct GatherBatch {
+    std::vector<const uint32_t*> ptrs; std::vector<uint64_t> idx; std::vector<uint32_t> vals;
+    size_t add(const uint32_t* p, uint64_t i) { ptrs.push_back(p); idx.push_back(i); return ptrs.size() - 1; }
+    int run(nx_ctx* ctx) { vals.resize(ptrs.size()); return nx_gather(ctx, ptrs.data(), idx.data(), ptrs.size(), vals.data()); }
+};
+struct DecommitPlan { size_t first = 0; std::vector<uint8_t> kind; };  // kind: 0 hash word, 1 queried value, 2 column witness
+
+static DecommitPlan merkle_decommit_plan(const nx_tree* tree, const std::map<uint32_t, std::vector<size_t>>& queries_per_log, std::vector<ColumnRef> cols,
+                                         GatherBatch* gb) {
     std::stable_sort(cols.begin(), cols.end(), [](const ColumnRef& a, const ColumnRef& b) { return a.log > b.log; });
-    std::vector<const uint32_t*> ptrs; std::vector<uint64_t> idx; std::vector<uint8_t> kind;  // 0 hash word, 1 queried, 2 column witness
+    DecommitPlan plan; plan.first = gb->ptrs.size();
     size_t ci = 0;
     std::vector<size_t> last;
     uint32_t n_layers = nx_merkle_n_layers(tree);
@@ -66,25 +74,26 @@ static int merkle_decommit(nx_ctx* ctx, const nx_tree* tree, const std::map<uint
             if (prev) {
                 for (size_t child = 2 * node; child <= 2 * node + 1; child++) {
                     if (pi < last.size() && last[pi] == child) { pi++; continue; }
-                    for (int w = 0; w < 8; w++) { ptrs.push_back(prev); idx.push_back(child * 8 + w); kind.push_back(0); }
+                    for (int w = 0; w < 8; w++) { gb->add(prev, child * 8 + w); plan.kind.push_back(0); }
                 }
             }
             uint8_t k = 2;
             if (qi < lq.size() && lq[qi] == node) { qi++; k = 1; }
-            for (auto c : lc) { ptrs.push_back(c); idx.push_back(node); kind.push_back(k); }
+            for (auto c : lc) { gb->add(c, node); plan.kind.push_back(k); }
             total.push_back(node);
         }
         last.swap(total);
     }
-    std::vector<uint32_t> vals(ptrs.size());
-    H_TRY(nx_gather(ctx, ptrs.data(), idx.data(), ptrs.size(), vals.data()));
+    return plan;
+}
+static void merkle_decommit_fill(const DecommitPlan& plan, const GatherBatch& gb, std::vector<uint32_t>* queried_values, MerkleDecommitment* d) {
     Blake2sHash cur; int hw = 0;
-    for (size_t i = 0; i < vals.size(); i++) {
-        if (kind[i] == 0) { cur.w[hw++] = vals[i]; if (hw == 8) { d->hash_witness.push_back(cur); hw = 0; } }
-        else if (kind[i] == 1) { if (queried_values) queried_values->push_back(vals[i]); }
-        else d->column_witness.push_back(vals[i]);
+    for (size_t i = 0; i < plan.kind.size(); i++) {
+        const uint32_t v = gb.vals[plan.first + i];
+        if (plan.kind[i] == 0) { cur.w[hw++] = v; if (hw == 8) { d->hash_witness.push_back(cur); hw = 0; } }
+        else if (plan.kind[i] == 1) { if (queried_values) queried_values->push_back(v); }
+        else d->column_witness.push_back(v);
     }
-    return NX_OK;
 }
 
 // ---------------------------------------------------------------- commitment scheme ----------
@@ -306,57 +315,73 @@ class FriProver {
             i = j;
         }
     }
-    int gather_secure(const SecureColumn& col, const std::vector<size_t>& pos, std::vector<QM31>* out) {
-        std::vector<const uint32_t*> p; std::vector<uint64_t> idx;
-        for (size_t q : pos) for (int k = 0; k < 4; k++) { p.push_back(col.c[k]); idx.push_back(q); }
-        std::vector<uint32_t> v(p.size());
-        H_TRY(nx_gather(ctx, p.data(), idx.data(), p.size(), v.data()));
-        for (size_t i = 0; i < pos.size(); i++) out->push_back(qm(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]));
-        return NX_OK;
+    struct SecurePlan { size_t first, count; };
+    static SecurePlan plan_secure(const SecureColumn& col, const std::vector<size_t>& pos, GatherBatch* gb) {
+        SecurePlan p{gb->ptrs.size(), pos.size()};
+        for (size_t q : pos) for (int k = 0; k < 4; k++) gb->add(col.c[k], q);
+        return p;
+    }
+    static void fill_secure(const SecurePlan& p, const GatherBatch& gb, std::vector<QM31>* out) {
+        for (size_t i = 0; i < p.count; i++) { const uint32_t* v = &gb.vals[p.first + 4 * i]; out->push_back(qm(v[0], v[1], v[2], v[3])); }
     }
 
-    // FriProver::decommit
-    int decommit(Blake2sChannel& channel, Proof* proof, std::map<uint32_t, std::vector<size_t>>* query_positions_per_log) {
+    // Queries::generate + the folded positions per column size (FriProver::decommit, first half)
+    std::vector<size_t> queries;
+    void draw_queries(Blake2sChannel& channel, std::map<uint32_t, std::vector<size_t>>* query_positions_per_log) {
         uint32_t max_log = columns[0].log;
-        // Queries::generate
-        std::vector<size_t> queries;
-        {
-            std::set<size_t> q; uint32_t cnt = 0; size_t mask = ((size_t)1 << max_log) - 1; bool done = false;
-            while (!done) {
-                uint32_t w[8]; channel.draw_u32s(w);
-                for (int i = 0; i < 8 && !done; i++) { q.insert((size_t)w[i] & mask); if (++cnt == cfg.n_queries) done = true; }
-            }
-            queries.assign(q.begin(), q.end());
+        std::set<size_t> q; uint32_t cnt = 0; size_t mask = ((size_t)1 << max_log) - 1; bool done = false;
+        while (!done) {
+            uint32_t w[8]; channel.draw_u32s(w);
+            for (int i = 0; i < 8 && !done; i++) { q.insert((size_t)w[i] & mask); if (++cnt == cfg.n_queries) done = true; }
         }
+        queries.assign(q.begin(), q.end());
         for (auto& c : columns) (*query_positions_per_log)[c.log] = queries_fold(queries, max_log - c.log);
+    }
+
+    // FriProver::decommit in two steps around the proof-wide gather: plan (records every read) ... fill
+    struct LayerPlan { std::vector<SecurePlan> witness; DecommitPlan merkle; };
+    std::vector<LayerPlan> plans;   // [0] first layer, then the inner layers
+    void decommit_plan(GatherBatch* gb) {
+        uint32_t max_log = columns[0].log;
         {   // first layer
+            LayerPlan lp;
             std::map<uint32_t, std::vector<size_t>> pos_by_log;
             std::vector<ColumnRef> refs;
             for (auto& c : columns) {
                 std::vector<size_t> pos, wpos;
                 decommit_positions(queries_fold(queries, max_log - c.log), &pos, &wpos);
-                H_TRY(gather_secure(c, wpos, &proof->first_layer.fri_witness));
+                lp.witness.push_back(plan_secure(c, wpos, gb));
                 pos_by_log[c.log] = pos;
                 for (int k = 0; k < 4; k++) refs.push_back({c.c[k], c.log});
             }
-            H_TRY(merkle_decommit(ctx, first_merkle, pos_by_log, refs, nullptr, &proof->first_layer.decommitment));
-            proof->first_layer.commitment = first_root;
+            lp.merkle = merkle_decommit_plan(first_merkle, pos_by_log, refs, gb);
+            plans.push_back(std::move(lp));
         }
         std::vector<size_t> lq = queries_fold(queries, 1);
         for (auto& L : inner) {
-            FriLayerProof lp;
+            LayerPlan lp;
             std::vector<size_t> pos, wpos;
             decommit_positions(lq, &pos, &wpos);
-            H_TRY(gather_secure(L.eval, wpos, &lp.fri_witness));
+            lp.witness.push_back(plan_secure(L.eval, wpos, gb));
             std::map<uint32_t, std::vector<size_t>> pos_by_log; pos_by_log[L.eval.log] = pos;
             std::vector<ColumnRef> refs; for (int k = 0; k < 4; k++) refs.push_back({L.eval.c[k], L.eval.log});
-            H_TRY(merkle_decommit(ctx, L.merkle, pos_by_log, refs, nullptr, &lp.decommitment));
-            lp.commitment = L.root;
-            proof->inner_layers.push_back(std::move(lp));
+            lp.merkle = merkle_decommit_plan(L.merkle, pos_by_log, refs, gb);
+            plans.push_back(std::move(lp));
             lq = queries_fold(lq, 1);
         }
+    }
+    void decommit_fill(const GatherBatch& gb, Proof* proof) {
+        for (auto& w : plans[0].witness) fill_secure(w, gb, &proof->first_layer.fri_witness);
+        merkle_decommit_fill(plans[0].merkle, gb, nullptr, &proof->first_layer.decommitment);
+        proof->first_layer.commitment = first_root;
+        for (size_t i = 0; i < inner.size(); i++) {
+            FriLayerProof lp;
+            for (auto& w : plans[i + 1].witness) fill_secure(w, gb, &lp.fri_witness);
+            merkle_decommit_fill(plans[i + 1].merkle, gb, nullptr, &lp.decommitment);
+            lp.commitment = inner[i].root;
+            proof->inner_layers.push_back(std::move(lp));
+        }
         proof->last_layer_poly = last_layer_poly;
-        return NX_OK;
     }
 };
 
@@ -637,10 +662,16 @@ static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_c
     channel.mix_u64(proof.proof_of_work);
     lap(&st->pow);
     std::map<uint32_t, std::vector<size_t>> qpos;
-    H_TRY(fri.decommit(channel, &proof, &qpos));
+    fri.draw_queries(channel, &qpos);
+    GatherBatch gb;
+    fri.decommit_plan(&gb);
+    DecommitPlan tree_plans[4];
+    for (int t = 0; t < 4; t++) tree_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, cs.trees[t].evals, &gb);
+    H_TRY(gb.run(ctx));
+    fri.decommit_fill(gb, &proof);
     proof.decommitments.resize(4); proof.queried_values.resize(4);
     for (int t = 0; t < 4; t++) {
-        H_TRY(merkle_decommit(ctx, cs.trees[t].merkle, qpos, cs.trees[t].evals, &proof.queried_values[t], &proof.decommitments[t]));
+        merkle_decommit_fill(tree_plans[t], gb, &proof.queried_values[t], &proof.decommitments[t]);
         proof.commitments.push_back(cs.trees[t].root);
     }
     lap(&st->decommit);
