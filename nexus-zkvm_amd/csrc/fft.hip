@@ -234,7 +234,7 @@ __global__ void fft_tiny_kernel(ColSet src, ColSet dst, u32 n_cols, int n, int l
 
 // ---- planning ----
 struct FftTune { int smax, bmax, threads, batch_cols, legacy, streams; };
-static FftTune g_tune = {13, 5, 256, 4, 0, 4};
+static FftTune g_tune = {13, 5, 256, 2, 0, 2};   // 2 streams x 2 columns in flight: the working set of a batch (48 MiB per column at 2^22) stays in the 256 MiB Infinity Cache between its four passes
 static bool g_tune_init = false;
 static void tune_init() {
     if (g_tune_init) return;

@@ -78,46 +78,86 @@ struct QBatchDev {       // one ColumnSampleBatch, device-resident description
     u32 coeff[4];                        // alpha^{count}
 };
 
+// Each lane owns 4 consecutive rows (one 16-byte read per column: 1 KB contiguous per wave and column instead of 256 B, which
+// is what lets ~440 concurrent column streams run near HBM speed).  In bit-reversed order the 4 domain points of rows
+// 4j..4j+3 are (x, y), (x, -y), (-x, -y), (-x, y): one scalar-multiple walk for all four.
 __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, const QBatchDev* __restrict__ batches, u32 n_batches,
                                                        const u32* __restrict__ col_idx, const u32* __restrict__ cks /*4 per entry*/,
                                                        u32* __restrict__ o0, u32* __restrict__ o1, u32* __restrict__ o2, u32* __restrict__ o3) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (1u << (log - 2))) return;
+    const u32 r = 4 * j;
+    Pt dp[4];
+    dp[0] = pt_from_index(circle_domain_index(log, bitrev(r, log)));
+    // bitrev(4j + i) = bitrev2(i) * 2^(log-2) + bitrev(j): i = 1 lands in the conjugate half of the domain, i = 2 is
+    // 2^(log-2) steps of 2^(32-log) = half a turn further, i = 3 both
+    dp[1].x = dp[0].x; dp[1].y = m_neg(dp[0].y);
+    dp[2].x = m_neg(dp[0].x); dp[2].y = dp[1].y;
+    dp[3].x = dp[2].x; dp[3].y = dp[0].y;
+    QM31 acc[4] = {q_zero(), q_zero(), q_zero(), q_zero()};
+    for (u32 b = 0; b < n_batches; b++) {
+        const QBatchDev& B = batches[b];
+        // numerators: Σ_k c_k f_k(d) - (d.y Σ a_k + Σ b_k), 4 rows x 4 coordinates, lazily reduced
+        u64 n[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) for (int q = 0; q < 4; q++) n[i][q] = 0;
+        const u32 end = B.first + B.count;
+        u32 k = B.first;
+        for (; k + 4 <= end; k += 4) {
+            uint4 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) f[u] = *reinterpret_cast<const uint4*>(cols.col(col_idx[k + u]) + r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const u32 c0 = cks[4 * (k + u)], c1 = cks[4 * (k + u) + 1], c2 = cks[4 * (k + u) + 2], c3 = cks[4 * (k + u) + 3];
+                const u32 fv[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    n[i][0] = acc_mad(n[i][0], c0, fv[i]); n[i][1] = acc_mad(n[i][1], c1, fv[i]);
+                    n[i][2] = acc_mad(n[i][2], c2, fv[i]); n[i][3] = acc_mad(n[i][3], c3, fv[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) for (int q = 0; q < 4; q++) n[i][q] = acc_fold(n[i][q]);
+        }
+        for (; k < end; k++) {   // < 4 products on top of a folded value: still below 2^64
+            const uint4 f = *reinterpret_cast<const uint4*>(cols.col(col_idx[k]) + r);
+            const u32 c0 = cks[4 * k], c1 = cks[4 * k + 1], c2 = cks[4 * k + 2], c3 = cks[4 * k + 3];
+            const u32 fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                n[i][0] = acc_mad(n[i][0], c0, fv[i]); n[i][1] = acc_mad(n[i][1], c1, fv[i]);
+                n[i][2] = acc_mad(n[i][2], c2, fv[i]); n[i][3] = acc_mad(n[i][3], c3, fv[i]);
+            }
+        }
+        const QM31 sa = q_load(B.sum_a), sb = q_load(B.sum_b), coeff = q_load(B.coeff);
+        const CM31 prx = cm(B.prx[0], B.prx[1]), pry = cm(B.pry[0], B.pry[1]), pix = cm(B.pix[0], B.pix[1]), piy = cm(B.piy[0], B.piy[1]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            QM31 num = q_sub(qm(acc_final(n[i][0]), acc_final(n[i][1]), acc_final(n[i][2]), acc_final(n[i][3])), q_add(q_mul_m(sa, dp[i].y), sb));
+            // denominator (CM31): (Re p.x - d.x) Im p.y - (Re p.y - d.y) Im p.x
+            CM31 den = c_sub(c_mul(c_sub(prx, cm(dp[i].x, 0)), piy), c_mul(c_sub(pry, cm(dp[i].y, 0)), pix));
+            acc[i] = q_add(q_mul(acc[i], coeff), q_mul_c(num, c_inv(den)));
+        }
+    }
+    *reinterpret_cast<uint4*>(o0 + r) = make_uint4(acc[0].a.a, acc[1].a.a, acc[2].a.a, acc[3].a.a);
+    *reinterpret_cast<uint4*>(o1 + r) = make_uint4(acc[0].a.b, acc[1].a.b, acc[2].a.b, acc[3].a.b);
+    *reinterpret_cast<uint4*>(o2 + r) = make_uint4(acc[0].b.a, acc[1].b.a, acc[2].b.a, acc[3].b.a);
+    *reinterpret_cast<uint4*>(o3 + r) = make_uint4(acc[0].b.b, acc[1].b.b, acc[2].b.b, acc[3].b.b);
+}
+
+// log_size < 2: one lane per row
+__global__ void quotient_small_kernel(ColSet cols, int log, const QBatchDev* __restrict__ batches, u32 n_batches, const u32* __restrict__ col_idx,
+                                      const u32* __restrict__ cks, u32* __restrict__ o0, u32* __restrict__ o1, u32* __restrict__ o2, u32* __restrict__ o3) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= (1u << log)) return;
     Pt dp = pt_from_index(circle_domain_index(log, bitrev(r, log)));
     QM31 acc = q_zero();
     for (u32 b = 0; b < n_batches; b++) {
         const QBatchDev& B = batches[b];
-        // numerator: Σ_k c_k f_k(d) - (d.y Σ a_k + Σ b_k)
-        u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-        const u32 end = B.first + B.count;
-        u32 k = B.first;
-        for (; k + 8 <= end; k += 8) {   // 8 column reads in flight per lane
-            u32 f[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) f[u] = cols.col(col_idx[k + u])[r];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                n0 = acc_mad(n0, cks[4 * (k + u)], f[u]); n1 = acc_mad(n1, cks[4 * (k + u) + 1], f[u]);
-                n2 = acc_mad(n2, cks[4 * (k + u) + 2], f[u]); n3 = acc_mad(n3, cks[4 * (k + u) + 3], f[u]);
-                if ((u & 3) == 3) { n0 = acc_fold(n0); n1 = acc_fold(n1); n2 = acc_fold(n2); n3 = acc_fold(n3); }
-            }
-        }
-        for (; k + 4 <= end; k += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                u32 f = cols.col(col_idx[k + u])[r];
-                n0 = acc_mad(n0, cks[4 * (k + u)], f); n1 = acc_mad(n1, cks[4 * (k + u) + 1], f);
-                n2 = acc_mad(n2, cks[4 * (k + u) + 2], f); n3 = acc_mad(n3, cks[4 * (k + u) + 3], f);
-            }
-            n0 = acc_fold(n0); n1 = acc_fold(n1); n2 = acc_fold(n2); n3 = acc_fold(n3);
-        }
-        for (; k < end; k++) {
-            u32 f = cols.col(col_idx[k])[r];
-            n0 = acc_mad(n0, cks[4 * k], f); n1 = acc_mad(n1, cks[4 * k + 1], f);
-            n2 = acc_mad(n2, cks[4 * k + 2], f); n3 = acc_mad(n3, cks[4 * k + 3], f);
-        }
-        QM31 num = q_sub(qm(acc_final(n0), acc_final(n1), acc_final(n2), acc_final(n3)), q_add(q_mul_m(q_load(B.sum_a), dp.y), q_load(B.sum_b)));
-        // denominator (CM31): (Re p.x - d.x) Im p.y - (Re p.y - d.y) Im p.x
+        QM31 num = q_zero();
+        for (u32 k = B.first; k < B.first + B.count; k++) num = q_add(num, q_mul_m(q_load(cks + 4 * k), cols.col(col_idx[k])[r]));
+        num = q_sub(num, q_add(q_mul_m(q_load(B.sum_a), dp.y), q_load(B.sum_b)));
         CM31 den = c_sub(c_mul(c_sub(cm(B.prx[0], B.prx[1]), cm(dp.x, 0)), cm(B.piy[0], B.piy[1])),
                          c_mul(c_sub(cm(B.pry[0], B.pry[1]), cm(dp.y, 0)), cm(B.pix[0], B.pix[1])));
         acc = q_add(q_mul(acc, q_load(B.coeff)), q_mul_c(num, c_inv(den)));
@@ -295,8 +335,12 @@ int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* cons
         uint64_t alg = ((uint64_t)n_cols * 4 + 16) << log_size;
         KTimer timer(ctx, NX_T_QUOT, alg);
         uint32_t n = 1u << log_size;
-        hipLaunchKernelGGL(quotient_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
-                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+        if (log_size >= 2)
+            hipLaunchKernelGGL(quotient_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
+                               (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+        else
+            hipLaunchKernelGGL(quotient_small_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
+                               (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
         e = hipGetLastError();
     }
     // the pageable host vectors above die at return: wait for the copies (kernel completion is not required for them,
