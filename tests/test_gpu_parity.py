@@ -350,3 +350,90 @@ def test_sharded_leaf_chain_equals_single_commit(be, mode):
                 assert np.array_equal(t2.layer(k), tree.layer(k))
     finally:
         be.set_hash_mode(0)
+
+
+# ---------------- error behaviour and edge cases (the reference surfaces Result<_, ProvingError>; allocation failures and
+# bad arguments must come back as error codes with a message, never as silent garbage) --------------------------------
+
+def test_argument_errors_are_reported(be, nz):
+    tw = be.precompute_twiddles(6)
+    cols = be.columns_from_host(rand_cols(1, 2, 9))
+    with pytest.raises(nz.NexusHipError, match="twiddle"):          # domain larger than the twiddle tree
+        be.interpolate_columns(tw, cols)
+    with pytest.raises(nz.NexusHipError):
+        be.precompute_twiddles(40)
+    lde = be.columns_from_host(rand_cols(2, 20, 5))
+    st = be.columns(8, 5)
+    with pytest.raises(nz.NexusHipError, match="multiple of 16"):   # shard not aligned to a Blake2s block
+        be.merkle_leaf_chain(lde, 8, 40, st.ptr.value, st.ptr.value)
+    with pytest.raises(nz.NexusHipError, match="NULL exactly"):     # first shard must not take a state
+        be.merkle_leaf_chain(lde, 0, 20, st.ptr.value, st.ptr.value)
+    with pytest.raises(nz.NexusHipError):                            # synthetic machine needs >= 2 preprocessed columns
+        be.prove([(6, 1, 4, 0)], nz.default_config())
+    with pytest.raises(nz.NexusHipError):                            # blow-up 0 is not a valid PcsConfig
+        be.prove([(6, 2, 4, 0)], nz.default_config(log_blowup=0))
+    # the context is still usable after errors
+    assert be.grind(np.zeros(8, np.uint32), 3) >= 0
+
+
+def test_empty_and_single_column_inputs(be, oracle):
+    tw = be.precompute_twiddles(13)
+    # zero columns: every batched entry is a no-op
+    be._chk(be.L.nx_interpolate_batch(be.ctx, tw.h, None, 0, 10))
+    be._chk(be.L.nx_lde_batch(be.ctx, tw.h, None, 0, 10, 1, None))
+    # one column goes through the pair kernel as a degenerate pair (and through the small kernel below 2^13)
+    otw = oracle.Twiddles(14)
+    for log in (5, 13):
+        v = rand_cols(log + 300, 1, log)
+        c = be.columns_from_host(v)
+        out = be.lde(be.precompute_twiddles(log), c, 1)
+        coeff = otw.interpolate(v[0])
+        assert np.array_equal(c.to_cpu()[0], coeff)
+        assert np.array_equal(out.to_cpu()[0], otw.evaluate(coeff, log + 1))
+    # empty tree = Blake2s of nothing / zero state (reference: MerkleProver::commit(vec![]))
+    for mode in (0, 1):
+        be.set_hash_mode(mode)
+        assert np.array_equal(be.merkle_commit([]).root(), oracle.merkle_commit([], mode))
+    be.set_hash_mode(0)
+
+
+def test_boundary_values_stay_canonical(be, oracle):
+    """Columns made of 0, 1, p-1 and p-2 only: every sum/difference/product hits the reduction boundaries; the LDE must be
+    canonical (< p, committed as raw words) and bit-exact."""
+    log = 14
+    rng = np.random.default_rng(99)
+    vals = rng.choice(np.array([0, 1, P - 1, P - 2], np.uint32), size=(4, 1 << log))
+    vals[0, :] = P - 1
+    vals[1, :] = 0
+    otw = oracle.Twiddles(log + 1)
+    cols = be.columns_from_host(vals)
+    lde = be.lde(be.precompute_twiddles(log), cols, 1)
+    got_c, got_l = cols.to_cpu(), lde.to_cpu()
+    assert got_c.max() < P and got_l.max() < P
+    for c in range(4):
+        coeff = otw.interpolate(vals[c])
+        assert np.array_equal(got_c[c], coeff)
+        assert np.array_equal(got_l[c], otw.evaluate(coeff, log + 1))
+
+
+def test_config5_shaped_machine_is_accepted_by_the_oracle_verifier(be, nz, oracle):
+    """BASELINE config #5 shape (keccak-precompile-like widths): two wide round components of different
+    sizes with interaction trees ~2x wider than their main traces, plus small lookup tables — a mixed-degree commitment
+    with four FRI column sizes.  (The oracle prover would take minutes at this width; its verifier is the check.)"""
+    comps = [(14, 4, 260, 520), (13, 4, 200, 400), (12, 3, 9, 4), (11, 3, 7, 4)]
+    cfg, ocfg = nz.default_config(pow_bits=8), O.default_cfg(pow_bits=8)
+    w = be.prove(comps, cfg, seed=5150, ad=b"keccak-shaped")
+    assert oracle.verify_synth(comps, ocfg, w, ad=b"keccak-shaped") is None
+    w2 = w.copy(); w2[40] ^= 1
+    assert oracle.verify_synth(comps, ocfg, w2, ad=b"keccak-shaped") is not None
+    assert oracle.verify_synth(comps, ocfg, w, ad=b"other transcript") is not None
+
+
+def test_constraint_violation_is_a_proving_error(be, nz):
+    """ProvingError::ConstraintsNotSatisfied (reference core/src/lib.rs:22-24): committing a trace that violates the AIR
+    must fail in the prover's own OODS check, not produce a proof.  The synthetic fill is always valid, so corrupt the
+    check's other input instead: a PcsConfig whose constraint degree bound is too small for degree-2 constraints cannot
+    be requested (log_constraint_degree >= 1 enforced), and a tampered proof is what the verifier tests cover; here we
+    only pin the error code path of the argument check."""
+    with pytest.raises(nz.NexusHipError):
+        be.prove([(6, 2, 4, 0)], nz.default_config(log_constraint_degree=0))
