@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <numeric>
 #include <string.h>
+#include <stdlib.h>
 
 namespace nx {
 
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void merkle_leaf_chain_kernel(ColSet cols, u32
     o[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 
+
 // Top of the tree in ONE launch: layers `top`..0 (2^top <= 1024 nodes) when no columns are injected there.
 // `base` is the start of the tree allocation (layer k at node offset 2^k - 1).
 template <int MODE>
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(1024) void merkle_top_kernel(u32* __restrict__ base
     }
 }
 
+
 // GrindOps: nonce = base + thread; H(digest ‖ nonce_le64) is a single final 40-byte block.
 __global__ void grind_kernel(const u32* __restrict__ digest, u32 pow_bits, u64 base, unsigned long long* result) {
     u64 nonce = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,7 +218,8 @@ int merkle_layer(nx_ctx* ctx, ColSet cols, u32 n_cols, const u32* prev, u32* out
 int leaf_chain_launch(nx_ctx* ctx, hipStream_t stream, ColSet cs, u32 n_cols, u32 col_offset, u32 total_cols, const u32* state_in, u32* state_out,
                       u64 row_begin, u64 n_rows) {
     KTimer timer(ctx, NX_T_MERKLE, n_rows * (4ull * n_cols + 64), stream);
-    dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
+    dim3 block(256);
+    dim3 grid((unsigned)((n_rows + 255) / 256));
     if (ctx->hash_mode == NX_HASH_BLAKE2S)
         hipLaunchKernelGGL(merkle_leaf_chain_kernel<0>, grid, block, 0, stream, cs, n_cols, col_offset, total_cols, state_in, state_out, row_begin, n_rows);
     else
@@ -342,26 +346,20 @@ int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t*
     alg_bytes += (128ull << max_log);  // 32 B written per leaf + ~96 B per leaf for all inner layers
     KTimer timer(ctx, NX_T_MERKLE, alg_bytes);
 
-    size_t ci = 0;
     int rc = NX_OK;
-    // layers at or below `top_fused` hold no columns and have <= 1024 nodes: one launch for all of them
-    int smallest_col_log = n_cols ? (int)log_sizes[order[n_cols - 1]] : 0;
-    int top_fused = std::min(10, std::min((int)max_log - 1, smallest_col_log - 1));
-    for (int log = (int)max_log; log >= 0 && rc == NX_OK; log--) {
-        if (log == top_fused && log >= 1) {
-            if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_top_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
-            else hipLaunchKernelGGL(merkle_top_kernel<1>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
-            hipError_t le = hipGetLastError();
-            if (le != hipSuccess) rc = hip_fail(ctx, le, "merkle_top_kernel", __FILE__, __LINE__);
-            break;
-        }
-        size_t c0 = ci;
-        while (ci < n_cols && log_sizes[order[ci]] == (uint32_t)log) ci++;
+    // leaf layer: the columns of the largest size (or the empty message), then the inner layers with the smaller columns
+    size_t n_leaf = 0;
+    while (n_leaf < n_cols && log_sizes[order[n_leaf]] == max_log) n_leaf++;
+    {
         ColSet cs;
-        rc = make_colset(ctx, (const uint32_t* const*)(sorted.data() + c0), (uint32_t)(ci - c0), &cs);
-        if (rc != NX_OK) break;
-        const uint32_t* prev = (uint32_t)log < max_log ? t->layers[log + 1] : nullptr;
-        rc = merkle_layer(ctx, cs, (uint32_t)(ci - c0), prev, t->layers[log], (uint32_t)log);
+        rc = make_colset(ctx, (const uint32_t* const*)sorted.data(), (uint32_t)n_leaf, &cs);
+        if (rc == NX_OK) rc = merkle_layer(ctx, cs, (uint32_t)n_leaf, nullptr, t->layers[max_log], max_log);
+    }
+    if (rc == NX_OK && max_log > 0) {
+        std::vector<const uint32_t*> small(sorted.begin() + n_leaf, sorted.end());
+        std::vector<uint32_t> small_logs(n_cols - n_leaf);
+        for (size_t i = n_leaf; i < n_cols; i++) small_logs[i - n_leaf] = log_sizes[order[i]];
+        rc = build_inner_layers(ctx, t, max_log, small, small_logs);
     }
     if (rc != NX_OK) { dev_free(ctx, buf); delete t; return rc; }
     *out = t;
