@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--pow-bits", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-rows", type=int, default=17)
+    ap.add_argument("--sharded", action="store_true",
+                    help="N > 1: ONE proof per step with its columns sharded over the N GPUs (config #4 style, strong scaling) instead of one independent proof per GPU")
     args = ap.parse_args()
 
     import torch
@@ -67,12 +69,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sharded = args.sharded and world > 1
+    if sharded:
+        from nexus_zkvm_amd.sharded import TorchDistComm
+        comm = nz.make_comm(rank, world, TorchDistComm(be, torch.device("cuda", local_rank)))
+        prove = lambda seed: be.prove_sharded(comps, comm, cfg, seed=seed)          # same seed on every rank: one proof
+    else:
+        prove = lambda seed: be.prove(comps, cfg, seed=seed + rank * 97)            # one independent proof per rank
     for w in range(args.warmup):
-        be.prove(comps, cfg, seed=1000 + rank * 97 + w)
+        prove(1000 + w)
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        be.prove(comps, cfg, seed=2000 + rank * 97 + s)
+        prove(2000 + s)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -85,7 +94,7 @@ def main():
     words, stats = be.prove(comps, cfg, seed=4242 + rank, want_stats=True)
     out = None
     if rank == 0:
-        n_cycles = (1 << args.log_rows) * args.steps * world
+        n_cycles = (1 << args.log_rows) * args.steps * (1 if sharded else world)
         lde_gbs = stats["lde_algorithmic_bytes"] / (stats["lde_kernel_ms"] * 1e-3) / 1e9 if stats["lde_kernel_ms"] > 0 else 0.0
         # HBM bytes of the same LDE work from the PMC passes of tools/pmc_traffic.py (FETCH_SIZE x2 + WRITE_SIZE, calibrated
         # on a known copy as MI355X_MICROARCH.md prescribes), measured per column at the same log size and scaled to this
@@ -108,13 +117,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "u32 (M31)",
             "data": "synthetic",
             "config": {"workload": "synthetic 2^%d-row trace, full prove (LDE+quotient+FRI+Merkle), %d preprocessed + %d main + %d interaction columns, blowup 2, %d queries, pow_bits %d"
                        % (args.log_rows, args.n_pre, args.n_main, args.n_inter, cfg.n_queries, cfg.pow_bits),
-                       "log_n_rows": args.log_rows, "parallelism": "1 proof per GPU" if world > 1 else "1 GPU",
+                       "log_n_rows": args.log_rows, "parallelism": ("1 proof, columns sharded over %d GPUs" % world) if sharded else ("1 proof per GPU" if world > 1 else "1 GPU"),
                        "proof_words": int(len(words))},
             "roofline": {"bound": "hbm", "achieved": lde_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "nx::fft13_kernel<INV, FIRST, 2, 4> (Circle iFFT+FFT = LDE, all passes of one prove)",

@@ -151,6 +151,15 @@ int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* cons
                             const uint32_t* batch_counts, const uint32_t* col_idx, const uint32_t* values,
                             uint32_t* const* d_out4);
 
+/* Column-sharded variant: the quotient is a sum over columns, so each GPU accumulates the entries whose
+ * columns it holds (entry_local[k] != 0; col_idx[k] then indexes ITS d_cols) with the alpha power of the entry's GLOBAL
+ * position, exactly one GPU adds the line terms of all entries (include_line_terms), and the partial results are summed
+ * mod p across GPUs (nx_comm.allreduce_m31).  Batches, counts, values describe ALL entries, on every GPU. */
+int nx_accumulate_quotients_partial(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols,
+                                    const uint32_t random_coeff[4], uint32_t n_batches, const uint32_t* points,
+                                    const uint32_t* batch_counts, const uint32_t* col_idx, const uint32_t* values,
+                                    const uint8_t* entry_local, int include_line_terms, uint32_t* const* d_out4);
+
 /* --------------------------------------------------------------- K9: FriOps ---------------- */
 /* FriOps::fold_circle_into_line: dst (line evaluation, 2^(src_log-1)) = dst*alpha^2 + fold(src). */
 int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4,
@@ -199,6 +208,33 @@ int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps
                    uint64_t seed, const uint8_t* ad, size_t ad_len, uint32_t** proof_words, size_t* n_words,
                    nx_prove_stats* stats);
 void nx_free_host(void* p);
+
+/* ------------------------------------------- one proof, columns sharded over the GPUs of a node (config #4) ---------
+ * One process (or thread) per GPU calls nx_prove_synth_sharded with the same arguments and its own nx_comm.  Columns of
+ * every trace tree are cut into contiguous 16-column-aligned blocks (rank r takes block r); LDE, OODS evaluation,
+ * constraint and quotient partial sums are local; the exchanges are exactly: the Blake2s chaining state ring per tree
+ * (send/recv, 32 B per row per hop), one modular all-reduce for the composition polynomial and one for the DEEP quotient
+ * (allreduce_m31), the sampled / queried values (allgather of a few KB) and the roots and Merkle witnesses (broadcast).
+ * FRI, proof of work and the composition tree are replicated.  Every rank returns the same proof, bit-identical to
+ * nx_prove_synth on one GPU.  The transport is the caller's: RCCL over xGMI (nexus-zkvm_amd/sharded.py wraps
+ * torch.distributed) or anything else; device-buffer calls must be complete when they return. */
+typedef struct nx_comm {
+    int32_t rank, world;
+    void* user;
+    int (*send)(void* user, int32_t dst, const uint32_t* d_buf, size_t n_words);          /* device buffer */
+    int (*recv)(void* user, int32_t src, uint32_t* d_buf, size_t n_words);                /* device buffer */
+    int (*allreduce_m31)(void* user, uint32_t* d_buf, size_t n_words);                    /* in place: sum over ranks mod p */
+    int (*allgather)(void* user, const void* h_send, size_t bytes, void* h_recv);         /* host: recv = world x bytes */
+    int (*broadcast)(void* user, void* h_buf, size_t bytes, int32_t root);                /* host */
+} nx_comm;
+int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg,
+                           uint64_t seed, const uint8_t* ad, size_t ad_len, const nx_comm* comm, uint32_t** proof_words,
+                           size_t* n_words, nx_prove_stats* stats);
+/* Building blocks for nx_comm.allreduce_m31 implementations: dst[i] = (dst[i] + src[i]) mod p;  widening to the 64-bit
+ * lanes a sum-all-reduce needs (RCCL has no modular reduction) and the reduction back. */
+int nx_m31_add_into(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words);
+int nx_m31_widen(nx_ctx* ctx, uint64_t* d_dst, const uint32_t* d_src, size_t n_words);
+int nx_m31_narrow(nx_ctx* ctx, uint32_t* d_dst, const uint64_t* d_src, size_t n_words);
 
 /* Config #2: LDE + Blake2s commit of n_cols random columns of 2^log_size rows (already resident,
  * bit-reversed evaluations, overwritten by their coefficients); d_lde receives the LDE columns. */

@@ -37,6 +37,48 @@ class PcsConfig(C.Structure):
                 ("log_constraint_degree", C.c_uint32)]
 
 
+_SEND_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t)
+_RECV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t)
+_ALLREDUCE_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+_ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_BROADCAST_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32)
+
+
+class NxComm(C.Structure):
+    """nx_comm of include/nexus_hip.h: the transport callbacks of a column-sharded prove."""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("send", _SEND_T), ("recv", _RECV_T),
+                ("allreduce_m31", _ALLREDUCE_T), ("allgather", _ALLGATHER_T), ("broadcast", _BROADCAST_T)]
+
+
+def make_comm(rank, world, impl):
+    """Wrap a Python object with send(dst, ptr, n_words) / recv(src, ptr, n_words) / allreduce_m31(ptr, n_words) /
+    allgather(bytes) -> list of bytes / broadcast(bytes_or_None, n, root) -> bytes into an NxComm.  Exceptions become a
+    non-zero return code (the library then fails the prove with NX_ERR_HIP)."""
+    def guard(f):
+        def g(*a):
+            try:
+                f(*a)
+                return 0
+            except Exception:   # noqa: BLE001 — must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        return g
+
+    def _allgather(_u, h_send, nbytes, h_recv):
+        parts = impl.allgather(C.string_at(h_send, nbytes))
+        C.memmove(h_recv, b"".join(parts), nbytes * world)
+
+    def _broadcast(_u, h_buf, nbytes, root):
+        data = impl.broadcast(C.string_at(h_buf, nbytes) if rank == root else None, nbytes, root)
+        C.memmove(h_buf, data, nbytes)
+
+    c = NxComm(rank, world, None, _SEND_T(guard(lambda _u, dst, p, n: impl.send(dst, p, n))), _RECV_T(guard(lambda _u, src, p, n: impl.recv(src, p, n))),
+               _ALLREDUCE_T(guard(lambda _u, p, n: impl.allreduce_m31(p, n))), _ALLGATHER_T(guard(_allgather)), _BROADCAST_T(guard(_broadcast)))
+    c._impl = impl   # keep the callbacks' target alive
+    return c
+
+
 class ProveStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")] + \
                [("lde_kernel_ms", C.c_double), ("lde_algorithmic_bytes", C.c_uint64), ("merkle_kernel_ms", C.c_double),
@@ -353,6 +395,19 @@ class HipBackend:
         adb = (C.c_uint8 * max(1, len(ad)))(*ad)
         self._chk(self.L.nx_prove_synth(self.ctx, self._comps(comps), len(comps), C.byref(cfg), C.c_uint64(seed), adb, C.c_size_t(len(ad)),
                                         C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
+        out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
+        self.L.nx_free_host(words)
+        return (out, stats.as_dict()) if want_stats else out
+
+    def prove_sharded(self, comps, comm, cfg=None, seed=1, ad=b"", want_stats=False):
+        """One proof, columns sharded over the ranks of `comm` (an NxComm from make_comm); every rank calls this with the
+        same arguments and gets the same proof, bit-identical to `prove` on one GPU (nx_prove_synth_sharded)."""
+        cfg = cfg or default_config()
+        words, n = C.POINTER(C.c_uint32)(), C.c_size_t(0)
+        stats = ProveStats()
+        adb = (C.c_uint8 * max(1, len(ad)))(*ad)
+        self._chk(self.L.nx_prove_synth_sharded(self.ctx, self._comps(comps), len(comps), C.byref(cfg), C.c_uint64(seed), adb, C.c_size_t(len(ad)),
+                                                C.byref(comm), C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
         out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
         self.L.nx_free_host(words)
         return (out, stats.as_dict()) if want_stats else out

@@ -14,8 +14,13 @@ inline uint32_t synth_n_constraints(const nx_component_spec& c) {
     return n;
 }
 
-int synth_constraints(nx_ctx* ctx, ColSet pre, ColSet mainc, ColSet inter, u32 n_main, u32 n_inter, int log_size, int e, const u32* d_pw,
+// the columns one rank holds of a component: [main_begin, main_begin + n_main) of n_main_total main columns, likewise the
+// interaction columns; has_pre1: the preprocessed column 1 (is_last) is local.  A single GPU holds everything.
+struct SynthRange { u32 main_begin, n_main, n_main_total, inter_begin, n_inter; bool has_pre1; };
+int synth_constraints(nx_ctx* ctx, ColSet pre, ColSet mainc, ColSet inter, const SynthRange& rg, int log_size, int e, const u32* d_pw,
                       const u32* d_denom_inv, u32* const acc4[4]);
+int synth_fill_range(nx_ctx* ctx, const nx_component_spec& c, uint32_t ci, uint32_t tree, uint64_t seed, uint64_t inter_seed, uint32_t col_begin,
+                     uint32_t n_cols, uint32_t* const* d_cols);
 int secure_accumulate(nx_ctx* ctx, u32* const dst4[4], const u32* const src4[4], u32 n);
 int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size, uint32_t log_expand, ColSet out);
 int merkle_layer(nx_ctx* ctx, ColSet cols, u32 n_cols, const u32* prev, u32* out, u32 log);

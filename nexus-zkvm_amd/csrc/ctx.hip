@@ -140,6 +140,16 @@ __global__ __launch_bounds__(256) void copy_kernel(uint4* __restrict__ dst, cons
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(256) void m31_add_into_kernel(u32* __restrict__ dst, const u32* __restrict__ src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = m_add(dst[i], src[i]);
+}
+__global__ __launch_bounds__(256) void m31_widen_kernel(u64* __restrict__ dst, const u32* __restrict__ src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void m31_narrow_kernel(u32* __restrict__ dst, const u64* __restrict__ src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (u32)(src[i] % P);
+}
+
 __global__ void gather_kernel(const uint32_t* const* ptrs, const uint64_t* index, size_t n, uint32_t* out) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = ptrs[i][index[i]];
@@ -244,6 +254,26 @@ int nx_copy(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words)
     size_t n4 = n_words / 4;
     unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, (size_t)ctx->n_cus * 16);
     hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (uint4*)d_dst, (const uint4*)d_src, n4);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+static unsigned stream_grid(nx_ctx* ctx, size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, (size_t)ctx->n_cus * 16); }
+int nx_m31_add_into(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words) {
+    if (!n_words) return NX_OK;
+    hipLaunchKernelGGL(m31_add_into_kernel, dim3(stream_grid(ctx, n_words)), dim3(256), 0, ctx->stream, d_dst, d_src, n_words);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+int nx_m31_widen(nx_ctx* ctx, uint64_t* d_dst, const uint32_t* d_src, size_t n_words) {
+    if (!n_words) return NX_OK;
+    hipLaunchKernelGGL(m31_widen_kernel, dim3(stream_grid(ctx, n_words)), dim3(256), 0, ctx->stream, (u64*)d_dst, d_src, n_words);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+int nx_m31_narrow(nx_ctx* ctx, uint32_t* d_dst, const uint64_t* d_src, size_t n_words) {
+    if (!n_words) return NX_OK;
+    hipLaunchKernelGGL(m31_narrow_kernel, dim3(stream_grid(ctx, n_words)), dim3(256), 0, ctx->stream, d_dst, (const u64*)d_src, n_words);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }

@@ -291,44 +291,56 @@ int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_
     return NX_OK;
 }
 
-int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
-                            uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
-                            const uint32_t* values, uint32_t* const* d_out4) {
+// `entry_local` (NULL = all): which flattened (column, value) entries this GPU holds the column of; the others only advance
+// the alpha powers.  `include_line`: add the -(a·y + b) line terms of ALL entries (exactly one GPU of a column-sharded prove
+// does, so that the partial accumulations of the GPUs sum to the full quotient).
+static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
+                                     uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
+                                     const uint32_t* values, const uint8_t* entry_local, int include_line, uint32_t* const* d_out4) {
     if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: bad log_size");
     QM31 alpha = q_load(random_coeff);
     size_t total = 0;
     for (uint32_t b = 0; b < n_batches; b++) total += batch_counts[b];
     std::vector<QBatchDev> hb(n_batches);
-    std::vector<uint32_t> cks(4 * total);
+    std::vector<uint32_t> cks; cks.reserve(4 * total);
+    std::vector<uint32_t> lidx; lidx.reserve(total);
     size_t k = 0;
     for (uint32_t b = 0; b < n_batches; b++) {
         QBatchDev& B = hb[b];
         QPt p; p.x = q_load(points + 8 * b); p.y = q_load(points + 8 * b + 4);
-        B.first = (uint32_t)k; B.count = batch_counts[b];
+        B.first = (uint32_t)lidx.size();
         B.prx[0] = p.x.a.a; B.prx[1] = p.x.a.b; B.pix[0] = p.x.b.a; B.pix[1] = p.x.b.b;
         B.pry[0] = p.y.a.a; B.pry[1] = p.y.a.b; B.piy[0] = p.y.b.a; B.piy[1] = p.y.b.b;
         QM31 a_pow = q_one(), sa = q_zero(), sb = q_zero();
         QM31 c0 = q_sub(q_conj(p.y), p.y);  // conj(p.y) - p.y
         for (uint32_t j = 0; j < batch_counts[b]; j++, k++) {
-            if (col_idx[k] >= n_cols) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: column index out of range");
             a_pow = q_mul(a_pow, alpha);
             QM31 v = q_load(values + 4 * k);
-            QM31 a = q_sub(q_conj(v), v);
-            QM31 bb = q_sub(q_mul(v, c0), q_mul(a, p.y));
-            sa = q_add(sa, q_mul(a_pow, a));
-            sb = q_add(sb, q_mul(a_pow, bb));
-            q_store(&cks[4 * k], q_mul(a_pow, c0));
+            if (include_line) {
+                QM31 a = q_sub(q_conj(v), v);
+                QM31 bb = q_sub(q_mul(v, c0), q_mul(a, p.y));
+                sa = q_add(sa, q_mul(a_pow, a));
+                sb = q_add(sb, q_mul(a_pow, bb));
+            }
+            if (!entry_local || entry_local[k]) {
+                if (col_idx[k] >= n_cols) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: column index out of range");
+                lidx.push_back(col_idx[k]);
+                uint32_t w[4]; q_store(w, q_mul(a_pow, c0));
+                cks.insert(cks.end(), w, w + 4);
+            }
         }
+        B.count = (uint32_t)lidx.size() - B.first;
         q_store(B.sum_a, sa); q_store(B.sum_b, sb); q_store(B.coeff, a_pow);
     }
-    // stage descriptors (persist until the kernel ran: own allocation, freed after sync-free enqueue via stream callback-less pattern)
+    const size_t n_local = lidx.size();
+    // stage descriptors in one allocation that outlives the kernel
     uint8_t* blob = nullptr;
-    size_t bytes_b = hb.size() * sizeof(QBatchDev), bytes_i = total * 4, bytes_c = cks.size() * 4, bytes_t = (size_t)n_cols * 8;
+    size_t bytes_b = hb.size() * sizeof(QBatchDev), bytes_i = n_local * 4, bytes_c = cks.size() * 4, bytes_t = (size_t)n_cols * 8;
     size_t off_i = (bytes_b + 15) & ~(size_t)15, off_c = off_i + ((bytes_i + 15) & ~(size_t)15), off_t = off_c + ((bytes_c + 15) & ~(size_t)15);
     NX_TRY(dev_alloc(ctx, off_t + bytes_t + 16, (void**)&blob));
     hipError_t e = hipMemcpyAsync(blob, hb.data(), bytes_b, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && total) e = hipMemcpyAsync(blob + off_i, col_idx, bytes_i, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && total) e = hipMemcpyAsync(blob + off_c, cks.data(), bytes_c, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_local) e = hipMemcpyAsync(blob + off_i, lidx.data(), bytes_i, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_local) e = hipMemcpyAsync(blob + off_c, cks.data(), bytes_c, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n_cols) e = hipMemcpyAsync(blob + off_t, d_cols, bytes_t, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         ColSet cs; cs.base = nullptr; cs.stride = 0; cs.table = (uint32_t* const*)(blob + off_t);
@@ -343,13 +355,25 @@ int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* cons
                                (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
         e = hipGetLastError();
     }
-    // the pageable host vectors above die at return: wait for the copies (kernel completion is not required for them,
-    // but the blob must outlive the kernel, so synchronise before freeing it)
+    // the pageable host vectors above die at return, and the blob must outlive the kernel: synchronise before freeing it
     hipError_t e2 = hipStreamSynchronize(ctx->stream);
     dev_free(ctx, blob);
     if (e != hipSuccess) return hip_fail(ctx, e, "nx_accumulate_quotients", __FILE__, __LINE__);
     if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_accumulate_quotients(sync)", __FILE__, __LINE__);
     return NX_OK;
+}
+
+int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
+                            uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
+                            const uint32_t* values, uint32_t* const* d_out4) {
+    return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, nullptr, 1, d_out4);
+}
+
+int nx_accumulate_quotients_partial(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
+                                    uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
+                                    const uint32_t* values, const uint8_t* entry_local, int include_line_terms, uint32_t* const* d_out4) {
+    return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, entry_local,
+                                     include_line_terms, d_out4);
 }
 
 int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log,

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <map>
 #include <set>
+#include <tuple>
 #include <string.h>
 #include <stdlib.h>
 
@@ -475,7 +476,8 @@ static int compute_composition(CommitmentSchemeProver& cs, const nx_component_sp
             inter = slab_set(ext.p + ((size_t)(c.n_pre + c.n_main) << e), e);
         }
         if (!sub.count(e)) { H_TRY(sub[e].alloc(ctx, e)); H_TRY(nx_memset_zero(ctx, sub[e].buf.p, sub[e].buf.words)); }
-        H_TRY(synth_constraints(ctx, pre, mainc, inter, c.n_main, c.n_inter, (int)c.log_size, (int)e, (const u32*)d_pw, (const u32*)d_den, sub[e].c));
+        SynthRange rg{0, c.n_main, c.n_main, 0, c.n_inter, true};
+        H_TRY(synth_constraints(ctx, pre, mainc, inter, rg, (int)c.log_size, (int)e, (const u32*)d_pw, (const u32*)d_den, sub[e].c));
     }
     // DomainEvaluationAccumulator::finalize — ascending size: lift the running polynomial, add, interpolate
     DevBuf cur; uint32_t cur_log = 0; bool have = false;
@@ -692,6 +694,344 @@ static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_c
     return NX_OK;
 }
 
+// ================================================================ one proof, columns sharded over the GPUs of a node ===
+// SURVEY.md §8(e), BASELINE config #4.  Same protocol, same transcript, same proof bytes as prove_synth; every rank holds a
+// contiguous 16-column-aligned block of each trace tree.  What crosses the links (nx_comm): the Blake2s chaining state of
+// the leaf layers (ring, 32 B per row per hop), two modular all-reduces (composition accumulator, DEEP quotient), the
+// sampled and queried values (KBs) and roots / Merkle witnesses (broadcast).  FRI, grinding and the 4-column composition
+// tree are replicated.  Restricted to one component (the shape of config #4).
+struct Shard {
+    const nx_comm* comm; int rank, world;
+    uint32_t total[3];
+    std::vector<std::pair<uint32_t, uint32_t>> ranges[3];   // per tree, per rank: [lo, hi)
+    uint32_t lo(int t) const { return ranges[t][rank].first; }
+    uint32_t hi(int t) const { return ranges[t][rank].second; }
+    uint32_t n_local(int t) const { return hi(t) - lo(t); }
+    int owner(int t, uint32_t c) const { for (int r = 0; r < world; r++) if (c >= ranges[t][r].first && c < ranges[t][r].second) return r; return -1; }
+    std::vector<int> active(int t) const { std::vector<int> a; for (int r = 0; r < world; r++) if (ranges[t][r].second > ranges[t][r].first) a.push_back(r); return a; }
+};
+static void plan_column_shards(uint32_t n_cols, int world, std::vector<std::pair<uint32_t, uint32_t>>* out) {   // == nexus_zkvm_amd.sharded.plan_column_shards
+    uint32_t blocks = (n_cols + 15) / 16, per = blocks / world, extra = blocks % world, b = 0;
+    out->clear();
+    for (int r = 0; r < world; r++) {
+        uint32_t nb = per + ((uint32_t)r < extra ? 1 : 0);
+        out->push_back({std::min(n_cols, 16 * b), std::min(n_cols, 16 * (b + nb))});
+        b += nb;
+    }
+}
+#define C_TRY(call) do { if ((call) != 0) return set_err(ctx, NX_ERR_HIP, "nx_comm callback failed: " #call); } while (0)
+
+// TreeBuilder::commit of one sharded trace tree: local LDE, chaining-state ring over row chunks, inner layers on the last
+// active rank, root to everybody.
+static int commit_sharded_tree(CommitmentSchemeProver& cs, const Shard& sh, int t, DevBuf&& slab, uint32_t log, Blake2sChannel& channel) {
+    nx_ctx* ctx = cs.ctx;
+    const uint32_t el = log + cs.cfg.log_blowup, n_local = sh.n_local(t);
+    CommitmentTreeProver tr;
+    DevBuf lde;
+    std::vector<uint32_t*> out;
+    if (n_local) {
+        H_TRY(lde.alloc(ctx, (size_t)n_local << el));
+        auto in = col_ptrs(slab.p, n_local, log); out = col_ptrs(lde.p, n_local, el);
+        H_TRY(nx_lde_batch(ctx, cs.tw, in.data(), n_local, log, cs.cfg.log_blowup, out.data()));
+        for (uint32_t i = 0; i < n_local; i++) { tr.polys.push_back({in[i], log}); tr.evals.push_back({out[i], el}); }
+    }
+    const std::vector<int> act = sh.active(t);
+    if (act.empty()) {   // a tree without columns: every rank commits the empty tree
+        H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &tr.merkle));
+        H_TRY(nx_merkle_root(ctx, tr.merkle, (uint8_t*)tr.root.w));
+    } else {
+        const int last = act.back();
+        if (n_local) {
+            size_t pos = std::find(act.begin(), act.end(), sh.rank) - act.begin();
+            const int prev = pos > 0 ? act[pos - 1] : -1, next = pos + 1 < act.size() ? act[pos + 1] : -1;
+            const uint64_t n_rows = (uint64_t)1 << el;
+            DevBuf st; H_TRY(st.alloc(ctx, (size_t)8 << el));
+            const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(8, n_rows);
+            for (uint32_t j = 0; j < n_chunks; j++) {
+                const uint64_t rb = n_rows * j / n_chunks, re = n_rows * (j + 1) / n_chunks;
+                uint32_t* sp = st.p + rb * 8;
+                if (prev >= 0) C_TRY(sh.comm->recv(sh.comm->user, prev, sp, (size_t)(re - rb) * 8));
+                H_TRY(nx_merkle_leaf_chain(ctx, (const uint32_t* const*)out.data(), n_local, el, sh.lo(t), sh.total[t], prev >= 0 ? sp : nullptr, sp, rb, re - rb));
+                if (next >= 0) { H_TRY(nx_sync(ctx)); C_TRY(sh.comm->send(sh.comm->user, next, sp, (size_t)(re - rb) * 8)); }
+            }
+            if (sh.rank == last) {
+                H_TRY(nx_merkle_from_leaves(ctx, st.p, el, &tr.merkle));
+                H_TRY(nx_merkle_root(ctx, tr.merkle, (uint8_t*)tr.root.w));
+            }
+        }
+        C_TRY(sh.comm->broadcast(sh.comm->user, tr.root.w, 32, last));
+    }
+    tr.bufs.push_back(std::move(slab));
+    tr.bufs.push_back(std::move(lde));
+    channel.mix_root(tr.root);
+    cs.trees.push_back(std::move(tr));
+    return NX_OK;
+}
+
+static int prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
+                               size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st) {
+    PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
+    if (n_comps != 1) return set_err(ctx, NX_ERR_ARG, "sharded prove: exactly one component (BASELINE config #4 shape)");
+    if (cfg.log_blowup < 1 || cfg.log_constraint_degree < 1 || cfg.log_constraint_degree > 2) return set_err(ctx, NX_ERR_ARG, "prove: log_blowup >= 1 and log_constraint_degree in {1,2} required");
+    if (!comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || !comm->send || !comm->recv || !comm->allreduce_m31 || !comm->allgather || !comm->broadcast)
+        return set_err(ctx, NX_ERR_ARG, "sharded prove: incomplete nx_comm");
+    const nx_component_spec& c = comps[0];
+    if (c.n_pre < 2 || c.n_main < 2 || c.log_size < 1 || c.log_size > 28) return set_err(ctx, NX_ERR_ARG, "synthetic component needs n_pre >= 2, n_main >= 2, 1 <= log_size <= 28");
+    H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
+    Shard sh; sh.comm = comm; sh.rank = comm->rank; sh.world = comm->world;
+    sh.total[0] = c.n_pre; sh.total[1] = c.n_main; sh.total[2] = c.n_inter;
+    for (int t = 0; t < 3; t++) plan_column_shards(sh.total[t], sh.world, &sh.ranges[t]);
+    std::vector<Loc> locs{{0, 0, 0}};
+    const bool timed = st != nullptr;
+    nx_prove_stats local_stats;
+    if (!st) st = &local_stats;
+    memset(st, 0, sizeof *st);
+    if (timed) { ctx->timing = true; timing_reset(ctx); }
+    double t_start = 0, t0 = 0;
+    auto lap = [&](double* slot) { if (!timed) return; (void)nx_sync(ctx); double t = now_ms(); *slot += t - t0; t0 = t; };
+    if (timed) { (void)nx_sync(ctx); t_start = t0 = now_ms(); }
+
+    nx_twiddles* tw = nullptr;
+    H_TRY(nx_twiddles_create(ctx, c.log_size + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));
+    struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
+    Blake2sChannel channel;
+    for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);
+    CommitmentSchemeProver cs(ctx, tw, cfg);
+    channel.mix_u64(c.log_size);
+    lap(&st->commit);
+
+    auto fill_and_commit = [&](uint32_t tree, uint64_t inter_seed) -> int {
+        const uint32_t n_local = sh.n_local((int)tree);
+        DevBuf slab;
+        if (n_local) {
+            H_TRY(slab.alloc(ctx, (size_t)n_local << c.log_size));
+            auto p = col_ptrs(slab.p, n_local, c.log_size);
+            H_TRY(synth_fill_range(ctx, c, 0, tree, seed, inter_seed, sh.lo((int)tree), n_local, p.data()));
+        }
+        lap(&st->trace_gen);
+        H_TRY(commit_sharded_tree(cs, sh, (int)tree, std::move(slab), c.log_size, channel));
+        lap(&st->commit);
+        return NX_OK;
+    };
+    H_TRY(fill_and_commit(0, 0));
+    H_TRY(fill_and_commit(1, 0));
+    QM31 z = channel.draw_secure_felt();
+    uint64_t inter_seed = ((u64)z.a.a << 32) ^ (u64)z.a.b ^ ((u64)z.b.a << 16) ^ ((u64)z.b.b << 48);
+    channel.mix_felts(std::vector<QM31>(1, q_zero()));
+    H_TRY(fill_and_commit(2, inter_seed));
+
+    // ---------------- composition polynomial: local constraints, one modular all-reduce, replicated interpolation ----------------
+    QM31 random_coeff = channel.draw_secure_felt();
+    const uint32_t lcd = cfg.log_constraint_degree, blow = cfg.log_blowup, e = c.log_size + lcd;
+    DevBuf comp_polys;
+    {
+        const size_t nc = synth_n_constraints(c);
+        std::vector<uint32_t> pw(4 * nc);
+        { QM31 a = q_one(); std::vector<QM31> powers(nc); for (size_t i = 0; i < nc; i++) { powers[i] = a; a = q_mul(a, random_coeff); }
+          for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[nc - 1 - j]); }
+        void* d_pw = nullptr; H_TRY(stage(ctx, pw.data(), pw.size() * 4, &d_pw));
+        const uint32_t log_expand = e - c.log_size;
+        std::vector<uint32_t> den((size_t)1 << log_expand);
+        for (uint32_t i = 0; i < den.size(); i++) {
+            u32 x = pt_from_index(circle_domain_index((int)e, i)).x;
+            for (uint32_t k = 1; k < c.log_size; k++) x = m_double_x(x);
+            den[bitrev(i, (int)log_expand)] = m_inv(x);
+        }
+        void* d_den = nullptr; H_TRY(stage(ctx, den.data(), den.size() * 4, &d_den));
+        auto slab_set = [](uint32_t* base, uint32_t log) { ColSet s; s.base = base; s.stride = (uint64_t)1 << log; s.table = nullptr; return s; };
+        ColSet pre, mainc, inter;
+        DevBuf ext;
+        const uint32_t np = sh.n_local(0), nm = sh.n_local(1), ni = sh.n_local(2);
+        if (e == c.log_size + blow) {
+            pre = slab_set(np ? cs.trees[0].evals[0].ptr : nullptr, e);
+            mainc = slab_set(nm ? cs.trees[1].evals[0].ptr : nullptr, e);
+            inter = slab_set(ni ? cs.trees[2].evals[0].ptr : nullptr, e);
+        } else {
+            const uint32_t ncols = np + nm + ni;
+            H_TRY(ext.alloc(ctx, (size_t)std::max<uint32_t>(ncols, 1) << e));
+            std::vector<const uint32_t*> src;
+            for (int t = 0; t < 3; t++) for (auto& p : cs.trees[t].polys) src.push_back(p.ptr);
+            auto dst = col_ptrs(ext.p, ncols, e);
+            if (ncols) H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), ncols, c.log_size, e - c.log_size, dst.data()));
+            pre = slab_set(ext.p, e);
+            mainc = slab_set(ext.p + ((size_t)np << e), e);
+            inter = slab_set(ext.p + ((size_t)(np + nm) << e), e);
+        }
+        SecureColumn acc; H_TRY(acc.alloc(ctx, e)); H_TRY(nx_memset_zero(ctx, acc.buf.p, acc.buf.words));
+        SynthRange rg{sh.lo(1), nm, c.n_main, sh.lo(2), ni, sh.lo(0) == 0 && sh.hi(0) >= 2};
+        if (nm || ni) H_TRY(synth_constraints(ctx, pre, mainc, inter, rg, (int)c.log_size, (int)e, (const u32*)d_pw, (const u32*)d_den, acc.c));
+        H_TRY(nx_sync(ctx));
+        C_TRY(comm->allreduce_m31(comm->user, acc.buf.p, acc.buf.words));
+        H_TRY(nx_interpolate_batch(ctx, cs.tw, acc.c, 4, e));
+        comp_polys = std::move(acc.buf);
+    }
+    lap(&st->composition);
+    { TreeBuilder tb = cs.tree_builder(); tb.extend_polys(std::move(comp_polys), 4, e); H_TRY(tb.commit(channel)); }   // replicated
+    lap(&st->commit);
+    QPt oods = get_random_point(channel);
+
+    // mask points per GLOBAL column
+    std::vector<std::vector<std::vector<QPt>>> points(4);
+    {
+        QPt step; { Pt s0 = pt_from_index(1u << (31 - c.log_size)); step.x = q_from_m(s0.x); step.y = q_from_m(s0.y); }
+        for (uint32_t k = 0; k < c.n_pre; k++) points[0].push_back({oods});
+        for (uint32_t k = 0; k < c.n_main; k++) { if (k < 2) points[1].push_back({oods, qpt_add(oods, step)}); else points[1].push_back({oods}); }
+        for (uint32_t k = 0; k < c.n_inter; k++) points[2].push_back({oods});
+        for (int k = 0; k < 4; k++) points[3].push_back({oods});
+    }
+    // ---------------- prove_values: local columns, then an all-gather of the (few KB of) sampled values ----------------
+    Proof proof;
+    proof.sampled_values.resize(4);
+    for (int t = 0; t < 4; t++) { proof.sampled_values[t].resize(points[t].size()); for (size_t k = 0; k < points[t].size(); k++) proof.sampled_values[t][k].assign(points[t][k].size(), q_zero()); }
+    for (int t = 0; t < 4; t++) {
+        auto& tr = cs.trees[t];
+        const uint32_t g0 = t < 3 ? sh.lo(t) : 0;
+        if (tr.polys.empty()) continue;
+        std::vector<const uint32_t*> pp; std::vector<uint32_t> pidx, pts; std::vector<std::pair<uint32_t, uint32_t>> where;
+        for (uint32_t li = 0; li < tr.polys.size(); li++) {
+            const uint32_t g = g0 + li;
+            pp.push_back(tr.polys[li].ptr);
+            for (uint32_t s2 = 0; s2 < points[t][g].size(); s2++) {
+                pidx.push_back(li);
+                uint32_t w[8]; q_store(w, points[t][g][s2].x); q_store(w + 4, points[t][g][s2].y);
+                pts.insert(pts.end(), w, w + 8);
+                where.push_back({g, s2});
+            }
+        }
+        std::vector<uint32_t> out(4 * pidx.size());
+        H_TRY(nx_eval_at_points(ctx, pp.data(), tr.polys[0].log, pidx.data(), pts.data(), (uint32_t)pidx.size(), out.data()));
+        for (size_t i = 0; i < where.size(); i++) proof.sampled_values[t][where[i].first][where[i].second] = q_load(&out[4 * i]);
+    }
+    {   // exchange trees 0..2: every rank contributes the slots of its columns
+        std::vector<uint32_t> mine;
+        for (int t = 0; t < 3; t++) for (auto& col : proof.sampled_values[t]) for (auto& v : col) { uint32_t w[4]; q_store(w, v); mine.insert(mine.end(), w, w + 4); }
+        std::vector<uint32_t> everyone(mine.size() * (size_t)sh.world);
+        C_TRY(comm->allgather(comm->user, mine.data(), mine.size() * 4, everyone.data()));
+        size_t slot = 0;
+        for (int t = 0; t < 3; t++) for (uint32_t g = 0; g < proof.sampled_values[t].size(); g++) {
+            const int r = sh.owner(t, g);
+            for (auto& v : proof.sampled_values[t][g]) { v = q_load(&everyone[(size_t)r * mine.size() + 4 * slot]); slot++; }
+        }
+    }
+    { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& col : t) for (auto& v : col) flat.push_back(v); channel.mix_felts(flat); }
+    lap(&st->oods);
+    QM31 q_coeff = channel.draw_secure_felt();
+    // ---------------- DEEP quotients: size groups over the GLOBAL column list; sharded groups = partial sums + all-reduce ----------------
+    struct Flat { const uint32_t* ptr; uint32_t log; int t; uint32_t c; };
+    std::vector<Flat> all;
+    for (int t = 0; t < 3; t++) for (uint32_t g = 0; g < sh.total[t]; g++) {
+        const bool local = g >= sh.lo(t) && g < sh.hi(t);
+        all.push_back({local ? cs.trees[t].evals[g - sh.lo(t)].ptr : nullptr, c.log_size + blow, t, g});
+    }
+    for (uint32_t g = 0; g < 4; g++) all.push_back({cs.trees[3].evals[g].ptr, cs.trees[3].evals[g].log, 3, g});
+    std::stable_sort(all.begin(), all.end(), [](const Flat& a, const Flat& b) { return a.log > b.log; });
+    std::vector<SecureColumn> quotients;
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i; while (j < all.size() && all[j].log == all[i].log) j++;
+        std::vector<QPt> bpts; std::vector<std::vector<std::tuple<uint32_t, QM31, bool>>> bcols;
+        std::vector<const uint32_t*> gcols;
+        bool sharded_group = false;   // decided by the group's CONTENT (trace-tree columns), identically on every rank
+        for (size_t k = i; k < j; k++) {
+            const bool local = all[k].ptr != nullptr;
+            uint32_t lidx = 0;
+            if (local) { lidx = (uint32_t)gcols.size(); gcols.push_back(all[k].ptr); }
+            if (all[k].t < 3) sharded_group = true;
+            const auto& ps = points[all[k].t][all[k].c];
+            for (size_t s2 = 0; s2 < ps.size(); s2++) {
+                size_t b = 0;
+                for (; b < bpts.size(); b++) if (q_eq(bpts[b].x, ps[s2].x) && q_eq(bpts[b].y, ps[s2].y)) break;
+                if (b == bpts.size()) { bpts.push_back(ps[s2]); bcols.emplace_back(); }
+                bcols[b].push_back(std::make_tuple(lidx, proof.sampled_values[all[k].t][all[k].c][s2], local));
+            }
+        }
+        std::vector<uint32_t> fpts, counts, cidx, vals; std::vector<uint8_t> is_local;
+        for (size_t b = 0; b < bpts.size(); b++) {
+            uint32_t w[8]; q_store(w, bpts[b].x); q_store(w + 4, bpts[b].y); fpts.insert(fpts.end(), w, w + 8);
+            counts.push_back((uint32_t)bcols[b].size());
+            for (auto& cv : bcols[b]) { cidx.push_back(std::get<0>(cv)); uint32_t q[4]; q_store(q, std::get<1>(cv)); vals.insert(vals.end(), q, q + 4); is_local.push_back(std::get<2>(cv) ? 1 : 0); }
+        }
+        SecureColumn qc; H_TRY(qc.alloc(ctx, all[i].log));
+        uint32_t aw[4]; q_store(aw, q_coeff);
+        if (sharded_group) {
+            H_TRY(nx_accumulate_quotients_partial(ctx, all[i].log, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(),
+                                                  cidx.data(), vals.data(), is_local.data(), sh.rank == 0 ? 1 : 0, qc.c));
+            H_TRY(nx_sync(ctx));
+            C_TRY(comm->allreduce_m31(comm->user, qc.buf.p, qc.buf.words));
+        } else {
+            H_TRY(nx_accumulate_quotients(ctx, all[i].log, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(),
+                                          cidx.data(), vals.data(), qc.c));
+        }
+        quotients.push_back(std::move(qc));
+        for (int k = 0; k < 4; k++) quotients.back().c[k] = quotients.back().buf.p + ((size_t)k << quotients.back().log);
+        i = j;
+    }
+    lap(&st->quotients);
+    FriProver fri(ctx, tw, cfg);
+    H_TRY(fri.commit(channel, std::move(quotients)));                    // replicated
+    lap(&st->fri);
+    H_TRY(nx_grind(ctx, (const uint8_t*)channel.digest.w, cfg.pow_bits, &proof.proof_of_work));
+    channel.mix_u64(proof.proof_of_work);
+    lap(&st->pow);
+    // ---------------- decommit ----------------
+    std::map<uint32_t, std::vector<size_t>> qpos;
+    fri.draw_queries(channel, &qpos);
+    GatherBatch gb;
+    fri.decommit_plan(&gb);
+    const std::vector<size_t>& tq = qpos[c.log_size + blow];             // query positions of the trace trees' single column size
+    size_t value_first[3];
+    for (int t = 0; t < 3; t++) { value_first[t] = gb.ptrs.size(); for (size_t q : tq) for (auto& ev : cs.trees[t].evals) gb.add(ev.ptr, q); }
+    DecommitPlan hash_plans[4];
+    for (int t = 0; t < 3; t++) if (cs.trees[t].merkle) hash_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, std::vector<ColumnRef>(), &gb);
+    hash_plans[3] = merkle_decommit_plan(cs.trees[3].merkle, qpos, cs.trees[3].evals, &gb);
+    H_TRY(gb.run(ctx));
+    fri.decommit_fill(gb, &proof);
+    proof.decommitments.resize(4); proof.queried_values.resize(4);
+    for (int t = 0; t < 3; t++) {
+        // queried values: [query][global column]; every rank contributes its columns
+        const uint32_t nl = sh.n_local(t), tot = sh.total[t];
+        uint32_t max_local = 0; for (int r = 0; r < sh.world; r++) max_local = std::max(max_local, sh.ranges[t][r].second - sh.ranges[t][r].first);
+        std::vector<uint32_t> mine(std::max<size_t>(1, tq.size() * (size_t)max_local), 0);
+        for (size_t qi = 0; qi < tq.size(); qi++) for (uint32_t l = 0; l < nl; l++) mine[qi * max_local + l] = gb.vals[value_first[t] + qi * nl + l];
+        std::vector<uint32_t> everyone(mine.size() * (size_t)sh.world);
+        C_TRY(comm->allgather(comm->user, mine.data(), mine.size() * 4, everyone.data()));
+        for (size_t qi = 0; qi < tq.size(); qi++) for (uint32_t g = 0; g < tot; g++) {
+            const int r = sh.owner(t, g);
+            proof.queried_values[t].push_back(everyone[(size_t)r * mine.size() + qi * max_local + (g - sh.ranges[t][r].first)]);
+        }
+        // hash witness: from the rank that holds the tree (the last active one; rank 0 for an empty tree, which is replicated)
+        const std::vector<int> act = sh.active(t);
+        const int holder = act.empty() ? 0 : act.back();
+        std::vector<uint32_t> wit;
+        if (sh.rank == holder) {
+            MerkleDecommitment d; merkle_decommit_fill(hash_plans[t], gb, nullptr, &d);
+            for (auto& h : d.hash_witness) wit.insert(wit.end(), h.w, h.w + 8);
+        }
+        uint32_t n_wit = (uint32_t)wit.size();
+        C_TRY(comm->broadcast(comm->user, &n_wit, 4, holder));
+        wit.resize(n_wit);
+        if (n_wit) C_TRY(comm->broadcast(comm->user, wit.data(), (size_t)n_wit * 4, holder));
+        for (uint32_t k = 0; k + 8 <= n_wit; k += 8) { Blake2sHash h; memcpy(h.w, &wit[k], 32); proof.decommitments[t].hash_witness.push_back(h); }
+        proof.commitments.push_back(cs.trees[t].root);
+    }
+    merkle_decommit_fill(hash_plans[3], gb, &proof.queried_values[3], &proof.decommitments[3]);
+    proof.commitments.push_back(cs.trees[3].root);
+    lap(&st->decommit);
+    QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
+    QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
+    if (!q_eq(lhs, eval_composition_at_point(comps, n_comps, locs, oods, proof.sampled_values, random_coeff)))
+        return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
+    *words = serialize(proof, cfg);
+    if (timed) {
+        (void)nx_sync(ctx);
+        st->total = now_ms() - t_start;
+        timing_flush(ctx);
+        st->lde_kernel_ms = ctx->kind_ms[NX_T_LDE]; st->lde_algorithmic_bytes = ctx->kind_bytes[NX_T_LDE];
+        st->merkle_kernel_ms = ctx->kind_ms[NX_T_MERKLE]; st->merkle_algorithmic_bytes = ctx->kind_bytes[NX_T_MERKLE];
+        ctx->timing = false;
+    }
+    return NX_OK;
+}
+
 }  // namespace nxhip
 
 using namespace nx;
@@ -716,6 +1056,20 @@ int nx_lde_commit(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, u
     int rc = nx_merkle_root(ctx, t, root);
     nx_tree_destroy(t);
     return rc;
+}
+
+int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
+                           size_t ad_len, const nx_comm* comm, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    if (!ctx || !comps || !cfg || !proof_words || !n_words || !comm) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth_sharded: NULL argument");
+    std::vector<uint32_t> w;
+    int rc = nxhip::prove_synth_sharded(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
+    ctx->timing = false;
+    if (rc != NX_OK) return rc;
+    uint32_t* out = (uint32_t*)malloc(w.size() * 4);
+    if (!out) return set_err(ctx, NX_ERR_OOM, "nx_prove_synth_sharded: malloc failed");
+    memcpy(out, w.data(), w.size() * 4);
+    *proof_words = out; *n_words = w.size();
+    return NX_OK;
 }
 
 int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,

@@ -116,3 +116,141 @@ def sharded_commit(ops, comm, local_lde, col_range, total_cols, lde_log_size, n_
     comm.broadcast(root, active[-1])
     comm.device_sync()
     return root.cpu().numpy().view(np.uint32).copy(), tree
+
+
+# ---------------------------------------------------------------- transports of the full sharded prove (nx_comm) ----------
+
+class ThreadGroup:
+    """All ranks in ONE process (one thread per rank, e.g. several contexts on one GPU): the loopback transport used to
+    check nx_prove_synth_sharded against the single-GPU proof on real hardware.  Device buffers are plain pointers in one
+    address space, so a 'send' is a device-to-device copy by the receiver."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.lock = threading.Lock()
+        self.mail = {}            # (src, dst) -> (ptr, n_words)
+        self.cv = threading.Condition(self.lock)
+        self.slots = [None] * world
+
+    def comm(self, rank, backend):
+        return _ThreadComm(self, rank, backend)
+
+
+class _ThreadComm:
+    def __init__(self, group, rank, backend):
+        self.g, self.rank, self.be = group, rank, backend
+
+    def send(self, dst, ptr, n):
+        g = self.g
+        with g.cv:
+            g.mail[(self.rank, dst)] = (ptr, n)
+            g.cv.notify_all()
+            g.cv.wait_for(lambda: (self.rank, dst) not in g.mail)     # the receiver copied it
+
+    def recv(self, src, ptr, n):
+        import ctypes as C
+        g = self.g
+        with g.cv:
+            g.cv.wait_for(lambda: (src, self.rank) in g.mail)
+            sp, sn = g.mail[(src, self.rank)]
+        assert sn == n
+        self.be._chk(self.be.L.nx_copy(self.be.ctx, C.c_void_p(ptr), C.c_void_p(sp), C.c_size_t(n)))
+        self.be.sync()
+        with g.cv:
+            del g.mail[(src, self.rank)]
+            g.cv.notify_all()
+
+    def allreduce_m31(self, ptr, n):
+        import ctypes as C
+        g, be = self.g, self.be
+        snap = C.c_void_p()
+        be._chk(be.L.nx_alloc(be.ctx, C.c_size_t(n), C.byref(snap)))
+        be._chk(be.L.nx_copy(be.ctx, snap, C.c_void_p(ptr), C.c_size_t(n)))
+        be.sync()
+        g.slots[self.rank] = snap.value
+        g.barrier.wait()
+        for r in range(g.world):
+            if r != self.rank:
+                be._chk(be.L.nx_m31_add_into(be.ctx, C.c_void_p(ptr), C.c_void_p(g.slots[r]), C.c_size_t(n)))
+        be.sync()
+        g.barrier.wait()
+        be._chk(be.L.nx_free(be.ctx, snap))
+
+    def allgather(self, data):
+        g = self.g
+        g.slots[self.rank] = data
+        g.barrier.wait()
+        out = list(g.slots)
+        g.barrier.wait()
+        return out
+
+    def broadcast(self, data, nbytes, root):
+        g = self.g
+        if self.rank == root:
+            g.slots[root] = data
+        g.barrier.wait()
+        out = g.slots[root]
+        g.barrier.wait()
+        return out
+
+
+class TorchDistComm:
+    """One process per GPU over torch.distributed (backend 'nccl' = RCCL over xGMI).  Device buffers of the library are
+    staged through torch tensors (plumbing): the modular all-reduce is a 64-bit sum all-reduce between nx_m31_widen and
+    nx_m31_narrow, since RCCL has no modular reduction (8 ranks x (p-1) < 2^34)."""
+
+    def __init__(self, backend, device):
+        import torch
+        import torch.distributed as dist
+        self.be, self.torch, self.dist, self.device = backend, torch, dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def _sync(self):
+        self.be.sync()
+        self.torch.cuda.synchronize(self.device)
+
+    def send(self, dst, ptr, n):
+        import ctypes as C
+        t = self.torch.empty(n, dtype=self.torch.int32, device=self.device)
+        self.be._chk(self.be.L.nx_copy(self.be.ctx, C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(n)))
+        self._sync()
+        self.dist.send(t, dst)
+        self.torch.cuda.synchronize(self.device)
+
+    def recv(self, src, ptr, n):
+        import ctypes as C
+        t = self.torch.empty(n, dtype=self.torch.int32, device=self.device)
+        self.dist.recv(t, src)
+        self.torch.cuda.synchronize(self.device)
+        self.be._chk(self.be.L.nx_copy(self.be.ctx, C.c_void_p(ptr), C.c_void_p(t.data_ptr()), C.c_size_t(n)))
+        self.be.sync()
+
+    def allreduce_m31(self, ptr, n):
+        import ctypes as C
+        t = self.torch.empty(n, dtype=self.torch.int64, device=self.device)
+        self.be._chk(self.be.L.nx_m31_widen(self.be.ctx, C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(n)))
+        self._sync()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.torch.cuda.synchronize(self.device)
+        self.be._chk(self.be.L.nx_m31_narrow(self.be.ctx, C.c_void_p(ptr), C.c_void_p(t.data_ptr()), C.c_size_t(n)))
+        self.be.sync()
+
+    def _bytes_tensor(self, data, nbytes):
+        t = self.torch.zeros(max(nbytes, 1), dtype=self.torch.uint8, device=self.device)
+        if data is not None and nbytes:
+            t[:nbytes] = self.torch.frombuffer(bytearray(data), dtype=self.torch.uint8).to(self.device)
+        return t
+
+    def allgather(self, data):
+        n = len(data)
+        mine = self._bytes_tensor(data, n)
+        outs = [self.torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(outs, mine)
+        return [bytes(o[:n].cpu().numpy().tobytes()) for o in outs]
+
+    def broadcast(self, data, nbytes, root):
+        t = self._bytes_tensor(data, nbytes)
+        self.dist.broadcast(t, root)
+        return bytes(t[:nbytes].cpu().numpy().tobytes())

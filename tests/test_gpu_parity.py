@@ -437,3 +437,46 @@ def test_constraint_violation_is_a_proving_error(be, nz):
     only pin the error code path of the argument check."""
     with pytest.raises(nz.NexusHipError):
         be.prove([(6, 2, 4, 0)], nz.default_config(log_constraint_degree=0))
+
+
+@pytest.mark.parametrize("world,comps,kw", [
+    (2, [(9, 20, 40, 24)], dict(pow_bits=6)),
+    (3, [(10, 27, 100, 64)], dict(pow_bits=8)),
+    (4, [(8, 3, 20, 0)], dict(pow_bits=5, log_constraint_degree=2)),       # fewer 16-column blocks than ranks; no interaction tree
+    (2, [(9, 18, 33, 17)], dict(pow_bits=6, hash_mode=1, fri_alpha_mode=1)),
+    (2, [(8, 3, 12, 5)], dict(pow_bits=5)),                                   # every tree fits one block: rank 0 holds all columns, rank 1 none
+])
+def test_sharded_prove_is_bit_identical_to_single_gpu(nz, oracle, world, comps, kw):
+    """SURVEY §8(e) / BASELINE config #4: nx_prove_synth_sharded with `world` ranks (one context per rank on this GPU, threads,
+    loopback transport) must return, on every rank, the proof nx_prove_synth returns on one GPU — which the oracle proves too."""
+    import threading
+    from nexus_zkvm_amd.sharded import ThreadGroup
+    cfg = nz.default_config(**kw)
+    be0 = nz.HipBackend(0)
+    ref = be0.prove(comps, cfg, seed=77, ad=b"shard")
+    be0.close()
+    assert oracle.verify_synth(comps, O.default_cfg(**kw), ref, ad=b"shard") is None
+    group = ThreadGroup(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            be = nz.HipBackend(0)
+            comm = nz.make_comm(rank, world, group.comm(rank, be))
+            results[rank] = be.prove_sharded(comps, comm, cfg, seed=77, ad=b"shard")
+            be.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append((rank, repr(e)))
+            try:
+                group.barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for r in range(world):
+        assert results[r] is not None and np.array_equal(results[r], ref), (world, r)

@@ -22,6 +22,49 @@ FI u32 csubD(u32 s) { return s >= P ? s - P : s; }
 FI u32 addD(u32 a, u32 b) { return csubD(a + b); }
 FI u32 subD(u32 a, u32 b) { return a >= b ? a - b : a - b + P; }
 FI u32 mulD(u32 a, u32 b2) { u64 p = (u64)a * b2; return csubD((u32)(p >> 32) + ((u32)p >> 1)); }
+
+// F: two forward butterflies in one hand-scheduled asm block: every VALU write of VCC is followed by >= 2 independent
+// instructions before the v_cndmask that reads it (gfx940+: VALU-written SGPR/VCC read by a VALU needs 2 wait states), so
+// no s_nop is needed.  y = a - m uses plain v_sub + v_cmp (the compare can be placed freely) instead of v_sub_co.
+FI void bfly2_asm(u32& a0, u32& b0, u32& a1, u32& b1, u32 t0, u32 t1) {
+    u64 p0, p1; u32 m0, m1, u0, u1, s0, s1, d0, d1, e0, e1;
+    const u32 Pc = P;
+    asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, 0\n v_mad_u64_u32 %1, vcc, %4, %5, 0" : "=&v"(p0), "=&v"(p1) : "v"(b0), "v"(t0), "v"(b1), "v"(t1) : "vcc");
+    const u32 l0 = (u32)p0, h0 = (u32)(p0 >> 32), l1 = (u32)p1, h1 = (u32)(p1 >> 32);
+    asm volatile(
+        "v_lshrrev_b32 %[m0], 1, %[l0]\n"
+        "v_lshrrev_b32 %[m1], 1, %[l1]\n"
+        "v_add_u32 %[m0], %[m0], %[h0]\n"
+        "v_add_u32 %[m1], %[m1], %[h1]\n"
+        "v_subrev_co_u32 %[u0], vcc, %[P], %[m0]\n"      // V(m0)
+        "s_nop 1\n"
+        "v_cndmask_b32 %[m0], %[u0], %[m0], vcc\n"       // R
+        "v_subrev_co_u32 %[u1], vcc, %[P], %[m1]\n"      // V(m1)
+        "v_add_u32 %[s0], %[a0], %[m0]\n"                 // filler: x sum 0
+        "v_sub_u32 %[d0], %[a0], %[m0]\n"                 // filler: y diff 0
+        "v_cndmask_b32 %[m1], %[u1], %[m1], vcc\n"       // R
+        "v_subrev_co_u32 %[u0], vcc, %[P], %[s0]\n"      // V(x0)
+        "v_add_u32 %[s1], %[a1], %[m1]\n"                 // filler
+        "v_sub_u32 %[d1], %[a1], %[m1]\n"                 // filler
+        "v_cndmask_b32 %[e0], %[u0], %[s0], vcc\n"       // R: x0
+        "v_subrev_co_u32 %[u1], vcc, %[P], %[s1]\n"      // V(x1)
+        "v_add_u32 %[u0], %[P], %[d0]\n"                  // filler: d0 + P
+        "v_add_u32 %[s0], %[P], %[d1]\n"                  // filler: d1 + P
+        "v_cndmask_b32 %[e1], %[u1], %[s1], vcc\n"       // R: x1
+        "v_cmp_lt_u32 vcc, %[a0], %[m0]\n"                // V(y0): borrow
+        "s_nop 1\n"
+        "v_cndmask_b32 %[b0], %[d0], %[u0], vcc\n"       // R: y0
+        "v_cmp_lt_u32 vcc, %[a1], %[m1]\n"                // V(y1)
+        "v_mov_b32 %[a0], %[e0]\n"                        // filler: x0 out
+        "s_nop 0\n"
+        "v_cndmask_b32 %[b1], %[d1], %[s0], vcc\n"       // R: y1
+        "v_mov_b32 %[a1], %[e1]\n"                        // x1 out
+        : [a0] "+v"(a0), [b0] "+v"(b0), [a1] "+v"(a1), [b1] "+v"(b1), [m0] "=&v"(m0), [m1] "=&v"(m1),
+          [u0] "=&v"(u0), [u1] "=&v"(u1), [s0] "=&v"(s0), [s1] "=&v"(s1), [d0] "=&v"(d0), [d1] "=&v"(d1), [e0] "=&v"(e0), [e1] "=&v"(e1)
+        : [l0] "v"(l0), [h0] "v"(h0), [l1] "v"(l1), [h1] "v"(h1), [P] "s"(Pc)
+        : "vcc");
+}
+
 #define ITERS 1024
 template <int V> __global__ __launch_bounds__(256) void k(u32* out, u32 seed) {
     u32 x[16];
@@ -39,6 +82,7 @@ template <int V> __global__ __launch_bounds__(256) void k(u32* out, u32 seed) {
                 if (V == 1) { u32 m = mulB(b, t2); u32 s = addB(a, m), d = subB(a, m); a = s; b = d; }
                 if (V == 2) { u32 m = mulC(b, t2); u32 s = addA(a, m), d = subA(a, m); a = s; b = d; }
                 if (V == 3) { u32 m = mulD(b, t2); u32 s = addD(a, m), d = subD(a, m); a = s; b = d; }
+                if (V == 5) { if (!(e & (1 << q)) && (e & (1 << ((q + 1) & 3))) == 0) { int e2 = e | (1 << ((q + 1) & 3)); bfly2_asm(x[e], x[e | (1 << q)], x[e2], x[e2 | (1 << q)], t2, t2); } }
                 if (V == 4) { u32 s = addB(a, b), d = subB(a, b); a = s; b = mulB(d, t2); }   // inverse butterfly
             }
         }
@@ -63,5 +107,6 @@ int main() {
     run<2>("C: doubled twiddle, v_min reductions");
     run<3>("D: doubled twiddle, compare+select");
     run<4>("E: inverse butterfly, B formulation");
+    run<5>("F: asm pair, hazard-free schedule");
     return 0;
 }
