@@ -19,6 +19,9 @@
 
 namespace nx {
 
+#ifndef NX_FFT_MINWAVES   // A/B knob: 5 forces <= 96 VGPRs (measured: spills, slower)
+#define NX_FFT_MINWAVES 1
+#endif
 constexpr int T13_S = 13;
 constexpr u32 T13_ROWS = 1u << T13_S;
 constexpr u32 T13_HALF = T13_ROWS / 2;
@@ -188,7 +191,7 @@ __device__ __forceinline__ u32 get4(const uint4& v, int i) { return i == 0 ? v.x
 // FIRST: the pass that owns layers [0, 13) on a contiguous tile (lo == 0, B == 0), including the circle layer.
 // One block = one (tile, group of CB columns), 2^(13-RB) lanes.
 template <bool INV, bool FIRST, int CB, int RB>
-__global__ __launch_bounds__(T13_ROWS >> RB) void fft13_kernel(Pass13 a) {
+__global__ __launch_bounds__(T13_ROWS >> RB, NX_FFT_MINWAVES) void fft13_kernel(Pass13 a) {
     constexpr int NT = T13_ROWS >> RB;
     constexpr int MAXR = (T13_S - 1 + RB - 1) / RB;       // full rounds in a 13-layer pass
     extern __shared__ __attribute__((aligned(16))) u32 lds13[];

@@ -121,3 +121,37 @@ def test_sharded_commit_ring_matches_single_process_root(tmp_path, world, n_cols
     expected = np.load(tmp_path / "expected.npy")
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"root_{r}.npy"), expected), (world, n_cols, mode, r)
+
+
+def _host_comm_worker(rank, world, port, result_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from nexus_zkvm_amd.sharded import TorchDistComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = TorchDistComm(None, torch.device("cpu"))     # host-buffer half of the transport needs no GPU
+        parts = comm.allgather(bytes([rank + 1]) * 5 + b"x" * rank)[:world] if False else comm.allgather(bytes([rank + 1]) * 6)
+        assert parts == [bytes([r + 1]) * 6 for r in range(world)]
+        for root in range(world):
+            got = comm.broadcast(b"root%d!" % root if rank == root else None, 6, root)
+            assert got == b"root%d!" % root
+        assert comm.broadcast(None if rank else b"", 0, 0) == b""
+        open(os.path.join(result_dir, f"ok_{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_transport_host_buffers_over_gloo(tmp_path):
+    """allgather / broadcast of nexus_zkvm_amd.sharded.TorchDistComm (sampled values, queried values, roots, witnesses of the
+    sharded prove) with world_size 3 over gloo; the device-buffer half (ring, modular all-reduce) is covered on the GPU box."""
+    import torch.multiprocessing as mp
+    world = 3
+    mp.spawn(_host_comm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok_{r}").exists() for r in range(world))
