@@ -128,6 +128,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": lde_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "nx::fft13_kernel<INV, FIRST, 2, 4> (Circle iFFT+FFT = LDE, all passes of one prove)",
                          "algorithmic_bytes": stats["lde_algorithmic_bytes"], "kernel_ms": stats["lde_kernel_ms"]},
+            # the FFT is VALU-issue bound on gfx950, not HBM bound: butterflies of one prove's iFFT + LDE work
+            # (n/2 * N per iFFT, n * N per 2x LDE: the trivial top layer is not computed) against the measured chip ceiling of the
+            # butterfly instruction sequence itself (tools/ubench/bfly_rates.hip, variant B: 4.73e12 butterflies/s)
+            "roofline_valu": (lambda nb: {"bound": "valu", "achieved": nb / (stats["lde_kernel_ms"] * 1e-3) / 1e12, "peak": 4.73, "unit": "T butterflies/s",
+                                          "frac": nb / (stats["lde_kernel_ms"] * 1e-3) / 4.73e12, "butterflies": nb})(
+                (args.n_pre + args.n_main + args.n_inter) * 1.5 * args.log_rows * (1 << args.log_rows)
+                + 4 * ((args.log_rows + 1) / 2.0 + (args.log_rows + 1)) * (2 << args.log_rows)),
             "stages_ms": {k: round(stats[k], 3) for k in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")},
             "merkle": {"kernel_ms": stats["merkle_kernel_ms"], "algorithmic_bytes": stats["merkle_algorithmic_bytes"],
                        "achieved_GBs": stats["merkle_algorithmic_bytes"] / (stats["merkle_kernel_ms"] * 1e-3) / 1e9 if stats["merkle_kernel_ms"] > 0 else 0.0},

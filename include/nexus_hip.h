@@ -236,6 +236,34 @@ int nx_m31_add_into(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t 
 int nx_m31_widen(nx_ctx* ctx, uint64_t* d_dst, const uint32_t* d_src, size_t n_words);
 int nx_m31_narrow(nx_ctx* ctx, uint32_t* d_dst, const uint64_t* d_src, size_t n_words);
 
+/* ------------------------------------------- "next" row R9: recorded AIR constraints evaluated on device ---------------
+ * The reference's AIR closures (MachineEval::evaluate, prover/src/components/mod.rs:39-57; BuiltInComponentEval::evaluate,
+ * prover2/machine/src/framework/eval.rs:19-33) cannot cross a C ABI, but a recording EvalAtRow — the trick Stwo's
+ * InfoEvaluator already plays to discover masks (prover/src/components/mod.rs:59-67) — turns them into a straight-line
+ * program over the field tower, and that can.  Registers are indices of a per-row register file (a secure-field value takes
+ * 4 consecutive registers); the host allocates them.  For every row of the evaluation domain (bit-reversed circle-domain
+ * order, log size log_eval) the program runs once and  acc[row] += (sum_j alpha_powers[j] * C_j(row)) * denom_inv[row >> log_size]
+ * (FrameworkComponent::evaluate_constraint_quotients_on_domain). */
+enum {
+    NX_C_LOAD = 0,          /* B[dst] = cols[a][row + (int32)b trace steps]                          */
+    NX_C_CONST = 1,         /* B[dst] = a (canonical M31 immediate)                                  */
+    NX_C_ADD = 2, NX_C_SUB = 3, NX_C_MUL = 4, /* B[dst] = B[a] op B[b]                               */
+    NX_C_NEG = 5,           /* B[dst] = -B[a]                                                        */
+    NX_C_CONSTE = 6,        /* E[dst] = econsts[a]   (QM31: lookup elements, ...)                    */
+    NX_C_ADDE = 7, NX_C_SUBE = 8, NX_C_MULE = 9, /* E[dst] = E[a] op E[b]                            */
+    NX_C_MULEB = 10,        /* E[dst] = E[a] * B[b]                                                  */
+    NX_C_ADDEB = 11,        /* E[dst] = E[a] + B[b]                                                  */
+    NX_C_LOADE = 12,        /* E[dst] = (cols[a], cols[a+1], cols[a+2], cols[a+3])[row + (int32)b steps]  (a secure column) */
+    NX_C_CONSTRAINT_B = 13, /* add_constraint(B[a])                                                  */
+    NX_C_CONSTRAINT_E = 14  /* add_constraint(E[a])                                                  */
+};
+typedef struct nx_cinstr { uint32_t op, dst, a, b; } nx_cinstr;
+int nx_eval_constraint_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs,
+                               const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t* econsts /* 4 words each */,
+                               uint32_t n_econsts, const uint32_t* alpha_powers /* 4 words per constraint */,
+                               uint32_t n_constraints, const uint32_t* denom_inv /* 2^(log_eval-log_size) words */,
+                               uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4);
+
 /* Config #2: LDE + Blake2s commit of n_cols random columns of 2^log_size rows (already resident,
  * bit-reversed evaluations, overwritten by their coefficients); d_lde receives the LDE columns. */
 int nx_lde_commit(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size,

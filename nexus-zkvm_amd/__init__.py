@@ -351,6 +351,20 @@ class HipBackend:
                                                  cidx.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), out.col_ptrs()))
         return out
 
+    # ---- recorded AIR constraints ----
+    def eval_constraint_program(self, program, column_ptrs, alpha_powers, denom_inv, log_size, log_eval, acc4):
+        """Run an air_program.Program over every row of the evaluation domain and accumulate into acc4 (a 4-column
+        DeviceColumns of log size log_eval).  column_ptrs: device addresses (ints) of the columns the program's LOADs index."""
+        ins = _u32(program.instrs).reshape(-1)
+        ptrs = (C.c_void_p * max(1, len(column_ptrs)))(*column_ptrs)
+        ec = _u32(program.econsts).reshape(-1)
+        pw = _u32(alpha_powers).reshape(-1)
+        den = _u32(denom_inv)
+        self._chk(self.L.nx_eval_constraint_program(self.ctx, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, ptrs, len(column_ptrs),
+                                                    ec.ctypes.data_as(C.c_void_p), len(ec) // 4, pw.ctypes.data_as(C.c_void_p), len(pw) // 4,
+                                                    den.ctypes.data_as(C.c_void_p), log_size, log_eval, acc4.col_ptrs()))
+        return acc4
+
     # ---- FriOps ----
     def fold_circle_into_line(self, tw, dst4, src4, alpha):
         a = _u32(alpha)

@@ -12,6 +12,7 @@
 #include "merkle.h"
 #include "air.h"
 #include "pcs.h"
+#include "constraints.h"
 
 using namespace orc;
 
@@ -192,6 +193,11 @@ int orc_verify_synth(const int* comps, int ncomp, const int* cfg, const uint32_t
     try { e = verify_synth(air_from(comps, ncomp), cfg_from(cfg), p, ad, ad_len); } catch (const std::string& x) { e = x; }
     if (e.empty()) return 0;
     g_err = e; return 1;
+}
+
+void orc_eval_constraint_program(const uint32_t* prog, uint32_t n_instr, uint32_t n_regs, const uint32_t** cols, const uint32_t* econsts, const uint32_t* pw,
+                                 const uint32_t* denom_inv, int log_size, int log_eval, uint32_t** acc4) {
+    eval_constraint_program((const CInstr*)prog, n_instr, n_regs, cols, econsts, pw, denom_inv, log_size, log_eval, acc4);
 }
 
 // Timed CPU baseline leg: one full prove, returns seconds (negative on error).

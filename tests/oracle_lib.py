@@ -181,3 +181,18 @@ def verify_synth(comps, cfg, words, ad=b""):
 def time_prove_synth(comps, cfg, seed=1, threads=1):
     comps = comps_array(comps)
     return lib().orc_time_prove_synth(ptr(comps), len(comps), ptr(cfg), seed, threads)
+
+
+def eval_constraint_program(program, cols, alpha_powers, denom_inv, log_size, log_eval, acc4=None):
+    """oracle/constraints.h: the recorded-constraint program over every row of the evaluation domain; returns the 4
+    accumulator columns (numpy uint32, 2^log_eval each)."""
+    L = lib()
+    cols = [u32(c) for c in cols]
+    n = 1 << log_eval
+    acc = [np.zeros(n, np.uint32) for _ in range(4)] if acc4 is None else [u32(a).copy() for a in acc4]
+    ins = u32(program.instrs).reshape(-1)
+    ec = u32(program.econsts).reshape(-1) if len(program.econsts) else np.zeros(4, np.uint32)
+    pw = u32(alpha_powers).reshape(-1)
+    den = u32(denom_inv)
+    L.orc_eval_constraint_program(ptr(ins), len(ins) // 4, program.n_regs, ptr_array(cols), ptr(ec), ptr(pw), ptr(den), log_size, log_eval, ptr_array(acc))
+    return acc

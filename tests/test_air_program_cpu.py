@@ -1,0 +1,130 @@
+"""Recorded AIR constraints: the recorder (nexus-zkvm_amd/air_program.py) and the CPU oracle of the
+program semantics (oracle/constraints.h).  The oracle is pinned by the only property the maths offers without Stwo: for a
+trace that satisfies the AIR, sum_j alpha^j C_j / Z_trace evaluated on the constraint domain is a POLYNOMIAL of the degree the
+constraint degree allows (its upper coefficients vanish) — wrong masks, wrong row offsets or wrong vanishing denominators
+all break that."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+P = O.P
+
+
+def _pt_from_index(idx):
+    def add(p, q):
+        return ((p[0] * q[0] - p[1] * q[1]) % P, (p[0] * q[1] + p[1] * q[0]) % P)
+    res, cur = (1, 0), (2, 1268011823)
+    idx &= (1 << 31) - 1
+    while idx:
+        if idx & 1:
+            res = add(res, cur)
+        cur = add(cur, cur)
+        idx >>= 1
+    return res
+
+
+def _circle_domain_index(log, i):
+    half = 1 << (log - 1)
+    ho = lambda l, j: ((1 << (31 - l - 2)) + (j << (31 - l))) & ((1 << 31) - 1)
+    return ho(log - 1, i) if i < half else (-ho(log - 1, i - half)) & ((1 << 31) - 1)
+
+
+def _bitrev(i, log):
+    return int(format(i, "0%db" % log)[::-1], 2) if log else 0
+
+
+def denominators(log_size, log_eval):
+    """1 / coset_vanishing(trace coset) on the 2^(log_eval-log_size) cosets of the evaluation domain, bit-reversed
+    (what nexus-zkvm_amd/csrc/prover.hip::compute_composition builds on the host)."""
+    le = log_eval - log_size
+    den = np.zeros(1 << le, np.uint32)
+    for i in range(1 << le):
+        x = _pt_from_index(_circle_domain_index(log_eval, i))[0]
+        for _ in range(1, log_size):
+            x = (2 * x * x - 1) % P
+        den[_bitrev(i, le)] = pow(x, P - 2, P)
+    return den
+
+
+def synthetic_program(ap, n_pre, n_main, n_inter):
+    """The synthetic machine of oracle/air.h recorded through the generic evaluator: columns are numbered pre | main | inter."""
+    pb = ap.ProgramBuilder()
+    pre = [pb.next_trace_mask(k)[0] for k in range(n_pre)]
+    m0, m0n = pb.next_trace_mask(n_pre + 0, (0, 1))
+    m1, m1n = pb.next_trace_mask(n_pre + 1, (0, 1))
+    main = [m0, m1] + [pb.next_trace_mask(n_pre + k)[0] for k in range(2, n_main)]
+    inter = [pb.next_trace_mask(n_pre + n_main + k)[0] for k in range(n_inter)]
+    not_last = pb.const(1) - pre[1]
+    pb.add_constraint((m0n - m0 - 1) * not_last)
+    pb.add_constraint((m1n - m1 - m0) * not_last)
+    for k in range(2, n_main):
+        if k % 16 >= 2:
+            pb.add_constraint(main[k] - main[k - 1] * main[k - 1] - main[k - 2] * main[k - 2])
+    for k in range(n_inter):
+        if k % 16 >= 2:
+            pb.add_constraint(inter[k] - inter[k - 1] * inter[k - 1] - inter[k - 2] * inter[k - 2])
+    return pb.build()
+
+
+def test_recorder_shares_subexpressions_and_reuses_registers():
+    import nexus_zkvm_amd.air_program as ap
+    pb = ap.ProgramBuilder()
+    (a,) = pb.next_trace_mask(0)
+    (b,) = pb.next_trace_mask(1)
+    x = a * b
+    y = b * a                      # commutative: same node
+    assert x.id == y.id
+    pb.add_constraint(x + 1)
+    pb.add_constraint(x - a)
+    dead = a * a * a               # not reachable from a constraint: not emitted
+    prog = pb.build()
+    assert prog.n_constraints == 2 and (prog.instrs[:, 0] == ap.MUL).sum() == 1 and dead.id >= 0
+    # a long chain needs a bounded register file
+    pb = ap.ProgramBuilder()
+    cols = [pb.next_trace_mask(k)[0] for k in range(64)]
+    acc = cols[0]
+    for c in cols[1:]:
+        acc = acc * c + 3
+        pb.add_constraint(acc)
+    assert pb.build().n_regs <= 70    # the 64 loads are emitted up front (program order = recording order) + a few temporaries
+    # constraints keep their declaration order (alpha power j belongs to the j-th add_constraint)
+    pb = ap.ProgramBuilder()
+    (a,) = pb.next_trace_mask(0)
+    (b,) = pb.next_trace_mask(1)
+    late = a + b
+    pb.add_constraint(b * b)       # recorded first although its node is created after `late`
+    pb.add_constraint(late)
+    prog = pb.build()
+    cons = [tuple(r) for r in prog.instrs if r[0] in (ap.CONSTRAINT_B, ap.CONSTRAINT_E)]
+    assert len(cons) == 2
+
+
+@pytest.mark.parametrize("lcd", [1, 2])
+def test_oracle_program_of_a_valid_trace_is_a_low_degree_quotient(oracle, lcd):
+    import nexus_zkvm_amd.air_program as ap
+    log, n_pre, n_main, n_inter = 6, 3, 20, 19
+    comps = [(log, n_pre, n_main, n_inter)]
+    cols = []
+    for tree in range(3):
+        cols += oracle.synth_tree_columns(comps, tree, 11, 0x1234)
+    e = log + lcd
+    tw = oracle.Twiddles(e)
+    ext = [tw.evaluate(tw.interpolate(c), e) for c in cols]
+    prog = synthetic_program(ap, n_pre, n_main, n_inter)
+    rng = np.random.default_rng(5)
+    pw = rng.integers(0, P, (prog.n_constraints, 4), dtype=np.uint32)
+    acc = oracle.eval_constraint_program(prog, ext, pw, denominators(log, e), log, e)
+    for k in range(4):
+        coeffs = tw.interpolate(acc[k])
+        # degree-2 constraints over a trace in the N-dimensional space, divided by the vanishing polynomial of the trace coset:
+        # at most N + 1 coefficients survive (products of circle polynomials pick up the one extra basis element)
+        assert not coeffs[(1 << log) + 1:].any(), (lcd, k)
+        assert coeffs[:1 << log].any()
+    # a trace that violates one constraint is NOT a polynomial quotient any more
+    bad = [c.copy() for c in cols]
+    bad[n_pre + 5][7] = (int(bad[n_pre + 5][7]) + 1) % P
+    ext_bad = [tw.evaluate(tw.interpolate(c), e) for c in bad]
+    acc_bad = oracle.eval_constraint_program(prog, ext_bad, pw, denominators(log, e), log, e)
+    if lcd == 2:
+        assert any(tw.interpolate(acc_bad[k])[1 << (log + 1):].any() for k in range(4))

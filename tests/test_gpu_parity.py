@@ -480,3 +480,93 @@ def test_sharded_prove_is_bit_identical_to_single_gpu(nz, oracle, world, comps, 
     assert not errors, errors
     for r in range(world):
         assert results[r] is not None and np.array_equal(results[r], ref), (world, r)
+
+
+# ---------------- "next" row R9: recorded AIR constraints on device (nx_eval_constraint_program) ----------------------------
+
+def _random_program(ap, rng, n_cols, n_ops):
+    """A random straight-line program that uses every opcode: base and secure arithmetic, masks at -1/0/+1, secure columns."""
+    pb = ap.ProgramBuilder()
+    base = [e for k in range(n_cols - 4) for e in pb.next_trace_mask(k, (0, 1) if k % 3 == 0 else (-1,) if k % 5 == 0 else (0,))]
+    sec = pb.next_secure_mask(n_cols - 4, (0, 1))
+    sec.append(pb.econst(rng.integers(0, P, 4)))
+    for _ in range(n_ops):
+        r = rng.integers(0, 8)
+        if r < 3:
+            a, b = base[rng.integers(len(base))], base[rng.integers(len(base))]
+            base.append([a + b, a - b, a * b][r])
+        elif r == 3:
+            base.append(-base[rng.integers(len(base))] + int(rng.integers(0, P)))
+        elif r < 6:
+            a, b = sec[rng.integers(len(sec))], sec[rng.integers(len(sec))]
+            sec.append([a + b, a * b][r - 4])
+        elif r == 6:
+            sec.append(sec[rng.integers(len(sec))] * base[rng.integers(len(base))] - sec[rng.integers(len(sec))])
+        else:
+            sec.append(base[rng.integers(len(base))] - sec[rng.integers(len(sec))] + base[rng.integers(len(base))])
+        if rng.integers(0, 3) == 0:
+            pb.add_constraint(base[-1] if rng.integers(0, 2) else sec[-1])
+    pb.add_constraint(base[-1]); pb.add_constraint(sec[-1])
+    return pb.build()
+
+
+@pytest.mark.parametrize("log,lcd,seed", [(5, 1, 1), (6, 2, 2), (9, 1, 3)])
+def test_constraint_program_matches_oracle(be, oracle, log, lcd, seed):
+    import nexus_zkvm_amd.air_program as ap
+    from test_air_program_cpu import denominators
+    rng = np.random.default_rng(seed)
+    e, n_cols = log + lcd, 12
+    prog = _random_program(ap, rng, n_cols, 120)
+    cols = rng.integers(0, P, (n_cols, 1 << e), dtype=np.uint32)
+    pw = rng.integers(0, P, (prog.n_constraints, 4), dtype=np.uint32)
+    den = denominators(log, e)
+    start = rng.integers(0, P, (4, 1 << e), dtype=np.uint32)          # the accumulator is added to, not overwritten
+    d_cols, acc = be.columns_from_host(cols), be.columns_from_host(start)
+    ptrs = [d_cols.ptr.value + k * (4 << e) for k in range(n_cols)]
+    be.eval_constraint_program(prog, ptrs, pw, den, log, e, acc)
+    ref = oracle.eval_constraint_program(prog, list(cols), pw, den, log, e, acc4=list(start))
+    assert np.array_equal(acc.to_cpu(), np.stack(ref))
+    assert prog.n_regs <= 160
+
+
+def test_constraint_program_reproduces_the_synthetic_machine(be, nz, oracle):
+    """The synthetic AIR recorded through the generic evaluator gives, on the device's own LDE columns, the same accumulator as
+    the oracle's interpreter, and a quotient that is a polynomial (the property that pins the oracle, now on GPU data)."""
+    import nexus_zkvm_amd.air_program as ap
+    from test_air_program_cpu import denominators, synthetic_program
+    log, n_pre, n_main, n_inter = 10, 4, 37, 18
+    comps = [(log, n_pre, n_main, n_inter)]
+    e = log + 1
+    tw = be.precompute_twiddles(e)
+    ldes = []
+    for tree in range(3):
+        for s in be.synth_fill_tree(comps, tree, seed=5, inter_seed=99):
+            ldes.append(be.lde(tw, s, 1))
+    ptrs = [l.ptr.value + k * (4 << e) for l in ldes for k in range(l.n_cols)]
+    host = np.concatenate([l.to_cpu() for l in ldes])
+    prog = synthetic_program(ap, n_pre, n_main, n_inter)
+    pw = np.random.default_rng(8).integers(0, P, (prog.n_constraints, 4), dtype=np.uint32)
+    den = denominators(log, e)
+    acc = be.columns(4, e)
+    be._chk(be.L.nx_memset_zero(be.ctx, acc.ptr, C.c_size_t(4 << e)))
+    be.eval_constraint_program(prog, ptrs, pw, den, log, e, acc)
+    got = acc.to_cpu()
+    assert np.array_equal(got, np.stack(oracle.eval_constraint_program(prog, list(host), pw, den, log, e)))
+    be.interpolate_columns(tw, acc)
+    coeffs = acc.to_cpu()
+    assert not coeffs[:, (1 << log) + 1:].any() and coeffs[:, :1 << log].any()
+
+
+def test_constraint_program_rejects_malformed_programs(be, nz):
+    import nexus_zkvm_amd.air_program as ap
+    pb = ap.ProgramBuilder()
+    (a,) = pb.next_trace_mask(3)           # column 3 of a 2-column table
+    pb.add_constraint(a)
+    prog = pb.build()
+    acc = be.columns(4, 5)
+    cols = be.columns(2, 5)
+    ptrs = [cols.ptr.value, cols.ptr.value + (4 << 5)]
+    with pytest.raises(nz.NexusHipError, match="malformed"):
+        be.eval_constraint_program(prog, ptrs, np.zeros((1, 4), np.uint32), np.ones(2, np.uint32), 4, 5, acc)
+    with pytest.raises(nz.NexusHipError, match="alpha powers"):
+        be.eval_constraint_program(prog, ptrs + ptrs, np.zeros((2, 4), np.uint32), np.ones(2, np.uint32), 4, 5, acc)
