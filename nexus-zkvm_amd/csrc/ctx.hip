@@ -79,7 +79,7 @@ void dev_free(nx_ctx* ctx, void* p) {
     ctx->free_blocks.insert({it->second, p});
     ctx->cached_bytes += it->second;
     ctx->live_blocks.erase(it);
-    if (ctx->cached_bytes > ((size_t)96 << 30)) dev_cache_release(ctx);  // keep the cache bounded
+    if (ctx->cached_bytes > ((size_t)192 << 30)) dev_cache_release(ctx);  // keep the cache bounded (a 2^24-row prove recycles ~100 GB)
 }
 void dev_cache_release(nx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
