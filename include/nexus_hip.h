@@ -264,6 +264,35 @@ int nx_eval_constraint_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n
                                uint32_t n_constraints, const uint32_t* denom_inv /* 2^(log_eval-log_size) words */,
                                uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4);
 
+/* ------------------------------------------- "next" row R8: logup interaction trace on device ------------------------
+ * The reference fills the interaction trace on the CPU (prover/src/traits.rs:124-145 generate_interaction_trace -> per chip,
+ * e.g. prover/src/chips/range_check/range256.rs:271-288; prover2/machine/src/lookups/logup_trace_builder.rs:22-121) through
+ * stwo-constraint-framework's LogupTraceGenerator.  For main-trace columns that already live in HBM: */
+/* Relation::combine: denom(row) = sum_i alpha_powers[i] * tuple_i(row) - z   (alpha_powers: 4 words per tuple column) */
+int nx_logup_combine(nx_ctx* ctx, const uint32_t* const* d_tuple_cols, uint32_t n_cols, const uint32_t* alpha_powers,
+                     const uint32_t z[4], uint32_t log_size, uint32_t* const* d_out4);
+/* LogupColGenerator::{write_frac, finalize_col}: out(row) = num/den + prev(row).  A numerator is scale * mult(row)
+ * (d_mult NULL: the constant `scale`, e.g. 1 or -1).  With a second fraction (d_den_b4 != NULL) the two are merged first,
+ * (a d + b c) / (b d), as prover2's LogupTraceBuilder::add_to_relation_with does (logup_trace_builder.rs:93-97).
+ * d_prev4 NULL for the first column.  out may alias prev. */
+int nx_logup_finalize_col(nx_ctx* ctx, uint32_t log_size, const uint32_t* d_mult_a, const uint32_t scale_a[4],
+                          const uint32_t* const* d_den_a4, const uint32_t* d_mult_b, const uint32_t scale_b[4],
+                          const uint32_t* const* d_den_b4, const uint32_t* const* d_prev4, uint32_t* const* d_out4);
+/* Fused form of the two calls above (the denominators never touch memory): one interaction column from one or two
+ * fractions given by their tuple columns.  frac_b NULL = a single fraction; d_prev4 NULL = the first column. */
+typedef struct nx_logup_frac {
+    const uint32_t* const* d_tuple_cols; uint32_t n_tuple_cols;   /* relation tuple (main-trace columns)                */
+    const uint32_t* alpha_powers;                                 /* 4 words per tuple column                           */
+    const uint32_t* z;                                            /* 4 words                                            */
+    const uint32_t* d_mult;                                       /* multiplicity column or NULL                        */
+    const uint32_t* scale;                                        /* 4 words: numerator = scale * mult (or scale)       */
+} nx_logup_frac;
+int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, const nx_logup_frac* frac_b,
+                 const uint32_t* const* d_prev4, uint32_t* const* d_out4);
+/* LogupTraceGenerator::finalize_last on the last column (in place): claimed_sum = sum over all rows; the column becomes
+ * the inclusive prefix sum, in natural coset order, of (value - claimed_sum / 2^log_size). */
+int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_col4, uint32_t claimed_sum[4]);
+
 /* Config #2: LDE + Blake2s commit of n_cols random columns of 2^log_size rows (already resident,
  * bit-reversed evaluations, overwritten by their coefficients); d_lde receives the LDE columns. */
 int nx_lde_commit(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size,

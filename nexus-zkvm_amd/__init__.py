@@ -79,6 +79,12 @@ def make_comm(rank, world, impl):
     return c
 
 
+class LogupFrac(C.Structure):
+    """nx_logup_frac of include/nexus_hip.h."""
+    _fields_ = [("d_tuple_cols", C.c_void_p), ("n_tuple_cols", C.c_uint32), ("alpha_powers", C.c_void_p), ("z", C.c_void_p), ("d_mult", C.c_void_p),
+                ("scale", C.c_void_p)]
+
+
 class ProveStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")] + \
                [("lde_kernel_ms", C.c_double), ("lde_algorithmic_bytes", C.c_uint64), ("merkle_kernel_ms", C.c_double),
@@ -364,6 +370,53 @@ class HipBackend:
                                                     ec.ctypes.data_as(C.c_void_p), len(ec) // 4, pw.ctypes.data_as(C.c_void_p), len(pw) // 4,
                                                     den.ctypes.data_as(C.c_void_p), log_size, log_eval, acc4.col_ptrs()))
         return acc4
+
+    # ---- logup interaction trace ----
+    @staticmethod
+    def _ptr4(cols4):
+        return cols4.col_ptrs() if cols4 is not None else None
+
+    def logup_combine(self, tuple_cols, alpha_powers, z):
+        """Relation::combine over device columns: sum_i alpha_powers[i] * tuple_i - z -> a secure (4-column) DeviceColumns."""
+        out = DeviceColumns(self, 4, tuple_cols.log_size)
+        ap, zz = _u32(alpha_powers).reshape(-1), _u32(z)
+        self._chk(self.L.nx_logup_combine(self.ctx, tuple_cols.col_ptrs(), tuple_cols.n_cols, ap.ctypes.data_as(C.c_void_p), zz.ctypes.data_as(C.c_void_p),
+                                          tuple_cols.log_size, out.col_ptrs()))
+        return out
+
+    def logup_finalize_col(self, den_a, scale_a=(1, 0, 0, 0), mult_a=None, den_b=None, scale_b=(1, 0, 0, 0), mult_b=None, prev=None, out=None):
+        """LogupColGenerator::write_frac + finalize_col (one fraction, or two merged as prover2 does).  mult_*: a 1-column
+        DeviceColumns (numerator = scale * mult) or None (numerator = scale)."""
+        out = out or DeviceColumns(self, 4, den_a.log_size)
+        sa, sb = _u32(scale_a), _u32(scale_b)
+        self._chk(self.L.nx_logup_finalize_col(self.ctx, den_a.log_size, mult_a.ptr if mult_a is not None else None, sa.ctypes.data_as(C.c_void_p),
+                                               den_a.col_ptrs(), mult_b.ptr if mult_b is not None else None, sb.ctypes.data_as(C.c_void_p),
+                                               self._ptr4(den_b), self._ptr4(prev), out.col_ptrs()))
+        return out
+
+    def logup_col(self, frac_a, frac_b=None, prev=None, out=None):
+        """Fused combine + write_frac + finalize_col (nx_logup_col).  A fraction is a dict: tuple (DeviceColumns), alphas
+        (n x 4), z (4), optional mult (1-column DeviceColumns), optional scale (4, default 1)."""
+        keep = []
+
+        def mk(f):
+            t = f["tuple"]
+            ptrs = t.col_ptrs(); ap = _u32(f["alphas"]).reshape(-1); z = _u32(f["z"]); sc = _u32(f.get("scale", (1, 0, 0, 0)))
+            keep.extend([ptrs, ap, z, sc])
+            m = f.get("mult")
+            return LogupFrac(C.cast(ptrs, C.c_void_p), t.n_cols, ap.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                             m.ptr if m is not None else None, sc.ctypes.data_as(C.c_void_p))
+        fa = mk(frac_a)
+        fb = mk(frac_b) if frac_b is not None else None
+        out = out or DeviceColumns(self, 4, frac_a["tuple"].log_size)
+        self._chk(self.L.nx_logup_col(self.ctx, frac_a["tuple"].log_size, C.byref(fa), C.byref(fb) if fb is not None else None, self._ptr4(prev), out.col_ptrs()))
+        return out
+
+    def logup_finalize_last(self, col4):
+        """LogupTraceGenerator::finalize_last in place; returns the claimed sum (4 words)."""
+        cs = np.zeros(4, np.uint32)
+        self._chk(self.L.nx_logup_finalize_last(self.ctx, col4.log_size, col4.col_ptrs(), cs.ctypes.data_as(C.c_void_p)))
+        return cs
 
     # ---- FriOps ----
     def fold_circle_into_line(self, tw, dst4, src4, alpha):

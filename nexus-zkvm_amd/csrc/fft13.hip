@@ -350,14 +350,20 @@ __global__ __launch_bounds__(T13_ROWS >> RB, NX_FFT_MINWAVES) void fft13_kernel(
     }
 }
 
-// ---- planning: layers [0, m) -> the FIRST pass [0, 13) plus passes of <= 9 layers (runs of >= 16 words) ----
+// ---- planning: layers [0, m) -> the FIRST pass [0, 13) plus passes of <= kmax layers (runs of 2^(13-kmax) words) ----
 struct Plan13 { int lo, K, B; };
+static int plan13_kmax() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("NX_FFT_KMAX"); v = e ? std::max(1, std::min(11, atoi(e))) : 9; }
+    return v;
+}
 static std::vector<Plan13> plan13(int m) {
     std::vector<Plan13> p;
     p.push_back({0, T13_S, 0});
     int rest = m - T13_S;
     if (rest <= 0) return p;
-    int nhi = (rest + 8) / 9, lo = T13_S;
+    const int kmax = plan13_kmax();
+    int nhi = (rest + kmax - 1) / kmax, lo = T13_S;
     for (int i = 0; i < nhi; i++) {
         int k = rest / nhi + (i < rest % nhi ? 1 : 0);
         p.push_back({lo, k, T13_S - k});

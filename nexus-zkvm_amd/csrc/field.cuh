@@ -41,7 +41,19 @@ NX_HD u32 m_pow(u32 a, u32 e) {
     while (e) { if (e & 1) r = m_mul(r, a); a = m_sqr(a); e >>= 1; }
     return r;
 }
-NX_HD u32 m_inv(u32 a) { return m_pow(a, P - 2); }
+// a^(p-2) = a^(2^31-3) by an addition chain: 30 squarings + 7 multiplications (the square-and-multiply walk of m_pow
+// spends 30 + 29); same chain as Stwo's M31 inverse (pow2147483645) [upstream-recollection].
+NX_HD u32 m_sqn(u32 a, int n) { for (int i = 0; i < n; i++) a = m_sqr(a); return a; }
+NX_HD u32 m_inv(u32 a) {
+    const u32 t2 = m_mul(m_sqr(a), a);              // a^(2^2-1)
+    const u32 t4 = m_mul(m_sqn(t2, 2), t2);         // a^(2^4-1)
+    const u32 t8 = m_mul(m_sqn(t4, 4), t4);         // a^(2^8-1)
+    const u32 t16 = m_mul(m_sqn(t8, 8), t8);        // a^(2^16-1)
+    const u32 t24 = m_mul(m_sqn(t16, 8), t8);       // a^(2^24-1)
+    const u32 t28 = m_mul(m_sqn(t24, 4), t4);       // a^(2^28-1)
+    const u32 t29 = m_mul(m_sqr(t28), a);           // a^(2^29-1)
+    return m_mul(m_sqn(t29, 2), a);                 // a^(4(2^29-1)+1) = a^(2^31-3)
+}
 NX_HD u32 m_double_x(u32 x) { u32 s = m_sqr(x); return m_sub(m_add(s, s), 1); }
 
 // Lazy dot-product accumulation: products of canonical values are added as raw 64-bit integers

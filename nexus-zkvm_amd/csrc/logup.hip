@@ -1,0 +1,242 @@
+// Logup interaction-trace generation on device: SURVEY.md §8(f) rank 2 ("next" row R8).
+//
+// Replaces, for columns that are already resident in HBM, the CPU loops of the reference's interaction-trace fill
+// (prover/src/traits.rs:124-145 -> per chip e.g. prover/src/chips/range_check/range256.rs:271-288;
+// prover2/machine/src/lookups/logup_trace_builder.rs:22-121) and the Stwo `LogupTraceGenerator` they drive:
+//   relation.combine(tuple)            denom(row) = sum_i alpha^i * tuple_i(row) - z                      -> nx_logup_combine
+//   LogupColGenerator::finalize_col    col_k(row) = num(row) / denom(row) + col_{k-1}(row)                 -> nx_logup_finalize_col
+//       (prover2 merges two fractions per column first: (a d + b c) / (b d), logup_trace_builder.rs:93-97)
+//   LogupTraceGenerator::finalize_last claimed_sum = sum over rows of the last column; the column becomes the inclusive
+//       prefix sum, IN NATURAL COSET ORDER, of (value - claimed_sum / N)                                   -> nx_logup_finalize_last
+// All columns are bit-reversed circle-domain order like every other column here; a secure (QM31) column is 4 coordinate
+// columns.  One lane per row; the only cross-row step is the scan, done per 4096-row block in LDS with the block offsets
+// scanned on the host (<= 4096 QM31 values).
+#include "internal.h"
+#include <algorithm>
+#include <string.h>
+
+namespace nx {
+
+struct Sec4 { u32* c[4]; };
+struct Sec4C { const u32* c[4]; };
+
+__global__ __launch_bounds__(256) void logup_combine_kernel(ColSet cols, u32 n_cols, const u32* __restrict__ coeffs /*4 per column*/, QM31 z, u32 n, Sec4 out) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (u32 k = 0; k < n_cols; k++) {
+        const u32 v = cols.col(k)[r];
+        s0 = acc_mad(s0, coeffs[4 * k], v); s1 = acc_mad(s1, coeffs[4 * k + 1], v); s2 = acc_mad(s2, coeffs[4 * k + 2], v); s3 = acc_mad(s3, coeffs[4 * k + 3], v);
+        if ((k & 3) == 3) { s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3); }
+    }
+    const QM31 d = q_sub(qm(acc_final(s0), acc_final(s1), acc_final(s2), acc_final(s3)), z);
+    out.c[0][r] = d.a.a; out.c[1][r] = d.a.b; out.c[2][r] = d.b.a; out.c[3][r] = d.b.b;
+}
+
+// numerator = scale * mult[row] (mult == nullptr: scale): covers 1, -1, a multiplicity column and its negation
+struct LogupFrac { const u32* mult; QM31 scale; Sec4C den; };
+
+__device__ __forceinline__ QM31 frac_num(const LogupFrac& f, u32 r) { return f.mult ? q_mul_m(f.scale, f.mult[r]) : f.scale; }
+__device__ __forceinline__ QM31 sec_at(const Sec4C& s, u32 r) { return qm(s.c[0][r], s.c[1][r], s.c[2][r], s.c[3][r]); }
+
+__global__ __launch_bounds__(256) void logup_finalize_col_kernel(LogupFrac fa, LogupFrac fb, bool two, Sec4C prev, bool has_prev, u32 n, Sec4 out) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    QM31 num = frac_num(fa, r), den = sec_at(fa.den, r);
+    if (two) {
+        const QM31 c = frac_num(fb, r), d = sec_at(fb.den, r);
+        num = q_add(q_mul(num, d), q_mul(den, c));   // a d + b c
+        den = q_mul(den, d);                          // b d
+    }
+    QM31 v = q_mul(num, q_inv(den));
+    if (has_prev) v = q_add(v, sec_at(prev, r));
+    out.c[0][r] = v.a.a; out.c[1][r] = v.a.b; out.c[2][r] = v.b.a; out.c[3][r] = v.b.b;
+}
+
+
+// Fused form: the denominators never touch memory.  A fraction is (scale * mult(row)) / (sum_i alpha^i tuple_i(row) - z);
+// per output column the kernel reads the tuple columns and multiplicities of one or two fractions plus the previous column and
+// writes 4 words per row — for a one-limb range check 10 words per row instead of 26 through combine + finalize_col.
+struct LogupTupleFrac { ColSet cols; u32 n_cols; const u32* coeffs; QM31 z; const u32* mult; QM31 scale; };
+
+__device__ __forceinline__ QM31 tuple_den(const LogupTupleFrac& f, u32 r) {
+    u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (u32 k = 0; k < f.n_cols; k++) {
+        const u32 v = f.cols.col(k)[r];
+        s0 = acc_mad(s0, f.coeffs[4 * k], v); s1 = acc_mad(s1, f.coeffs[4 * k + 1], v); s2 = acc_mad(s2, f.coeffs[4 * k + 2], v); s3 = acc_mad(s3, f.coeffs[4 * k + 3], v);
+        if ((k & 3) == 3) { s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3); }
+    }
+    return q_sub(qm(acc_final(s0), acc_final(s1), acc_final(s2), acc_final(s3)), f.z);
+}
+
+__global__ __launch_bounds__(256) void logup_col_kernel(LogupTupleFrac fa, LogupTupleFrac fb, bool two, Sec4C prev, bool has_prev, u32 n, Sec4 out) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    QM31 num = fa.mult ? q_mul_m(fa.scale, fa.mult[r]) : fa.scale, den = tuple_den(fa, r);
+    if (two) {
+        const QM31 c = fb.mult ? q_mul_m(fb.scale, fb.mult[r]) : fb.scale, d = tuple_den(fb, r);
+        num = q_add(q_mul(num, d), q_mul(den, c));
+        den = q_mul(den, d);
+    }
+    QM31 v = q_mul(num, q_inv(den));
+    if (has_prev) v = q_add(v, sec_at(prev, r));
+    out.c[0][r] = v.a.a; out.c[1][r] = v.a.b; out.c[2][r] = v.b.a; out.c[3][r] = v.b.b;
+}
+
+// position (bit-reversed circle-domain order) of natural coset row c
+__device__ __forceinline__ u32 pos_of_coset_row(u32 c, int log) {
+    const u32 N = 1u << log;
+    const u32 d = (c & 1) ? N - 1 - (c >> 1) : (c >> 1);
+    return bitrev(d, log);
+}
+
+constexpr int SCAN_ITEMS = 16, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;
+
+// phase 1: per block of 4096 consecutive coset rows, the block-local inclusive scan (written back in place) and the block total
+__global__ __launch_bounds__(SCAN_THREADS) void logup_scan_local_kernel(Sec4 col, int log, u32* __restrict__ block_sums /*4 per block*/) {
+    __shared__ u32 lds[4][SCAN_THREADS];
+    const u32 n = 1u << log;
+    const u32 c0 = (blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
+    u32 pos[SCAN_ITEMS];
+    u32 v[4][SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        pos[i] = c0 + i < n ? pos_of_coset_row(c0 + i, log) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q][i] = pos[i] != 0xFFFFFFFFu ? col.c[q][pos[i]] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int i = 1; i < SCAN_ITEMS; i++) v[q][i] = m_add(v[q][i], v[q][i - 1]);
+        lds[q][threadIdx.x] = v[q][SCAN_ITEMS - 1];
+    }
+    __syncthreads();
+    // Hillis-Steele over the 256 lane totals (4 coordinates)
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        u32 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) t[q] = threadIdx.x >= (u32)off ? lds[q][threadIdx.x - off] : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) lds[q][threadIdx.x] = m_add(lds[q][threadIdx.x], t[q]);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const u32 before = threadIdx.x ? lds[q][threadIdx.x - 1] : 0u;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) if (pos[i] != 0xFFFFFFFFu) col.c[q][pos[i]] = m_add(v[q][i], before);
+    }
+    if (threadIdx.x == SCAN_THREADS - 1)
+        for (int q = 0; q < 4; q++) block_sums[4 * blockIdx.x + q] = lds[q][SCAN_THREADS - 1];
+}
+
+// phase 3: value = local + offset[block of its coset row] - (coset row + 1) * shift
+__global__ __launch_bounds__(256) void logup_scan_fix_kernel(Sec4 col, int log, const u32* __restrict__ block_offsets /*exclusive, 4 per block*/, QM31 shift) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (1u << log)) return;
+    const u32 p = pos_of_coset_row(c, log), b = c / SCAN_BLOCK;
+    const QM31 off = qm(block_offsets[4 * b], block_offsets[4 * b + 1], block_offsets[4 * b + 2], block_offsets[4 * b + 3]);
+    const QM31 v = q_sub(q_add(qm(col.c[0][p], col.c[1][p], col.c[2][p], col.c[3][p]), off), q_mul_m(shift, m_reduce64((u64)c + 1)));
+    col.c[0][p] = v.a.a; col.c[1][p] = v.a.b; col.c[2][p] = v.b.a; col.c[3][p] = v.b.b;
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+int nx_logup_combine(nx_ctx* ctx, const uint32_t* const* d_tuple_cols, uint32_t n_cols, const uint32_t* alpha_powers, const uint32_t z[4], uint32_t log_size,
+                     uint32_t* const* d_out4) {
+    if (!ctx || !d_out4 || !z || (n_cols && (!d_tuple_cols || !alpha_powers))) return set_err(ctx, NX_ERR_ARG, "nx_logup_combine: NULL argument");
+    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_combine: log_size too large");
+    ColSet cs; NX_TRY(make_colset(ctx, d_tuple_cols, n_cols, &cs));
+    void* d_co = nullptr;
+    if (n_cols) NX_TRY(stage(ctx, alpha_powers, (size_t)n_cols * 16, &d_co));
+    Sec4 o; for (int q = 0; q < 4; q++) o.c[q] = d_out4[q];
+    const u32 n = 1u << log_size;
+    hipLaunchKernelGGL(logup_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, cs, n_cols, (const u32*)d_co, q_load(z), n, o);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+static LogupFrac make_frac(const uint32_t* d_mult, const uint32_t scale[4], const uint32_t* const* d_den4) {
+    LogupFrac f; f.mult = d_mult; f.scale = q_load(scale);
+    for (int q = 0; q < 4; q++) f.den.c[q] = d_den4[q];
+    return f;
+}
+
+int nx_logup_finalize_col(nx_ctx* ctx, uint32_t log_size, const uint32_t* d_mult_a, const uint32_t scale_a[4], const uint32_t* const* d_den_a4,
+                          const uint32_t* d_mult_b, const uint32_t scale_b[4], const uint32_t* const* d_den_b4, const uint32_t* const* d_prev4,
+                          uint32_t* const* d_out4) {
+    if (!ctx || !scale_a || !d_den_a4 || !d_out4) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_col: NULL argument");
+    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_col: log_size too large");
+    const bool two = d_den_b4 != nullptr;
+    if (two && !scale_b) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_col: second fraction without a numerator scale");
+    LogupFrac fa = make_frac(d_mult_a, scale_a, d_den_a4), fb = two ? make_frac(d_mult_b, scale_b, d_den_b4) : fa;
+    Sec4C prev; Sec4 o;
+    for (int q = 0; q < 4; q++) { prev.c[q] = d_prev4 ? d_prev4[q] : nullptr; o.c[q] = d_out4[q]; }
+    const u32 n = 1u << log_size;
+    hipLaunchKernelGGL(logup_finalize_col_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fa, fb, two, prev, d_prev4 != nullptr, n, o);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+
+static int make_tuple_frac(nx_ctx* ctx, const nx_logup_frac* f, LogupTupleFrac* out) {
+    if (!f->alpha_powers || !f->z || !f->scale || (f->n_tuple_cols && !f->d_tuple_cols)) return set_err(ctx, NX_ERR_ARG, "nx_logup_col: incomplete fraction");
+    NX_TRY(make_colset(ctx, f->d_tuple_cols, f->n_tuple_cols, &out->cols));
+    void* d_co = nullptr;
+    if (f->n_tuple_cols) NX_TRY(stage(ctx, f->alpha_powers, (size_t)f->n_tuple_cols * 16, &d_co));
+    out->n_cols = f->n_tuple_cols; out->coeffs = (const u32*)d_co; out->z = q_load(f->z); out->mult = f->d_mult; out->scale = q_load(f->scale);
+    return NX_OK;
+}
+
+int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, const nx_logup_frac* frac_b, const uint32_t* const* d_prev4, uint32_t* const* d_out4) {
+    if (!ctx || !frac_a || !d_out4) return set_err(ctx, NX_ERR_ARG, "nx_logup_col: NULL argument");
+    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_col: log_size too large");
+    LogupTupleFrac fa, fb;
+    NX_TRY(make_tuple_frac(ctx, frac_a, &fa));
+    fb = fa;
+    if (frac_b) NX_TRY(make_tuple_frac(ctx, frac_b, &fb));
+    Sec4C prev; Sec4 o;
+    for (int q = 0; q < 4; q++) { prev.c[q] = d_prev4 ? d_prev4[q] : nullptr; o.c[q] = d_out4[q]; }
+    const u32 n = 1u << log_size;
+    hipLaunchKernelGGL(logup_col_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fa, fb, frac_b != nullptr, prev, d_prev4 != nullptr, n, o);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_col4, uint32_t claimed_sum[4]) {
+    if (!ctx || !d_col4 || !claimed_sum) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: NULL argument");
+    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: log_size too large");
+    Sec4 col; for (int q = 0; q < 4; q++) col.c[q] = d_col4[q];
+    const u32 n = 1u << log_size, n_blocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    u32* d_sums = nullptr;
+    NX_TRY(dev_alloc(ctx, (size_t)n_blocks * 16, (void**)&d_sums));
+    hipLaunchKernelGGL(logup_scan_local_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, col, (int)log_size, d_sums);
+    hipError_t e = hipGetLastError();
+    std::vector<u32> sums((size_t)n_blocks * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_sums, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { dev_free(ctx, d_sums); return hip_fail(ctx, e, "nx_logup_finalize_last", __FILE__, __LINE__); }
+    // exclusive scan of the block totals on the host; the grand total is the claimed sum
+    QM31 run = q_zero();
+    for (u32 b = 0; b < n_blocks; b++) { QM31 t = q_load(&sums[4 * b]); q_store(&sums[4 * b], run); run = q_add(run, t); }
+    q_store(claimed_sum, run);
+    const QM31 shift = q_mul_m(run, m_inv(n % P));   // claimed_sum / N
+    e = hipMemcpyAsync(d_sums, sums.data(), sums.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(logup_scan_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, col, (int)log_size, (const u32*)d_sums, shift);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);   // `sums` and d_sums must outlive the copy / kernel
+    dev_free(ctx, d_sums);
+    if (e != hipSuccess) return hip_fail(ctx, e, "nx_logup_finalize_last", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_logup_finalize_last(sync)", __FILE__, __LINE__);
+    return NX_OK;
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@
 #include "air.h"
 #include "pcs.h"
 #include "constraints.h"
+#include "logup.h"
 
 using namespace orc;
 
@@ -199,6 +200,19 @@ void orc_eval_constraint_program(const uint32_t* prog, uint32_t n_instr, uint32_
                                  const uint32_t* denom_inv, int log_size, int log_eval, uint32_t** acc4) {
     eval_constraint_program((const CInstr*)prog, n_instr, n_regs, cols, econsts, pw, denom_inv, log_size, log_eval, acc4);
 }
+
+void orc_logup_combine(const uint32_t** cols, uint32_t n_cols, const uint32_t* alpha_powers, const uint32_t* z, int log, uint32_t** out4) {
+    logup_combine(cols, n_cols, alpha_powers, z, log, out4);
+}
+// mult_x may be NULL (constant numerator = scale_x); den_b4 NULL = a single fraction; prev4 NULL = first column
+void orc_logup_finalize_col(int log, const uint32_t* mult_a, const uint32_t* scale_a, const uint32_t** den_a4, const uint32_t* mult_b, const uint32_t* scale_b,
+                            const uint32_t** den_b4, const uint32_t** prev4, uint32_t** out4) {
+    LogupFrac fa{mult_a, qm31_load(scale_a), {den_a4[0], den_a4[1], den_a4[2], den_a4[3]}};
+    LogupFrac fb{};
+    if (den_b4) fb = LogupFrac{mult_b, qm31_load(scale_b), {den_b4[0], den_b4[1], den_b4[2], den_b4[3]}};
+    logup_finalize_col(log, fa, den_b4 ? &fb : nullptr, prev4, out4);
+}
+void orc_logup_finalize_last(int log, uint32_t** col4, uint32_t* claimed_sum) { logup_finalize_last(log, col4, claimed_sum); }
 
 // Timed CPU baseline leg: one full prove, returns seconds (negative on error).
 double orc_time_prove_synth(const int* comps, int ncomp, const int* cfg, uint64_t seed, int n_threads) {

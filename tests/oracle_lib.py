@@ -196,3 +196,31 @@ def eval_constraint_program(program, cols, alpha_powers, denom_inv, log_size, lo
     den = u32(denom_inv)
     L.orc_eval_constraint_program(ptr(ins), len(ins) // 4, program.n_regs, ptr_array(cols), ptr(ec), ptr(pw), ptr(den), log_size, log_eval, ptr_array(acc))
     return acc
+
+
+def logup_combine(cols, alpha_powers, z):
+    cols = [u32(c) for c in cols]
+    log = int(np.log2(len(cols[0])))
+    out = [np.zeros(1 << log, np.uint32) for _ in range(4)]
+    lib().orc_logup_combine(ptr_array(cols), len(cols), ptr(u32(alpha_powers).reshape(-1)), ptr(u32(z)), log, ptr_array(out))
+    return out
+
+
+def logup_finalize_col(den_a, scale_a=(1, 0, 0, 0), mult_a=None, den_b=None, scale_b=(1, 0, 0, 0), mult_b=None, prev=None):
+    den_a = [u32(c) for c in den_a]
+    log = int(np.log2(len(den_a[0])))
+    out = [np.zeros(1 << log, np.uint32) for _ in range(4)]
+    keep = [u32(mult_a) if mult_a is not None else None, u32(mult_b) if mult_b is not None else None,
+            [u32(c) for c in den_b] if den_b is not None else None, [u32(c) for c in prev] if prev is not None else None]
+    lib().orc_logup_finalize_col(log, ptr(keep[0]) if keep[0] is not None else None, ptr(u32(scale_a)), ptr_array(den_a),
+                                 ptr(keep[1]) if keep[1] is not None else None, ptr(u32(scale_b)), ptr_array(keep[2]) if keep[2] is not None else None,
+                                 ptr_array(keep[3]) if keep[3] is not None else None, ptr_array(out))
+    return out
+
+
+def logup_finalize_last(col4):
+    col = [u32(c).copy() for c in col4]
+    log = int(np.log2(len(col[0])))
+    cs = np.zeros(4, np.uint32)
+    lib().orc_logup_finalize_last(log, ptr_array(col), ptr(cs))
+    return col, cs
