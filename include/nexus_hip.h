@@ -85,6 +85,12 @@ int nx_finalize_columns(nx_ctx* ctx, const uint32_t* const* d_src_natural, uint3
                         uint32_t n_cols, uint32_t log_size);
 /* Same, source on the host (the trace the AIR layer filled, TracesBuilder cols, trace_builder.rs:19-32). */
 int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst);
+/* The same for a whole host-resident trace: every host column is pinned in place, streamed over
+ * PCIe on a side stream and permuted on device behind the copy (coset_order != 0) or stored as is (the host already holds
+ * bit-reversed circle-domain order).  Blocking: the host columns are free on return.  Replaces the per-column CPU passes of
+ * finalize_columns + into_circle_evaluation's clones (reference prover/src/trace/utils.rs:94-106, trace_builder.rs:156-164). */
+int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_cols, uint32_t log_size,
+                      uint32_t* const* d_cols, int coset_order);
 
 /* ----------------------------------------------------- K2-K4, K7: PolyOps ------------------ */
 /* K2 — PolyOps::precompute_twiddles(CanonicCoset::new(log_half_coset + 1).half_coset())

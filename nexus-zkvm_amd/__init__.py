@@ -280,6 +280,17 @@ class HipBackend:
         self._chk(self.L.nx_upload_coset_order(self.ctx, a.ctypes.data_as(C.c_void_p), out.log_size, out.ptr))
         return out
 
+    def upload_columns(self, host_cols, coset_order=True):
+        """A whole host trace (list of 1-D uint32 arrays of one size) -> DeviceColumns, pinned in place and streamed
+        (nx_upload_columns); coset_order: the host holds natural coset order (reference trace builders) and wants the
+        bit-reversed circle-domain order on device."""
+        cols = [_u32(c) for c in host_cols]
+        log = int(np.log2(cols[0].size))
+        out = DeviceColumns(self, len(cols), log)
+        hp = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        self._chk(self.L.nx_upload_columns(self.ctx, hp, len(cols), log, out.col_ptrs(), 1 if coset_order else 0))
+        return out
+
     # ---- PolyOps ----
     def precompute_twiddles(self, log_half_coset):
         return Twiddles(self, log_half_coset)

@@ -509,6 +509,54 @@ int nx_finalize_columns(nx_ctx* ctx, const uint32_t* const* d_src_natural, uint3
     return NX_OK;
 }
 
+
+// R3 + R4 for a whole host-resident trace: pin every host column in place (hipHostRegister, no
+// staging copy), stream it over PCIe on a side stream and run the coset-order -> bit-reversed-circle-domain permutation
+// (or nothing, when the host already holds that order) behind it on the main stream, two columns in flight.  This replaces
+// the reference's per-column CPU passes (coset_order_to_circle_domain_order + from_iter + bit_reverse_column + clone).
+int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_cols, uint32_t log_size, uint32_t* const* d_cols, int coset_order) {
+    if (!ctx || (n_cols && (!h_cols || !d_cols))) return set_err(ctx, NX_ERR_ARG, "nx_upload_columns: NULL argument");
+    if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_upload_columns: bad log_size");
+    const size_t n = (size_t)1 << log_size, bytes = n * 4;
+    uint32_t* d_tmp[2] = {nullptr, nullptr};
+    hipEvent_t copied[2], consumed[2];
+    int rc = NX_OK;
+    if (coset_order) for (int k = 0; k < 2 && rc == NX_OK; k++) rc = dev_alloc(ctx, bytes, (void**)&d_tmp[k]);
+    for (int k = 0; k < 2; k++) { (void)hipEventCreateWithFlags(&copied[k], hipEventDisableTiming); (void)hipEventCreateWithFlags(&consumed[k], hipEventDisableTiming); }
+    hipStream_t copy_stream = ctx->side[0];
+    hipError_t e = hipEventRecord(ctx->fork_ev, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream, ctx->fork_ev, 0);
+    std::vector<bool> registered(n_cols, false);
+    for (uint32_t c = 0; c < n_cols && rc == NX_OK && e == hipSuccess; c++) {
+        const int k = c & 1;
+        registered[c] = hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess;   // falls back to a pageable copy
+        if (!registered[c]) (void)hipGetLastError();
+        uint32_t* dst = coset_order ? d_tmp[k] : d_cols[c];
+        if (coset_order && c >= 2) e = hipStreamWaitEvent(copy_stream, consumed[k], 0);      // the permute kernel of column c-2 has read d_tmp[k]
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, h_cols[c], bytes, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(copied[k], copy_stream);
+        if (e == hipSuccess && coset_order) {
+            e = hipStreamWaitEvent(ctx->stream, copied[k], 0);
+            if (e == hipSuccess) {
+                ColSet s1, d1; s1.base = d_tmp[k]; s1.stride = 0; s1.table = nullptr; d1.base = d_cols[c]; d1.stride = 0; d1.table = nullptr;
+                hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, ctx->stream, s1, d1, 1u, (int)log_size);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipEventRecord(consumed[k], ctx->stream);
+        }
+    }
+    // the caller may reuse / free the host columns on return: everything must have left them
+    hipError_t e2 = hipStreamSynchronize(copy_stream);
+    hipError_t e3 = hipStreamSynchronize(ctx->stream);
+    for (uint32_t c = 0; c < n_cols; c++) if (registered[c]) (void)hipHostUnregister((void*)h_cols[c]);
+    for (int k = 0; k < 2; k++) { (void)hipEventDestroy(copied[k]); (void)hipEventDestroy(consumed[k]); dev_free(ctx, d_tmp[k]); }
+    if (rc != NX_OK) return rc;
+    if (e != hipSuccess) return hip_fail(ctx, e, "nx_upload_columns", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_upload_columns(copy sync)", __FILE__, __LINE__);
+    if (e3 != hipSuccess) return hip_fail(ctx, e3, "nx_upload_columns(sync)", __FILE__, __LINE__);
+    return NX_OK;
+}
+
 int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst) {
     uint32_t* d_tmp = nullptr;
     size_t n = (size_t)1 << log_size;

@@ -116,6 +116,10 @@ def test_layout_permutations(be, oracle):
             assert np.array_equal(fin[c], oracle.finalize_column(nat[c]))
         up = be.upload_coset_order(nat[0]).to_cpu()[0]
         assert np.array_equal(up, fin[0])
+        # whole-trace upload: pinned in place, streamed, permuted on device
+        up_all = be.upload_columns(list(nat)).to_cpu()
+        assert np.array_equal(up_all, fin)
+        assert np.array_equal(be.upload_columns(list(nat), coset_order=False).to_cpu(), nat)
         # K1: bit_reverse_column
         br = be.columns_from_host(nat[:1])
         be.bit_reverse_column(br)
