@@ -31,9 +31,30 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_at_point_kernel(ColSet poly
 #pragma unroll
     for (int k = 0; k < EVAL_KL; k++) for (int q = 0; q < 4; q++) acc[k][q] = 0;
     u32 h0 = chunk * hi_per_block, h1 = min(n_hi, h0 + hi_per_block);
-    u32 pending = 0;
-    for (u32 jh = h0; jh < h1; jh++) {
-        const u32 th0 = t_hi[4 * jh], th1 = t_hi[4 * jh + 1], th2 = t_hi[4 * jh + 2], th3 = t_hi[4 * jh + 3];  // wave-uniform
+    u32 jh = h0;
+    // 4 rows of coefficients per step: 16 independent 1 KB reads in flight per wave before the first multiply-add, one fold per step
+    for (; jh + 4 <= h1; jh += 4) {
+        u32 cv[4][EVAL_KL];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32* row = c + ((size_t)(jh + u) << L);
+#pragma unroll
+            for (int k = 0; k < EVAL_KL; k++) { u32 jl = threadIdx.x + k * EVAL_THREADS; cv[u][k] = jl < n_lo ? row[jl] : 0u; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 th0 = t_hi[4 * (jh + u)], th1 = t_hi[4 * (jh + u) + 1], th2 = t_hi[4 * (jh + u) + 2], th3 = t_hi[4 * (jh + u) + 3];  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < EVAL_KL; k++) {
+                acc[k][0] = acc_mad(acc[k][0], th0, cv[u][k]); acc[k][1] = acc_mad(acc[k][1], th1, cv[u][k]);
+                acc[k][2] = acc_mad(acc[k][2], th2, cv[u][k]); acc[k][3] = acc_mad(acc[k][3], th3, cv[u][k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < EVAL_KL; k++) for (int q = 0; q < 4; q++) acc[k][q] = acc_fold(acc[k][q]);
+    }
+    for (; jh < h1; jh++) {   // < 4 leftover rows: still within one fold period
+        const u32 th0 = t_hi[4 * jh], th1 = t_hi[4 * jh + 1], th2 = t_hi[4 * jh + 2], th3 = t_hi[4 * jh + 3];
         const u32* row = c + ((size_t)jh << L);
 #pragma unroll
         for (int k = 0; k < EVAL_KL; k++) {
@@ -41,11 +62,6 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_at_point_kernel(ColSet poly
             u32 cv = jl < n_lo ? row[jl] : 0u;
             acc[k][0] = acc_mad(acc[k][0], th0, cv); acc[k][1] = acc_mad(acc[k][1], th1, cv);
             acc[k][2] = acc_mad(acc[k][2], th2, cv); acc[k][3] = acc_mad(acc[k][3], th3, cv);
-        }
-        if (++pending == 4) {
-            pending = 0;
-#pragma unroll
-            for (int k = 0; k < EVAL_KL; k++) for (int q = 0; q < 4; q++) acc[k][q] = acc_fold(acc[k][q]);
         }
     }
     QM31 tot = q_zero();

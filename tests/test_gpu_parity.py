@@ -619,3 +619,25 @@ def test_logup_pipeline_matches_oracle(be, oracle, log):
     assert np.array_equal(claimed, ref_claimed)
     got = col1.to_cpu()
     assert np.array_equal(got, np.stack(ref_last)) and got.max() < P
+
+
+def test_column_utilities(be):
+    """nx_copy (Column::clone) and the building blocks of a modular all-reduce (nx_m31_add_into / widen / narrow)."""
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, P, (3, 1 << 10), dtype=np.uint32)
+    b = rng.integers(0, P, (3, 1 << 10), dtype=np.uint32)
+    a[0, :4] = [0, P - 1, 1, P - 1]; b[0, :4] = [0, P - 1, P - 1, 1]
+    da, db = be.columns_from_host(a), be.columns_from_host(b)
+    dc = be.clone_columns(da)
+    assert np.array_equal(dc.to_cpu(), a)
+    n = a.size
+    be._chk(be.L.nx_m31_add_into(be.ctx, dc.ptr, db.ptr, C.c_size_t(n)))
+    assert np.array_equal(dc.to_cpu(), ((a.astype(np.uint64) + b) % P).astype(np.uint32))
+    wide = be.columns(6, 10)                                   # 3 x 2^10 u64 lanes
+    be._chk(be.L.nx_m31_widen(be.ctx, wide.ptr, da.ptr, C.c_size_t(n)))
+    w = wide.to_cpu().reshape(-1).view(np.uint64)
+    assert np.array_equal(w, a.reshape(-1).astype(np.uint64))
+    w8 = (w * 8 + 7).astype(np.uint64)                         # what an 8-rank sum all-reduce could leave in a lane
+    be._chk(be.L.nx_upload(be.ctx, wide.ptr, w8.view(np.uint32).ctypes.data_as(C.c_void_p), C.c_size_t(2 * n)))
+    be._chk(be.L.nx_m31_narrow(be.ctx, dc.ptr, wide.ptr, C.c_size_t(n)))
+    assert np.array_equal(dc.to_cpu().reshape(-1), (w8 % P).astype(np.uint32))

@@ -23,6 +23,9 @@ template <int OP> __global__ __launch_bounds__(256) void k(u32* out, u32 seed) {
         if (OP == 10) { REP8(asm volatile("v_mad_u32_u24 %0, %0, %2, %3\n v_mad_u32_u24 %1, %1, %2, %3" : "+v"(a), "+v"(b) : "v"(t), "v"(c));) }
         if (OP == 11) { REP8(asm volatile("v_lshl_add_u32 %0, %0, 1, %2\n v_lshl_add_u32 %1, %1, 1, %2" : "+v"(a), "+v"(b) : "v"(t));) }
         if (OP == 12) { REP8(asm volatile("v_pk_add_u16 %0, %0, %2\n v_pk_add_u16 %1, %1, %2" : "+v"(a), "+v"(b) : "v"(t));) }
+        if (OP == 14) { REP8(asm volatile("v_subrev_co_u32 %0, vcc, %2, %0\n s_nop 1\n v_cndmask_b32 %1, %1, %0, vcc" : "+v"(a), "+v"(b) : "v"(t) : "vcc");) }
+        if (OP == 15) { REP8(asm volatile("v_subrev_co_u32 %0, vcc, %2, %0\n v_cndmask_b32 %1, %1, %0, vcc" : "+v"(a), "+v"(b) : "v"(t) : "vcc");) }
+        if (OP == 16) { REP8(asm volatile("v_subrev_co_u32 %0, vcc, %2, %0\n v_add_u32 %3, %3, %2\n v_add_u32 %4, %4, %2\n v_cndmask_b32 %1, %1, %0, vcc" : "+v"(a), "+v"(b), "+v"(t), "+v"(c), "+v"(d) : : "vcc");) }
         if (OP == 13) { REP8(asm volatile("v_dot4_u32_u8 %0, %2, %3, %0\n v_dot4_u32_u8 %1, %2, %3, %1" : "+v"(a), "+v"(b) : "v"(t), "v"(c));) }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ (u32)q ^ (u32)(q >> 32) ^ (u32)r;
@@ -44,5 +47,7 @@ int main() {
     run<1>("v_and_b32", 8); run<2>("v_min_u32", 8); run<3>("v_alignbit_b32", 8); run<4>("v_mul_lo_u32", 8); run<5>("v_mul_hi_u32", 8);
     run<6>("v_mad_u64_u32", 8); run<7>("v_add3_u32", 8); run<8>("v_mul_u32_u24", 8); run<9>("v_sub+v_min (dep)", 8); run<10>("v_mad_u32_u24", 8);
     run<11>("v_lshl_add_u32", 8); run<12>("v_pk_add_u16", 8); run<13>("v_dot4_u32_u8", 8);
+    run<14>("sub_co, s_nop 1, cndmask", 8); run<15>("sub_co, cndmask NO nop (timing only)", 8); run<16>("sub_co, add, add, cndmask (2 counted)", 8);
+    run<14>("sub_co, s_nop 1, cndmask w=4", 4); run<15>("sub_co, cndmask NO nop w=4", 4); run<16>("sub_co, add, add, cndmask w=4", 4);
     return 0;
 }
