@@ -250,6 +250,8 @@ PROVE_CASES = [
     ([(8, 3, 20, 6), (8, 2, 3, 0), (5, 2, 2, 2)], dict(pow_bits=6, hash_mode=1, fri_alpha_mode=1)),
     ([(12, 27, 347, 64)], dict(pow_bits=10)),
     ([(13, 4, 33, 0), (11, 3, 17, 16), (4, 2, 2, 0)], dict(pow_bits=7, log_constraint_degree=2)),
+    ([(15, 8, 61, 20), (14, 3, 17, 16)], dict(pow_bits=9)),                       # every transform through the multi-pass wide kernel (13 + 2/3 layers)
+    ([(16, 5, 35, 0)], dict(pow_bits=8, log_constraint_degree=2)),                # constraint domain 2^18: replicas x4 in the LDE top pass
 ]
 
 
