@@ -270,6 +270,18 @@ int nx_eval_constraint_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n
                                uint32_t n_constraints, const uint32_t* denom_inv /* 2^(log_eval-log_size) words */,
                                uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4);
 
+/* The same program compiled into a gfx950 kernel at run time (hiprtc): straight-line code over VGPRs instead of an LDS
+ * register file, ~3x faster than the interpreter; lookup elements and alpha powers stay run-time arguments, so one compilation
+ * serves every proof of an AIR.  h_source_out (optional, may be the only output: then ctx may be NULL and no GPU is needed)
+ * receives the generated HIP source (free with nx_free_host). */
+typedef struct nx_air_kernel nx_air_kernel;
+int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols,
+                   uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out, char** h_source_out);
+int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* kernel, const uint32_t* const* d_cols, const uint32_t* econsts,
+                const uint32_t* alpha_powers, const uint32_t* denom_inv, uint32_t log_size, uint32_t log_eval,
+                uint32_t* const* d_acc4);
+void nx_air_kernel_destroy(nx_air_kernel* kernel);
+
 /* ------------------------------------------- "next" row R8: logup interaction trace on device ------------------------
  * The reference fills the interaction trace on the CPU (prover/src/traits.rs:124-145 generate_interaction_trace -> per chip,
  * e.g. prover/src/chips/range_check/range256.rs:271-288; prover2/machine/src/lookups/logup_trace_builder.rs:22-121) through

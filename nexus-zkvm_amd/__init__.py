@@ -79,6 +79,56 @@ def make_comm(rank, world, impl):
     return c
 
 
+def air_source(program, n_cols):
+    """The HIP source nx_air_compile generates for a recorded program (needs no GPU and no context)."""
+    L = load_library()
+    ins = _u32(program.instrs).reshape(-1)
+    n_c = int(sum(1 for op in ins[0::4] if op in (13, 14)))
+    src = C.c_void_p()
+    rc = L.nx_air_compile(None, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, n_cols, len(_u32(program.econsts).reshape(-1)) // 4, n_c, None, C.byref(src))
+    if rc != 0:
+        raise NexusHipError(f"nx_air_compile failed ({rc}): {L.nx_last_error(None).decode()}")
+    try:
+        return C.string_at(src.value).decode()
+    finally:
+        L.nx_free_host(src)
+
+
+class AirKernel:
+    """A recorded AIR compiled by hiprtc (nx_air_compile); eval() matches HipBackend.eval_constraint_program."""
+
+    def __init__(self, be, program, n_cols):
+        self.be, self.program, self.n_cols = be, program, n_cols
+        ins = _u32(program.instrs).reshape(-1)
+        self.n_constraints = int(sum(1 for op in ins[0::4] if op in (13, 14)))
+        self.h = C.c_void_p()
+        be._chk(be.L.nx_air_compile(be.ctx, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, n_cols, len(_u32(program.econsts).reshape(-1)) // 4,
+                                    self.n_constraints, C.byref(self.h), None))
+
+    def eval(self, column_ptrs, alpha_powers, denom_inv, log_size, log_eval, acc4, econsts=None):
+        assert len(column_ptrs) == self.n_cols
+        ptrs = (C.c_void_p * max(1, len(column_ptrs)))(*column_ptrs)
+        ec = _u32(self.program.econsts if econsts is None else econsts).reshape(-1)
+        pw = _u32(alpha_powers).reshape(-1)
+        assert len(pw) // 4 == self.n_constraints
+        den = _u32(denom_inv)
+        assert len(den) == 1 << (log_eval - log_size)
+        self.be._chk(self.be.L.nx_air_eval(self.be.ctx, self.h, ptrs, ec.ctypes.data_as(C.c_void_p), pw.ctypes.data_as(C.c_void_p), den.ctypes.data_as(C.c_void_p),
+                                           log_size, log_eval, acc4.col_ptrs()))
+        return acc4
+
+    def close(self):
+        if self.h and self.be.ctx:
+            self.be.L.nx_air_kernel_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class LogupFrac(C.Structure):
     """nx_logup_frac of include/nexus_hip.h."""
     _fields_ = [("d_tuple_cols", C.c_void_p), ("n_tuple_cols", C.c_uint32), ("alpha_powers", C.c_void_p), ("z", C.c_void_p), ("d_mult", C.c_void_p),
@@ -112,7 +162,9 @@ def load_library():
     L.nx_ctx_stream.restype = C.c_void_p
     L.nx_merkle_layer.restype = C.c_void_p
     L.nx_merkle_n_layers.restype = C.c_uint32
-    for name in ("nx_ctx_destroy", "nx_twiddles_destroy", "nx_tree_destroy", "nx_free_host"):
+    L.nx_free_host.argtypes = [C.c_void_p]
+    L.nx_air_kernel_destroy.argtypes = [C.c_void_p]
+    for name in ("nx_ctx_destroy", "nx_twiddles_destroy", "nx_tree_destroy", "nx_free_host", "nx_air_kernel_destroy"):
         getattr(L, name).restype = None
     _lib = L
     return L
@@ -381,6 +433,10 @@ class HipBackend:
                                                     ec.ctypes.data_as(C.c_void_p), len(ec) // 4, pw.ctypes.data_as(C.c_void_p), len(pw) // 4,
                                                     den.ctypes.data_as(C.c_void_p), log_size, log_eval, acc4.col_ptrs()))
         return acc4
+
+    def compile_air(self, program, n_cols):
+        """nx_air_compile: the recorded program as a run-time-compiled gfx950 kernel (same semantics as the interpreter)."""
+        return AirKernel(self, program, n_cols)
 
     # ---- logup interaction trace (SURVEY §8(f) rank 2) ----
     @staticmethod

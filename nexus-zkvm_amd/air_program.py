@@ -49,8 +49,37 @@ class Expr:
 
 
 class Program:
-    def __init__(self, instrs, n_regs, econsts, n_constraints):
+    def __init__(self, instrs, n_regs, econsts, n_constraints, masks=None):
         self.instrs, self.n_regs, self.econsts, self.n_constraints = instrs, n_regs, econsts, n_constraints
+        self.masks = masks or {}     # column -> row offsets, in declaration order (what InfoEvaluator collects)
+
+
+class Component:
+    """What FrameworkComponent<E> is to Stwo (reference prover/src/components/mod.rs:15-57): a trace log size, the recorded
+    constraints, the place of the component's columns in the three trace trees (TraceLocationAllocator) and the mask offsets
+    each column is sampled at.  cols[k] = (tree, column index in that tree) for the program's column k; a column the program
+    never loads is still sampled at offset 0 (every committed column must be claimed by a component)."""
+
+    def __init__(self, log_size, program, cols, masks=None):
+        self.log_size, self.program, self.cols = int(log_size), program, [(int(t), int(i)) for t, i in cols]
+        self.masks = [list(masks[k]) if masks is not None else list(program.masks.get(k, (0,))) for k in range(len(self.cols))]
+
+    def encode(self):
+        """The flat u32 description tests/oracle_lib.py hands to the oracle (oracle/air_generic.h::gair_decode)."""
+        import numpy as np
+        pr = self.program
+        ins = np.asarray(pr.instrs, dtype=np.uint32).reshape(-1)
+        ec = np.asarray(pr.econsts, dtype=np.uint32).reshape(-1)
+        offs = [o for m in self.masks for o in m]
+        head = [self.log_size, len(ins) // 4, pr.n_regs, len(ec) // 4, pr.n_constraints, len(self.cols), len(offs)]
+        parts = [np.array(head, np.uint32), ins, ec, np.array([t for t, _ in self.cols], np.uint32), np.array([i for _, i in self.cols], np.uint32),
+                 np.array([len(m) for m in self.masks], np.uint32), np.array(offs, np.int32).view(np.uint32)]
+        return np.concatenate(parts)
+
+
+def encode_air(components):
+    import numpy as np
+    return np.concatenate([np.array([len(components)], np.uint32)] + [c.encode() for c in components])
 
 
 class ProgramBuilder:
@@ -59,6 +88,7 @@ class ProgramBuilder:
         self.cse = {}
         self.constraints = []    # node ids in declaration order
         self.econsts = []
+        self.masks = {}
 
     def _node(self, key, kind):
         if key in self.cse:
@@ -70,10 +100,15 @@ class ProgramBuilder:
     # ---- leaves
     def next_trace_mask(self, col, offsets=(0,)):
         """Base-field column `col` (index into the column table handed to nx_eval_constraint_program) at the given row offsets."""
+        m = self.masks.setdefault(int(col), [])
+        m.extend(int(o) for o in offsets if int(o) not in m)
         return [self._node(("load", int(col), int(o)), "B") for o in offsets]
 
     def next_secure_mask(self, first_col, offsets=(0,)):
         """A secure (QM31) column stored as 4 consecutive coordinate columns starting at first_col (logup columns)."""
+        for k in range(4):
+            m = self.masks.setdefault(int(first_col) + k, [])
+            m.extend(int(o) for o in offsets if int(o) not in m)
         return [self._node(("loade", int(first_col), int(o)), "E") for o in offsets]
 
     def const(self, v):
@@ -237,4 +272,4 @@ class ProgramBuilder:
                 out.append((opmap[key[0]], reg(i), reg(key[1]), reg(key[2])))
         instrs = np.array(out, dtype=np.uint32).reshape(-1, 4)
         econsts = np.array(self.econsts, dtype=np.uint32).reshape(-1, 4) if self.econsts else np.zeros((0, 4), np.uint32)
-        return Program(instrs, n_regs, econsts, len(self.constraints))
+        return Program(instrs, n_regs, econsts, len(self.constraints), {k: list(v) for k, v in self.masks.items()})

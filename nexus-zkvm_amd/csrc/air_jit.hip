@@ -1,0 +1,221 @@
+// Recorded AIR constraints compiled to a gfx950 kernel at run time (hiprtc): the fast form of nx_eval_constraint_program
+// ("a HIP interpreter/JIT that evaluates the recorded expression DAG per row").
+//
+// The interpreter (constraints.hip) pays an LDS round trip and a scalar dispatch per instruction; a recorded program is
+// straight-line code, so it can simply be emitted as HIP source — one statement per instruction over named registers, the
+// alpha-power folding schedule resolved at generation time — and handed to the compiler, which keeps values in VGPRs and
+// schedules the column loads.  Same semantics, same operand encoding, same accumulation as the interpreter; the lookup
+// elements (econsts) and alpha powers stay run-time arguments, so one compilation serves every proof of an AIR.
+#include "internal.h"
+#include <hip/hiprtc.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+struct nx_air_kernel {
+    nx_ctx* ctx;
+    hipModule_t module;
+    hipFunction_t fn;
+    uint32_t n_cols, n_econsts, n_constraints;
+};
+
+namespace nx {
+
+static const char* AIR_PRELUDE = R"SRC(
+typedef unsigned int u32; typedef unsigned long long u64;
+#define P 0x7fffffffu
+// header-free on purpose: only compiler builtins, so hiprtc and an offline hipcc see the same text
+#define FI __attribute__((device)) __attribute__((always_inline)) inline
+FI u32 m_csub(u32 s) { u32 d; bool b = __builtin_usub_overflow(s, P, &d); return b ? s : d; }
+FI u32 m_add(u32 a, u32 b) { return m_csub(a + b); }
+FI u32 m_sub(u32 a, u32 b) { u32 d; bool br = __builtin_usub_overflow(a, b, &d); return br ? d + P : d; }
+FI u32 m_neg(u32 a) { return a ? P - a : 0; }
+FI u32 m_mul(u32 a, u32 b) { u64 p = (u64)a * (u64)(b << 1); return m_csub((u32)(p >> 32) + ((u32)p >> 1)); }
+FI u64 acc_mad(u64 acc, u32 a, u32 b) { return acc + (u64)a * (u64)b; }
+FI u64 acc_fold(u64 x) { return (x & (u64)P) + (x >> 31); }
+FI u32 acc_final(u64 x) { x = acc_fold(x); u32 s = ((u32)x & P) + (u32)(x >> 31); return m_csub(s); }
+struct Q { u32 a, b, c, d; };
+FI Q q_add(Q x, Q y) { Q r = {m_add(x.a, y.a), m_add(x.b, y.b), m_add(x.c, y.c), m_add(x.d, y.d)}; return r; }
+FI Q q_sub(Q x, Q y) { Q r = {m_sub(x.a, y.a), m_sub(x.b, y.b), m_sub(x.c, y.c), m_sub(x.d, y.d)}; return r; }
+// (xa + xb u)(ya + yb u), u^2 = 2 + i, CM31 = M31[i]/(i^2+1)
+FI void c_mul(u32 xa, u32 xb, u32 ya, u32 yb, u32& ra, u32& rb) { ra = m_sub(m_mul(xa, ya), m_mul(xb, yb)); rb = m_add(m_mul(xa, yb), m_mul(xb, ya)); }
+FI Q q_mul(Q x, Q y) {
+    u32 aa0, aa1, bb0, bb1, ab0, ab1, ba0, ba1;
+    c_mul(x.a, x.b, y.a, y.b, aa0, aa1); c_mul(x.c, x.d, y.c, y.d, bb0, bb1);
+    c_mul(x.a, x.b, y.c, y.d, ab0, ab1); c_mul(x.c, x.d, y.a, y.b, ba0, ba1);
+    u32 r0 = m_sub(m_add(bb0, bb0), bb1), r1 = m_add(m_add(bb1, bb1), bb0);      // bb * (2 + i)
+    Q r = {m_add(aa0, r0), m_add(aa1, r1), m_add(ab0, ba0), m_add(ab1, ba1)};
+    return r;
+}
+FI u32 bitrev(u32 i, int log) { return log ? (__builtin_bitreverse32(i) >> (32 - log)) : i; }
+FI u32 row_offset(u32 r, int log_size, int e, int offset) {
+    if (offset == 0) return r;
+    u32 idx = bitrev(r, e);
+    const u32 half = 1u << (e - 1);
+    const u32 step = (u32)offset << (e - log_size - 1);
+    if (idx < half) idx = (idx + step) & (half - 1);
+    else idx = ((idx - half - step) & (half - 1)) + half;
+    return bitrev(idx, e);
+}
+)SRC";
+
+static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs) {
+    std::string s = AIR_PRELUDE;
+    s += "extern \"C\" __attribute__((global)) __attribute__((amdgpu_flat_work_group_size(256, 256))) void air_kernel(const u32* const* __restrict__ cols, const u32* __restrict__ econst, const u32* __restrict__ pw,\n"
+         "    const u32* __restrict__ denom_inv, int log_size, int e, u32* a0, u32* a1, u32* a2, u32* a3) {\n"
+         "  const u32 r = __builtin_amdgcn_workgroup_id_x() * 256 + __builtin_amdgcn_workitem_id_x();\n  if (r >= (1u << e)) return;\n"
+         "  u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;\n";
+    // which row offsets occur
+    std::vector<int> offs;
+    for (uint32_t i = 0; i < n_instr; i++)
+        if (prog[i].op == NX_C_LOAD || prog[i].op == NX_C_LOADE) { int o = (int)prog[i].b; if (std::find(offs.begin(), offs.end(), o) == offs.end()) offs.push_back(o); }
+    auto off_name = [](int o) { return std::string("row_") + (o < 0 ? "m" : "p") + std::to_string(o < 0 ? -o : o); };
+    for (int o : offs) s += "  const u32 " + off_name(o) + " = row_offset(r, log_size, e, " + std::to_string(o) + ");\n";
+    for (uint32_t k = 0; k < n_regs; k++) s += (k % 16 == 0 ? std::string("  u32 ") : std::string(", ")) + "r" + std::to_string(k) + ((k % 16 == 15 || k + 1 == n_regs) ? " = 0;\n" : " = 0");
+    auto R = [](uint32_t i) { return "r" + std::to_string(i); };
+    auto E = [&](uint32_t i) { return "Q{" + R(i) + ", " + R(i + 1) + ", " + R(i + 2) + ", " + R(i + 3) + "}"; };
+    auto setE = [&](uint32_t d, const std::string& expr) {
+        return "  { const Q t_ = " + expr + "; " + R(d) + " = t_.a; " + R(d + 1) + " = t_.b; " + R(d + 2) + " = t_.c; " + R(d + 3) + " = t_.d; }\n";
+    };
+    uint32_t j = 0, pending = 0;
+    const std::string fold = "  s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3);\n";
+    for (uint32_t i = 0; i < n_instr; i++) {
+        const nx_cinstr& in = prog[i];
+        switch (in.op) {
+        case NX_C_LOAD: s += "  " + R(in.dst) + " = cols[" + std::to_string(in.a) + "][" + off_name((int)in.b) + "];\n"; break;
+        case NX_C_CONST: s += "  " + R(in.dst) + " = " + std::to_string(in.a) + "u;\n"; break;
+        case NX_C_ADD: s += "  " + R(in.dst) + " = m_add(" + R(in.a) + ", " + R(in.b) + ");\n"; break;
+        case NX_C_SUB: s += "  " + R(in.dst) + " = m_sub(" + R(in.a) + ", " + R(in.b) + ");\n"; break;
+        case NX_C_MUL: s += "  " + R(in.dst) + " = m_mul(" + R(in.a) + ", " + R(in.b) + ");\n"; break;
+        case NX_C_NEG: s += "  " + R(in.dst) + " = m_neg(" + R(in.a) + ");\n"; break;
+        case NX_C_CONSTE: { std::string b = std::to_string(4 * in.a); s += setE(in.dst, "Q{econst[" + b + "], econst[" + b + " + 1], econst[" + b + " + 2], econst[" + b + " + 3]}"); break; }
+        case NX_C_ADDE: s += setE(in.dst, "q_add(" + E(in.a) + ", " + E(in.b) + ")"); break;
+        case NX_C_SUBE: s += setE(in.dst, "q_sub(" + E(in.a) + ", " + E(in.b) + ")"); break;
+        case NX_C_MULE: s += setE(in.dst, "q_mul(" + E(in.a) + ", " + E(in.b) + ")"); break;
+        case NX_C_MULEB: s += setE(in.dst, "Q{m_mul(" + R(in.a) + ", " + R(in.b) + "), m_mul(" + R(in.a + 1) + ", " + R(in.b) + "), m_mul(" + R(in.a + 2) + ", " + R(in.b) + "), m_mul(" + R(in.a + 3) + ", " + R(in.b) + ")}"); break;
+        case NX_C_ADDEB: s += setE(in.dst, "Q{m_add(" + R(in.a) + ", " + R(in.b) + "), " + R(in.a + 1) + ", " + R(in.a + 2) + ", " + R(in.a + 3) + "}"); break;
+        case NX_C_LOADE: {
+            std::string o = off_name((int)in.b);
+            s += setE(in.dst, "Q{cols[" + std::to_string(in.a) + "][" + o + "], cols[" + std::to_string(in.a + 1) + "][" + o + "], cols[" + std::to_string(in.a + 2) + "][" + o + "], cols[" +
+                                  std::to_string(in.a + 3) + "][" + o + "]}");
+            break;
+        }
+        case NX_C_CONSTRAINT_B: {
+            std::string b = std::to_string(4 * j);
+            s += "  s0 = acc_mad(s0, pw[" + b + "], " + R(in.a) + "); s1 = acc_mad(s1, pw[" + b + " + 1], " + R(in.a) + "); s2 = acc_mad(s2, pw[" + b + " + 2], " + R(in.a) + "); s3 = acc_mad(s3, pw[" + b +
+                 " + 3], " + R(in.a) + ");\n";
+            j++;
+            if (++pending == 4) { s += fold; pending = 0; }
+            break;
+        }
+        case NX_C_CONSTRAINT_E: {
+            std::string b = std::to_string(4 * j);
+            s += "  { const Q t_ = q_mul(Q{pw[" + b + "], pw[" + b + " + 1], pw[" + b + " + 2], pw[" + b + " + 3]}, " + E(in.a) + "); s0 += t_.a; s1 += t_.b; s2 += t_.c; s3 += t_.d; }\n";
+            j++;
+            if (++pending == 4) { s += fold; pending = 0; }
+            break;
+        }
+        default: break;
+        }
+    }
+    s += "  const u32 di = denom_inv[r >> log_size];\n"
+         "  a0[r] = m_add(a0[r], m_mul(acc_final(s0), di)); a1[r] = m_add(a1[r], m_mul(acc_final(s1), di));\n"
+         "  a2[r] = m_add(a2[r], m_mul(acc_final(s2), di)); a3[r] = m_add(a3[r], m_mul(acc_final(s3), di));\n}\n";
+    return s;
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+// Validates like nx_eval_constraint_program, generates the source, compiles it for gfx950 and loads the module.
+// h_source_out (optional): receives a malloc'd copy of the generated source (free with nx_free_host) — also usable without a GPU.
+int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints,
+                   nx_air_kernel** out, char** h_source_out) {
+    if (!program || (!out && !h_source_out)) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: NULL argument");
+    if (n_regs == 0 || n_regs > 4096) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: register count out of range");
+    uint32_t n_c = 0;
+    for (uint32_t i = 0; i < n_instr; i++) {
+        const nx_cinstr& in = program[i];
+        auto reg_ok = [&](uint32_t rg, uint32_t width) { return rg + width <= n_regs; };
+        bool ok = true;
+        switch (in.op) {
+        case NX_C_LOAD: ok = reg_ok(in.dst, 1) && in.a < n_cols; break;
+        case NX_C_CONST: ok = reg_ok(in.dst, 1) && in.a < P; break;
+        case NX_C_ADD: case NX_C_SUB: case NX_C_MUL: ok = reg_ok(in.dst, 1) && reg_ok(in.a, 1) && reg_ok(in.b, 1); break;
+        case NX_C_NEG: ok = reg_ok(in.dst, 1) && reg_ok(in.a, 1); break;
+        case NX_C_CONSTE: ok = reg_ok(in.dst, 4) && in.a < n_econsts; break;
+        case NX_C_ADDE: case NX_C_SUBE: case NX_C_MULE: ok = reg_ok(in.dst, 4) && reg_ok(in.a, 4) && reg_ok(in.b, 4); break;
+        case NX_C_MULEB: case NX_C_ADDEB: ok = reg_ok(in.dst, 4) && reg_ok(in.a, 4) && reg_ok(in.b, 1); break;
+        case NX_C_LOADE: ok = reg_ok(in.dst, 4) && in.a + 4 <= n_cols; break;
+        case NX_C_CONSTRAINT_B: ok = reg_ok(in.a, 1); n_c++; break;
+        case NX_C_CONSTRAINT_E: ok = reg_ok(in.a, 4); n_c++; break;
+        default: ok = false;
+        }
+        if (!ok) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: malformed instruction " + std::to_string(i));
+    }
+    if (n_c != n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: the program adds a different number of constraints than announced");
+    const std::string src = generate_air_source(program, n_instr, n_regs);
+    if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
+    if (!out) return NX_OK;
+    if (!ctx) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: a context is needed to load the kernel");
+    hiprtcProgram rp;
+    if (hiprtcCreateProgram(&rp, src.c_str(), "nx_air_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return set_err(ctx, NX_ERR_HIP, "hiprtcCreateProgram failed");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3"};
+    hiprtcResult cr = hiprtcCompileProgram(rp, 2, opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t ls = 0; (void)hiprtcGetProgramLogSize(rp, &ls);
+        std::string log(ls, '\0'); if (ls) (void)hiprtcGetProgramLog(rp, &log[0]);
+        (void)hiprtcDestroyProgram(&rp);
+        return set_err(ctx, NX_ERR_HIP, "hiprtc compilation of the recorded AIR failed: " + log.substr(0, 400));
+    }
+    size_t cs = 0; (void)hiprtcGetCodeSize(rp, &cs);
+    std::vector<char> code(cs);
+    (void)hiprtcGetCode(rp, code.data());
+    (void)hiprtcDestroyProgram(&rp);
+    nx_air_kernel* k = new nx_air_kernel();
+    k->ctx = ctx; k->n_cols = n_cols; k->n_econsts = n_econsts; k->n_constraints = n_constraints;
+    hipError_t e = hipModuleLoadData(&k->module, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "air_kernel");
+    if (e != hipSuccess) { delete k; return hip_fail(ctx, e, "hipModuleLoadData(air kernel)", __FILE__, __LINE__); }
+    *out = k;
+    return NX_OK;
+}
+
+void nx_air_kernel_destroy(nx_air_kernel* k) {
+    if (!k) return;
+    (void)hipStreamSynchronize(k->ctx->stream);
+    (void)hipModuleUnload(k->module);
+    delete k;
+}
+
+int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_cols, const uint32_t* econsts, const uint32_t* alpha_powers, const uint32_t* denom_inv,
+                uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4) {
+    if (!ctx || !k || !d_acc4 || (k->n_cols && !d_cols)) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: NULL argument");
+    if (log_size < 1 || log_eval <= log_size || log_eval > 30) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: need 1 <= log_size < log_eval <= 30");
+    const size_t b_cols = (size_t)k->n_cols * 8, b_ec = (size_t)k->n_econsts * 16, b_pw = (size_t)k->n_constraints * 16, b_den = (size_t)4 << (log_eval - log_size);
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_ec = al(b_cols), o_pw = o_ec + al(b_ec), o_den = o_pw + al(b_pw), total = o_den + al(b_den) + 16;
+    uint8_t* blob = nullptr;
+    NX_TRY(dev_alloc(ctx, total, (void**)&blob));
+    hipError_t er = hipSuccess;
+    auto up = [&](size_t off, const void* src, size_t bytes) { if (er == hipSuccess && bytes) er = hipMemcpyAsync(blob + off, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
+    up(0, d_cols, b_cols); up(o_ec, econsts, b_ec); up(o_pw, alpha_powers, b_pw); up(o_den, denom_inv, b_den);
+    if (er == hipSuccess) {
+        const void* p_cols = blob; const void* p_ec = blob + o_ec; const void* p_pw = blob + o_pw; const void* p_den = blob + o_den;
+        int ls = (int)log_size, le = (int)log_eval;
+        uint32_t* a0 = d_acc4[0]; uint32_t* a1 = d_acc4[1]; uint32_t* a2 = d_acc4[2]; uint32_t* a3 = d_acc4[3];
+        void* args[] = {&p_cols, &p_ec, &p_pw, &p_den, &ls, &le, &a0, &a1, &a2, &a3};
+        const uint32_t n = 1u << log_eval;
+        er = hipModuleLaunchKernel(k->fn, (n + 255) / 256, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+    }
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    dev_free(ctx, blob);
+    if (er != hipSuccess) return hip_fail(ctx, er, "nx_air_eval", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_air_eval(sync)", __FILE__, __LINE__);
+    return NX_OK;
+}
+
+}  // extern "C"

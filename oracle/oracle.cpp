@@ -13,6 +13,7 @@
 #include "air.h"
 #include "pcs.h"
 #include "constraints.h"
+#include "air_generic.h"
 #include "logup.h"
 
 using namespace orc;
@@ -192,6 +193,43 @@ int orc_verify_synth(const int* comps, int ncomp, const int* cfg, const uint32_t
     if (!proof_deserialize(words, n_words, p)) { g_err = "Deserialize"; return 1; }
     std::string e;
     try { e = verify_synth(air_from(comps, ncomp), cfg_from(cfg), p, ad, ad_len); } catch (const std::string& x) { e = x; }
+    if (e.empty()) return 0;
+    g_err = e; return 1;
+}
+
+// ---- generic (recorded-AIR) prove / verify sessions (air_generic.h) ----
+void* orc_prover_new(const int* cfg, int max_log, int n_threads) { return new ProverSession(cfg_from(cfg), max_log, n_threads); }
+void orc_prover_free(void* p) { delete (ProverSession*)p; }
+void* orc_prover_channel(void* p) { return &((ProverSession*)p)->ch; }          // use with orc_channel_* (do not free)
+// columns: bit-reversed evaluations on CanonicCoset(log).circle_domain(); copied.
+void orc_prover_commit(void* p, const uint32_t** cols, const int* logs, int n, uint32_t* root_out) {
+    ProverSession* s = (ProverSession*)p;
+    std::vector<std::vector<u32>> c(n); std::vector<int> l(logs, logs + n);
+    for (int i = 0; i < n; i++) c[i].assign(cols[i], cols[i] + ((size_t)1 << logs[i]));
+    s->cs.commit_evals(std::move(c), l, s->ch);
+    memcpy(root_out, s->cs.trees.back().merkle.root().w, 32);
+}
+uint32_t* orc_prover_prove(void* p, const uint32_t* air_words, size_t n_air, size_t* n_words) {
+    try {
+        GAir air; if (!gair_decode(air_words, n_air, air)) throw std::string("malformed AIR description");
+        Proof pr = ((ProverSession*)p)->prove(air);
+        std::vector<u32> w = proof_serialize(pr);
+        uint32_t* out = (uint32_t*)malloc(w.size() * 4);
+        memcpy(out, w.data(), w.size() * 4);
+        *n_words = w.size();
+        return out;
+    } catch (const std::string& e) { g_err = e; return nullptr; }
+}
+void* orc_verifier_new(const int* cfg) { VerifierSession* v = new VerifierSession(); v->cfg = cfg_from(cfg); return v; }
+void orc_verifier_free(void* v) { delete (VerifierSession*)v; }
+void* orc_verifier_channel(void* v) { return &((VerifierSession*)v)->ch; }
+void orc_verifier_commit(void* v, const uint32_t* root, const int* logs, int n) { Hash h; memcpy(h.w, root, 32); ((VerifierSession*)v)->commit(h, std::vector<int>(logs, logs + n)); }
+int orc_verifier_verify(void* v, const uint32_t* air_words, size_t n_air, const uint32_t* words, size_t n_words) {
+    GAir air; if (!gair_decode(air_words, n_air, air)) { g_err = "malformed AIR description"; return 1; }
+    Proof p;
+    if (!proof_deserialize(words, n_words, p)) { g_err = "Deserialize"; return 1; }
+    std::string e;
+    try { e = ((VerifierSession*)v)->verify(air, p); } catch (const std::string& x) { e = x; }
     if (e.empty()) return 0;
     g_err = e; return 1;
 }

@@ -516,6 +516,18 @@ static inline QPt get_random_point(Channel& ch) {
     return p;
 }
 
+// What stwo::prover::prove / core::verifier::verify need from the components (Components / ComponentProvers): the
+// synthetic machine below and the recorded AIRs of air_generic.h both provide it.
+struct TreeData;
+typedef std::vector<std::vector<std::vector<QM31>>> SampledValues;   // tree -> column -> mask
+typedef std::vector<std::vector<std::vector<QPt>>> MaskPoints;
+struct AirHooks {
+    int composition_log;
+    std::function<std::vector<std::vector<u32>>(const Twiddles&, const std::vector<TreeData>&, QM31, int)> compute_composition;
+    std::function<MaskPoints(QPt)> mask_points;                                     // trees 0..2 (the composition tree is added by the driver)
+    std::function<QM31(QPt, const SampledValues&, QM31)> eval_composition_at_point;
+};
+
 static inline int composition_log(const AirSpec& air, const PcsConfig& cfg) {
     int m = 0; for (auto& c : air.comps) m = std::max(m, c.log_size + cfg.log_constraint_degree); return m;
 }
@@ -637,6 +649,16 @@ static inline u64 inter_seed_from(QM31 z) { return ((u64)z.a.a << 32) ^ (u64)z.a
 
 struct ProveStats { double t_commit, t_composition, t_oods, t_quotients, t_fri, t_decommit; };
 
+static inline AirHooks synth_hooks(const AirSpec& air, const PcsConfig& cfg) {
+    AirHooks h;
+    h.composition_log = composition_log(air, cfg);
+    h.compute_composition = [&air, cfg](const Twiddles& tw, const std::vector<TreeData>& trees, QM31 rc, int nt) { return compute_composition(air, cfg, tw, trees, rc, nt); };
+    h.mask_points = [&air](QPt oods) { return mask_points(air, oods); };
+    h.eval_composition_at_point = [&air](QPt p, const SampledValues& sv, QM31 rc) { return eval_composition_at_point(air, p, sv, rc); };
+    return h;
+}
+static inline Proof prove_core(CommitmentSchemeProver& cs, Channel& ch, const PcsConfig& cfg, const Twiddles& tw, const AirHooks& air, int n_threads);
+
 // The synthetic-machine prove: orchestration of reference prover/src/machine.rs:184-296 followed
 // by stwo prover/mod.rs::prove and prover/pcs/mod.rs::prove_values.
 static inline Proof prove_synth(const AirSpec& air, const PcsConfig& cfg, u64 seed, const uint8_t* ad, size_t ad_len, int n_threads) {
@@ -655,14 +677,18 @@ static inline Proof prove_synth(const AirSpec& air, const PcsConfig& cfg, u64 se
     std::vector<QM31> claimed(air.comps.size(), qm31_zero());
     ch.mix_felts(claimed.data(), claimed.size());                          // machine.rs:262
     cs.commit_evals(std::move(cols), logs, ch);                            // tree 2 (machine.rs:263)
+    return prove_core(cs, ch, cfg, tw, synth_hooks(air, cfg), n_threads);
+}
 
+static inline Proof prove_core(CommitmentSchemeProver& cs, Channel& ch, const PcsConfig& cfg, const Twiddles& tw, const AirHooks& air, int n_threads) {
     // ---- stwo::prover::prove ----
     QM31 random_coeff = ch.draw_secure_felt();
-    std::vector<std::vector<u32>> comp = compute_composition(air, cfg, tw, cs.trees, random_coeff, n_threads);
-    int clog = composition_log(air, cfg);
+    std::vector<std::vector<u32>> comp = air.compute_composition(tw, cs.trees, random_coeff, n_threads);
+    int clog = air.composition_log;
     cs.commit_polys(comp, std::vector<int>(4, clog), ch);                  // tree 3
     QPt oods = get_random_point(ch);
-    auto points = mask_points(air, oods);
+    auto points = air.mask_points(oods);
+    points.resize(4); points[3].assign(4, std::vector<QPt>{oods});
 
     // ---- prove_values ----
     Proof proof; proof.config = cfg;
@@ -707,12 +733,13 @@ static inline Proof prove_synth(const AirSpec& air, const PcsConfig& cfg, u64 se
     }
     // sanity check of stwo prover/mod.rs::prove
     QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
-    if (!qm31_eq(from_partial_evals(ce), eval_composition_at_point(air, oods, proof.sampled_values, random_coeff)))
+    if (!qm31_eq(from_partial_evals(ce), air.eval_composition_at_point(oods, proof.sampled_values, random_coeff)))
         throw std::string("ConstraintsNotSatisfied");
     return proof;
 }
 
 // ---------------- verifier ----------------
+static inline std::string verify_core(Channel& ch, const PcsConfig& cfg, const Proof& proof, std::vector<std::vector<int>> tree_logs, const AirHooks& air);
 // core/verifier.rs::verify + core/pcs/verifier.rs::verify_values + core/fri.rs FriVerifier, with the
 // transcript prefix of reference prover/src/machine.rs:299-485.
 static inline std::string verify_synth(const AirSpec& air, const PcsConfig& cfg, const Proof& proof, const uint8_t* ad, size_t ad_len) {
@@ -729,24 +756,33 @@ static inline std::string verify_synth(const AirSpec& air, const PcsConfig& cfg,
         for (int k = 0; k < c.n_main; k++) tree_logs[1].push_back(c.log_size);
         for (int k = 0; k < c.n_inter; k++) tree_logs[2].push_back(c.log_size);
     }
-    int clog = composition_log(air, cfg);
-    tree_logs[3].assign(4, clog);
     ch.mix_root(proof.commitments[0]);
     ch.mix_root(proof.commitments[1]);
     (void)ch.draw_secure_felt();  // lookup elements
     std::vector<QM31> claimed(air.comps.size(), qm31_zero());
     ch.mix_felts(claimed.data(), claimed.size());
     ch.mix_root(proof.commitments[2]);
+    return verify_core(ch, cfg, proof, tree_logs, synth_hooks(air, cfg));
+}
+
+// core/verifier.rs::verify from the point where the trace trees are in the transcript.
+static inline std::string verify_core(Channel& ch, const PcsConfig& cfg, const Proof& proof, std::vector<std::vector<int>> tree_logs, const AirHooks& air) {
+    if (proof.commitments.size() != 4 || proof.sampled_values.size() != 4) return "InvalidStructure";
+    if (proof.config.pow_bits != cfg.pow_bits || proof.config.log_blowup != cfg.log_blowup || proof.config.n_queries != cfg.n_queries ||
+        proof.config.log_last_layer_degree_bound != cfg.log_last_layer_degree_bound) return "ConfigMismatch";
+    tree_logs.resize(4);
+    tree_logs[3].assign(4, air.composition_log);
     QM31 random_coeff = ch.draw_secure_felt();
     ch.mix_root(proof.commitments[3]);
     QPt oods = get_random_point(ch);
-    auto points = mask_points(air, oods);
+    auto points = air.mask_points(oods);
+    points.resize(4); points[3].assign(4, std::vector<QPt>{oods});
     for (int t = 0; t < 4; t++) {
         if (proof.sampled_values[t].size() != points[t].size()) return "InvalidStructure";
         for (size_t c = 0; c < points[t].size(); c++) if (proof.sampled_values[t][c].size() != points[t][c].size()) return "InvalidStructure";
     }
     QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
-    if (!qm31_eq(from_partial_evals(ce), eval_composition_at_point(air, oods, proof.sampled_values, random_coeff))) return "OodsNotMatching";
+    if (!qm31_eq(from_partial_evals(ce), air.eval_composition_at_point(oods, proof.sampled_values, random_coeff))) return "OodsNotMatching";
     // verify_values
     { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); ch.mix_felts(flat.data(), flat.size()); }
     QM31 q_coeff = ch.draw_secure_felt();

@@ -1,0 +1,86 @@
+"""AIRs recorded through nexus_zkvm_amd.air_program, with valid traces, for the prover-session tests (CPU oracle and GPU).
+
+synthetic_component: the synthetic machine of oracle/air.h as a generic Component (its proof must equal prove_synth's).
+logup_component:     a small lookup-style component: main columns a, b, c with c = a*b + 3, a free multiplicity-less logup
+                     column S (secure, 4 coordinates in the interaction tree) with the running-sum constraint
+                     (S(row) - S(row-1) + shift) * (z - a - alpha*b) = 1, S in natural trace order minus (row+1)*shift so that it
+                     wraps to zero — the shape of stwo-constraint-framework's logup constraints (mask [-1, 0] on the
+                     interaction column, lookup elements z/alpha and claimed-sum shift as secure constants)."""
+import numpy as np
+
+import oracle_lib as O
+
+P = O.P
+
+
+def qmul(a, b):
+    out = np.zeros(4, np.uint32)
+    O.lib().orc_qm31_mul(O.ptr(O.u32(a)), O.ptr(O.u32(b)), O.ptr(out))
+    return out
+
+
+def qinv(a):
+    out = np.zeros(4, np.uint32)
+    O.lib().orc_qm31_inv(O.ptr(O.u32(a)), O.ptr(out))
+    return out
+
+
+def qadd(a, b):
+    return ((np.asarray(a, np.uint64) + np.asarray(b, np.uint64)) % P).astype(np.uint32)
+
+
+def qsub(a, b):
+    return ((np.asarray(a, np.uint64) + P - np.asarray(b, np.uint64)) % P).astype(np.uint32)
+
+
+def synthetic_component(ap, log, n_pre, n_main, n_inter, pre0=0, main0=0, inter0=0):
+    from test_air_program_cpu import synthetic_program
+    prog = synthetic_program(ap, n_pre, n_main, n_inter)
+    cols = [(0, pre0 + k) for k in range(n_pre)] + [(1, main0 + k) for k in range(n_main)] + [(2, inter0 + k) for k in range(n_inter)]
+    return ap.Component(log, prog, cols)
+
+
+def logup_main_trace(log, seed):
+    """a, b random, c = a*b + 3 — natural order, finalized to bit-reversed circle-domain order."""
+    rng = np.random.default_rng(seed)
+    n = 1 << log
+    a = rng.integers(0, P, n, dtype=np.uint64)
+    b = rng.integers(0, P, n, dtype=np.uint64)
+    c = (a * b + 3) % P
+    nat = [a.astype(np.uint32), b.astype(np.uint32), c.astype(np.uint32)]
+    return nat, [O.finalize_column(x) for x in nat]
+
+
+def logup_interaction_trace(log, nat_main, z, alpha):
+    """Returns (4 coordinate columns of S finalized, shift)."""
+    n = 1 << log
+    a, b = nat_main[0], nat_main[1]
+    fr = []
+    for i in range(n):
+        den = qsub(qsub(z, [a[i], 0, 0, 0]), qmul(alpha, [b[i], 0, 0, 0]))
+        fr.append(qinv(den))
+    total = np.zeros(4, np.uint32)
+    for f in fr:
+        total = qadd(total, f)
+    shift = qmul(total, [pow(n, P - 2, P), 0, 0, 0])
+    S = np.zeros((n, 4), np.uint32)
+    run = np.zeros(4, np.uint32)
+    for i in range(n):
+        run = qsub(qadd(run, fr[i]), shift)
+        S[i] = run
+    assert not S[n - 1].any()
+    return [O.finalize_column(S[:, k].copy()) for k in range(4)], shift
+
+
+def logup_component(ap, log, z, alpha, shift, main0=0, inter0=0):
+    pb = ap.ProgramBuilder()
+    (a,) = pb.next_trace_mask(0)
+    (b,) = pb.next_trace_mask(1)
+    (c,) = pb.next_trace_mask(2)
+    s_prev, s_cur = pb.next_secure_mask(3, (-1, 0))
+    pb.add_constraint(c - a * b - 3)
+    ze, al, sh = pb.econst(z), pb.econst(alpha), pb.econst(shift)
+    den = ze - a - al * b
+    pb.add_constraint((s_cur - s_prev + sh) * den - 1)
+    cols = [(1, main0), (1, main0 + 1), (1, main0 + 2)] + [(2, inter0 + k) for k in range(4)]
+    return ap.Component(log, pb.build(), cols)

@@ -63,6 +63,17 @@ def lib():
         L.orc_synth_tree_columns.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         L.orc_synth_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_blake2s.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        for f in ("orc_prover_new", "orc_prover_channel", "orc_verifier_new", "orc_verifier_channel"):
+            getattr(L, f).restype = C.c_void_p
+        L.orc_prover_new.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_verifier_new.argtypes = [C.c_void_p]
+        for f in ("orc_prover_free", "orc_prover_channel", "orc_verifier_free", "orc_verifier_channel"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.orc_prover_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_prover_prove.restype = u32p
+        L.orc_prover_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_verifier_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_verifier_verify.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -224,3 +235,91 @@ def logup_finalize_last(col4):
     cs = np.zeros(4, np.uint32)
     lib().orc_logup_finalize_last(log, ptr_array(col), ptr(cs))
     return col, cs
+
+
+class _SessionChannel:
+    """The Blake2sChannel of a prover / verifier session (owned by the session)."""
+
+    def __init__(self, h):
+        self.h = C.c_void_p(h)
+
+    def mix_u64(self, v):
+        lib().orc_channel_mix_u64(self.h, v)
+
+    def mix_felts(self, felts):
+        f = u32(felts).reshape(-1)
+        lib().orc_channel_mix_felts(self.h, ptr(f), C.c_size_t(len(f) // 4))
+
+    def draw_felt(self):
+        out = np.zeros(4, np.uint32)
+        lib().orc_channel_draw_secure_felt(self.h, ptr(out))
+        return out
+
+    def digest(self):
+        out = np.zeros(8, np.uint32)
+        lib().orc_channel_digest(self.h, ptr(out))
+        return out
+
+
+class ProverSession(_SessionChannel):
+    """oracle/air_generic.h::ProverSession — CommitmentSchemeProver + channel + stwo::prover::prove over recorded AIRs."""
+
+    def __init__(self, cfg, max_log, threads=4):
+        self.cfg = cfg
+        self.p = C.c_void_p(lib().orc_prover_new(ptr(cfg), max_log, threads))
+        super().__init__(lib().orc_prover_channel(self.p))
+
+    def commit(self, cols):
+        cols = [u32(c) for c in cols]
+        logs = np.array([int(np.log2(len(c))) for c in cols], np.int32)
+        root = np.zeros(8, np.uint32)
+        lib().orc_prover_commit(self.p, ptr_array(cols) if cols else None, ptr(logs), len(cols), ptr(root))
+        return root
+
+    def prove(self, components):
+        from nexus_zkvm_amd.air_program import encode_air
+        w = encode_air(components)
+        n = C.c_size_t(0)
+        p = lib().orc_prover_prove(self.p, ptr(w), len(w), C.byref(n))
+        if not p:
+            raise RuntimeError("oracle prove failed: " + lib().orc_last_error().decode())
+        words = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+        lib().orc_free(p)
+        return words
+
+    def __del__(self):
+        try:
+            lib().orc_prover_free(self.p)
+        except Exception:
+            pass
+
+
+class VerifierSession(_SessionChannel):
+    """oracle/air_generic.h::VerifierSession — CommitmentSchemeVerifier + channel + core::verifier::verify."""
+
+    def __init__(self, cfg):
+        self.v = C.c_void_p(lib().orc_verifier_new(ptr(cfg)))
+        super().__init__(lib().orc_verifier_channel(self.v))
+
+    def commit(self, root, logs):
+        r, l = u32(root), np.array(logs, np.int32)
+        lib().orc_verifier_commit(self.v, ptr(r), ptr(l), len(l))
+
+    def verify(self, components, words):
+        """None when the proof is accepted, else the verifier's error text."""
+        from nexus_zkvm_amd.air_program import encode_air
+        w, pw = encode_air(components), u32(words)
+        rc = lib().orc_verifier_verify(self.v, ptr(w), len(w), ptr(pw), len(pw))
+        return None if rc == 0 else lib().orc_last_error().decode()
+
+    def __del__(self):
+        try:
+            lib().orc_verifier_free(self.v)
+        except Exception:
+            pass
+
+
+def proof_header_words():
+    """NXP1 (oracle/pcs.h::proof_serialize): magic, pow_bits, log_blowup, n_queries, log_last_layer_degree_bound; then the
+    commitment count and the roots."""
+    return 5

@@ -128,3 +128,29 @@ def test_oracle_program_of_a_valid_trace_is_a_low_degree_quotient(oracle, lcd):
     acc_bad = oracle.eval_constraint_program(prog, ext_bad, pw, denominators(log, e), log, e)
     if lcd == 2:
         assert any(tw.interpolate(acc_bad[k])[1 << (log + 1):].any() for k in range(4))
+
+
+def _small_program():
+    import nexus_zkvm_amd.air_program as ap
+    return synthetic_program(ap, 3, 20, 19), 3 + 20 + 19
+
+
+def test_air_jit_source_generates_and_cross_compiles(tmp_path):
+    """nx_air_compile's code generator needs no GPU: the source for the synthetic machine's recorded program must compile
+    for gfx950 (hipcc cross-compiles here); the run-time path hands the same text to hiprtc."""
+    import shutil, subprocess
+    import nexus_zkvm_amd as nx
+    prog, n_cols = _small_program()
+    src = nx.air_source(prog, n_cols)
+    assert "air_kernel" in src and src.count("acc_mad") >= 4
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    f = tmp_path / "k.hip"
+    f.write_text(src)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-c", str(f), "-o", str(tmp_path / "k.o")], check=True, timeout=300)
+
+
+def test_air_jit_rejects_malformed_program():
+    import nexus_zkvm_amd as nx
+    prog, n_cols = _small_program()
+    with pytest.raises(nx.NexusHipError):
+        nx.air_source(prog, n_cols - 1)          # a LOAD now indexes past the column table

@@ -578,6 +578,67 @@ def test_constraint_program_rejects_malformed_programs(be, nz):
         be.eval_constraint_program(prog, ptrs + ptrs, np.zeros((2, 4), np.uint32), np.ones(2, np.uint32), 4, 5, acc)
 
 
+@pytest.mark.parametrize("log,lcd,seed", [(5, 1, 11), (6, 2, 12), (9, 1, 13), (12, 1, 14)])
+def test_air_jit_matches_oracle_and_interpreter(be, oracle, log, lcd, seed):
+    """nx_air_compile/nx_air_eval (hiprtc) == oracle == interpreter on random programs covering every opcode; one compiled kernel
+    is reused with different lookup elements and alpha powers (they are run-time arguments)."""
+    import nexus_zkvm_amd.air_program as ap
+    from test_air_program_cpu import denominators
+    rng = np.random.default_rng(seed)
+    e, n_cols = log + lcd, 12
+    prog = _random_program(ap, rng, n_cols, 150)
+    kern = be.compile_air(prog, n_cols)
+    den = denominators(log, e)
+    for rep in range(2):
+        cols = rng.integers(0, P, (n_cols, 1 << e), dtype=np.uint32)
+        pw = rng.integers(0, P, (prog.n_constraints, 4), dtype=np.uint32)
+        if rep:
+            prog.econsts = rng.integers(0, P, np.asarray(prog.econsts).shape, dtype=np.uint32)
+        start = rng.integers(0, P, (4, 1 << e), dtype=np.uint32)
+        d_cols, acc, acc2 = be.columns_from_host(cols), be.columns_from_host(start), be.columns_from_host(start)
+        ptrs = [d_cols.ptr.value + k * (4 << e) for k in range(n_cols)]
+        kern.eval(ptrs, pw, den, log, e, acc)
+        be.eval_constraint_program(prog, ptrs, pw, den, log, e, acc2)
+        got = acc.to_cpu()
+        assert np.array_equal(got, acc2.to_cpu())
+        if log <= 9:
+            assert np.array_equal(got, np.stack(oracle.eval_constraint_program(prog, list(cols), pw, den, log, e, acc4=list(start))))
+    kern.close()
+
+
+def test_air_jit_reproduces_the_synthetic_machine(be, nz, oracle):
+    import nexus_zkvm_amd.air_program as ap
+    from test_air_program_cpu import denominators, synthetic_program
+    log, n_pre, n_main, n_inter = 10, 4, 37, 18
+    e = log + 1
+    tw = be.precompute_twiddles(e)
+    ldes = []
+    for tree in range(3):
+        for s in be.synth_fill_tree([(log, n_pre, n_main, n_inter)], tree, seed=5, inter_seed=99):
+            ldes.append(be.lde(tw, s, 1))
+    ptrs = [l.ptr.value + k * (4 << e) for l in ldes for k in range(l.n_cols)]
+    host = np.concatenate([l.to_cpu() for l in ldes])
+    prog = synthetic_program(ap, n_pre, n_main, n_inter)
+    pw = np.random.default_rng(8).integers(0, P, (prog.n_constraints, 4), dtype=np.uint32)
+    den = denominators(log, e)
+    acc = be.columns(4, e)
+    be._chk(be.L.nx_memset_zero(be.ctx, acc.ptr, C.c_size_t(4 << e)))
+    kern = be.compile_air(prog, len(ptrs))
+    kern.eval(ptrs, pw, den, log, e, acc)
+    assert np.array_equal(acc.to_cpu(), np.stack(oracle.eval_constraint_program(prog, list(host), pw, den, log, e)))
+    with pytest.raises(nz.NexusHipError, match="log_size"):
+        kern.eval(ptrs, pw, den[:1], log, log, acc)
+
+
+def test_air_jit_rejects_malformed_programs(be, nz):
+    import nexus_zkvm_amd.air_program as ap
+    pb = ap.ProgramBuilder()
+    (a,) = pb.next_trace_mask(3)
+    pb.add_constraint(a)
+    with pytest.raises(nz.NexusHipError, match="malformed"):
+        be.compile_air(pb.build(), 2)
+
+
 # ---------------- "next" row R8: logup interaction trace on device --------------------------------------------------------
 
 @pytest.mark.parametrize("log", [4, 9, 13, 16])

@@ -26,5 +26,18 @@ for r in range(4):
     be.eval_constraint_program(prog, ptrs, pw, den, log, e, acc)
     be.sync(); best = min(best, time.perf_counter() - t0)
 n_cols = len(ptrs)
+import ctypes as C
+t0 = time.perf_counter(); kern = be.compile_air(prog, n_cols); t_compile = time.perf_counter() - t0
+acc2 = be.columns(4, e)
+for a in (acc, acc2):
+    be._chk(be.L.nx_memset_zero(be.ctx, a.ptr, C.c_size_t(4 << e)))
+be.eval_constraint_program(prog, ptrs, pw, den, log, e, acc)
+kern.eval(ptrs, pw, den, log, e, acc2)
+same = bool(np.array_equal(acc.to_cpu(), acc2.to_cpu()))
+jit = 1e9
+for r in range(5):
+    be.sync(); t0 = time.perf_counter()
+    kern.eval(ptrs, pw, den, log, e, acc2)
+    be.sync(); jit = min(jit, time.perf_counter() - t0)
 print(json.dumps({"log_size": log, "columns": n_cols, "instructions": int(len(prog.instrs)), "registers": prog.n_regs, "constraints": prog.n_constraints,
-                  "ms": best * 1e3, "column_GBs": n_cols * (4 << e) / best / 1e9, "G_instr_rows_per_s": len(prog.instrs) * (1 << e) / best / 1e9}))
+                  "ms": best * 1e3, "jit_ms": jit * 1e3, "jit_equals_interpreter": same, "jit_compile_s": t_compile, "jit_column_GBs": n_cols * (4 << e) / jit / 1e9, "column_GBs": n_cols * (4 << e) / best / 1e9, "G_instr_rows_per_s": len(prog.instrs) * (1 << e) / best / 1e9}))
