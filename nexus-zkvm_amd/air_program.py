@@ -64,23 +64,6 @@ class Component:
         self.log_size, self.program, self.cols = int(log_size), program, [(int(t), int(i)) for t, i in cols]
         self.masks = [list(masks[k]) if masks is not None else list(program.masks.get(k, (0,))) for k in range(len(self.cols))]
 
-    def encode(self):
-        """The flat u32 description tests/oracle_lib.py hands to the oracle (oracle/air_generic.h::gair_decode)."""
-        import numpy as np
-        pr = self.program
-        ins = np.asarray(pr.instrs, dtype=np.uint32).reshape(-1)
-        ec = np.asarray(pr.econsts, dtype=np.uint32).reshape(-1)
-        offs = [o for m in self.masks for o in m]
-        head = [self.log_size, len(ins) // 4, pr.n_regs, len(ec) // 4, pr.n_constraints, len(self.cols), len(offs)]
-        parts = [np.array(head, np.uint32), ins, ec, np.array([t for t, _ in self.cols], np.uint32), np.array([i for _, i in self.cols], np.uint32),
-                 np.array([len(m) for m in self.masks], np.uint32), np.array(offs, np.int32).view(np.uint32)]
-        return np.concatenate(parts)
-
-
-def encode_air(components):
-    import numpy as np
-    return np.concatenate([np.array([len(components)], np.uint32)] + [c.encode() for c in components])
-
 
 class ProgramBuilder:
     def __init__(self):

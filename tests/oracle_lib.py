@@ -277,7 +277,6 @@ class ProverSession(_SessionChannel):
         return root
 
     def prove(self, components):
-        from nexus_zkvm_amd.air_program import encode_air
         w = encode_air(components)
         n = C.c_size_t(0)
         p = lib().orc_prover_prove(self.p, ptr(w), len(w), C.byref(n))
@@ -307,7 +306,6 @@ class VerifierSession(_SessionChannel):
 
     def verify(self, components, words):
         """None when the proof is accepted, else the verifier's error text."""
-        from nexus_zkvm_amd.air_program import encode_air
         w, pw = encode_air(components), u32(words)
         rc = lib().orc_verifier_verify(self.v, ptr(w), len(w), ptr(pw), len(pw))
         return None if rc == 0 else lib().orc_last_error().decode()
@@ -323,3 +321,19 @@ def proof_header_words():
     """NXP1 (oracle/pcs.h::proof_serialize): magic, pow_bits, log_blowup, n_queries, log_last_layer_degree_bound; then the
     commitment count and the roots."""
     return 5
+
+
+def encode_component(c):
+    """The flat u32 description of a nexus_zkvm_amd.air_program.Component that oracle/air_generic.h::gair_decode reads."""
+    pr = c.program
+    ins = np.asarray(pr.instrs, dtype=np.uint32).reshape(-1)
+    ec = np.asarray(pr.econsts, dtype=np.uint32).reshape(-1)
+    offs = [o for m in c.masks for o in m]
+    head = [c.log_size, len(ins) // 4, pr.n_regs, len(ec) // 4, pr.n_constraints, len(c.cols), len(offs)]
+    parts = [np.array(head, np.uint32), ins, ec, np.array([t for t, _ in c.cols], np.uint32), np.array([i for _, i in c.cols], np.uint32),
+             np.array([len(m) for m in c.masks], np.uint32), np.array(offs, np.int32).view(np.uint32)]
+    return np.concatenate(parts)
+
+
+def encode_air(components):
+    return np.concatenate([np.array([len(components)], np.uint32)] + [encode_component(c) for c in components])
