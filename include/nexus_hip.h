@@ -282,6 +282,45 @@ int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* kernel, const uint32_t* const*
                 uint32_t* const* d_acc4);
 void nx_air_kernel_destroy(nx_air_kernel* kernel);
 
+/* ------------------------------------------- the prover session: stwo::prover::prove over recorded AIRs
+ * What `nexus_vm_prover::prove` does around Stwo (reference prover/src/machine.rs:184-296; prover2/machine/src/prove.rs) with
+ * the AIR supplied as recorded constraint programs instead of Rust closures.  The caller replays the reference's transcript
+ * prefix through the session — mix the program description (machine.rs:198-206), commit the preprocessed tree (:208-228) and the
+ * main tree (:230-237), draw lookup elements (:239-240), build the interaction trace (nx_logup_*), mix the claimed sums (:262),
+ * commit the interaction tree (:263) — and nx_prover_prove runs CommitmentSchemeProver / stwo::prover::prove (:286-290) on the
+ * device: composition polynomial (nx_air_eval), OODS sampling, DEEP quotients, FRI, proof of work, decommitment.  The proof is
+ * in the NXP1 word format of nx_prove_synth.  Exactly three trace trees. */
+typedef struct nx_prover nx_prover;
+int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_size, nx_prover** out);
+void nx_prover_destroy(nx_prover* prover);
+/* Blake2sChannel of the session */
+int nx_prover_mix_u64(nx_prover* prover, uint64_t v);
+int nx_prover_mix_felts(nx_prover* prover, const uint32_t* felts, uint32_t n_felts); /* 4 words per QM31 */
+int nx_prover_draw_felt(nx_prover* prover, uint32_t out[4]);
+int nx_prover_channel_digest(const nx_prover* prover, uint8_t digest[32]);
+/* TreeBuilder::extend_evals + commit (machine.rs:208-263).  tree_begin allocates the tree's columns in the session (one slab per
+ * run of equal log sizes) and returns their device addresses; the caller fills them with bit-reversed circle-domain evaluations
+ * (trace generation on the device, nx_upload_columns, nx_copy ...); tree_commit interpolates, extends, commits and mixes the root.
+ * The columns then belong to the session (they hold the coefficients afterwards). */
+int nx_prover_tree_begin(nx_prover* prover, const uint32_t* log_sizes, uint32_t n_cols, uint32_t** d_cols_out);
+int nx_prover_tree_commit(nx_prover* prover, uint8_t root[32]);
+/* A component: what FrameworkComponent<E> is to Stwo (reference prover/src/components/mod.rs:15-57).  Column k of the program is
+ * column col_index[k] of tree col_tree[k] (TraceLocationAllocator); it is sampled at the mask_count[k] row offsets listed next in
+ * mask_offsets (InfoEvaluator, components/mod.rs:59-67) — every LOAD offset must be listed, every committed column must be
+ * claimed by some component.  kernel: the program compiled by nx_air_compile, or NULL to let nx_prover_prove compile it. */
+typedef struct {
+    uint32_t log_size;
+    const nx_cinstr* program; uint32_t n_instr, n_regs;
+    const uint32_t* econsts; uint32_t n_econsts;
+    uint32_t n_constraints;
+    const uint32_t* col_tree; const uint32_t* col_index; uint32_t n_cols;
+    const uint32_t* mask_count; const int32_t* mask_offsets;
+    const nx_air_kernel* kernel;
+} nx_air_component;
+/* stwo::prover::prove.  NX_ERR_PROTOCOL = ProvingError::ConstraintsNotSatisfied.  *proof_words: free with nx_free_host. */
+int nx_prover_prove(nx_prover* prover, const nx_air_component* components, uint32_t n_components, uint32_t** proof_words,
+                    size_t* n_words, nx_prove_stats* stats);
+
 /* ------------------------------------------- "next" row R8: logup interaction trace on device ------------------------
  * The reference fills the interaction trace on the CPU (prover/src/traits.rs:124-145 generate_interaction_trace -> per chip,
  * e.g. prover/src/chips/range_check/range256.rs:271-288; prover2/machine/src/lookups/logup_trace_builder.rs:22-121) through

@@ -129,6 +129,94 @@ class AirKernel:
             pass
 
 
+class AirComponentC(C.Structure):
+    _fields_ = [("log_size", C.c_uint32), ("program", C.c_void_p), ("n_instr", C.c_uint32), ("n_regs", C.c_uint32), ("econsts", C.c_void_p),
+                ("n_econsts", C.c_uint32), ("n_constraints", C.c_uint32), ("col_tree", C.c_void_p), ("col_index", C.c_void_p), ("n_cols", C.c_uint32),
+                ("mask_count", C.c_void_p), ("mask_offsets", C.c_void_p), ("kernel", C.c_void_p)]
+
+
+class ProverSession:
+    """nx_prover_*: CommitmentSchemeProver + Blake2sChannel + stwo::prover::prove over recorded AIRs
+    (air_program.Component).  The caller drives the reference's transcript prefix (machine.rs:198-263)."""
+
+    def __init__(self, be, cfg, max_log_size):
+        self.be, self.cfg = be, cfg
+        self.h = C.c_void_p()
+        be._chk(be.L.nx_prover_create(be.ctx, C.byref(cfg), max_log_size, C.byref(self.h)))
+
+    def mix_u64(self, v):
+        self.be._chk(self.be.L.nx_prover_mix_u64(self.h, C.c_uint64(int(v))))
+
+    def mix_felts(self, felts):
+        f = _u32(felts).reshape(-1)
+        self.be._chk(self.be.L.nx_prover_mix_felts(self.h, f.ctypes.data_as(C.c_void_p), len(f) // 4))
+
+    def draw_felt(self):
+        out = np.zeros(4, np.uint32)
+        self.be._chk(self.be.L.nx_prover_draw_felt(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def digest(self):
+        out = np.zeros(8, np.uint32)
+        self.be._chk(self.be.L.nx_prover_channel_digest(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def tree_begin(self, log_sizes):
+        """Device addresses (ints) of the next tree's columns, to be filled with bit-reversed circle-domain evaluations."""
+        logs = _u32(log_sizes)
+        ptrs = (C.c_void_p * max(1, len(logs)))()
+        self.be._chk(self.be.L.nx_prover_tree_begin(self.h, logs.ctypes.data_as(C.c_void_p), len(logs), ptrs))
+        return [int(ptrs[i] or 0) for i in range(len(logs))]
+
+    def tree_commit(self):
+        root = np.zeros(8, np.uint32)
+        self.be._chk(self.be.L.nx_prover_tree_commit(self.h, root.ctypes.data_as(C.c_void_p)))
+        return root
+
+    def commit(self, cols):
+        """Host columns (numpy, bit-reversed circle-domain evaluations): tree_begin + upload + tree_commit; returns the root."""
+        cols = [_u32(c) for c in cols]
+        ptrs = self.tree_begin([int(np.log2(len(c))) for c in cols])
+        for c, d in zip(cols, ptrs):
+            self.be._chk(self.be.L.nx_upload(self.be.ctx, C.c_void_p(d), c.ctypes.data_as(C.c_void_p), C.c_size_t(len(c))))
+        return self.tree_commit()
+
+    def prove(self, components, kernels=None, want_stats=False):
+        """components: air_program.Component list; kernels: optional AirKernel per component (compiled once, reused)."""
+        arr = (AirComponentC * len(components))()
+        keep = []
+        for i, c in enumerate(components):
+            pr = c.program
+            ins, ec = _u32(pr.instrs).reshape(-1), _u32(pr.econsts).reshape(-1)
+            ct, ci = _u32([t for t, _ in c.cols]), _u32([k for _, k in c.cols])
+            mc = _u32([len(m) for m in c.masks])
+            mo = np.ascontiguousarray([o for m in c.masks for o in m], dtype=np.int32)
+            keep += [ins, ec, ct, ci, mc, mo]
+            a = arr[i]
+            a.log_size, a.program, a.n_instr, a.n_regs = c.log_size, ins.ctypes.data, len(ins) // 4, pr.n_regs
+            a.econsts, a.n_econsts, a.n_constraints = ec.ctypes.data if len(ec) else None, len(ec) // 4, pr.n_constraints
+            a.col_tree, a.col_index, a.n_cols = ct.ctypes.data if len(ct) else None, ci.ctypes.data if len(ci) else None, len(c.cols)
+            a.mask_count, a.mask_offsets = mc.ctypes.data if len(mc) else None, mo.ctypes.data if len(mo) else None
+            a.kernel = kernels[i].h if kernels else None
+        words, n = C.POINTER(C.c_uint32)(), C.c_size_t(0)
+        stats = ProveStats()
+        self.be._chk(self.be.L.nx_prover_prove(self.h, arr, len(components), C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
+        out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
+        self.be.L.nx_free_host(words)
+        return (out, stats.as_dict()) if want_stats else out
+
+    def close(self):
+        if self.h and self.be.ctx:
+            self.be.L.nx_prover_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class LogupFrac(C.Structure):
     """nx_logup_frac of include/nexus_hip.h."""
     _fields_ = [("d_tuple_cols", C.c_void_p), ("n_tuple_cols", C.c_uint32), ("alpha_powers", C.c_void_p), ("z", C.c_void_p), ("d_mult", C.c_void_p),
@@ -164,7 +252,8 @@ def load_library():
     L.nx_merkle_n_layers.restype = C.c_uint32
     L.nx_free_host.argtypes = [C.c_void_p]
     L.nx_air_kernel_destroy.argtypes = [C.c_void_p]
-    for name in ("nx_ctx_destroy", "nx_twiddles_destroy", "nx_tree_destroy", "nx_free_host", "nx_air_kernel_destroy"):
+    L.nx_prover_destroy.argtypes = [C.c_void_p]
+    for name in ("nx_ctx_destroy", "nx_twiddles_destroy", "nx_tree_destroy", "nx_free_host", "nx_air_kernel_destroy", "nx_prover_destroy"):
         getattr(L, name).restype = None
     _lib = L
     return L
@@ -433,6 +522,9 @@ class HipBackend:
                                                     ec.ctypes.data_as(C.c_void_p), len(ec) // 4, pw.ctypes.data_as(C.c_void_p), len(pw) // 4,
                                                     den.ctypes.data_as(C.c_void_p), log_size, log_eval, acc4.col_ptrs()))
         return acc4
+
+    def prover_session(self, cfg, max_log_size):
+        return ProverSession(self, cfg, max_log_size)
 
     def compile_air(self, program, n_cols):
         """nx_air_compile: the recorded program as a run-time-compiled gfx950 kernel (same semantics as the interpreter)."""

@@ -426,6 +426,49 @@ static QPt get_random_point(Blake2sChannel& ch) {  // CirclePoint::get_random_po
 }
 static QM31 coset_vanishing_q(uint32_t n, QPt p) { QM31 x = p.x; for (uint32_t i = 1; i < n; i++) x = q_double_x(x); return x; }
 
+// DomainEvaluationAccumulator::finalize — ascending size: lift the running polynomial, add, interpolate
+static int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, DevBuf* out_polys, uint32_t* out_log) {
+    nx_ctx* ctx = cs.ctx;
+    DevBuf cur; uint32_t cur_log = 0; bool have = false;
+    for (auto& kv : sub) {
+        uint32_t log = kv.first; SecureColumn& values = kv.second;
+        if (have) {
+            DevBuf lifted; H_TRY(lifted.alloc(ctx, (size_t)4 << log));
+            auto src = col_ptrs(cur.p, 4, cur_log), dst = col_ptrs(lifted.p, 4, log);
+            H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)src.data(), 4, cur_log, log - cur_log, dst.data()));
+            const u32* s4[4] = {dst[0], dst[1], dst[2], dst[3]};
+            H_TRY(secure_accumulate(ctx, values.c, s4, 1u << log));
+            H_TRY(nx_sync(ctx));
+        }
+        H_TRY(nx_interpolate_batch(ctx, cs.tw, values.c, 4, log));
+        cur = std::move(values.buf); cur_log = log; have = true;
+    }
+    *out_polys = std::move(cur); *out_log = cur_log;
+    return NX_OK;
+}
+
+// 1 / coset_vanishing(trace coset, eval_domain.at(i)) over the 2^(e - log_size) cosets of the evaluation domain, bit-reversed
+static std::vector<uint32_t> vanishing_denominators(uint32_t log_size, uint32_t e) {
+    const uint32_t log_expand = e - log_size;
+    std::vector<uint32_t> den((size_t)1 << log_expand);
+    for (uint32_t i = 0; i < den.size(); i++) {
+        u32 x = pt_from_index(circle_domain_index((int)e, i)).x;
+        for (uint32_t k = 1; k < log_size; k++) x = m_double_x(x);
+        den[bitrev(i, (int)log_expand)] = m_inv(x);
+    }
+    return den;
+}
+
+// What stwo::prover::prove needs from the components (ComponentProvers): the synthetic machine and recorded AIRs provide it.
+typedef std::vector<std::vector<std::vector<QM31>>> SampledValues;   // tree -> column -> mask
+typedef std::vector<std::vector<std::vector<QPt>>> MaskPoints;
+struct AirProver {
+    virtual ~AirProver() {}
+    virtual int compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) = 0;
+    virtual void mask_points(QPt oods, MaskPoints* points) = 0;          // the three trace trees
+    virtual QM31 eval_composition_at_point(QPt point, const SampledValues& sv, QM31 random_coeff) = 0;
+};
+
 // ComponentProvers::compute_composition_polynomial for the synthetic machine.
 static int compute_composition(CommitmentSchemeProver& cs, const nx_component_spec* comps, uint32_t n_comps, const std::vector<Loc>& locs,
                                QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) {
@@ -479,23 +522,7 @@ static int compute_composition(CommitmentSchemeProver& cs, const nx_component_sp
         SynthRange rg{0, c.n_main, c.n_main, 0, c.n_inter, true};
         H_TRY(synth_constraints(ctx, pre, mainc, inter, rg, (int)c.log_size, (int)e, (const u32*)d_pw, (const u32*)d_den, sub[e].c));
     }
-    // DomainEvaluationAccumulator::finalize — ascending size: lift the running polynomial, add, interpolate
-    DevBuf cur; uint32_t cur_log = 0; bool have = false;
-    for (auto& kv : sub) {
-        uint32_t log = kv.first; SecureColumn& values = kv.second;
-        if (have) {
-            DevBuf lifted; H_TRY(lifted.alloc(ctx, (size_t)4 << log));
-            auto src = col_ptrs(cur.p, 4, cur_log), dst = col_ptrs(lifted.p, 4, log);
-            H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)src.data(), 4, cur_log, log - cur_log, dst.data()));
-            const u32* s4[4] = {dst[0], dst[1], dst[2], dst[3]};
-            H_TRY(secure_accumulate(ctx, values.c, s4, 1u << log));
-            H_TRY(nx_sync(ctx));
-        }
-        H_TRY(nx_interpolate_batch(ctx, cs.tw, values.c, 4, log));
-        cur = std::move(values.buf); cur_log = log; have = true;
-    }
-    *out_polys = std::move(cur); *out_log = cur_log;
-    return NX_OK;
+    return finalize_accumulation(cs, sub, out_polys, out_log);
 }
 
 // eval_composition_polynomial_at_point (the prover's OODS sanity check, stwo prover/mod.rs::prove)
@@ -519,78 +546,52 @@ static QM31 eval_composition_at_point(const nx_component_spec* comps, uint32_t n
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
-                       size_t ad_len, std::vector<uint32_t>* words, nx_prove_stats* st) {
-    PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
-    if (n_comps == 0) return set_err(ctx, NX_ERR_ARG, "prove: no components");
-    if (cfg.log_blowup < 1 || cfg.log_constraint_degree < 1 || cfg.log_constraint_degree > 2) return set_err(ctx, NX_ERR_ARG, "prove: log_blowup >= 1 and log_constraint_degree in {1,2} required");
-    H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
-    uint32_t max_log = 0;
-    std::vector<Loc> locs; { size_t a = 0, b = 0, c = 0; for (uint32_t i = 0; i < n_comps; i++) { locs.push_back({a, b, c}); a += comps[i].n_pre; b += comps[i].n_main; c += comps[i].n_inter; max_log = std::max(max_log, comps[i].log_size); } }
-    const bool timed = st != nullptr;
-    nx_prove_stats local_stats;
-    if (!st) st = &local_stats;
-    memset(st, 0, sizeof *st);
-    if (timed) { ctx->timing = true; timing_reset(ctx); }
-    double t_start = 0, t0 = 0;
-    auto lap = [&](double* slot) { if (!timed) return; (void)nx_sync(ctx); double t = now_ms(); *slot += t - t0; t0 = t; };
-    if (timed) { (void)nx_sync(ctx); t_start = t0 = now_ms(); }
-
-    // machine.rs:184-194 — twiddles for CanonicCoset(max_log + LOG_CONSTRAINT_DEGREE + log_blowup).half_coset
-    nx_twiddles* tw = nullptr;
-    H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));
-    struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
-    Blake2sChannel channel;
-    for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
-    CommitmentSchemeProver cs(ctx, tw, cfg);                                          // machine.rs:202-203
-    for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
-    lap(&st->commit);
-
-    auto fill_and_commit = [&](uint32_t tree, uint64_t inter_seed) -> int {
-        TreeBuilder tb = cs.tree_builder();
-        std::vector<uint32_t*> all;
-        std::vector<DevBuf> slabs(n_comps);
+struct SynthAir : AirProver {
+    const nx_component_spec* comps; uint32_t n_comps; const std::vector<Loc>& locs;
+    SynthAir(const nx_component_spec* c, uint32_t n, const std::vector<Loc>& l) : comps(c), n_comps(n), locs(l) {}
+    int compute_composition(CommitmentSchemeProver& cs, QM31 rc, DevBuf* out, uint32_t* out_log) override { return nxhip::compute_composition(cs, comps, n_comps, locs, rc, out, out_log); }
+    void mask_points(QPt oods, MaskPoints* points) override {
+        points->assign(3, {});
         for (uint32_t i = 0; i < n_comps; i++) {
-            uint32_t n = tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter;
-            if (n) H_TRY(slabs[i].alloc(ctx, (size_t)n << comps[i].log_size));
-            auto p = col_ptrs(slabs[i].p, n, comps[i].log_size);
-            all.insert(all.end(), p.begin(), p.end());
+            QPt step; { Pt s = pt_from_index(1u << (31 - comps[i].log_size)); step.x = q_from_m(s.x); step.y = q_from_m(s.y); }
+            for (uint32_t k = 0; k < comps[i].n_pre; k++) (*points)[0].push_back({oods});
+            for (uint32_t k = 0; k < comps[i].n_main; k++) { if (k < 2) (*points)[1].push_back({oods, qpt_add(oods, step)}); else (*points)[1].push_back({oods}); }
+            for (uint32_t k = 0; k < comps[i].n_inter; k++) (*points)[2].push_back({oods});
         }
-        H_TRY(nx_synth_fill_tree(ctx, comps, n_comps, tree, seed, inter_seed, all.data()));
-        lap(&st->trace_gen);
-        for (uint32_t i = 0; i < n_comps; i++) {
-            uint32_t n = tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter;
-            tb.extend_evals(std::move(slabs[i]), n, comps[i].log_size);
-        }
-        H_TRY(tb.commit(channel));
-        lap(&st->commit);
-        return NX_OK;
-    };
-    H_TRY(fill_and_commit(0, 0));                                                     // machine.rs:208-228
-    H_TRY(fill_and_commit(1, 0));                                                     // machine.rs:230-237
-    QM31 z = channel.draw_secure_felt();                                              // machine.rs:239-240 (lookup elements)
-    uint64_t inter_seed = ((u64)z.a.a << 32) ^ (u64)z.a.b ^ ((u64)z.b.a << 16) ^ ((u64)z.b.b << 48);
-    channel.mix_felts(std::vector<QM31>(n_comps, q_zero()));                          // machine.rs:262 (claimed sums)
-    H_TRY(fill_and_commit(2, inter_seed));                                            // machine.rs:249-263
+    }
+    QM31 eval_composition_at_point(QPt point, const SampledValues& sv, QM31 rc) override { return nxhip::eval_composition_at_point(comps, n_comps, locs, point, sv, rc); }
+};
 
+struct Lap {   // per-stage wall clock of nx_prove_stats (only when the caller asked for stats)
+    nx_ctx* ctx; bool timed; double t0;
+    void operator()(double* slot) { if (!timed) return; (void)nx_sync(ctx); double t = now_ms(); *slot += t - t0; t0 = t; }
+};
+static void finish_stats(nx_ctx* ctx, nx_prove_stats* st, double t_start) {
+    (void)nx_sync(ctx);
+    st->total = now_ms() - t_start;
+    timing_flush(ctx);
+    st->lde_kernel_ms = ctx->kind_ms[NX_T_LDE]; st->lde_algorithmic_bytes = ctx->kind_bytes[NX_T_LDE];
+    st->merkle_kernel_ms = ctx->kind_ms[NX_T_MERKLE]; st->merkle_algorithmic_bytes = ctx->kind_bytes[NX_T_MERKLE];
+    ctx->timing = false;
+}
+
+// stwo::prover::prove from the point where the three trace trees are committed: composition polynomial, OODS sampling, DEEP
+// quotients, FRI, proof of work, decommitment.
+static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel, const PcsConfig& cfg, const nx_twiddles* tw, AirProver& air,
+                      std::vector<uint32_t>* words, nx_prove_stats* st, Lap& lap) {
     // ---------------- stwo::prover::prove ----------------
     QM31 random_coeff = channel.draw_secure_felt();
     DevBuf comp_polys; uint32_t clog = 0;
-    H_TRY(compute_composition(cs, comps, n_comps, locs, random_coeff, &comp_polys, &clog));
+    H_TRY(air.compute_composition(cs, random_coeff, &comp_polys, &clog));
     lap(&st->composition);
     { TreeBuilder tb = cs.tree_builder(); tb.extend_polys(std::move(comp_polys), 4, clog); H_TRY(tb.commit(channel)); }
     lap(&st->commit);
     QPt oods = get_random_point(channel);
 
-    // mask points: tree -> column -> points
-    std::vector<std::vector<std::vector<QPt>>> points(4);
-    for (uint32_t i = 0; i < n_comps; i++) {
-        QPt step; { Pt s = pt_from_index(1u << (31 - comps[i].log_size)); step.x = q_from_m(s.x); step.y = q_from_m(s.y); }
-        for (uint32_t k = 0; k < comps[i].n_pre; k++) points[0].push_back({oods});
-        for (uint32_t k = 0; k < comps[i].n_main; k++) { if (k < 2) points[1].push_back({oods, qpt_add(oods, step)}); else points[1].push_back({oods}); }
-        for (uint32_t k = 0; k < comps[i].n_inter; k++) points[2].push_back({oods});
-    }
-    for (int k = 0; k < 4; k++) points[3].push_back({oods});
+    MaskPoints points;                                                    // tree -> column -> points
+    air.mask_points(oods, &points);
+    points.resize(4);
+    points[3].assign(4, std::vector<QPt>{oods});
 
     // ---------------- prove_values ----------------
     Proof proof;
@@ -680,17 +681,69 @@ static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_c
     // ProvingError::ConstraintsNotSatisfied sanity check
     QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
     QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
-    if (!q_eq(lhs, eval_composition_at_point(comps, n_comps, locs, oods, proof.sampled_values, random_coeff)))
+    if (!q_eq(lhs, air.eval_composition_at_point(oods, proof.sampled_values, random_coeff)))
         return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
     *words = serialize(proof, cfg);
-    if (timed) {
-        (void)nx_sync(ctx);
-        st->total = now_ms() - t_start;
-        timing_flush(ctx);
-        st->lde_kernel_ms = ctx->kind_ms[NX_T_LDE]; st->lde_algorithmic_bytes = ctx->kind_bytes[NX_T_LDE];
-        st->merkle_kernel_ms = ctx->kind_ms[NX_T_MERKLE]; st->merkle_algorithmic_bytes = ctx->kind_bytes[NX_T_MERKLE];
-        ctx->timing = false;
-    }
+    return NX_OK;
+}
+
+static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
+                       size_t ad_len, std::vector<uint32_t>* words, nx_prove_stats* st) {
+    PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
+    if (n_comps == 0) return set_err(ctx, NX_ERR_ARG, "prove: no components");
+    if (cfg.log_blowup < 1 || cfg.log_constraint_degree < 1 || cfg.log_constraint_degree > 2) return set_err(ctx, NX_ERR_ARG, "prove: log_blowup >= 1 and log_constraint_degree in {1,2} required");
+    H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
+    uint32_t max_log = 0;
+    std::vector<Loc> locs; { size_t a = 0, b = 0, c = 0; for (uint32_t i = 0; i < n_comps; i++) { locs.push_back({a, b, c}); a += comps[i].n_pre; b += comps[i].n_main; c += comps[i].n_inter; max_log = std::max(max_log, comps[i].log_size); } }
+    const bool timed = st != nullptr;
+    nx_prove_stats local_stats;
+    if (!st) st = &local_stats;
+    memset(st, 0, sizeof *st);
+    if (timed) { ctx->timing = true; timing_reset(ctx); }
+    double t_start = 0;
+    Lap lap{ctx, timed, 0};
+    if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = now_ms(); }
+
+    // machine.rs:184-194 — twiddles for CanonicCoset(max_log + LOG_CONSTRAINT_DEGREE + log_blowup).half_coset
+    nx_twiddles* tw = nullptr;
+    H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));
+    struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
+    Blake2sChannel channel;
+    for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
+    CommitmentSchemeProver cs(ctx, tw, cfg);                                          // machine.rs:202-203
+    for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
+    lap(&st->commit);
+
+    auto fill_and_commit = [&](uint32_t tree, uint64_t inter_seed) -> int {
+        TreeBuilder tb = cs.tree_builder();
+        std::vector<uint32_t*> all;
+        std::vector<DevBuf> slabs(n_comps);
+        for (uint32_t i = 0; i < n_comps; i++) {
+            uint32_t n = tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter;
+            if (n) H_TRY(slabs[i].alloc(ctx, (size_t)n << comps[i].log_size));
+            auto p = col_ptrs(slabs[i].p, n, comps[i].log_size);
+            all.insert(all.end(), p.begin(), p.end());
+        }
+        H_TRY(nx_synth_fill_tree(ctx, comps, n_comps, tree, seed, inter_seed, all.data()));
+        lap(&st->trace_gen);
+        for (uint32_t i = 0; i < n_comps; i++) {
+            uint32_t n = tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter;
+            tb.extend_evals(std::move(slabs[i]), n, comps[i].log_size);
+        }
+        H_TRY(tb.commit(channel));
+        lap(&st->commit);
+        return NX_OK;
+    };
+    H_TRY(fill_and_commit(0, 0));                                                     // machine.rs:208-228
+    H_TRY(fill_and_commit(1, 0));                                                     // machine.rs:230-237
+    QM31 z = channel.draw_secure_felt();                                              // machine.rs:239-240 (lookup elements)
+    uint64_t inter_seed = ((u64)z.a.a << 32) ^ (u64)z.a.b ^ ((u64)z.b.a << 16) ^ ((u64)z.b.b << 48);
+    channel.mix_felts(std::vector<QM31>(n_comps, q_zero()));                          // machine.rs:262 (claimed sums)
+    H_TRY(fill_and_commit(2, inter_seed));                                            // machine.rs:249-263
+
+    SynthAir air(comps, n_comps, locs);
+    H_TRY(prove_core(ctx, cs, channel, cfg, tw, air, words, st, lap));
+    if (timed) finish_stats(ctx, st, t_start);
     return NX_OK;
 }
 
@@ -1032,6 +1085,159 @@ static int prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint
     return NX_OK;
 }
 
+
+// ================================================================ recorded AIRs: the nx_prover session ================
+// The generic counterpart of prove_synth: components are RECORDED constraint programs (include/nexus_hip.h, nx_air_component —
+// what FrameworkComponent<E> is to Stwo, reference prover/src/components/mod.rs:15-57), the caller drives the transcript
+// prefix (reference machine.rs:198-263) through the session and nx_prover_prove runs stwo::prover::prove on the device.
+struct GComponent {
+    uint32_t log_size = 0, n_regs = 0, n_constraints = 0;
+    std::vector<nx_cinstr> prog;
+    std::vector<uint32_t> econsts;
+    std::vector<std::pair<uint32_t, uint32_t>> cols;     // component column -> (tree, column in tree)
+    std::vector<std::vector<int>> masks;                 // component column -> row offsets sampled
+    const nx_air_kernel* kernel = nullptr; nx_air_kernel* owned = nullptr;
+};
+
+struct GenericAir : AirProver {
+    nx_ctx* ctx; std::vector<GComponent> comps;
+    std::vector<std::vector<std::vector<int>>> offs;     // tree -> column -> union of sampled offsets (first-appearance order)
+    std::vector<std::vector<uint32_t>> tree_logs;
+    ~GenericAir() override { for (auto& c : comps) if (c.owned) nx_air_kernel_destroy(c.owned); }
+
+    // the consistency rules of oracle-side gair_check: every committed column claimed, sizes agree, loads inside the masks
+    int check(const CommitmentSchemeProver& cs) {
+        if (cs.trees.size() != 3) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: exactly three trace trees (preprocessed, main, interaction) must be committed first");
+        if (comps.empty()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: no components");
+        tree_logs.assign(3, {}); offs.assign(3, {});
+        std::vector<std::vector<char>> claimed(3);
+        for (int t = 0; t < 3; t++) { for (auto& c : cs.trees[t].polys) tree_logs[t].push_back(c.log); claimed[t].assign(tree_logs[t].size(), 0); offs[t].resize(tree_logs[t].size()); }
+        for (auto& c : comps) {
+            for (size_t k = 0; k < c.cols.size(); k++) {
+                const uint32_t t = c.cols[k].first, i = c.cols[k].second;
+                if (t > 2 || i >= tree_logs[t].size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column outside the committed trees");
+                if (tree_logs[t][i] != c.log_size) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column of a different log size than the component");
+                claimed[t][i] = 1;
+                for (int o : c.masks[k]) if (std::find(offs[t][i].begin(), offs[t][i].end(), o) == offs[t][i].end()) offs[t][i].push_back(o);
+            }
+            uint32_t n_c = 0;
+            for (auto& in : c.prog) {
+                if (in.op == NX_C_CONSTRAINT_B || in.op == NX_C_CONSTRAINT_E) n_c++;
+                if (in.op == NX_C_LOAD || in.op == NX_C_LOADE) {
+                    const uint32_t w = in.op == NX_C_LOADE ? 4 : 1;
+                    for (uint32_t j = 0; j < w; j++) {
+                        if (in.a + j >= c.cols.size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: LOAD of a column the component does not claim");
+                        const auto& m = c.masks[in.a + j];
+                        if (std::find(m.begin(), m.end(), (int)in.b) == m.end()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: LOAD at an offset missing from the column's mask");
+                    }
+                }
+            }
+            if (n_c != c.n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: constraint count mismatch");
+        }
+        for (int t = 0; t < 3; t++) for (char x : claimed[t]) if (!x) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: a committed column is claimed by no component");
+        return NX_OK;
+    }
+
+    int compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) override {
+        const uint32_t lcd = cs.cfg.log_constraint_degree, blow = cs.cfg.log_blowup;
+        size_t total = 0;
+        for (auto& c : comps) total += c.n_constraints;
+        std::vector<QM31> powers(total);
+        { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
+        std::map<uint32_t, SecureColumn> sub;
+        size_t remaining = total;
+        for (auto& c : comps) {
+            const uint32_t e = c.log_size + lcd;
+            const size_t nc = c.n_constraints;
+            std::vector<uint32_t> pw(4 * nc);          // the LAST nc remaining powers, reversed (accumulator.columns())
+            for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[remaining - 1 - j]);
+            remaining -= nc;
+            const std::vector<uint32_t> den = vanishing_denominators(c.log_size, e);
+            std::vector<const uint32_t*> ptrs(c.cols.size());
+            DevBuf ext;
+            if (e == c.log_size + blow) {
+                for (size_t k = 0; k < c.cols.size(); k++) ptrs[k] = cs.trees[c.cols[k].first].evals[c.cols[k].second].ptr;
+            } else {                                   // "need_to_extend": re-evaluate the polynomials on the constraint domain
+                H_TRY(ext.alloc(ctx, c.cols.size() << e));
+                std::vector<const uint32_t*> src(c.cols.size());
+                for (size_t k = 0; k < c.cols.size(); k++) src[k] = cs.trees[c.cols[k].first].polys[c.cols[k].second].ptr;
+                auto dst = col_ptrs(ext.p, (uint32_t)c.cols.size(), e);
+                H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), (uint32_t)c.cols.size(), c.log_size, e - c.log_size, dst.data()));
+                for (size_t k = 0; k < c.cols.size(); k++) ptrs[k] = dst[k];
+            }
+            if (!sub.count(e)) { H_TRY(sub[e].alloc(ctx, e)); H_TRY(nx_memset_zero(ctx, sub[e].buf.p, sub[e].buf.words)); }
+            if (!c.kernel) {
+                H_TRY(nx_air_compile(ctx, c.prog.data(), (uint32_t)c.prog.size(), c.n_regs, (uint32_t)c.cols.size(), (uint32_t)c.econsts.size() / 4, c.n_constraints, &c.owned, nullptr));
+                c.kernel = c.owned;
+            }
+            H_TRY(nx_air_eval(ctx, c.kernel, ptrs.data(), c.econsts.data(), pw.data(), den.data(), c.log_size, e, sub[e].c));
+        }
+        return finalize_accumulation(cs, sub, out_polys, out_log);
+    }
+
+    void mask_points(QPt oods, MaskPoints* points) override {
+        points->assign(3, {});
+        for (int t = 0; t < 3; t++)
+            for (size_t c = 0; c < offs[t].size(); c++) {
+                std::vector<QPt> pts;
+                for (int o : offs[t][c]) {
+                    if (o == 0) { pts.push_back(oods); continue; }
+                    const int64_t idx = ((int64_t)o * ((int64_t)1 << (31 - tree_logs[t][c]))) & 0x7fffffffLL;
+                    Pt s = pt_from_index((u32)idx);
+                    QPt step; step.x = q_from_m(s.x); step.y = q_from_m(s.y);
+                    pts.push_back(qpt_add(oods, step));
+                }
+                points->at(t).push_back(pts);
+            }
+    }
+
+    // the recorded program over QM31: every register holds the value of its expression at the OODS point
+    QM31 eval_composition_at_point(QPt point, const SampledValues& sv, QM31 rc) override {
+        QM31 acc = q_zero();
+        for (auto& c : comps) {
+            const QM31 di = q_inv(coset_vanishing_q(c.log_size, point));
+            std::vector<QM31> R(c.n_regs, q_zero());
+            auto sampled = [&](uint32_t col, int off) {
+                const uint32_t t = c.cols[col].first, i = c.cols[col].second;
+                const size_t k = std::find(offs[t][i].begin(), offs[t][i].end(), off) - offs[t][i].begin();
+                return sv[t][i][k];
+            };
+            for (auto& in : c.prog) {
+                switch (in.op) {
+                case NX_C_LOAD: R[in.dst] = sampled(in.a, (int)in.b); break;
+                case NX_C_CONST: R[in.dst] = q_from_m(in.a); break;
+                case NX_C_ADD: case NX_C_ADDE: case NX_C_ADDEB: R[in.dst] = q_add(R[in.a], R[in.b]); break;
+                case NX_C_SUB: case NX_C_SUBE: R[in.dst] = q_sub(R[in.a], R[in.b]); break;
+                case NX_C_MUL: case NX_C_MULE: case NX_C_MULEB: R[in.dst] = q_mul(R[in.a], R[in.b]); break;
+                case NX_C_NEG: R[in.dst] = q_sub(q_zero(), R[in.a]); break;
+                case NX_C_CONSTE: R[in.dst] = q_load(&c.econsts[4 * in.a]); break;
+                case NX_C_LOADE: {
+                    QM31 v = sampled(in.a, (int)in.b);
+                    v = q_add(v, q_mul(sampled(in.a + 1, (int)in.b), qm(0, 1, 0, 0)));
+                    v = q_add(v, q_mul(sampled(in.a + 2, (int)in.b), qm(0, 0, 1, 0)));
+                    v = q_add(v, q_mul(sampled(in.a + 3, (int)in.b), qm(0, 0, 0, 1)));
+                    R[in.dst] = v; break;
+                }
+                case NX_C_CONSTRAINT_B: case NX_C_CONSTRAINT_E: acc = q_add(q_mul(acc, rc), q_mul(di, R[in.a])); break;
+                default: break;
+                }
+            }
+        }
+        return acc;
+    }
+};
+
+}  // namespace nxhip
+
+struct nx_prover {
+    nx_ctx* ctx; nx_pcs_config ucfg; nxhip::PcsConfig cfg; nx_twiddles* tw = nullptr; uint32_t max_log;
+    nxhip::Blake2sChannel channel;
+    nxhip::CommitmentSchemeProver* cs = nullptr;
+    struct Run { nxhip::DevBuf slab; uint32_t n_cols, log; };
+    std::vector<Run> pending; bool open = false;
+};
+
+namespace nxhip {
 }  // namespace nxhip
 
 using namespace nx;
@@ -1081,6 +1287,122 @@ int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps
     if (rc != NX_OK) return rc;
     uint32_t* out = (uint32_t*)malloc(w.size() * 4);
     if (!out) return set_err(ctx, NX_ERR_OOM, "nx_prove_synth: malloc failed");
+    memcpy(out, w.data(), w.size() * 4);
+    *proof_words = out; *n_words = w.size();
+    return NX_OK;
+}
+
+// ---------------------------------------------------------------- nx_prover session (recorded AIRs) --
+int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_size, nx_prover** out) {
+    if (!ctx || !cfg || !out) return set_err(ctx, NX_ERR_ARG, "nx_prover_create: NULL argument");
+    if (cfg->log_blowup < 1 || cfg->log_constraint_degree < 1 || cfg->log_constraint_degree > 2 || max_log_size < 1 || max_log_size + cfg->log_constraint_degree + cfg->log_blowup > 31)
+        return set_err(ctx, NX_ERR_ARG, "nx_prover_create: log_blowup >= 1, log_constraint_degree in {1,2}, 1 <= max_log_size required");
+    NX_TRY(nx_ctx_set_hash_mode(ctx, (int)cfg->hash_mode));
+    nx_prover* p = new nx_prover();
+    p->ctx = ctx; p->ucfg = *cfg; p->max_log = max_log_size;
+    p->cfg = {cfg->pow_bits, cfg->log_blowup, cfg->n_queries, cfg->log_last_layer_degree_bound, cfg->fri_alpha_mode, cfg->log_constraint_degree};
+    int rc = nx_twiddles_create(ctx, max_log_size + cfg->log_constraint_degree + cfg->log_blowup - 1, &p->tw);      // machine.rs:184-194
+    if (rc != NX_OK) { delete p; return rc; }
+    p->cs = new nxhip::CommitmentSchemeProver(ctx, p->tw, p->cfg);
+    *out = p;
+    return NX_OK;
+}
+
+void nx_prover_destroy(nx_prover* p) {
+    if (!p) return;
+    (void)nx_sync(p->ctx);
+    p->pending.clear();
+    delete p->cs;
+    nx_twiddles_destroy(p->tw);
+    delete p;
+}
+
+int nx_prover_mix_u64(nx_prover* p, uint64_t v) { if (!p) return set_err(nullptr, NX_ERR_ARG, "nx_prover_mix_u64: NULL prover"); p->channel.mix_u64(v); return NX_OK; }
+int nx_prover_mix_felts(nx_prover* p, const uint32_t* felts, uint32_t n) {
+    if (!p || (n && !felts)) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_mix_felts: NULL argument");
+    std::vector<QM31> v(n);
+    for (uint32_t i = 0; i < n; i++) v[i] = q_load(felts + 4 * i);
+    p->channel.mix_felts(v);
+    return NX_OK;
+}
+int nx_prover_draw_felt(nx_prover* p, uint32_t out[4]) {
+    if (!p || !out) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_draw_felt: NULL argument");
+    q_store(out, p->channel.draw_secure_felt());
+    return NX_OK;
+}
+int nx_prover_channel_digest(const nx_prover* p, uint8_t digest[32]) {
+    if (!p || !digest) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_channel_digest: NULL argument");
+    memcpy(digest, p->channel.digest.w, 32);
+    return NX_OK;
+}
+
+int nx_prover_tree_begin(nx_prover* p, const uint32_t* log_sizes, uint32_t n_cols, uint32_t** d_cols_out) {
+    if (!p || (n_cols && (!log_sizes || !d_cols_out))) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_tree_begin: NULL argument");
+    if (p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: the previous tree was not committed");
+    if (p->cs->trees.size() >= 3) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: the three trace trees are already committed");
+    for (uint32_t i = 0; i < n_cols; i++) if (log_sizes[i] < 1 || log_sizes[i] > p->max_log) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: column log size outside [1, max_log_size]");
+    p->pending.clear();
+    for (uint32_t i = 0; i < n_cols;) {             // one slab per run of equal sizes (TreeBuilder::extend_evals groups)
+        uint32_t j = i; while (j < n_cols && log_sizes[j] == log_sizes[i]) j++;
+        nx_prover::Run r; r.n_cols = j - i; r.log = log_sizes[i];
+        int rc = r.slab.alloc(p->ctx, (size_t)r.n_cols << r.log);
+        if (rc != NX_OK) { p->pending.clear(); return rc; }
+        for (uint32_t k = 0; k < r.n_cols; k++) d_cols_out[i + k] = r.slab.p + ((size_t)k << r.log);
+        p->pending.push_back(std::move(r));
+        i = j;
+    }
+    p->open = true;
+    return NX_OK;
+}
+
+int nx_prover_tree_commit(nx_prover* p, uint8_t root[32]) {
+    if (!p) return set_err(nullptr, NX_ERR_ARG, "nx_prover_tree_commit: NULL prover");
+    if (!p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit: no tree was begun");
+    nxhip::TreeBuilder tb = p->cs->tree_builder();
+    for (auto& r : p->pending) tb.extend_evals(std::move(r.slab), r.n_cols, r.log);
+    p->pending.clear(); p->open = false;
+    NX_TRY(tb.commit(p->channel));
+    if (root) memcpy(root, p->cs->trees.back().root.w, 32);
+    return NX_OK;
+}
+
+int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comps, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    if (!p || !comps || !proof_words || !n_words) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_prove: NULL argument");
+    nx_ctx* ctx = p->ctx;
+    if (p->open) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: a tree is begun but not committed");
+    nxhip::GenericAir air; air.ctx = ctx;
+    for (uint32_t i = 0; i < n_comps; i++) {
+        const nx_air_component& u = comps[i];
+        if (!u.program || (u.n_cols && (!u.col_tree || !u.col_index || !u.mask_count)) || (u.n_econsts && !u.econsts)) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: NULL pointer in a component");
+        nxhip::GComponent g;
+        g.log_size = u.log_size; g.n_regs = u.n_regs; g.n_constraints = u.n_constraints; g.kernel = u.kernel;
+        g.prog.assign(u.program, u.program + u.n_instr);
+        if (u.n_econsts) g.econsts.assign(u.econsts, u.econsts + 4 * (size_t)u.n_econsts);
+        size_t m = 0;
+        for (uint32_t k = 0; k < u.n_cols; k++) {
+            g.cols.push_back({u.col_tree[k], u.col_index[k]});
+            std::vector<int> o;
+            for (uint32_t j = 0; j < u.mask_count[k]; j++) o.push_back((int)u.mask_offsets[m++]);
+            g.masks.push_back(o);
+        }
+        air.comps.push_back(std::move(g));
+    }
+    NX_TRY(air.check(*p->cs));
+    const bool timed = stats != nullptr;
+    nx_prove_stats local;
+    nx_prove_stats* st = stats ? stats : &local;
+    memset(st, 0, sizeof *st);
+    if (timed) { ctx->timing = true; timing_reset(ctx); }
+    nxhip::Lap lap{ctx, timed, 0};
+    double t_start = 0;
+    if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = nxhip::now_ms(); }
+    std::vector<uint32_t> w;
+    int rc = nxhip::prove_core(ctx, *p->cs, p->channel, p->cfg, p->tw, air, &w, st, lap);
+    if (timed) nxhip::finish_stats(ctx, st, t_start);
+    ctx->timing = false;
+    if (rc != NX_OK) return rc;
+    uint32_t* out = (uint32_t*)malloc(w.size() * 4);
+    if (!out) return set_err(ctx, NX_ERR_OOM, "nx_prover_prove: malloc failed");
     memcpy(out, w.data(), w.size() * 4);
     *proof_words = out; *n_words = w.size();
     return NX_OK;

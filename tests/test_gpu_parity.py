@@ -639,6 +639,92 @@ def test_air_jit_rejects_malformed_programs(be, nz):
         be.compile_air(pb.build(), 2)
 
 
+# ---------------- the prover session: stwo::prover::prove over recorded AIRs (nx_prover_*) ----------------------------------
+
+def _hip_cfg(nz, ocfg):
+    return nz.default_config(pow_bits=int(ocfg[0]), log_blowup=int(ocfg[1]), n_queries=int(ocfg[2]), log_last_layer_degree_bound=int(ocfg[3]),
+                             hash_mode=int(ocfg[4]), fri_alpha_mode=int(ocfg[5]), log_constraint_degree=int(ocfg[6]))
+
+
+@pytest.mark.parametrize("comps,lcd", [([(6, 3, 20, 19)], 1), ([(5, 2, 18, 4), (7, 3, 5, 17)], 2), ([(10, 3, 40, 33)], 1), ([(6, 2, 3, 0)], 1)])
+def test_session_proves_the_recorded_synthetic_machine_identically(be, nz, oracle, comps, lcd):
+    """The synthetic machine as recorded components through nx_prover_* == nx_prove_synth == the oracle's built-in prove, byte
+    for byte: composition via the JIT-compiled program, mask points from the recorded masks, OODS check via the host
+    interpreter, and the session's own TreeBuilder/channel all agree with the hand-written path."""
+    from test_prover_session_cpu import drive_synthetic, synthetic_components
+    ocfg = oracle.default_cfg(pow_bits=3, log_constraint_degree=lcd, log_blowup=max(1, lcd))
+    cfg = _hip_cfg(nz, ocfg)
+    ad = b"\x07\x2a"
+    ref = oracle.prove_synth(comps, ocfg, seed=9, ad=ad)
+    s = be.prover_session(cfg, max(c[0] for c in comps))
+    drive_synthetic(None, comps, 9, ad, s.commit, s)
+    words = s.prove(synthetic_components(comps))
+    assert np.array_equal(words, ref)
+    assert np.array_equal(be.prove(comps, cfg, seed=9, ad=ad), ref)
+    s.close()
+
+
+@pytest.mark.parametrize("logs,lcd", [((5, 7), 1), ((6,), 2), ((7, 5, 6), 1), ((11, 9), 1)])
+def test_session_logup_air_matches_the_oracle_session(be, nz, oracle, logs, lcd):
+    """A multi-component AIR with a secure logup column at offsets [-1, 0] and lookup elements drawn from the session's
+    channel: same draws, same roots, same proof bytes as the CPU oracle's session, and the oracle's verifier accepts."""
+    from test_prover_session_cpu import build_mixed_air
+    ocfg = oracle.default_cfg(pow_bits=2, log_constraint_degree=lcd, log_blowup=lcd)
+    cfg = _hip_cfg(nz, ocfg)
+    drive, tree_logs = build_mixed_air(logs, lcd=lcd)
+    so = oracle.ProverSession(ocfg, max(logs))
+    oroots = []
+    ocomps = drive(so, lambda cols: oroots.append(so.commit(cols)))
+    ref = so.prove(ocomps)
+    sh = be.prover_session(cfg, max(logs))
+    hroots = []
+    hcomps = drive(sh, lambda cols: hroots.append(sh.commit(cols)))
+    assert all(np.array_equal(a, b) for a, b in zip(oroots, hroots))
+    kernels = [be.compile_air(c.program, len(c.cols)) for c in hcomps]
+    words, stats = sh.prove(hcomps, kernels=kernels, want_stats=True)
+    assert np.array_equal(words, ref) and stats["total"] > 0
+    assert np.array_equal(sh.digest(), so.digest())
+    v = oracle.VerifierSession(ocfg)
+    v.mix_u64(len(logs))
+    v.commit(hroots[0], tree_logs[0]); v.commit(hroots[1], tree_logs[1])
+    v.draw_felt(); v.draw_felt()
+    for c in hcomps:
+        v.mix_felts(np.asarray(c.program.econsts, np.uint32)[2])
+    v.commit(hroots[2], tree_logs[2])
+    assert v.verify(hcomps, words) is None
+    sh.close()
+
+
+def test_session_refuses_invalid_traces_and_misuse(be, nz, oracle):
+    from test_prover_session_cpu import build_mixed_air
+    import nexus_zkvm_amd.air_program as ap
+    cfg = _hip_cfg(nz, oracle.default_cfg(pow_bits=2))
+    drive, _ = build_mixed_air((5,))
+    s = be.prover_session(cfg, 5)
+    comps = drive(s, s.commit, tamper="main")
+    with pytest.raises(nz.NexusHipError, match="ConstraintsNotSatisfied"):
+        s.prove(comps)
+    s = be.prover_session(cfg, 5)
+    comps = drive(s, s.commit)
+    c0 = comps[0]
+    with pytest.raises(nz.NexusHipError, match="claimed by no component"):
+        s.prove([ap.Component(c0.log_size, c0.program, c0.cols[:-1], c0.masks[:-1])])
+    with pytest.raises(nz.NexusHipError, match="missing from the column's mask"):
+        s.prove([ap.Component(c0.log_size, c0.program, c0.cols, [[0]] * len(c0.cols))])
+    with pytest.raises(nz.NexusHipError, match="already committed"):
+        s.tree_begin([5])
+    assert len(s.prove(comps)) > 0                       # the session is still usable after the refused calls
+    s = be.prover_session(cfg, 5)
+    s.commit([np.zeros(32, np.uint32)])
+    with pytest.raises(nz.NexusHipError, match="three trace trees"):
+        s.prove(comps)
+    s.tree_begin([5, 5])
+    with pytest.raises(nz.NexusHipError, match="not committed"):
+        s.tree_begin([5])
+    with pytest.raises(nz.NexusHipError, match="log size"):
+        be.prover_session(cfg, 5).tree_begin([6])
+
+
 # ---------------- "next" row R8: logup interaction trace on device --------------------------------------------------------
 
 @pytest.mark.parametrize("log", [4, 9, 13, 16])
