@@ -437,6 +437,11 @@ __global__ void finalize_kernel(ColSet src, ColSet dst, u32 n_cols, int log) {
     dst.col(c)[i] = src.col(c)[natural_index_of(i, log)];
 }
 
+__global__ void twiddle_double_kernel(const u32* tw, const u32* itw, u32* tw2, u32* itw2, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { tw2[i] = tw[i] << 1; itw2[i] = itw[i] << 1; }
+}
+
 }  // namespace nx
 
 using namespace nx;
@@ -447,23 +452,26 @@ int nx_twiddles_create(nx_ctx* ctx, uint32_t log_half_coset, nx_twiddles** out) 
     if (!ctx || !out) return set_err(ctx, NX_ERR_ARG, "nx_twiddles_create: NULL argument");
     if (log_half_coset < 1 || log_half_coset > 28) return set_err(ctx, NX_ERR_ARG, "nx_twiddles_create: log_half_coset out of range [1,28]");
     nx_twiddles* t = new nx_twiddles();
-    t->ctx = ctx; t->log_half = log_half_coset; t->d_tw = nullptr; t->d_itw = nullptr;
+    t->ctx = ctx; t->log_half = log_half_coset; t->d_tw = nullptr; t->d_itw = nullptr; t->d_tw2 = nullptr; t->d_itw2 = nullptr;
     size_t bytes = (size_t)4 << log_half_coset;
     int rc0 = dev_alloc(ctx, bytes, (void**)&t->d_tw);
     if (rc0 == NX_OK) rc0 = dev_alloc(ctx, bytes, (void**)&t->d_itw);
-    if (rc0 != NX_OK) { dev_free(ctx, t->d_tw); delete t; return rc0; }
+    if (rc0 == NX_OK) rc0 = dev_alloc(ctx, bytes, (void**)&t->d_tw2);
+    if (rc0 == NX_OK) rc0 = dev_alloc(ctx, bytes, (void**)&t->d_itw2);
+    if (rc0 != NX_OK) { dev_free(ctx, t->d_tw); dev_free(ctx, t->d_itw); dev_free(ctx, t->d_tw2); dev_free(ctx, t->d_itw2); delete t; return rc0; }
     hipError_t e;
     u32 total = 1u << log_half_coset;
     hipLaunchKernelGGL(twiddle_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, t->d_tw, t->d_itw, (int)log_half_coset);
+    hipLaunchKernelGGL(twiddle_double_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, t->d_tw, t->d_itw, t->d_tw2, t->d_itw2, total);
     e = hipGetLastError();
-    if (e != hipSuccess) { dev_free(ctx, t->d_tw); dev_free(ctx, t->d_itw); delete t; return hip_fail(ctx, e, "twiddle_kernel", __FILE__, __LINE__); }
+    if (e != hipSuccess) { dev_free(ctx, t->d_tw); dev_free(ctx, t->d_itw); dev_free(ctx, t->d_tw2); dev_free(ctx, t->d_itw2); delete t; return hip_fail(ctx, e, "twiddle_kernel", __FILE__, __LINE__); }
     *out = t;
     return NX_OK;
 }
 
 void nx_twiddles_destroy(nx_twiddles* tw) {
     if (!tw) return;
-    dev_free(tw->ctx, tw->d_tw); dev_free(tw->ctx, tw->d_itw);
+    dev_free(tw->ctx, tw->d_tw); dev_free(tw->ctx, tw->d_itw); dev_free(tw->ctx, tw->d_tw2); dev_free(tw->ctx, tw->d_itw2);
     delete tw;
 }
 

@@ -22,13 +22,16 @@ namespace nx {
 #ifndef NX_FFT_MINWAVES   // A/B knob: 5 forces <= 96 VGPRs (measured: spills, slower)
 #define NX_FFT_MINWAVES 1
 #endif
+#ifndef NX_FFT_MINWAVES1  // single-column tiles: forcing 8 waves/SIMD (<= 64 VGPRs, 4 blocks per CU) measured 9 % slower than the natural 58-70
+#define NX_FFT_MINWAVES1 1
+#endif
 constexpr int T13_S = 13;
 constexpr u32 T13_ROWS = 1u << T13_S;
 constexpr u32 T13_HALF = T13_ROWS / 2;
 
 struct Pass13 {
     ColSet src, dst;
-    const u32* tw;   // forward or inverse twiddle buffer (2^tw_log words)
+    const u32* tw;   // forward or inverse DOUBLED twiddle buffer (2^tw_log words, 2 * twiddle each)
     u32 tw_log;
     int n;           // log size of the whole transform (index space of dst)
     int log_in;      // src holds 2^log_in words; dst index bits >= log_in select a replica
@@ -40,9 +43,30 @@ struct Pass13 {
 
 template <int CB> struct alignas(4 * CB) Row { u32 c[CB]; };
 
+// Global-memory accessors.  The column and twiddle pointers reach the kernel inside a by-value struct, so clang types them as
+// generic ("flat"): a flat access may alias LDS, is ordered against every ds_read/ds_write and counts on lgkmcnt as well — the
+// staging loads of a tile were issued one at a time, each waiting for the previous tile quarter's LDS write.  Casting to
+// address space 1 turns them into global_load/global_store that the compiler is free to issue together.
+#define NX_GLOBAL __attribute__((address_space(1)))
+typedef u32 v4u32 __attribute__((ext_vector_type(4)));
+typedef u32 v2u32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 gload4(const u32* p) { const v4u32 v = *(NX_GLOBAL const v4u32*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 gload2(const u32* p) { const v2u32 v = *(NX_GLOBAL const v2u32*)p; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ u32 gload1(const u32* p) { return *(NX_GLOBAL const u32*)p; }
+__device__ __forceinline__ void gstore4(u32* p, uint4 v) { v4u32 w = {v.x, v.y, v.z, v.w}; *(NX_GLOBAL v4u32*)p = w; }
+
+#ifdef NX_FFT_TRACE   // tools/fft_trace.py: per-block phase times (100 MHz wall clock), summed per kernel kind; never in the product build
+__device__ unsigned long long g_trace13[4][8];
+#define TRACE_MARK(slot) do { if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); atomicAdd(&g_trace13[(INV ? 2 : 0) + (FIRST ? 1 : 0)][slot], t_ - t_prev_); t_prev_ = t_; } } while (0)
+#define TRACE_BEGIN() unsigned long long t_prev_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_trace13[(INV ? 2 : 0) + (FIRST ? 1 : 0)][7], 1ull)
+#else
+#define TRACE_MARK(slot) do {} while (0)
+#define TRACE_BEGIN() do {} while (0)
+#endif
+
 __device__ __forceinline__ u32 pad13(u32 t) { return t + (t >> 4); }
 
-// t2 = 2 * twiddle (doubled once per lane after the load, see field.cuh m_mul_dbl)
+// t2 = 2 * twiddle (read from the doubled tables, see field.cuh m_mul_dbl)
 template <bool INV>
 __device__ __forceinline__ void bfly13(u32& x0, u32& x1, u32 t2, bool neg) {
     if (INV) {
@@ -59,16 +83,16 @@ __device__ __forceinline__ void bfly13(u32& x0, u32& x1, u32 t2, bool neg) {
 template <int CNT>
 __device__ __forceinline__ void load_tw13(const u32* __restrict__ p, u32* dst) {
     if constexpr (CNT == 8) {
-        uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
+        uint4 a = gload4(p), b = gload4(p + 4);
         dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
     } else if constexpr (CNT == 4) {
-        uint4 a = *reinterpret_cast<const uint4*>(p);
+        uint4 a = gload4(p);
         dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
     } else if constexpr (CNT == 2) {
-        uint2 a = *reinterpret_cast<const uint2*>(p);
+        uint2 a = gload2(p);
         dst[0] = a.x; dst[1] = a.y;
     } else {
-        dst[0] = p[0];
+        dst[0] = gload1(p);
     }
 }
 
@@ -121,8 +145,6 @@ __device__ __forceinline__ void tw_request(const Pass13& a, int bp, u32 tile_bas
 #pragma unroll
     for (int q = 0; q < RB; q++) twl[q] = a.tw + ((1u << a.tw_log) - (1u << (a.n - (l0 + q))));
     load_round_tw13<RB, 0, CIRCLE>(twl, g0, l0, tw);
-#pragma unroll
-    for (int k = CIRCLE ? (1 << (RB - 1)) : 0; k < (1 << RB) - 1; k++) tw[k] <<= 1;
 }
 
 // One full LDS round trip (every lane owns 2^RB rows): tile bits [bp, bp+RB), twiddles already in registers.
@@ -170,8 +192,6 @@ __device__ __forceinline__ void round_rem(Row<CB>* lds, const Pass13& a, int bp,
         const u32 g0 = tile_base + ((t0 >> a.B) << a.lo) + (t0 & maskB);
         u32 tw[1 << R];
         load_round_tw13<R, 0, false>(twl, g0, l0, tw);
-#pragma unroll
-        for (int k = 0; k < (1 << R) - 1; k++) tw[k] <<= 1;
         butterflies<R, CB, INV, false>(v, tw);
 #pragma unroll
         for (int e = 0; e < (1 << R); e++) lds[p0 + e * estride] = v[e];
@@ -190,164 +210,193 @@ __device__ __forceinline__ u32 get4(const uint4& v, int i) { return i == 0 ? v.x
 
 // FIRST: the pass that owns layers [0, 13) on a contiguous tile (lo == 0, B == 0), including the circle layer.
 // One block = one (tile, group of CB columns), 2^(13-RB) lanes.
-template <bool INV, bool FIRST, int CB, int RB>
-__global__ __launch_bounds__(T13_ROWS >> RB, NX_FFT_MINWAVES) void fft13_kernel(Pass13 a) {
+// KT: the pass's layer count as a compile-time constant (0 = read it from the pass descriptor).  With K known the round
+// sequence is straight-line code; with a run-time K the twiddle registers are merged across branches, the register allocator
+// inserts copies right after the prefetch loads and every round waits for its successor's twiddles (measured: the specialised
+// kernels are the ones the 2^20..2^24 transforms use).
+template <bool INV, bool FIRST, int CB, int RB, int KT>
+__global__ __launch_bounds__(T13_ROWS >> RB, CB == 1 ? NX_FFT_MINWAVES1 : NX_FFT_MINWAVES) void fft13_kernel(Pass13 a) {
     constexpr int NT = T13_ROWS >> RB;
     constexpr int MAXR = (T13_S - 1 + RB - 1) / RB;       // full rounds in a 13-layer pass
     extern __shared__ __attribute__((aligned(16))) u32 lds13[];
     Row<CB>* lds = reinterpret_cast<Row<CB>*>(lds13);
-    u32 tile, grp;
-    {
-        const u32 b = blockIdx.x;
+    TRACE_BEGIN();
+
+    const int K = FIRST ? T13_S : (KT ? KT : a.K), B = FIRST ? 0 : (KT ? T13_S - KT : a.B), lo = FIRST ? 0 : a.lo;
+    const int lb = lo - B;
+    const u32 maskB = (1u << B) - 1;
+    auto goff = [&](u32 t) -> u32 { return FIRST ? t : (((t >> B) << lo) + (t & maskB)); };
+    // full rounds sit at tile bits bp(i) = B + rem + RB i, i < nfull; the remainder round (K-1 mod RB layers) at bit B
+    const int K1 = K - 1, nfull = K1 / RB, rem = K1 % RB;
+    auto bp_of = [&](int i) -> int { return B + rem + RB * i; };
+
+    struct Work { u32 grp, tile_base, src_base, high; };
+    // work item -> (tile, column group).  XCD x owns source tiles [x, x+1) * src_tiles/8; the replicas of a source tile and its
+    // column groups run back to back on that XCD, so the tile's coefficients and twiddles are fetched into one L2 once.
+    auto decode = [&](u32 b) -> Work {
+        u32 tile, grp;
         const u32 src_tiles = a.tiles >> a.rep_log;
         if (src_tiles >= 8) {
-            // XCD x owns source tiles [x, x+1) * src_tiles/8; the replicas of a source tile and its column groups run back to
-            // back on that XCD, so the tile's coefficients and twiddles are fetched into one L2 once
             const u32 xcd = b & 7, y = b >> 3, idx = y / a.n_groups;
             grp = y % a.n_groups;
             tile = ((idx & ((1u << a.rep_log) - 1)) * src_tiles) + xcd * (src_tiles >> 3) + (idx >> a.rep_log);
         } else { grp = b % a.n_groups; tile = b / a.n_groups; }
-    }
-    const u32* __restrict__ s[CB];
-    u32* __restrict__ d[CB];
-    bool live[CB];
+        const u32 lowblock = tile & ((1u << lb) - 1), high = tile >> lb;
+        Work w; w.grp = grp; w.high = high;
+        w.tile_base = (high << (lo + K)) | (lowblock << B);
+        w.src_base = w.tile_base & ((1u << a.log_in) - 1);
+        return w;
+    };
+
+    // every global load of a tile is issued before the first LDS write (one memory round trip, not one per quarter)
+    constexpr int IT = INV ? (int)(T13_ROWS / 4) / NT : (int)(T13_HALF / 4) / NT;
+    uint4 xa[IT][CB], xb[INV ? 1 : IT][CB];
+    auto issue = [&](const Work& wk) {
+        const u32* __restrict__ s[CB];
 #pragma unroll
-    for (int k = 0; k < CB; k++) {
-        const u32 c = min(grp * CB + k, a.n_cols - 1);
-        live[k] = grp * CB + k < a.n_cols;
-        s[k] = a.src.col(c); d[k] = a.dst.col(c);
-    }
-
-    const int B = FIRST ? 0 : a.B, lo = FIRST ? 0 : a.lo, K = FIRST ? T13_S : a.K;
-    const int lb = lo - B;
-    const u32 lowblock = tile & ((1u << lb) - 1), high = tile >> lb;
-    const u32 tile_base = (high << (lo + K)) | (lowblock << B);
-    const u32 src_base = tile_base & ((1u << a.log_in) - 1);
-    const u32 maskB = (1u << B) - 1;
-    auto goff = [&](u32 t) -> u32 { return FIRST ? t : (((t >> B) << lo) + (t & maskB)); };
-
-    // full rounds sit at tile bits bp(i) = B + rem + RB i, i < nfull; the remainder round (K-1 mod RB layers) at bit B
-    const int K1 = K - 1, nfull = K1 / RB, rem = K1 % RB;
-    auto bp_of = [&](int i) -> int { return B + rem + RB * i; };
-    u32 twA[1 << RB], twB[1 << RB];
-    if (nfull) {
-        const int i0 = INV ? 0 : nfull - 1;
-        if (FIRST && i0 == 0) tw_request<RB, true>(a, 0, tile_base, twA); else tw_request<RB, false>(a, bp_of(i0), tile_base, twA);
-    }
-    // the pass's top layer (tile bit 12): one twiddle for the whole tile
-    const int le = lo + K - 1;
-    const u32 te = a.tw[((1u << a.tw_log) - (1u << (a.n - le))) + high], te2 = te << 1;
-
-    if (INV) {
+        for (int k = 0; k < CB; k++) s[k] = a.src.col(min(wk.grp * CB + k, a.n_cols - 1));
 #pragma unroll
-        for (int it = 0; it < (int)(T13_ROWS / 4) / NT; it++) {
+        for (int it = 0; it < IT; it++) {
             const u32 t = (threadIdx.x + it * NT) * 4;
-            const u32 g = src_base + goff(t);
-            uint4 x[CB];
+            if (INV) {
+                const u32 g = wk.src_base + goff(t);
 #pragma unroll
-            for (int k = 0; k < CB; k++) x[k] = *reinterpret_cast<const uint4*>(s[k] + g);
-            const u32 p = pad13(t);
+                for (int k = 0; k < CB; k++) xa[it][k] = gload4(s[k] + g);
+            } else {
+                const u32 ga = wk.src_base + goff(t), gb = wk.src_base + goff(t + T13_HALF);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                Row<CB> r;
-#pragma unroll
-                for (int k = 0; k < CB; k++) r.c[k] = get4(x[k], i);
-                lds[p + i] = r;
+                for (int k = 0; k < CB; k++) { xa[it][k] = gload4(s[k] + ga); xb[it][k] = gload4(s[k] + gb); }
             }
         }
-    } else {
+    };
+
+    const Work wk = decode(blockIdx.x);
+    issue(wk);
+    {
+        u32* __restrict__ d[CB];
+        bool live[CB];
 #pragma unroll
-        for (int it = 0; it < (int)(T13_HALF / 4) / NT; it++) {
+        for (int k = 0; k < CB; k++) {
+            const u32 c = min(wk.grp * CB + k, a.n_cols - 1);
+            live[k] = wk.grp * CB + k < a.n_cols;
+            d[k] = a.dst.col(c);
+        }
+        const u32 tile_base = wk.tile_base, high = wk.high;
+        u32 twA[1 << RB], twB[1 << RB];
+        if (nfull) {
+            const int i0 = INV ? 0 : nfull - 1;
+            if (FIRST && i0 == 0) tw_request<RB, true>(a, 0, tile_base, twA); else tw_request<RB, false>(a, bp_of(i0), tile_base, twA);
+        }
+        // the pass's top layer (tile bit 12): one twiddle for the whole tile
+        const int le = lo + K - 1;
+        const u32 te2 = a.tw[((1u << a.tw_log) - (1u << (a.n - le))) + high], te = te2 >> 1;
+
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
             const u32 t = (threadIdx.x + it * NT) * 4;
-            const u32 ga = src_base + goff(t), gb = src_base + goff(t + T13_HALF);
-            uint4 xa[CB], xb[CB];
+            if (INV) {
+                const u32 p = pad13(t);
 #pragma unroll
-            for (int k = 0; k < CB; k++) { xa[k] = *reinterpret_cast<const uint4*>(s[k] + ga); xb[k] = *reinterpret_cast<const uint4*>(s[k] + gb); }
-            const u32 pa = pad13(t), pb = pad13(t + T13_HALF);
+                for (int i = 0; i < 4; i++) {
+                    Row<CB> r;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                Row<CB> ra, rb;
+                    for (int k = 0; k < CB; k++) r.c[k] = get4(xa[it][k], i);
+                    lds[p + i] = r;
+                }
+            } else {
+                const u32 pa = pad13(t), pb = pad13(t + T13_HALF);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    Row<CB> ra, rb;
+#pragma unroll
+                    for (int k = 0; k < CB; k++) {
+                        u32 u = get4(xa[it][k], i), v = get4(xb[it][k], i);
+                        bfly13<false>(u, v, te2, false);
+                        ra.c[k] = u; rb.c[k] = v;
+                    }
+                    lds[pa + i] = ra;
+                    lds[pb + i] = rb;
+                }
+            }
+        }
+        __syncthreads();
+        TRACE_MARK(0);
+
+        // step j of the round sequence uses twiddle registers (j even ? twA : twB) and requests step j+1's into the other set
+        if (INV) {
+            if (rem) rem_round13<RB, CB, NT, true>(lds, a, rem, B, tile_base);
+#pragma unroll
+            for (int j = 0; j < MAXR; j++) {
+                if (j < nfull) {
+                    u32* cur = (j & 1) ? twB : twA;
+                    u32* nxt = (j & 1) ? twA : twB;
+                    if (j + 1 < nfull) tw_request<RB, false>(a, bp_of(j + 1), tile_base, nxt);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of this round's butterflies
+                    if (FIRST && j == 0) round_full<RB, CB, true, true>(lds, 0, cur); else round_full<RB, CB, true, false>(lds, bp_of(j), cur);
+                    __syncthreads();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MAXR; j++) {
+                if (j < nfull) {
+                    const int i = nfull - 1 - j;
+                    u32* cur = (j & 1) ? twB : twA;
+                    u32* nxt = (j & 1) ? twA : twB;
+                    if (i > 0) { if (FIRST && i == 1) tw_request<RB, true>(a, 0, tile_base, nxt); else tw_request<RB, false>(a, bp_of(i - 1), tile_base, nxt); }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of this round's butterflies
+                    if (FIRST && i == 0) round_full<RB, CB, false, true>(lds, 0, cur); else round_full<RB, CB, false, false>(lds, bp_of(i), cur);
+                    __syncthreads();
+                }
+            }
+            if (rem) rem_round13<RB, CB, NT, false>(lds, a, rem, B, tile_base);
+        }
+
+        TRACE_MARK(1);
+        if (INV) {
+            // top layer fused into the store; the 1/N scale rides on it (one multiply per output instead of two)
+            const u32 sc2 = a.scale << 1, tes2 = (a.scale ? m_mul(te, a.scale) : te) << 1;
+#pragma unroll
+            for (int it = 0; it < (int)(T13_HALF / 4) / NT; it++) {
+                const u32 t = (threadIdx.x + it * NT) * 4;
+                const u32 pa = pad13(t), pb = pad13(t + T13_HALF);
+                u32 oa[CB][4], ob[CB][4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const Row<CB> x = lds[pa + i], y = lds[pb + i];
+#pragma unroll
+                    for (int k = 0; k < CB; k++) {
+                        const u32 sm = m_add(x.c[k], y.c[k]), df = m_sub(x.c[k], y.c[k]);
+                        oa[k][i] = sc2 ? m_mul_dbl(sm, sc2) : sm; ob[k][i] = m_mul_dbl(df, tes2);
+                    }
+                }
+                const u32 ga = tile_base + goff(t), gb = tile_base + goff(t + T13_HALF);
 #pragma unroll
                 for (int k = 0; k < CB; k++) {
-                    u32 u = get4(xa[k], i), w = get4(xb[k], i);
-                    bfly13<false>(u, w, te2, false);
-                    ra.c[k] = u; rb.c[k] = w;
-                }
-                lds[pa + i] = ra;
-                lds[pb + i] = rb;
-            }
-        }
-    }
-    __syncthreads();
-
-    // step j of the round sequence uses twiddle registers (j even ? twA : twB) and requests step j+1's into the other set
-    if (INV) {
-        if (rem) rem_round13<RB, CB, NT, true>(lds, a, rem, B, tile_base);
-#pragma unroll
-        for (int j = 0; j < MAXR; j++) {
-            if (j < nfull) {
-                u32* cur = (j & 1) ? twB : twA;
-                u32* nxt = (j & 1) ? twA : twB;
-                if (j + 1 < nfull) tw_request<RB, false>(a, bp_of(j + 1), tile_base, nxt);
-                __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of this round's butterflies
-                if (FIRST && j == 0) round_full<RB, CB, true, true>(lds, 0, cur); else round_full<RB, CB, true, false>(lds, bp_of(j), cur);
-                __syncthreads();
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < MAXR; j++) {
-            if (j < nfull) {
-                const int i = nfull - 1 - j;
-                u32* cur = (j & 1) ? twB : twA;
-                u32* nxt = (j & 1) ? twA : twB;
-                if (i > 0) { if (FIRST && i == 1) tw_request<RB, true>(a, 0, tile_base, nxt); else tw_request<RB, false>(a, bp_of(i - 1), tile_base, nxt); }
-                __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of this round's butterflies
-                if (FIRST && i == 0) round_full<RB, CB, false, true>(lds, 0, cur); else round_full<RB, CB, false, false>(lds, bp_of(i), cur);
-                __syncthreads();
-            }
-        }
-        if (rem) rem_round13<RB, CB, NT, false>(lds, a, rem, B, tile_base);
-    }
-
-    if (INV) {
-        // top layer fused into the store; the 1/N scale rides on it (one multiply per output instead of two)
-        const u32 sc2 = a.scale << 1, tes2 = (a.scale ? m_mul(te, a.scale) : te) << 1;
-#pragma unroll
-        for (int it = 0; it < (int)(T13_HALF / 4) / NT; it++) {
-            const u32 t = (threadIdx.x + it * NT) * 4;
-            const u32 pa = pad13(t), pb = pad13(t + T13_HALF);
-            u32 oa[CB][4], ob[CB][4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const Row<CB> x = lds[pa + i], y = lds[pb + i];
-#pragma unroll
-                for (int k = 0; k < CB; k++) {
-                    const u32 sm = m_add(x.c[k], y.c[k]), df = m_sub(x.c[k], y.c[k]);
-                    oa[k][i] = sc2 ? m_mul_dbl(sm, sc2) : sm; ob[k][i] = m_mul_dbl(df, tes2);
+                    if (live[k]) {
+                        gstore4(d[k] + ga, make_uint4(oa[k][0], oa[k][1], oa[k][2], oa[k][3]));
+                        gstore4(d[k] + gb, make_uint4(ob[k][0], ob[k][1], ob[k][2], ob[k][3]));
+                    }
                 }
             }
-            const u32 ga = tile_base + goff(t), gb = tile_base + goff(t + T13_HALF);
+        } else {
 #pragma unroll
-            for (int k = 0; k < CB; k++) {
-                if (live[k]) {
-                    *reinterpret_cast<uint4*>(d[k] + ga) = make_uint4(oa[k][0], oa[k][1], oa[k][2], oa[k][3]);
-                    *reinterpret_cast<uint4*>(d[k] + gb) = make_uint4(ob[k][0], ob[k][1], ob[k][2], ob[k][3]);
-                }
+            for (int it = 0; it < (int)(T13_ROWS / 4) / NT; it++) {
+                const u32 t = (threadIdx.x + it * NT) * 4;
+                const u32 p = pad13(t);
+                const Row<CB> x0 = lds[p], x1 = lds[p + 1], x2 = lds[p + 2], x3 = lds[p + 3];
+                const u32 g = tile_base + goff(t);
+#pragma unroll
+                for (int k = 0; k < CB; k++)
+                    if (live[k]) gstore4(d[k] + g, make_uint4(x0.c[k], x1.c[k], x2.c[k], x3.c[k]));
             }
         }
-    } else {
-#pragma unroll
-        for (int it = 0; it < (int)(T13_ROWS / 4) / NT; it++) {
-            const u32 t = (threadIdx.x + it * NT) * 4;
-            const u32 p = pad13(t);
-            const Row<CB> x0 = lds[p], x1 = lds[p + 1], x2 = lds[p + 2], x3 = lds[p + 3];
-            const u32 g = tile_base + goff(t);
-#pragma unroll
-            for (int k = 0; k < CB; k++)
-                if (live[k]) *reinterpret_cast<uint4*>(d[k] + g) = make_uint4(x0.c[k], x1.c[k], x2.c[k], x3.c[k]);
-        }
+        TRACE_MARK(2);
     }
+#ifdef NX_FFT_TRACE
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): until this wave's stores are acknowledged
+    TRACE_MARK(3);
+#endif
 }
 
 // ---- planning: layers [0, m) -> the FIRST pass [0, 13) plus passes of <= kmax layers (runs of 2^(13-kmax) words) ----
@@ -372,53 +421,60 @@ static std::vector<Plan13> plan13(int m) {
     return p;
 }
 
-struct Shape13 { int cb, rb; };
-static Shape13 g_shape = {2, 4};
+struct Shape13 { int cb; };   // radix-8 rounds (RB = 3) measured slower in every shape and are no longer built
+static Shape13 g_shape = {1};  // one column per block: 34 KB tiles, 58-70 VGPRs -> 3-4 blocks per CU; measured 3 % faster than column pairs (2 blocks per CU)
 static bool g_shape_init = false;
 static void shape_init() {
     if (g_shape_init) return;
     g_shape_init = true;
     if (const char* e = getenv("NX_FFT_CB")) g_shape.cb = atoi(e) == 1 ? 1 : 2;
-    if (const char* e = getenv("NX_FFT_RB")) g_shape.rb = atoi(e) == 3 ? 3 : 4;
 }
 
-template <bool INV, bool FIRST, int CB, int RB>
+template <bool INV, bool FIRST, int CB, int RB, int KT>
 static int launch13_t(nx_ctx* ctx, const Pass13& a) {
     static bool attr_set = false;
     const size_t lds_bytes = ((size_t)T13_ROWS + (T13_ROWS >> 4)) * 4 * CB;
     if (!attr_set) {
-        NX_HIP(ctx, hipFuncSetAttribute((const void*)fft13_kernel<INV, FIRST, CB, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NX_HIP(ctx, hipFuncSetAttribute((const void*)fft13_kernel<INV, FIRST, CB, RB, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     dim3 grid(a.tiles * a.n_groups), block(T13_ROWS >> RB);
-    hipLaunchKernelGGL((fft13_kernel<INV, FIRST, CB, RB>), grid, block, lds_bytes, ctx->cur, a);
+    hipLaunchKernelGGL((fft13_kernel<INV, FIRST, CB, RB, KT>), grid, block, lds_bytes, ctx->cur, a);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
 
-template <int CB, int RB>
-static int launch13_s(nx_ctx* ctx, bool inv, bool first, const Pass13& a) {
-    if (inv && first) return launch13_t<true, true, CB, RB>(ctx, a);
-    if (inv) return launch13_t<true, false, CB, RB>(ctx, a);
-    if (first) return launch13_t<false, true, CB, RB>(ctx, a);
-    return launch13_t<false, false, CB, RB>(ctx, a);
+template <bool INV, int CB, int RB>
+static int launch13_k(nx_ctx* ctx, bool first, const Pass13& a) {
+    if (first) return launch13_t<INV, true, CB, RB, 0>(ctx, a);
+    switch (a.K) {
+    case 1: return launch13_t<INV, false, CB, RB, 1>(ctx, a);
+    case 2: return launch13_t<INV, false, CB, RB, 2>(ctx, a);
+    case 3: return launch13_t<INV, false, CB, RB, 3>(ctx, a);
+    case 4: return launch13_t<INV, false, CB, RB, 4>(ctx, a);
+    case 5: return launch13_t<INV, false, CB, RB, 5>(ctx, a);
+    case 6: return launch13_t<INV, false, CB, RB, 6>(ctx, a);
+    case 7: return launch13_t<INV, false, CB, RB, 7>(ctx, a);
+    case 8: return launch13_t<INV, false, CB, RB, 8>(ctx, a);
+    case 9: return launch13_t<INV, false, CB, RB, 9>(ctx, a);
+    default: return launch13_t<INV, false, CB, RB, 0>(ctx, a);   // NX_FFT_KMAX > 9
+    }
 }
 
 static int launch13(nx_ctx* ctx, bool inv, bool first, Pass13 a) {
     shape_init();
+
     const int cb = a.n_cols == 1 ? 1 : g_shape.cb;
     a.n_groups = (a.n_cols + cb - 1) / cb;
-    if (cb == 2 && g_shape.rb == 4) return launch13_s<2, 4>(ctx, inv, first, a);
-    if (cb == 2) return launch13_s<2, 3>(ctx, inv, first, a);
-    if (g_shape.rb == 4) return launch13_s<1, 4>(ctx, inv, first, a);
-    return launch13_s<1, 3>(ctx, inv, first, a);
+    if (cb == 2) return inv ? launch13_k<true, 2, 4>(ctx, first, a) : launch13_k<false, 2, 4>(ctx, first, a);
+    return inv ? launch13_k<true, 1, 4>(ctx, first, a) : launch13_k<false, 1, 4>(ctx, first, a);
 }
 
 // in-place iFFT of n_cols columns of 2^n words (n >= 13)
 int fft13_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_cols, int n) {
     std::vector<Plan13> plan = plan13(n);
     for (size_t i = 0; i < plan.size(); i++) {
-        Pass13 a; a.src = cols; a.dst = cols; a.tw = tw->d_itw; a.tw_log = tw->log_half; a.n = n; a.log_in = n;
+        Pass13 a; a.src = cols; a.dst = cols; a.tw = tw->d_itw2; a.tw_log = tw->log_half; a.n = n; a.log_in = n;
         a.lo = plan[i].lo; a.K = plan[i].K; a.B = plan[i].B; a.scale = i + 1 == plan.size() ? m_inv(1u << n) : 0;
         a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S); a.rep_log = 0;
         NX_TRY(launch13(ctx, true, i == 0, a));
@@ -431,12 +487,20 @@ int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n_cols,
     std::vector<Plan13> plan = plan13(log_in);
     for (size_t k = plan.size(); k-- > 0;) {
         const bool top = k + 1 == plan.size();
-        Pass13 a; a.src = top ? polys : out; a.dst = out; a.tw = tw->d_tw; a.tw_log = tw->log_half; a.n = n; a.log_in = top ? log_in : n;
+        Pass13 a; a.src = top ? polys : out; a.dst = out; a.tw = tw->d_tw2; a.tw_log = tw->log_half; a.n = n; a.log_in = top ? log_in : n;
         a.lo = plan[k].lo; a.K = plan[k].K; a.B = plan[k].B; a.scale = 0;
         a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S); a.rep_log = top ? (u32)(n - log_in) : 0;
         NX_TRY(launch13(ctx, false, k == 0, a));
     }
     return NX_OK;
 }
+
+#ifdef NX_FFT_TRACE
+extern "C" int nx_fft13_trace_read(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_trace13), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace13), z, sizeof z) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 }  // namespace nx

@@ -46,6 +46,8 @@ struct nx_twiddles {
     uint32_t log_half;  // root half coset log size; buffers hold 2^log_half words
     uint32_t* d_tw;
     uint32_t* d_itw;
+    uint32_t* d_tw2;    // 2 * twiddle (fits 32 bits): what fft13's m_mul_dbl butterflies consume, saves the per-lane doubling
+    uint32_t* d_itw2;
 };
 
 struct nx_tree {
