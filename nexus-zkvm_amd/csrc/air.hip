@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColS
             else idx = ((idx - half - step) & (half - 1)) + half;
             rn = bitrev(idx, e);
         }
-        u32 not_last = m_sub(1, pre.col(1)[r]);
-        u32 m0 = mainc.col(0)[r], m1 = mainc.col(1)[r];
-        u32 m0n = mainc.col(0)[rn], m1n = mainc.col(1)[rn];
+        u32 not_last = m_sub(1, gld(pre.col(1) + r));
+        u32 m0 = gld(mainc.col(0) + r), m1 = gld(mainc.col(1) + r);
+        u32 m0n = gld(mainc.col(0) + rn), m1n = gld(mainc.col(1) + rn);
         ACC(m_mul(m_sub(m_sub(m0n, m0), 1), not_last));
         ACC(m_mul(m_sub(m_sub(m1n, m1), m0), not_last));
         a = m0; b = m1; k = 2;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColS
         for (; k + 8 <= sh.n_main; k += 8) {
             u32 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = mainc.col(k + u)[r];
+            for (int u = 0; u < 8; u++) v[u] = gld(mainc.col(k + u) + r);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 if (((sh.main_begin + k + u) % SYNTH_GROUP) >= 2) ACC(m_sub(m_sub(v[u], m_sqr(b)), m_sqr(a)));
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColS
             }
         }
         for (; k < sh.n_main; k++) {
-            u32 v = mainc.col(k)[r];
+            u32 v = gld(mainc.col(k) + r);
             if (((sh.main_begin + k) % SYNTH_GROUP) >= 2) ACC(m_sub(m_sub(v, m_sqr(b)), m_sqr(a)));
             a = b; b = v;
         }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColS
         for (; k + 8 <= sh.n_inter; k += 8) {
             u32 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = inter.col(k + u)[r];
+            for (int u = 0; u < 8; u++) v[u] = gld(inter.col(k + u) + r);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 if (((sh.inter_begin + k + u) % SYNTH_GROUP) >= 2) ACC(m_sub(m_sub(v[u], m_sqr(b)), m_sqr(a)));
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColS
             }
         }
         for (; k < sh.n_inter; k++) {
-            u32 v = inter.col(k)[r];
+            u32 v = gld(inter.col(k) + r);
             if (((sh.inter_begin + k) % SYNTH_GROUP) >= 2) ACC(m_sub(m_sub(v, m_sqr(b)), m_sqr(a)));
             a = b; b = v;
         }

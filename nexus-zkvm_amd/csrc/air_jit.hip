@@ -26,6 +26,7 @@ typedef unsigned int u32; typedef unsigned long long u64;
 #define P 0x7fffffffu
 // header-free on purpose: only compiler builtins, so hiprtc and an offline hipcc see the same text
 #define FI __attribute__((device)) __attribute__((always_inline)) inline
+#define G(p) ((__attribute__((address_space(1))) const u32*)(p))   // the column pointers are global memory: global_load, not flat_load
 FI u32 m_csub(u32 s) { u32 d; bool b = __builtin_usub_overflow(s, P, &d); return b ? s : d; }
 FI u32 m_add(u32 a, u32 b) { return m_csub(a + b); }
 FI u32 m_sub(u32 a, u32 b) { u32 d; bool br = __builtin_usub_overflow(a, b, &d); return br ? d + P : d; }
@@ -82,7 +83,7 @@ static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, 
     for (uint32_t i = 0; i < n_instr; i++) {
         const nx_cinstr& in = prog[i];
         switch (in.op) {
-        case NX_C_LOAD: s += "  " + R(in.dst) + " = cols[" + std::to_string(in.a) + "][" + off_name((int)in.b) + "];\n"; break;
+        case NX_C_LOAD: s += "  " + R(in.dst) + " = G(cols[" + std::to_string(in.a) + "])[" + off_name((int)in.b) + "];\n"; break;
         case NX_C_CONST: s += "  " + R(in.dst) + " = " + std::to_string(in.a) + "u;\n"; break;
         case NX_C_ADD: s += "  " + R(in.dst) + " = m_add(" + R(in.a) + ", " + R(in.b) + ");\n"; break;
         case NX_C_SUB: s += "  " + R(in.dst) + " = m_sub(" + R(in.a) + ", " + R(in.b) + ");\n"; break;
@@ -96,8 +97,8 @@ static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, 
         case NX_C_ADDEB: s += setE(in.dst, "Q{m_add(" + R(in.a) + ", " + R(in.b) + "), " + R(in.a + 1) + ", " + R(in.a + 2) + ", " + R(in.a + 3) + "}"); break;
         case NX_C_LOADE: {
             std::string o = off_name((int)in.b);
-            s += setE(in.dst, "Q{cols[" + std::to_string(in.a) + "][" + o + "], cols[" + std::to_string(in.a + 1) + "][" + o + "], cols[" + std::to_string(in.a + 2) + "][" + o + "], cols[" +
-                                  std::to_string(in.a + 3) + "][" + o + "]}");
+            s += setE(in.dst, "Q{G(cols[" + std::to_string(in.a) + "])[" + o + "], G(cols[" + std::to_string(in.a + 1) + "])[" + o + "], G(cols[" + std::to_string(in.a + 2) + "])[" + o + "], G(cols[" +
+                                  std::to_string(in.a + 3) + "])[" + o + "]}");
             break;
         }
         case NX_C_CONSTRAINT_B: {

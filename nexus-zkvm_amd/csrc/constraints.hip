@@ -52,7 +52,7 @@ __global__ __launch_bounds__(CP_THREADS) void constraint_program_kernel(const nx
             while (cnt < 8 && pc + cnt < n_instr && prog[pc + cnt].op == NX_C_LOAD) cnt++;
             u32 v[8];
 #pragma unroll
-            for (u32 u = 0; u < 8; u++) if (u < cnt) { const nx_cinstr li = prog[pc + u]; v[u] = cols[li.a][row_offset(row, log_size, e, (int)li.b)]; }
+            for (u32 u = 0; u < 8; u++) if (u < cnt) { const nx_cinstr li = prog[pc + u]; v[u] = gld(cols[li.a] + row_offset(row, log_size, e, (int)li.b)); }
 #pragma unroll
             for (u32 u = 0; u < 8; u++) if (u < cnt) RG(prog[pc + u].dst) = v[u];
             pc += cnt - 1;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(CP_THREADS) void constraint_program_kernel(const nx
         }
         case NX_C_LOADE: {   // a secure column = 4 consecutive coordinate columns (SecureColumnByCoords)
             const u32 rr = row_offset(row, log_size, e, (int)in.b);
-            const u32 x0 = cols[in.a][rr], x1 = cols[in.a + 1][rr], x2 = cols[in.a + 2][rr], x3 = cols[in.a + 3][rr];
+            const u32 x0 = gld(cols[in.a] + rr), x1 = gld(cols[in.a + 1] + rr), x2 = gld(cols[in.a + 2] + rr), x3 = gld(cols[in.a + 3] + rr);
             RG(in.dst) = x0; RG(in.dst + 1) = x1; RG(in.dst + 2) = x2; RG(in.dst + 3) = x3;
             break;
         }

@@ -82,6 +82,19 @@ struct ColSet {
     __device__ __forceinline__ uint32_t* col(uint32_t c) const { return table ? table[c] : base + (uint64_t)c * stride; }
 };
 
+// Global-memory accessors for device code.  Column pointers reach the kernels inside by-value structs or pointer tables, so
+// clang types them generic and emits flat_load/flat_store: those also count on lgkmcnt (every later s_load or LDS wait then
+// waits for ALL outstanding column loads — the Merkle leaf kernel issued its 16 column loads one at a time) and are ordered
+// against LDS traffic.  These helpers cast to address space 1 (global_load/global_store).
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define NX_GLOBAL_AS __attribute__((address_space(1)))
+typedef uint32_t nx_v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t gld(const uint32_t* p) { return *(NX_GLOBAL_AS const uint32_t*)p; }
+__device__ __forceinline__ uint4 gld4(const uint32_t* p) { const nx_v4u32 v = *(NX_GLOBAL_AS const nx_v4u32*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void gst(uint32_t* p, uint32_t v) { *(NX_GLOBAL_AS uint32_t*)p = v; }
+__device__ __forceinline__ void gst4(uint32_t* p, uint4 v) { nx_v4u32 w = {v.x, v.y, v.z, v.w}; *(NX_GLOBAL_AS nx_v4u32*)p = w; }
+#endif
+
 // Builds a ColSet from a host array of device pointers: constant stride is detected, otherwise the
 // table is staged into the context's device scratch ring (stream-ordered).
 int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out);

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void merkle_layer_kernel(ColSet cols, u32 n_co
     u32 m[16];
     u32 t = 0;
     if (prev) {
-        const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
-        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        const u32* p = prev + (size_t)i * 16;
+        uint4 a = gld4(p), b = gld4(p + 4), c = gld4(p + 8), d = gld4(p + 12);
         m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
         m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
         t = 64;
@@ -91,12 +91,24 @@ __global__ __launch_bounds__(256) void merkle_layer_kernel(ColSet cols, u32 n_co
     // ~1000 VALU ops of chunk k's compression run
     u32 nx_[16];
     auto load_chunk = [&](u32 c0, u32* dst) {
+        // the 16 column addresses first (one uniform branch, wide scalar loads of the pointer table), then 16 global loads
+        // issued back to back
+        const u32* p[16];
         if (c0 + 16 <= n_cols) {
+            if (cols.table) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = cols.col(c0 + k)[i];
+                for (int k = 0; k < 16; k++) p[k] = cols.table[c0 + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) p[k] = cols.base + (uint64_t)(c0 + k) * cols.stride;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = gld(p[k] + i);
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? cols.col(c0 + k)[i] : 0u;
+            for (int k = 0; k < 16; k++) p[k] = cols.col(min(c0 + k, n_cols - 1));
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? gld(p[k] + i) : 0u;
         }
     };
     if (n_cols) load_chunk(0, nx_);
@@ -141,12 +153,24 @@ __global__ __launch_bounds__(256) void merkle_leaf_chain_kernel(ColSet cols, u32
     u32 t = 4u * col_offset;   // bytes hashed by the previous shards
     u32 m[16], nx_[16];
     auto load_chunk = [&](u32 c0, u32* dst) {
+        // the 16 column addresses first (one uniform branch, wide scalar loads of the pointer table), then 16 global loads
+        // issued back to back
+        const u32* p[16];
         if (c0 + 16 <= n_cols) {
+            if (cols.table) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = cols.col(c0 + k)[i];
+                for (int k = 0; k < 16; k++) p[k] = cols.table[c0 + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) p[k] = cols.base + (uint64_t)(c0 + k) * cols.stride;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = gld(p[k] + i);
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? cols.col(c0 + k)[i] : 0u;
+            for (int k = 0; k < 16; k++) p[k] = cols.col(min(c0 + k, n_cols - 1));
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? gld(p[k] + i) : 0u;
         }
     };
     if (n_cols) load_chunk(0, nx_);

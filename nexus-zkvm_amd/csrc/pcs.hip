@@ -39,7 +39,7 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_at_point_kernel(ColSet poly
         for (int u = 0; u < 4; u++) {
             const u32* row = c + ((size_t)(jh + u) << L);
 #pragma unroll
-            for (int k = 0; k < EVAL_KL; k++) { u32 jl = threadIdx.x + k * EVAL_THREADS; cv[u][k] = jl < n_lo ? row[jl] : 0u; }
+            for (int k = 0; k < EVAL_KL; k++) { u32 jl = threadIdx.x + k * EVAL_THREADS; cv[u][k] = jl < n_lo ? gld(row + jl) : 0u; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, con
         for (; k + 4 <= end; k += 4) {
             uint4 f[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) f[u] = *reinterpret_cast<const uint4*>(cols.col(col_idx[k + u]) + r);
+            for (int u = 0; u < 4; u++) f[u] = gld4(cols.col(col_idx[k + u]) + r);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const u32 c0 = cks[4 * (k + u)], c1 = cks[4 * (k + u) + 1], c2 = cks[4 * (k + u) + 2], c3 = cks[4 * (k + u) + 3];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, con
             for (int i = 0; i < 4; i++) for (int q = 0; q < 4; q++) n[i][q] = acc_fold(n[i][q]);
         }
         for (; k < end; k++) {   // < 4 products on top of a folded value: still below 2^64
-            const uint4 f = *reinterpret_cast<const uint4*>(cols.col(col_idx[k]) + r);
+            const uint4 f = gld4(cols.col(col_idx[k]) + r);
             const u32 c0 = cks[4 * k], c1 = cks[4 * k + 1], c2 = cks[4 * k + 2], c3 = cks[4 * k + 3];
             const u32 fv[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
