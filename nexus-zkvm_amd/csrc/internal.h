@@ -121,6 +121,12 @@ int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_co
 
 // Pipelined tree build (merkle.hip): the leaf layer is a per-row Blake2s chain over the largest columns in commit order,
 // so finished column groups can be absorbed (on ctx->hash_stream) while the main stream already transforms the next group.
+// FRI tail (merkle.hip): the last FRI layers (line layers of <= 2^FRI_TAIL_LOG points) committed and folded in one launch with the
+// channel on the device.
+constexpr int FRI_TAIL_LOG = 11, FRI_TAIL_MAX_LAYERS = 16;   // 2^12 and up: one CU is slower than the per-layer launches (measured)
+int tree_alloc(nx_ctx* ctx, uint32_t max_log, nx_tree** out);
+int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* evals, uint32_t* const* trees, int n_layers, int log0, uint32_t* h_state);
+
 struct TreePipe {
     nx_tree* tree = nullptr;
     uint32_t max_log = 0, total_leaf_cols = 0, absorbed = 0;

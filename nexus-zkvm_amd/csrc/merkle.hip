@@ -217,6 +217,160 @@ __global__ __launch_bounds__(1024) void merkle_top_kernel(u32* __restrict__ base
 }
 
 
+// ---------------------------------------------------------------- FRI tail: the last layers of FriProver::commit in ONE launch
+// Below ~2^12 points a FRI layer costs ~60 us of launches and host round trips (Merkle layers, root download, channel,
+// alpha upload, fold) for a few microseconds of work, and the layers are strictly sequential (alpha_{k+1} = H(root_k)).  This
+// kernel keeps the Blake2sChannel on the device: per layer, one 1024-lane block builds the layer's Merkle tree (same node rule
+// as merkle_layer_kernel), lane 0 mixes the root into the channel and draws the folding alpha (Blake2sChannel::mix_root /
+// draw_secure_felt, host/channel.h), then all lanes fold the line (fold_line_kernel's rule) into the next layer.
+struct FriTailArgs {
+    u32* eval[FRI_TAIL_MAX_LAYERS + 1];   // eval[j]: 4 coordinate columns of 2^(log0 - j) words, contiguous; eval[0] is the input
+    u32* tree[FRI_TAIL_MAX_LAYERS];       // tree[j]: (2^(log0 - j + 1) - 1) nodes x 8 words, layer k at node offset 2^k - 1
+    int n_layers, log0;
+    const u32* itw; u32 tw_log;
+    u32* state;                           // in: digest[8]; out: digest[8], n_sent, then n_layers x (root[8], alpha[4])
+};
+
+__device__ __forceinline__ void b2s_init_std(u32 h[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = B2S_IV_D[k];
+    h[0] ^= 0x01010020u;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void fri_tail_kernel(FriTailArgs a) {
+    __shared__ u32 sh_alpha[4];
+    __shared__ u32 sh_digest[8];
+    const u32 tid = threadIdx.x;
+    if (tid < 8) sh_digest[tid] = a.state[tid];
+    u32 n_sent = 0;
+    __syncthreads();
+    for (int j = 0; j < a.n_layers; j++) {
+        const int l = a.log0 - j;
+        const u32 n = 1u << l;
+        const u32* c0 = a.eval[j]; const u32* c1 = c0 + n; const u32* c2 = c1 + n; const u32* c3 = c2 + n;
+        u32* tree = a.tree[j];
+        // leaf layer: node i = H(c0[i], c1[i], c2[i], c3[i])  (merkle_layer_kernel with prev == NULL, n_cols == 4)
+        for (u32 i = tid; i < n; i += 1024) {
+            u32 h[8], m[16];
+            if (MODE == 0) b2s_init_std(h); else { for (int k = 0; k < 8; k++) h[k] = 0; }
+#pragma unroll
+            for (int k = 4; k < 16; k++) m[k] = 0;
+            m[0] = c0[i]; m[1] = c1[i]; m[2] = c2[i]; m[3] = c3[i];
+            if (MODE == 0) b2s_compress(h, m, 16, 0xFFFFFFFFu); else b2s_compress(h, m, 0, 0);
+            u32* o = tree + ((size_t)n - 1 + i) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[k] = h[k];
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int log = l - 1; log >= 0; log--) {
+            const u32* prev = tree + (((size_t)2 << log) - 1) * 8;
+            u32* out = tree + (((size_t)1 << log) - 1) * 8;
+            for (u32 i = tid; i < (1u << log); i += 1024) {
+                u32 h[8], m[16];
+                if (MODE == 0) b2s_init_std(h); else { for (int k = 0; k < 8; k++) h[k] = 0; }
+#pragma unroll
+                for (int k = 0; k < 16; k++) m[k] = prev[(size_t)i * 16 + k];
+                if (MODE == 0) b2s_compress(h, m, 64, 0xFFFFFFFFu); else b2s_compress(h, m, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 8; k++) out[(size_t)i * 8 + k] = h[k];
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (tid == 0) {
+            // Blake2sChannel::mix_root: digest = Blake2s(digest ‖ root)
+            u32 h[8], m[16];
+            b2s_init_std(h);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { m[k] = sh_digest[k]; m[8 + k] = tree[k]; }
+            b2s_compress(h, m, 64, 0xFFFFFFFFu);
+#pragma unroll
+            for (int k = 0; k < 8; k++) sh_digest[k] = h[k];
+            n_sent = 0;
+            // draw_secure_felt: Blake2s(digest ‖ n_sent_le32 ‖ 29 zero bytes) until all 8 words are < 2P; the first 4 reduced
+            for (;;) {
+                u32 g[8];
+                b2s_init_std(g);
+#pragma unroll
+                for (int k = 0; k < 8; k++) m[k] = sh_digest[k];
+                m[8] = n_sent;
+#pragma unroll
+                for (int k = 9; k < 16; k++) m[k] = 0;
+                b2s_compress(g, m, 64, 0);
+#pragma unroll
+                for (int k = 0; k < 16; k++) m[k] = 0;
+                b2s_compress(g, m, 65, 0xFFFFFFFFu);
+                n_sent++;
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 8; k++) ok = ok && g[k] < 2u * P;
+                if (ok) { for (int k = 0; k < 4; k++) sh_alpha[k] = g[k] >= P ? g[k] - P : g[k]; break; }
+            }
+            u32* rec = a.state + 9 + 12 * j;
+#pragma unroll
+            for (int k = 0; k < 8; k++) rec[k] = tree[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) rec[8 + k] = sh_alpha[k];
+        }
+        __syncthreads();
+        // fold_line: next[i] = (f0 + f1) + alpha * ((f0 - f1) / x_i), pairs (2i, 2i+1), 1/x_i = itw layer (H - l), entry i
+        const QM31 alpha = qm(sh_alpha[0], sh_alpha[1], sh_alpha[2], sh_alpha[3]);
+        u32* d0 = a.eval[j + 1]; const u32 nh = n >> 1;
+        for (u32 i = tid; i < nh; i += 1024) {
+            const u32 xi = a.itw[(1u << a.tw_log) - (1u << l) + i];
+            const QM31 f0 = qm(c0[2 * i], c1[2 * i], c2[2 * i], c3[2 * i]), f1 = qm(c0[2 * i + 1], c1[2 * i + 1], c2[2 * i + 1], c3[2 * i + 1]);
+            const QM31 sum = q_add(f0, f1), t = q_mul_m(q_sub(f0, f1), xi);
+            const QM31 o = q_add(sum, q_mul(alpha, t));
+            d0[i] = o.a.a; d0[nh + i] = o.a.b; d0[2 * nh + i] = o.b.a; d0[3 * nh + i] = o.b.b;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid < 8) a.state[tid] = sh_digest[tid];
+    if (tid == 0) a.state[8] = n_sent;
+}
+
+// An empty tree of 2^max_log leaves (one device allocation, layer k at node offset 2^k - 1).
+int tree_alloc(nx_ctx* ctx, uint32_t max_log, nx_tree** out) {
+    nx_tree* t = new nx_tree();
+    t->ctx = ctx;
+    uint32_t* buf = nullptr;
+    int rc = dev_alloc(ctx, (((size_t)2 << max_log) - 1) * 32, (void**)&buf);
+    if (rc != NX_OK) { delete t; return rc; }
+    t->layers.resize(max_log + 1);
+    for (uint32_t k = 0; k <= max_log; k++) t->layers[k] = buf + (((size_t)1 << k) - 1) * 8;
+    *out = t;
+    return NX_OK;
+}
+
+// Host side: h_state = digest[8] in; digest[8], n_sent, n_layers x (root[8], alpha[4]) out.  evals[j] / trees[j] are device buffers
+// the caller allocated (evals[0] = the input layer of log size log0; evals has n_layers + 1 entries).
+int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, u32* const* evals, u32* const* trees, int n_layers, int log0, u32* h_state) {
+    if (n_layers < 1 || n_layers > FRI_TAIL_MAX_LAYERS || log0 < n_layers || (u32)log0 > tw->log_half) return set_err(ctx, NX_ERR_ARG, "fri_tail: bad layer range");
+    FriTailArgs a;
+    for (int j = 0; j <= n_layers; j++) a.eval[j] = evals[j];
+    for (int j = 0; j < n_layers; j++) a.tree[j] = trees[j];
+    a.n_layers = n_layers; a.log0 = log0; a.itw = tw->d_itw; a.tw_log = tw->log_half;
+    const size_t words = 9 + 12 * (size_t)n_layers;
+    u32* d_state = nullptr;
+    NX_TRY(dev_alloc(ctx, words * 4, (void**)&d_state));
+    a.state = d_state;
+    hipError_t e = hipMemcpyAsync(d_state, h_state, 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(fri_tail_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(fri_tail_kernel<1>, dim3(1), dim3(1024), 0, ctx->stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_state, d_state, words * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    dev_free(ctx, d_state);
+    if (e != hipSuccess) return hip_fail(ctx, e, "fri_tail", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(ctx, e2, "fri_tail(sync)", __FILE__, __LINE__);
+    return NX_OK;
+}
+
 // GrindOps: nonce = base + thread; H(digest ‖ nonce_le64) is a single final 40-byte block.
 __global__ void grind_kernel(const u32* __restrict__ digest, u32 pow_bits, u64 base, unsigned long long* result) {
     u64 nonce = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;

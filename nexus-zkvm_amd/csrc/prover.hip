@@ -247,7 +247,34 @@ class FriProver {
         H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
         const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
         size_t ci = 0; uint32_t n_doublings = 0;
+        static const bool use_tail = []() { const char* e = getenv("NX_FRI_TAIL"); return !e || atoi(e) != 0; }();
         while (layer_log > last_log) {
+            if (use_tail && ci == columns.size() && layer_log <= (uint32_t)FRI_TAIL_LOG && layer_log - last_log <= (uint32_t)FRI_TAIL_MAX_LAYERS) {
+                // every circle column is folded in and the layers are small: the rest of the commit phase is one launch with the
+                // channel on the device (fri_tail, merkle.hip) — same trees, same transcript
+                const int n = (int)(layer_log - last_log);
+                std::vector<FriLayer> tl(n);
+                std::vector<uint32_t*> evals(n + 1), trees(n);
+                tl[0].eval = std::move(layer);
+                for (int j = 0; j < n; j++) {
+                    if (j) H_TRY(tl[j].eval.alloc(ctx, layer_log - j));
+                    for (int k = 0; k < 4; k++) tl[j].eval.c[k] = tl[j].eval.buf.p + ((size_t)k << (layer_log - j));
+                    H_TRY(tree_alloc(ctx, layer_log - j, &tl[j].merkle));
+                    evals[j] = tl[j].eval.buf.p; trees[j] = tl[j].merkle->layers[0];
+                }
+                SecureColumn fin; H_TRY(fin.alloc(ctx, last_log));
+                evals[n] = fin.buf.p;
+                std::vector<uint32_t> st(9 + 12 * (size_t)n);
+                memcpy(st.data(), channel.digest.w, 32);
+                H_TRY(fri_tail(ctx, tw, evals.data(), trees.data(), n, (int)layer_log, st.data()));
+                memcpy(channel.digest.w, st.data(), 32);
+                channel.n_challenges += (uint32_t)n; channel.n_sent = st[8];
+                for (int j = 0; j < n; j++) { memcpy(tl[j].root.w, &st[9 + 12 * j], 32); folding_alpha = q_load(&st[9 + 12 * j + 8]); inner.push_back(std::move(tl[j])); }
+                layer = std::move(fin);
+                for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << last_log);
+                n_doublings += (uint32_t)n; layer_log = last_log;
+                break;
+            }
             while (ci < columns.size() && columns[ci].log - 1 == layer_log) {
                 QM31 a = cfg.fri_alpha_mode == NX_FRI_ALPHA_PREV ? folding_alpha : first_alpha;
                 uint32_t aw[4]; q_store(aw, a);
