@@ -285,6 +285,13 @@ class DeviceColumns:
         self.ptr = C.c_void_p()
         backend._chk(backend.L.nx_alloc(backend.ctx, C.c_size_t(max(1, n_cols << log_size)), C.byref(self.ptr)))
 
+    @classmethod
+    def view(cls, backend, ptr, n_cols, log_size):
+        """A non-owning view of n_cols contiguous columns that live elsewhere (e.g. in a ProverSession tree)."""
+        v = cls.__new__(cls)
+        v.be, v.n_cols, v.log_size, v.ptr, v.borrowed = backend, n_cols, log_size, C.c_void_p(int(ptr)), True
+        return v
+
     def col_ptrs(self):
         stride = 4 << self.log_size
         return (C.c_void_p * max(1, self.n_cols))(*[self.ptr.value + i * stride for i in range(self.n_cols)])
@@ -301,6 +308,9 @@ class DeviceColumns:
         return out
 
     def free(self):
+        if getattr(self, "borrowed", False):
+            self.ptr = C.c_void_p()
+            return
         if self.ptr and self.ptr.value:
             if self.be.ctx:   # after HipBackend.close() the context (and every allocation it cached) is gone
                 self.be.L.nx_free(self.be.ctx, self.ptr)

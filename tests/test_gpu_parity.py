@@ -725,6 +725,50 @@ def test_session_refuses_invalid_traces_and_misuse(be, nz, oracle):
         be.prover_session(cfg, 5).tree_begin([6])
 
 
+@pytest.mark.parametrize("log", [6, 12])
+def test_session_end_to_end_with_device_logup(be, nz, oracle, log):
+    """Ranks 1 + 2 + the session together, nothing but the main trace and the lookup elements on the host: the interaction column
+    is generated by nx_logup_col / nx_logup_finalize_last straight into the session's interaction tree, the claimed sum it returns
+    feeds the recorded constraint's shift, and the proof verifies in the oracle's independent verifier session."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as X
+    ocfg = oracle.default_cfg(pow_bits=2)
+    cfg = _hip_cfg(nz, ocfg)
+    n = 1 << log
+    nat, fin = X.logup_main_trace(log, seed=21)
+    s = be.prover_session(cfg, log)
+    s.mix_u64(log)
+    r0 = s.commit([np.zeros(n, np.uint32)])
+    mptrs = s.tree_begin([log] * 3)
+    assert mptrs[1] - mptrs[0] == 4 * n                                   # one slab: the three main columns are contiguous
+    main = nz.DeviceColumns.view(be, mptrs[0], 3, log).upload(np.stack(fin))
+    tuple_cols = be.clone_columns(nz.DeviceColumns.view(be, mptrs[0], 2, log))      # (a, b): the commit turns the tree's copy into coefficients
+    r1 = s.tree_commit()
+    z, alpha = s.draw_felt(), s.draw_felt()
+    iptrs = s.tree_begin([log] * 4)
+    S = nz.DeviceColumns.view(be, iptrs[0], 4, log)
+    # frac = 1 / (z - a - alpha b) = (-1) / (a + alpha b - z): Relation::combine gives the bracket, scale = -1
+    be.logup_col({"tuple": tuple_cols, "alphas": np.array([[1, 0, 0, 0], alpha], np.uint32), "z": z, "scale": (P - 1, 0, 0, 0)}, out=S)
+    claimed = be.logup_finalize_last(S)
+    shift = X.qmul(claimed, [pow(n, P - 2, P), 0, 0, 0])
+    ref_cols, ref_shift = X.logup_interaction_trace(log, nat, z, alpha) if log <= 8 else (None, None)
+    if ref_cols is not None:
+        assert np.array_equal(S.to_cpu(), np.stack(ref_cols)) and np.array_equal(shift, ref_shift)
+    s.mix_felts(claimed)
+    r2 = s.tree_commit()
+    comp = X.logup_component(ap, log, z, alpha, shift)
+    comp = ap.Component(log, comp.program, comp.cols + [(0, 0)], comp.masks + [[0]])
+    words = s.prove([comp])
+    v = oracle.VerifierSession(ocfg)
+    v.mix_u64(log)
+    v.commit(r0, [log]); v.commit(r1, [log] * 3)
+    assert np.array_equal(v.draw_felt(), z) and np.array_equal(v.draw_felt(), alpha)
+    v.mix_felts(claimed)
+    v.commit(r2, [log] * 4)
+    assert v.verify([comp], words) is None
+    s.close()
+
+
 # ---------------- "next" row R8: logup interaction trace on device --------------------------------------------------------
 
 @pytest.mark.parametrize("log", [4, 9, 13, 16])
