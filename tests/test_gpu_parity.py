@@ -695,6 +695,24 @@ def test_session_logup_air_matches_the_oracle_session(be, nz, oracle, logs, lcd)
     sh.close()
 
 
+@pytest.mark.parametrize("kw", [dict(hash_mode=1), dict(fri_alpha_mode=1), dict(log_blowup=2, n_queries=7), dict(log_last=2, pow_bits=0),
+                                dict(log_blowup=3, log_constraint_degree=2, n_queries=2)])
+def test_session_under_every_protocol_switch(be, nz, oracle, kw):
+    """The session follows the same run-time switches as nx_prove_synth (Merkle node rule, FRI folding-alpha schedule, blow-up,
+    query count, last-layer bound, constraint degree): byte-identical to the oracle session under each."""
+    from test_prover_session_cpu import build_mixed_air
+    logs = (6, 8)
+    ocfg = oracle.default_cfg(**{"pow_bits": 2, **kw})
+    cfg = _hip_cfg(nz, ocfg)
+    drive, tree_logs = build_mixed_air(logs)
+    so = oracle.ProverSession(ocfg, max(logs))
+    ref = so.prove(drive(so, so.commit))
+    sh = be.prover_session(cfg, max(logs))
+    words = sh.prove(drive(sh, sh.commit))
+    assert np.array_equal(words, ref)
+    sh.close()
+
+
 def test_session_refuses_invalid_traces_and_misuse(be, nz, oracle):
     from test_prover_session_cpu import build_mixed_air
     import nexus_zkvm_amd.air_program as ap
