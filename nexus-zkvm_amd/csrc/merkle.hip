@@ -189,31 +189,132 @@ __global__ __launch_bounds__(256) void merkle_leaf_chain_kernel(ColSet cols, u32
 }
 
 
-// Top of the tree in ONE launch: layers `top`..0 (2^top <= 1024 nodes) when no columns are injected there.
-// `base` is the start of the tree allocation (layer k at node offset 2^k - 1).
-template <int MODE>
-__global__ __launch_bounds__(1024) void merkle_top_kernel(u32* __restrict__ base, int top) {
-    for (int log = top; log >= 0; log--) {
-        u32 i = threadIdx.x;
-        if (i < (1u << log)) {
-            const u32* prev = base + (((size_t)2 << log) - 1) * 8;
-            u32* out = base + (((size_t)1 << log) - 1) * 8;
-            u32 h[8], m[16];
+// ---- one Blake2s compression spread over the 4 lanes of a quad ----
+// The top of a tree is a chain of dependent compressions (a level has fewer nodes than the machine has lanes), so what matters
+// there is the LATENCY of one compression, ~1000 dependent-ish VALU ops for a single lane.  Lane q of a quad holds column q of the
+// 4x4 state (a_q, b_q, c_q, d_q): the column step is 4 G functions in parallel, the diagonal step the same after rotating b, c, d
+// by 1, 2, 3 lanes (DPP quad_perm) — ~300 ops per compression.  The message words each lane needs (4 per round) are fetched
+// from LDS through per-lane offsets prepared once per kernel.
+__device__ __constant__ const unsigned char B2S_SIGMA_D[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+
+struct QuadLane { u32 off[10]; u32 iv_lo, iv_hi; int q; };   // per-lane constants of the quad scheme; off[r]: the 4 message-word BYTE offsets of round r, one per byte
+
+__device__ __forceinline__ void quad_lane_init(QuadLane& L) {
+    const int q = threadIdx.x & 3;
+    L.q = q;
 #pragma unroll
-            for (int k = 0; k < 8; k++) h[k] = MODE == 0 ? B2S_IV_D[k] : 0u;
-            if (MODE == 0) h[0] ^= 0x01010020u;
-            const uint4* p = reinterpret_cast<const uint4*>(prev + (size_t)i * 16);
-            uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
-            m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
-            if (MODE == 0) b2s_compress(h, m, 64, 0xFFFFFFFFu); else b2s_compress(h, m, 0, 0);
-            uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
-            o[0] = make_uint4(h[0], h[1], h[2], h[3]);
-            o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    for (int r = 0; r < 10; r++)
+        L.off[r] = 4u * ((u32)B2S_SIGMA_D[r][2 * q] | ((u32)B2S_SIGMA_D[r][2 * q + 1] << 8) | ((u32)B2S_SIGMA_D[r][8 + 2 * q] << 16) | ((u32)B2S_SIGMA_D[r][9 + 2 * q] << 24));
+    L.iv_lo = B2S_IV_D[q]; L.iv_hi = B2S_IV_D[4 + q];
+}
+
+#define QROT(x, ctrl) (u32) __builtin_amdgcn_mov_dpp((int)(x), ctrl, 0xF, 0xF, true)
+
+__device__ __forceinline__ u32 quad_word(const u32* msg, u32 packed, int k) {
+    return *reinterpret_cast<const u32*>(reinterpret_cast<const char*>(msg) + ((packed >> (8 * k)) & 0xFFu));
+}
+// the 10 rounds on a quad-distributed state; the message words of round r + 1 are requested while round r computes (requesting
+// all 40 up front spills at the 128-VGPR limit of a 1024-lane block: measured 40 % slower)
+__device__ __forceinline__ void quad_rounds(const QuadLane& L, const u32* msg, u32& a, u32& b, u32& c, u32& d) {
+    u32 w0 = quad_word(msg, L.off[0], 0), w1 = quad_word(msg, L.off[0], 1), w2 = quad_word(msg, L.off[0], 2), w3 = quad_word(msg, L.off[0], 3);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        u32 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        if (r < 9) { n0 = quad_word(msg, L.off[r + 1], 0); n1 = quad_word(msg, L.off[r + 1], 1); n2 = quad_word(msg, L.off[r + 1], 2); n3 = quad_word(msg, L.off[r + 1], 3); }
+        B2S_G(a, b, c, d, w0, w1);
+        b = QROT(b, 0x39); c = QROT(c, 0x4E); d = QROT(d, 0x93);
+        B2S_G(a, b, c, d, w2, w3);
+        b = QROT(b, 0x93); c = QROT(c, 0x4E); d = QROT(d, 0x39);
+        w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+    }
+}
+
+// msg: the node's 16 message words in LDS; returns digest words q (lo) and 4 + q (hi).  MODE 0: standard Blake2s-256 with
+// counter t0 and final flag f0; MODE 1: raw compression on a zero state.
+template <int MODE>
+__device__ __forceinline__ void b2s_compress_quad(const QuadLane& L, const u32* msg, u32 t0, u32 f0, u32& lo, u32& hi) {
+    const u32 ha = MODE == 0 ? (L.iv_lo ^ (L.q == 0 ? 0x01010020u : 0u)) : 0u, hb = MODE == 0 ? L.iv_hi : 0u;
+    u32 a = ha, b = hb, c = L.iv_lo, d = L.iv_hi ^ (L.q == 0 ? t0 : 0u) ^ (L.q == 2 ? f0 : 0u);
+    quad_rounds(L, msg, a, b, c, d);
+    lo = ha ^ a ^ c; hi = hb ^ b ^ d;
+}
+
+// Levels from_log .. 0 of a tree whose level from_log + 1 is already in LDS (`nodes`: level k at word offset (2^k - 1) * 8), by a
+// 1024-lane block.  A level with 1024 nodes uses one lane per node, narrower levels one quad per node (4 nodes in flight per
+// 16 lanes, the compression ~3x shorter).  Every node is also written to the tree in global memory (`base`, same layout): the
+// decommitment reads it later.  Ends with a barrier.
+template <int MODE>
+__device__ __forceinline__ void tree_levels_lds(const QuadLane& L, u32* nodes, u32* __restrict__ base, int from_log) {
+    for (int log = from_log; log >= 0; log--) {
+        const u32 n = 1u << log;
+        u32* out_g = base + ((size_t)n - 1) * 8;
+        u32* out_l = nodes + ((size_t)n - 1) * 8;
+        const u32* in_l = nodes + (((size_t)2 << log) - 1) * 8;
+        if (n >= 1024) {
+            for (u32 i = threadIdx.x; i < n; i += 1024) {
+                u32 h[8], m[16];
+#pragma unroll
+                for (int k = 0; k < 8; k++) h[k] = MODE == 0 ? B2S_IV_D[k] : 0u;
+                if (MODE == 0) h[0] ^= 0x01010020u;
+#pragma unroll
+                for (int k = 0; k < 16; k++) m[k] = in_l[(size_t)i * 16 + k];
+                if (MODE == 0) b2s_compress(h, m, 64, 0xFFFFFFFFu); else b2s_compress(h, m, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 8; k++) out_l[(size_t)i * 8 + k] = h[k];
+                gst4(out_g + (size_t)i * 8, make_uint4(h[0], h[1], h[2], h[3]));
+                gst4(out_g + (size_t)i * 8 + 4, make_uint4(h[4], h[5], h[6], h[7]));
+            }
+        } else {
+            for (u32 i = threadIdx.x >> 2; i < n; i += 256) {   // whole quads are active or idle together (DPP stays inside the quad)
+                u32 lo, hi;
+                b2s_compress_quad<MODE>(L, in_l + (size_t)i * 16, MODE == 0 ? 64u : 0u, MODE == 0 ? 0xFFFFFFFFu : 0u, lo, hi);
+                out_l[(size_t)i * 8 + L.q] = lo; out_l[(size_t)i * 8 + 4 + L.q] = hi;
+                gst(out_g + (size_t)i * 8 + L.q, lo); gst(out_g + (size_t)i * 8 + 4 + L.q, hi);
+            }
         }
-        __threadfence_block();
         __syncthreads();
     }
+}
+
+// Top of the tree in ONE launch: layers `top`..0 (2^top <= 1024 nodes) when no columns are injected there.
+// `base` is the start of the tree allocation (layer k at node offset 2^k - 1).  Dynamic LDS: (2^(top+2) - 1) * 32 bytes.
+template <int MODE>
+__global__ __launch_bounds__(1024) void merkle_top_kernel(u32* __restrict__ base, int top) {
+    extern __shared__ __attribute__((aligned(16))) u32 top_nodes[];
+    QuadLane L;
+    quad_lane_init(L);
+    {   // level top + 1 (written by the previous launch) into LDS
+        const size_t w0 = (((size_t)2 << top) - 1) * 8, nw = ((size_t)2 << top) * 8;
+        uint4 v[4];   // <= 2048 nodes = 4 x uint4 per lane: all requested before the first LDS write
+#pragma unroll
+        for (int it = 0; it < 4; it++) { const size_t i = (size_t)threadIdx.x * 4 + (size_t)it * 4096; if (i < nw) v[it] = gld4(base + w0 + i); }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const size_t i = (size_t)threadIdx.x * 4 + (size_t)it * 4096;
+            if (i < nw) { top_nodes[w0 + i] = v[it].x; top_nodes[w0 + i + 1] = v[it].y; top_nodes[w0 + i + 2] = v[it].z; top_nodes[w0 + i + 3] = v[it].w; }
+        }
+    }
+    __syncthreads();
+    tree_levels_lds<MODE>(L, top_nodes, base, top);
+}
+
+static int launch_merkle_top(nx_ctx* ctx, u32* buf, int top) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        NX_HIP(ctx, hipFuncSetAttribute((const void*)merkle_top_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NX_HIP(ctx, hipFuncSetAttribute((const void*)merkle_top_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const size_t lds = (((size_t)4 << top) - 1) * 32;
+    if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_top_kernel<0>, dim3(1), dim3(1024), lds, ctx->stream, buf, top);
+    else hipLaunchKernelGGL(merkle_top_kernel<1>, dim3(1), dim3(1024), lds, ctx->stream, buf, top);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
 }
 
 
@@ -239,10 +340,13 @@ __device__ __forceinline__ void b2s_init_std(u32 h[8]) {
 
 template <int MODE>
 __global__ __launch_bounds__(1024) void fri_tail_kernel(FriTailArgs a) {
-    __shared__ u32 sh_alpha[4];
-    __shared__ u32 sh_digest[8];
+    extern __shared__ __attribute__((aligned(16))) u32 tail_lds[];   // tree nodes of the current layer (level k at (2^k - 1) * 8), then 32 channel words
+    u32* nodes = tail_lds;
+    u32* chan = tail_lds + (((size_t)2 << a.log0) - 1) * 8;          // [0,8) digest, [8,24) message block, [24,28) alpha
     const u32 tid = threadIdx.x;
-    if (tid < 8) sh_digest[tid] = a.state[tid];
+    QuadLane L;
+    quad_lane_init(L);
+    if (tid < 8) chan[tid] = a.state[tid];
     u32 n_sent = 0;
     __syncthreads();
     for (int j = 0; j < a.n_layers; j++) {
@@ -256,79 +360,72 @@ __global__ __launch_bounds__(1024) void fri_tail_kernel(FriTailArgs a) {
             if (MODE == 0) b2s_init_std(h); else { for (int k = 0; k < 8; k++) h[k] = 0; }
 #pragma unroll
             for (int k = 4; k < 16; k++) m[k] = 0;
-            m[0] = c0[i]; m[1] = c1[i]; m[2] = c2[i]; m[3] = c3[i];
+            m[0] = gld(c0 + i); m[1] = gld(c1 + i); m[2] = gld(c2 + i); m[3] = gld(c3 + i);
             if (MODE == 0) b2s_compress(h, m, 16, 0xFFFFFFFFu); else b2s_compress(h, m, 0, 0);
-            u32* o = tree + ((size_t)n - 1 + i) * 8;
+            u32* ol = nodes + ((size_t)n - 1 + i) * 8;
+            u32* og = tree + ((size_t)n - 1 + i) * 8;
 #pragma unroll
-            for (int k = 0; k < 8; k++) o[k] = h[k];
+            for (int k = 0; k < 8; k++) ol[k] = h[k];
+            gst4(og, make_uint4(h[0], h[1], h[2], h[3])); gst4(og + 4, make_uint4(h[4], h[5], h[6], h[7]));
         }
-        __threadfence_block();
         __syncthreads();
-        for (int log = l - 1; log >= 0; log--) {
-            const u32* prev = tree + (((size_t)2 << log) - 1) * 8;
-            u32* out = tree + (((size_t)1 << log) - 1) * 8;
-            for (u32 i = tid; i < (1u << log); i += 1024) {
-                u32 h[8], m[16];
-                if (MODE == 0) b2s_init_std(h); else { for (int k = 0; k < 8; k++) h[k] = 0; }
-#pragma unroll
-                for (int k = 0; k < 16; k++) m[k] = prev[(size_t)i * 16 + k];
-                if (MODE == 0) b2s_compress(h, m, 64, 0xFFFFFFFFu); else b2s_compress(h, m, 0, 0);
-#pragma unroll
-                for (int k = 0; k < 8; k++) out[(size_t)i * 8 + k] = h[k];
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-        if (tid == 0) {
+        tree_levels_lds<MODE>(L, nodes, tree, l - 1);
+        // the channel, on quad 0 (always standard Blake2s): mix_root, then draw_secure_felt
+        if (tid < 4) {
+            u32 lo, hi;
             // Blake2sChannel::mix_root: digest = Blake2s(digest ‖ root)
-            u32 h[8], m[16];
-            b2s_init_std(h);
-#pragma unroll
-            for (int k = 0; k < 8; k++) { m[k] = sh_digest[k]; m[8 + k] = tree[k]; }
-            b2s_compress(h, m, 64, 0xFFFFFFFFu);
-#pragma unroll
-            for (int k = 0; k < 8; k++) sh_digest[k] = h[k];
+            chan[8 + tid] = chan[tid]; chan[12 + tid] = chan[4 + tid]; chan[16 + tid] = nodes[tid]; chan[20 + tid] = nodes[4 + tid];
+            b2s_compress_quad<0>(L, chan + 8, 64, 0xFFFFFFFFu, lo, hi);
+            chan[tid] = lo; chan[4 + tid] = hi;
             n_sent = 0;
-            // draw_secure_felt: Blake2s(digest ‖ n_sent_le32 ‖ 29 zero bytes) until all 8 words are < 2P; the first 4 reduced
+            // draw_secure_felt: Blake2s(digest ‖ n_sent_le32 ‖ 29 zero bytes) until all 8 words are < 2P; the first 4, reduced
             for (;;) {
-                u32 g[8];
-                b2s_init_std(g);
+                chan[8 + tid] = lo; chan[12 + tid] = hi; chan[16 + tid] = tid == 0 ? n_sent : 0u; chan[20 + tid] = 0;
+                u32 g_lo, g_hi;
+                {   // two blocks: 64 bytes (not final), then 1 zero byte (final, t = 65): chain through the quad state
+                    // block 1 on the standard initial state
+                    const u32 ha = L.iv_lo ^ (L.q == 0 ? 0x01010020u : 0u), hb = L.iv_hi;
+                    u32 x = ha, y = hb, z = L.iv_lo, w = L.iv_hi ^ (L.q == 0 ? 64u : 0u);
+                    quad_rounds(L, chan + 8, x, y, z, w);
+                    const u32 h1a = ha ^ x ^ z, h1b = hb ^ y ^ w;
+                    // block 2: all-zero message, t = 65, final
+                    x = h1a; y = h1b; z = L.iv_lo; w = L.iv_hi ^ (L.q == 0 ? 65u : 0u) ^ (L.q == 2 ? 0xFFFFFFFFu : 0u);
 #pragma unroll
-                for (int k = 0; k < 8; k++) m[k] = sh_digest[k];
-                m[8] = n_sent;
-#pragma unroll
-                for (int k = 9; k < 16; k++) m[k] = 0;
-                b2s_compress(g, m, 64, 0);
-#pragma unroll
-                for (int k = 0; k < 16; k++) m[k] = 0;
-                b2s_compress(g, m, 65, 0xFFFFFFFFu);
+                    for (int r = 0; r < 10; r++) {
+                        B2S_G(x, y, z, w, 0u, 0u);
+                        y = QROT(y, 0x39); z = QROT(z, 0x4E); w = QROT(w, 0x93);
+                        B2S_G(x, y, z, w, 0u, 0u);
+                        y = QROT(y, 0x93); z = QROT(z, 0x4E); w = QROT(w, 0x39);
+                    }
+                    g_lo = h1a ^ x ^ z; g_hi = h1b ^ y ^ w;
+                }
                 n_sent++;
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < 8; k++) ok = ok && g[k] < 2u * P;
-                if (ok) { for (int k = 0; k < 4; k++) sh_alpha[k] = g[k] >= P ? g[k] - P : g[k]; break; }
+                const bool mine = g_lo < 2u * P && g_hi < 2u * P;
+                // all four lanes must agree: AND over the quad
+                int ok = mine ? 1 : 0;
+                ok &= __builtin_amdgcn_mov_dpp(ok, 0x39, 0xF, 0xF, true);   // lane q & lane q+1
+                ok &= __builtin_amdgcn_mov_dpp(ok, 0x4E, 0xF, 0xF, true);   // ... & the pair two lanes over
+                if (ok) { chan[24 + tid] = g_lo >= P ? g_lo - P : g_lo; break; }
             }
             u32* rec = a.state + 9 + 12 * j;
-#pragma unroll
-            for (int k = 0; k < 8; k++) rec[k] = tree[k];
-#pragma unroll
-            for (int k = 0; k < 4; k++) rec[8 + k] = sh_alpha[k];
+            rec[tid] = nodes[tid]; rec[4 + tid] = nodes[4 + tid]; rec[8 + tid] = chan[24 + tid];
         }
         __syncthreads();
         // fold_line: next[i] = (f0 + f1) + alpha * ((f0 - f1) / x_i), pairs (2i, 2i+1), 1/x_i = itw layer (H - l), entry i
-        const QM31 alpha = qm(sh_alpha[0], sh_alpha[1], sh_alpha[2], sh_alpha[3]);
+        const QM31 alpha = qm(chan[24], chan[25], chan[26], chan[27]);
         u32* d0 = a.eval[j + 1]; const u32 nh = n >> 1;
         for (u32 i = tid; i < nh; i += 1024) {
-            const u32 xi = a.itw[(1u << a.tw_log) - (1u << l) + i];
-            const QM31 f0 = qm(c0[2 * i], c1[2 * i], c2[2 * i], c3[2 * i]), f1 = qm(c0[2 * i + 1], c1[2 * i + 1], c2[2 * i + 1], c3[2 * i + 1]);
+            const u32 xi = gld(a.itw + ((1u << a.tw_log) - (1u << l) + i));
+            const QM31 f0 = qm(gld(c0 + 2 * i), gld(c1 + 2 * i), gld(c2 + 2 * i), gld(c3 + 2 * i));
+            const QM31 f1 = qm(gld(c0 + 2 * i + 1), gld(c1 + 2 * i + 1), gld(c2 + 2 * i + 1), gld(c3 + 2 * i + 1));
             const QM31 sum = q_add(f0, f1), t = q_mul_m(q_sub(f0, f1), xi);
             const QM31 o = q_add(sum, q_mul(alpha, t));
-            d0[i] = o.a.a; d0[nh + i] = o.a.b; d0[2 * nh + i] = o.b.a; d0[3 * nh + i] = o.b.b;
+            gst(d0 + i, o.a.a); gst(d0 + nh + i, o.a.b); gst(d0 + 2 * nh + i, o.b.a); gst(d0 + 3 * nh + i, o.b.b);
         }
         __threadfence_block();
         __syncthreads();
     }
-    if (tid < 8) a.state[tid] = sh_digest[tid];
+    if (tid < 8) a.state[tid] = chan[tid];
     if (tid == 0) a.state[8] = n_sent;
 }
 
@@ -348,7 +445,7 @@ int tree_alloc(nx_ctx* ctx, uint32_t max_log, nx_tree** out) {
 // Host side: h_state = digest[8] in; digest[8], n_sent, n_layers x (root[8], alpha[4]) out.  evals[j] / trees[j] are device buffers
 // the caller allocated (evals[0] = the input layer of log size log0; evals has n_layers + 1 entries).
 int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, u32* const* evals, u32* const* trees, int n_layers, int log0, u32* h_state) {
-    if (n_layers < 1 || n_layers > FRI_TAIL_MAX_LAYERS || log0 < n_layers || (u32)log0 > tw->log_half) return set_err(ctx, NX_ERR_ARG, "fri_tail: bad layer range");
+    if (n_layers < 1 || n_layers > FRI_TAIL_MAX_LAYERS || log0 < n_layers || log0 > 11 || (u32)log0 > tw->log_half) return set_err(ctx, NX_ERR_ARG, "fri_tail: bad layer range");
     FriTailArgs a;
     for (int j = 0; j <= n_layers; j++) a.eval[j] = evals[j];
     for (int j = 0; j < n_layers; j++) a.tree[j] = trees[j];
@@ -359,8 +456,15 @@ int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, u32* const* evals, u32* const* 
     a.state = d_state;
     hipError_t e = hipMemcpyAsync(d_state, h_state, 32, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(fri_tail_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(fri_tail_kernel<1>, dim3(1), dim3(1024), 0, ctx->stream, a);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)fri_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)fri_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        const size_t lds = ((((size_t)2 << log0) - 1) * 8 + 32) * 4;
+        if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(fri_tail_kernel<0>, dim3(1), dim3(1024), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(fri_tail_kernel<1>, dim3(1), dim3(1024), lds, ctx->stream, a);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h_state, d_state, words * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -415,9 +519,7 @@ static int build_inner_layers(nx_ctx* ctx, nx_tree* t, uint32_t max_log, const s
     int top_fused = std::min(10, std::min((int)max_log - 1, smallest_col_log - 1));
     for (int log = (int)max_log - 1; log >= 0; log--) {
         if (log == top_fused && log >= 1) {
-            if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_top_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
-            else hipLaunchKernelGGL(merkle_top_kernel<1>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
-            NX_LAUNCH_CHECK(ctx);
+            NX_TRY(launch_merkle_top(ctx, buf, log));
             break;
         }
         size_t c0 = ci;
@@ -574,10 +676,7 @@ int nx_merkle_from_leaves(nx_ctx* ctx, const uint32_t* d_leaf_digests, uint32_t 
     ColSet none; none.base = nullptr; none.stride = 0; none.table = nullptr;
     for (int log = (int)log_size - 1; log >= 0 && rc == NX_OK; log--) {
         if (log == top_fused && log >= 1) {
-            if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_top_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
-            else hipLaunchKernelGGL(merkle_top_kernel<1>, dim3(1), dim3(1024), 0, ctx->stream, buf, log);
-            hipError_t le = hipGetLastError();
-            if (le != hipSuccess) rc = hip_fail(ctx, le, "merkle_top_kernel", __FILE__, __LINE__);
+            rc = launch_merkle_top(ctx, buf, log);
             break;
         }
         rc = merkle_layer(ctx, none, 0, t->layers[log + 1], t->layers[log], (uint32_t)log);
