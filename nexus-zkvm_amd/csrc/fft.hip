@@ -410,6 +410,10 @@ int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, ui
     for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += g_tune.batch_cols, bi++) {
         u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
         streams_pick(ctx, (int)bi, ns);
+        if (log_expand == 1 && log_size >= 14 && !g_tune.legacy && fft13_lde_fused_enabled()) {
+            rc = fft13_lde(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, sub_colset(out, c0));   // middle passes fused (fft13.hip)
+            continue;
+        }
         rc = interpolate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size);
         if (rc == NX_OK) rc = evaluate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, n, sub_colset(out, c0));
     }

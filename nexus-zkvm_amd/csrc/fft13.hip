@@ -399,6 +399,150 @@ __global__ __launch_bounds__(T13_ROWS >> RB, CB == 1 ? NX_FFT_MINWAVES1 : NX_FFT
 #endif
 }
 
+// ---- the fused middle of an LDE with blow-up 2 ---------------------------------------------------------------------------------
+// The inverse transform's LAST pass and the forward transform's FIRST pass have the same tile geometry (layers [lo, lo+K) with
+// lo + K = n; the forward one runs on 2^(n+1) points whose index bit n selects a replica of the coefficient tile).  One block
+// therefore does both: 9 inverse layers on the tile, the 1/N scale, the coefficients out to the column (the commitment scheme keeps
+// them for the OODS evaluation), then — from registers, without a trip through memory — the forward edge layer of BOTH replicas
+// into two LDS tiles, their remaining layers, and the two output tiles.  Against the separate passes this saves one read of the
+// coefficients and two of the four block prologues/epilogues per tile; LDS: two single-column tiles (68 KB, 2 blocks per CU).
+struct PassMid {
+    ColSet cols, out;            // evaluations in / coefficients out (in place, 2^n words); LDE out (2^(n+1) words)
+    const u32* itw; const u32* tw;   // DOUBLED inverse / forward twiddle tables
+    u32 tw_log;
+    int n, lo, K, B;
+    u32 scale, n_cols, tiles;    // tiles = 2^(n - 13); one column per block (n_groups == n_cols)
+};
+
+template <int RB, int KT>
+__global__ __launch_bounds__(T13_ROWS >> RB, 1) void lde_mid_kernel(PassMid m) {
+    constexpr int CB = 1;
+    constexpr int NT = T13_ROWS >> RB;
+    constexpr int MAXR = (T13_S - 1 + RB - 1) / RB;
+    constexpr u32 TILE_ROWS_PADDED = T13_ROWS + (T13_ROWS >> 4);
+    extern __shared__ __attribute__((aligned(16))) u32 lds13[];
+    Row<CB>* ldsA = reinterpret_cast<Row<CB>*>(lds13);
+    Row<CB>* ldsB = ldsA + TILE_ROWS_PADDED;
+
+    const int K = KT ? KT : m.K, B = T13_S - K, lo = m.lo, lb = lo - B;
+    const u32 maskB = (1u << B) - 1;
+    auto goff = [&](u32 t) -> u32 { return ((t >> B) << lo) + (t & maskB); };
+    const int K1 = K - 1, nfull = K1 / RB, rem = K1 % RB;
+    auto bp_of = [&](int i) -> int { return B + rem + RB * i; };
+    // descriptors for the shared round helpers (they read tw, tw_log, n, lo, B)
+    Pass13 ai; ai.tw = m.itw; ai.tw_log = m.tw_log; ai.n = m.n; ai.log_in = m.n; ai.lo = lo; ai.K = K; ai.B = B;
+    ai.scale = 0; ai.n_cols = m.n_cols; ai.n_groups = m.n_cols; ai.tiles = m.tiles; ai.rep_log = 0;
+    Pass13 af = ai; af.tw = m.tw; af.n = m.n + 1;
+
+    u32 tile, col;
+    {
+        const u32 b = blockIdx.x;
+        if (m.tiles >= 8) { const u32 xcd = b & 7, y = b >> 3; col = y % m.n_cols; tile = xcd * (m.tiles >> 3) + y / m.n_cols; }
+        else { col = b % m.n_cols; tile = b / m.n_cols; }
+    }
+    const u32 lowblock = tile & ((1u << lb) - 1), high = tile >> lb;
+    const u32 tile_base = (high << (lo + K)) | (lowblock << B);
+    u32* __restrict__ cc = m.cols.col(col);
+    u32* __restrict__ oc = m.out.col(col);
+
+    constexpr int IT = (int)(T13_ROWS / 4) / NT;
+    uint4 xa[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) xa[it] = gload4(cc + tile_base + goff((threadIdx.x + it * NT) * 4));
+    u32 twA[1 << RB], twB[1 << RB];
+    if (nfull) tw_request<RB, false>(ai, bp_of(0), tile_base, twA);
+    const int le = lo + K - 1;
+    const u32 tei2 = m.itw[((1u << m.tw_log) - (1u << (m.n - le))) + high], tei = tei2 >> 1;
+    // forward geometry of replica r: tile index r * tiles + tile in the 2^(n+1) index space
+    u32 fbase[2], tef2[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const u32 tf = (u32)r * m.tiles + tile, lbk = tf & ((1u << lb) - 1), hf = tf >> lb;
+        fbase[r] = (hf << (lo + K)) | (lbk << B);
+        tef2[r] = m.tw[((1u << m.tw_log) - (1u << (m.n + 1 - le))) + hf];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const u32 p = pad13((threadIdx.x + it * NT) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { Row<CB> r; r.c[0] = get4(xa[it], i); ldsA[p + i] = r; }
+    }
+    __syncthreads();
+
+    // ---- inverse layers [lo, lo + K - 1)
+    if (rem) rem_round13<RB, CB, NT, true>(ldsA, ai, rem, B, tile_base);
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) {
+        if (j < nfull) {
+            u32* cur = (j & 1) ? twB : twA;
+            u32* nxt = (j & 1) ? twA : twB;
+            if (j + 1 < nfull) tw_request<RB, false>(ai, bp_of(j + 1), tile_base, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            round_full<RB, CB, true, false>(ldsA, bp_of(j), cur);
+            __syncthreads();
+        }
+    }
+    // forward step s = replica * nfull + j runs round i = nfull - 1 - j; step s uses (s odd ? twB : twA)
+    if (nfull) tw_request<RB, false>(af, bp_of(nfull - 1), fbase[0], twA);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- inverse top layer + scale -> coefficients (to the column); forward edge layer of both replicas -> the two LDS tiles
+    {
+        const u32 sc2 = m.scale << 1, tes2 = m_mul(tei, m.scale) << 1;
+#pragma unroll
+        for (int it = 0; it < (int)(T13_HALF / 4) / NT; it++) {
+            const u32 t = (threadIdx.x + it * NT) * 4;
+            const u32 pa = pad13(t), pb = pad13(t + T13_HALF);
+            u32 ca[4], cb[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32 x = ldsA[pa + i].c[0], y = ldsA[pb + i].c[0];
+                ca[i] = m_mul_dbl(m_add(x, y), sc2); cb[i] = m_mul_dbl(m_sub(x, y), tes2);
+            }
+            gstore4(cc + tile_base + goff(t), make_uint4(ca[0], ca[1], ca[2], ca[3]));
+            gstore4(cc + tile_base + goff(t + T13_HALF), make_uint4(cb[0], cb[1], cb[2], cb[3]));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                u32 u0 = ca[i], w0 = cb[i], u1 = ca[i], w1 = cb[i];
+                bfly13<false>(u0, w0, tef2[0], false);
+                bfly13<false>(u1, w1, tef2[1], false);
+                Row<CB> r;
+                r.c[0] = u0; ldsA[pa + i] = r; r.c[0] = w0; ldsA[pb + i] = r;
+                r.c[0] = u1; ldsB[pa + i] = r; r.c[0] = w1; ldsB[pb + i] = r;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- forward layers of the two replicas, then their tiles out
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        Row<CB>* lds = r ? ldsB : ldsA;
+#pragma unroll
+        for (int j = 0; j < MAXR; j++) {
+            if (j < nfull) {
+                const int i = nfull - 1 - j;
+                const int sidx = r * nfull + j;
+                u32* cur = (sidx & 1) ? twB : twA;
+                u32* nxt = (sidx & 1) ? twA : twB;
+                if (i > 0) tw_request<RB, false>(af, bp_of(i - 1), fbase[r], nxt);
+                else if (r == 0) tw_request<RB, false>(af, bp_of(nfull - 1), fbase[1], nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                round_full<RB, CB, false, false>(lds, bp_of(i), cur);
+                __syncthreads();
+            }
+        }
+        if (rem) rem_round13<RB, CB, NT, false>(lds, af, rem, B, fbase[r]);
+#pragma unroll
+        for (int it = 0; it < (int)(T13_ROWS / 4) / NT; it++) {
+            const u32 t = (threadIdx.x + it * NT) * 4;
+            const u32 p = pad13(t);
+            const Row<CB> x0 = lds[p], x1 = lds[p + 1], x2 = lds[p + 2], x3 = lds[p + 3];
+            gstore4(oc + fbase[r] + goff(t), make_uint4(x0.c[0], x1.c[0], x2.c[0], x3.c[0]));
+        }
+    }
+}
+
 // ---- planning: layers [0, m) -> the FIRST pass [0, 13) plus passes of <= kmax layers (runs of 2^(13-kmax) words) ----
 struct Plan13 { int lo, K, B; };
 static int plan13_kmax() {
@@ -502,5 +646,64 @@ extern "C" int nx_fft13_trace_read(unsigned long long* out32, int reset) {
     return 0;
 }
 #endif
+
+template <int RB, int KT>
+static int launch_mid_t(nx_ctx* ctx, const PassMid& m) {
+    static bool attr_set = false;
+    const size_t lds_bytes = ((size_t)T13_ROWS + (T13_ROWS >> 4)) * 4 * 2;
+    if (!attr_set) {
+        NX_HIP(ctx, hipFuncSetAttribute((const void*)lde_mid_kernel<RB, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lde_mid_kernel<RB, KT>), dim3(m.tiles * m.n_cols), dim3(T13_ROWS >> RB), lds_bytes, ctx->cur, m);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+static int launch_mid(nx_ctx* ctx, const PassMid& m) {
+    switch (m.K) {
+    case 1: return launch_mid_t<4, 1>(ctx, m);
+    case 2: return launch_mid_t<4, 2>(ctx, m);
+    case 3: return launch_mid_t<4, 3>(ctx, m);
+    case 4: return launch_mid_t<4, 4>(ctx, m);
+    case 5: return launch_mid_t<4, 5>(ctx, m);
+    case 6: return launch_mid_t<4, 6>(ctx, m);
+    case 7: return launch_mid_t<4, 7>(ctx, m);
+    case 8: return launch_mid_t<4, 8>(ctx, m);
+    case 9: return launch_mid_t<4, 9>(ctx, m);
+    default: return launch_mid_t<4, 0>(ctx, m);
+    }
+}
+
+bool fft13_lde_fused_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("NX_FFT_FUSED"); v = e ? (atoi(e) != 0) : 1; }
+    return v != 0;
+}
+
+// iFFT in place (coefficients stay in `cols`) + FFT onto 2^(n+1) points in `out`, n >= 14: every pass as in fft13_interpolate /
+// fft13_evaluate except the inverse transform's last pass and the forward transform's first pass, which are one launch.
+int fft13_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_cols, int n, ColSet out) {
+    std::vector<Plan13> plan = plan13(n);
+    const size_t P = plan.size();
+    if (P < 2) return set_err(ctx, NX_ERR_ARG, "fft13_lde: needs at least two passes");
+    for (size_t i = 0; i + 1 < P; i++) {
+        Pass13 a; a.src = cols; a.dst = cols; a.tw = tw->d_itw2; a.tw_log = tw->log_half; a.n = n; a.log_in = n;
+        a.lo = plan[i].lo; a.K = plan[i].K; a.B = plan[i].B; a.scale = 0;
+        a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n - T13_S); a.rep_log = 0;
+        NX_TRY(launch13(ctx, true, i == 0, a));
+    }
+    {
+        PassMid m; m.cols = cols; m.out = out; m.itw = tw->d_itw2; m.tw = tw->d_tw2; m.tw_log = tw->log_half; m.n = n;
+        m.lo = plan[P - 1].lo; m.K = plan[P - 1].K; m.B = plan[P - 1].B; m.scale = m_inv(1u << n); m.n_cols = n_cols; m.tiles = 1u << (n - T13_S);
+        NX_TRY(launch_mid(ctx, m));
+    }
+    for (size_t k = P - 1; k-- > 0;) {
+        Pass13 a; a.src = out; a.dst = out; a.tw = tw->d_tw2; a.tw_log = tw->log_half; a.n = n + 1; a.log_in = n + 1;
+        a.lo = plan[k].lo; a.K = plan[k].K; a.B = plan[k].B; a.scale = 0;
+        a.n_cols = n_cols; a.n_groups = 0; a.tiles = 1u << (n + 1 - T13_S); a.rep_log = 0;
+        NX_TRY(launch13(ctx, false, k == 0, a));
+    }
+    return NX_OK;
+}
 
 }  // namespace nx

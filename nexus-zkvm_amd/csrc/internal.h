@@ -147,5 +147,7 @@ int streams_join(nx_ctx* ctx, int n_streams);
 // fast path for transforms of >= 2^13 points (fft13.hip)
 int fft13_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n);
 int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_cols, int log_in, int n, ColSet out);
+int fft13_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n, ColSet out);   // blow-up 2, n >= 14: middle passes fused
+bool fft13_lde_fused_enabled();
 
 }  // namespace nx
