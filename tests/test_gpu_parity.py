@@ -326,6 +326,38 @@ def test_large_prove_accepted_by_oracle_verifier(be, nz, oracle):
     assert stats["total"] > 0 and stats["lde_kernel_ms"] > 0
 
 
+def test_headline_prove_verifies_and_the_session_reproduces_it(be, nz, oracle):
+    """BASELINE config #3 at full size (2^22 rows, 27 + 347 + 64 columns): the proof the bench times is accepted by the oracle's
+    verifier (a check whose cost does not grow with the trace), a tampered one is not, and the generic session — the same machine as
+    a recorded AIR, traces filled on the device into session-owned columns — emits the same bytes."""
+    import ctypes as C
+    import nexus_zkvm_amd.air_program as ap
+    from test_air_program_cpu import synthetic_program
+    log, n_pre, n_main, n_inter = 22, 27, 347, 64
+    comps = [(log, n_pre, n_main, n_inter)]
+    cfg, ocfg = nz.default_config(), O.default_cfg()
+    w = be.prove(comps, cfg, seed=1)
+    assert oracle.verify_synth(comps, ocfg, w) is None
+    w2 = w.copy(); w2[len(w) // 3] ^= 1
+    assert oracle.verify_synth(comps, ocfg, w2) is not None
+    cols = [(0, k) for k in range(n_pre)] + [(1, k) for k in range(n_main)] + [(2, k) for k in range(n_inter)]
+    comp = ap.Component(log, synthetic_program(ap, n_pre, n_main, n_inter), cols)
+    carr = be._comps(comps)
+    s = be.prover_session(cfg, log)
+
+    def fill(tree, n, inter_seed=0):
+        ptrs = s.tree_begin([log] * n)
+        be._chk(be.L.nx_synth_fill_tree(be.ctx, carr, 1, tree, C.c_uint64(1), C.c_uint64(inter_seed), (C.c_void_p * n)(*ptrs)))
+        return s.tree_commit()
+    s.mix_u64(log)
+    fill(0, n_pre); fill(1, n_main)
+    z = s.draw_felt()
+    s.mix_felts(np.zeros(4, np.uint32))
+    fill(2, n_inter, (int(z[0]) << 32) ^ int(z[1]) ^ (int(z[2]) << 16) ^ (int(z[3]) << 48))
+    assert np.array_equal(s.prove([comp]), w)
+    s.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_sharded_leaf_chain_equals_single_commit(be, mode):
     """SURVEY §8(e) / config #4 building blocks on one GPU: the columns of a tree are cut into 16-aligned shards (as
