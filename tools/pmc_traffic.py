@@ -56,7 +56,8 @@ def main():
             res[counter] = run_pass(counter, a.log, a.cols, wd)
     copy_bytes = a.cols * (4 << (a.log + 1))
     def pick(agg, pat):
-        return {k: v for k, v in agg.items() if pat in k}
+        pats = ("fft", "lde_mid") if pat == "fft" else (pat,)     # the LDE's kernels: fft13_kernel passes + the fused middle launch
+        return {k: v for k, v in agg.items() if any(q in k for q in pats)}
     cal = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         ck = pick(res[counter], "copy_kernel")

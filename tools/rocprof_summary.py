@@ -13,10 +13,10 @@ print("\n# per launch shape (grid threads, block, dynamic LDS bytes): calls, avg
 for r in cur.execute("select name, grid_x, workgroup_x, lds_size, count(*), avg(duration)/1000.0 from kernels group by name, grid_x, workgroup_x, lds_size having avg(duration) > 20000 order by 1, 6 desc"):
     print("%-50s grid=%-10d block=%-5d lds=%-6d calls=%-5d avg_us=%.1f" % (r[0][:50], r[1], r[2], r[3], r[4], r[5]), file=out)
 
-# The fft13 launches of a column batch run on two streams and overlap: the sum of their durations double-counts the time they
+# The LDE launches (fft13_kernel, lde_mid_kernel) of a column batch run on two streams and overlap: the sum of their durations double-counts the time they
 # occupy.  bench.py's roofline.kernel_ms is the wall time of the LDE work (HIP events around the stream fork/join); the matching
 # figure from this trace is the UNION of the fft13 kernel intervals.
-rows = list(cur.execute("select start, end from kernels where name like '%fft13_kernel%' order by start"))
+rows = list(cur.execute("select start, end from kernels where name like '%fft13_kernel%' or name like '%lde_mid_kernel%' order by start"))
 if rows:
     total = sum(b - a for a, b in rows)
     union, cs, ce = 0, rows[0][0], rows[0][1]
@@ -26,5 +26,5 @@ if rows:
     union += ce - cs
     n_fill = cur.execute("select count(*) from kernels where name like '%synth_fill%'").fetchone()[0]
     proves = max(1, n_fill // 3)
-    print("\n# fft13 kernels: %d launches, sum of durations %.1f us, union of their intervals %.1f us (%d proves -> %.2f ms of LDE wall time per prove; "
+    print("\n# LDE kernels (fft13_kernel passes + lde_mid_kernel): %d launches, sum of durations %.1f us, union of their intervals %.1f us (%d proves -> %.2f ms of LDE wall time per prove; "
           "bench.py roofline.kernel_ms measures this with HIP events)" % (len(rows), total / 1e3, union / 1e3, proves, union / 1e6 / proves), file=out)
