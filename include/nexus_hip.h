@@ -349,6 +349,10 @@ int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, co
 /* LogupTraceGenerator::finalize_last on the last column (in place): claimed_sum = sum over all rows; the column becomes
  * the inclusive prefix sum, in natural coset order, of (value - claimed_sum / 2^log_size). */
 int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_col4, uint32_t claimed_sum[4]);
+/* The same for n_cols secure columns of one size (d_cols4: n_cols x 4 coordinate pointers; claimed_sums: n_cols x 4 words) in three
+ * launches and one device-to-host copy: the form for AIRs with many components / logup columns (BASELINE config #5). */
+int nx_logup_finalize_last_batch(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_cols4, uint32_t n_cols,
+                                 uint32_t* claimed_sums);
 
 /* Config #2: LDE + Blake2s commit of n_cols random columns of 2^log_size rows (already resident,
  * bit-reversed evaluations, overwritten by their coefficients); d_lde receives the LDE columns. */

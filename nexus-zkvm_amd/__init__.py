@@ -587,6 +587,14 @@ class HipBackend:
         self._chk(self.L.nx_logup_finalize_last(self.ctx, col4.log_size, col4.col_ptrs(), cs.ctypes.data_as(C.c_void_p)))
         return cs
 
+    def logup_finalize_last_batch(self, cols4_list):
+        """finalize_last for several secure columns of one size in one call; returns the claimed sums (n x 4)."""
+        n = len(cols4_list)
+        ptrs = (C.c_void_p * max(1, 4 * n))(*[c.ptr.value + q * (4 << c.log_size) for c in cols4_list for q in range(4)])
+        cs = np.zeros((n, 4), np.uint32)
+        self._chk(self.L.nx_logup_finalize_last_batch(self.ctx, cols4_list[0].log_size if n else 0, ptrs, n, cs.ctypes.data_as(C.c_void_p)))
+        return cs
+
     # ---- FriOps ----
     def fold_circle_into_line(self, tw, dst4, src4, alpha):
         a = _u32(alpha)

@@ -93,8 +93,11 @@ __device__ __forceinline__ u32 pos_of_coset_row(u32 c, int log) {
 constexpr int SCAN_ITEMS = 16, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_ITEMS * SCAN_THREADS;
 
 // phase 1: per block of 4096 consecutive coset rows, the block-local inclusive scan (written back in place) and the block total
-__global__ __launch_bounds__(SCAN_THREADS) void logup_scan_local_kernel(Sec4 col, int log, u32* __restrict__ block_sums /*4 per block*/) {
+__global__ __launch_bounds__(SCAN_THREADS) void logup_scan_local_kernel(const Sec4* __restrict__ cols /*one per blockIdx.y*/, int log,
+                                                                        u32* __restrict__ all_sums /*[column][block][4]*/) {
     __shared__ u32 lds[4][SCAN_THREADS];
+    const Sec4 col = cols[blockIdx.y];
+    u32* __restrict__ block_sums = all_sums + (size_t)blockIdx.y * gridDim.x * 4;
     const u32 n = 1u << log;
     const u32 c0 = (blockIdx.x * SCAN_THREADS + threadIdx.x) * SCAN_ITEMS;
     u32 pos[SCAN_ITEMS];
@@ -132,10 +135,48 @@ __global__ __launch_bounds__(SCAN_THREADS) void logup_scan_local_kernel(Sec4 col
         for (int q = 0; q < 4; q++) block_sums[4 * blockIdx.x + q] = lds[q][SCAN_THREADS - 1];
 }
 
+// phase 2 (one block per column): exclusive scan of the block totals in place; meta[column] = claimed sum (4) ‖ claimed / N (4)
+__global__ __launch_bounds__(SCAN_THREADS) void logup_scan_sums_kernel(u32* __restrict__ all_sums, u32 n_blocks, int log, u32* __restrict__ meta) {
+    __shared__ u32 lds[4][SCAN_THREADS];
+    u32* sums = all_sums + (size_t)blockIdx.x * n_blocks * 4;
+    const u32 per = (n_blocks + SCAN_THREADS - 1) / SCAN_THREADS, b0 = threadIdx.x * per, b1 = min(n_blocks, b0 + per);
+    QM31 tot = q_zero();
+    for (u32 b = b0; b < b1; b++) tot = q_add(tot, qm(sums[4 * b], sums[4 * b + 1], sums[4 * b + 2], sums[4 * b + 3]));
+    lds[0][threadIdx.x] = tot.a.a; lds[1][threadIdx.x] = tot.a.b; lds[2][threadIdx.x] = tot.b.a; lds[3][threadIdx.x] = tot.b.b;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        u32 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) t[q] = threadIdx.x >= (u32)off ? lds[q][threadIdx.x - off] : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) lds[q][threadIdx.x] = m_add(lds[q][threadIdx.x], t[q]);
+        __syncthreads();
+    }
+    QM31 run = threadIdx.x ? qm(lds[0][threadIdx.x - 1], lds[1][threadIdx.x - 1], lds[2][threadIdx.x - 1], lds[3][threadIdx.x - 1]) : q_zero();
+    for (u32 b = b0; b < b1; b++) {
+        const QM31 t = qm(sums[4 * b], sums[4 * b + 1], sums[4 * b + 2], sums[4 * b + 3]);
+        sums[4 * b] = run.a.a; sums[4 * b + 1] = run.a.b; sums[4 * b + 2] = run.b.a; sums[4 * b + 3] = run.b.b;
+        run = q_add(run, t);
+    }
+    if (threadIdx.x == SCAN_THREADS - 1) {
+        const QM31 total = qm(lds[0][SCAN_THREADS - 1], lds[1][SCAN_THREADS - 1], lds[2][SCAN_THREADS - 1], lds[3][SCAN_THREADS - 1]);
+        const QM31 shift = q_mul_m(total, m_inv((1u << log) % P));
+        u32* o = meta + 8 * blockIdx.x;
+        o[0] = total.a.a; o[1] = total.a.b; o[2] = total.b.a; o[3] = total.b.b;
+        o[4] = shift.a.a; o[5] = shift.a.b; o[6] = shift.b.a; o[7] = shift.b.b;
+    }
+}
+
 // phase 3: value = local + offset[block of its coset row] - (coset row + 1) * shift
-__global__ __launch_bounds__(256) void logup_scan_fix_kernel(Sec4 col, int log, const u32* __restrict__ block_offsets /*exclusive, 4 per block*/, QM31 shift) {
+__global__ __launch_bounds__(256) void logup_scan_fix_kernel(const Sec4* __restrict__ cols, int log, const u32* __restrict__ all_offsets /*exclusive, [column][block][4]*/,
+                                                             u32 n_blocks, const u32* __restrict__ meta) {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (1u << log)) return;
+    const Sec4 col = cols[blockIdx.y];
+    const u32* __restrict__ block_offsets = all_offsets + (size_t)blockIdx.y * n_blocks * 4;
+    const u32* mm = meta + 8 * blockIdx.y;
+    const QM31 shift = qm(mm[4], mm[5], mm[6], mm[7]);
     const u32 p = pos_of_coset_row(c, log), b = c / SCAN_BLOCK;
     const QM31 off = qm(block_offsets[4 * b], block_offsets[4 * b + 1], block_offsets[4 * b + 2], block_offsets[4 * b + 3]);
     const QM31 v = q_sub(q_add(qm(col.c[0][p], col.c[1][p], col.c[2][p], col.c[3][p]), off), q_mul_m(shift, m_reduce64((u64)c + 1)));
@@ -209,34 +250,39 @@ int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, co
     return NX_OK;
 }
 
-int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_col4, uint32_t claimed_sum[4]) {
-    if (!ctx || !d_col4 || !claimed_sum) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: NULL argument");
+// LogupTraceGenerator::finalize_last for n_cols secure columns of one size in three launches and ONE device-to-host copy (the
+// claimed sums): per-block scans, a one-block scan of the block totals per column, the fix-up.  d_cols4: n_cols x 4 pointers.
+int nx_logup_finalize_last_batch(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_cols4, uint32_t n_cols, uint32_t* claimed_sums) {
+    if (!ctx || !d_cols4 || !claimed_sums) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: NULL argument");
     if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: log_size too large");
-    Sec4 col; for (int q = 0; q < 4; q++) col.c[q] = d_col4[q];
+    if (n_cols == 0) return NX_OK;
+    if (n_cols > 65535) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: at most 65535 columns per call");
     const u32 n = 1u << log_size, n_blocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    u32* d_sums = nullptr;
-    NX_TRY(dev_alloc(ctx, (size_t)n_blocks * 16, (void**)&d_sums));
-    hipLaunchKernelGGL(logup_scan_local_kernel, dim3(n_blocks), dim3(SCAN_THREADS), 0, ctx->stream, col, (int)log_size, d_sums);
-    hipError_t e = hipGetLastError();
-    std::vector<u32> sums((size_t)n_blocks * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(sums.data(), d_sums, sums.size() * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { dev_free(ctx, d_sums); return hip_fail(ctx, e, "nx_logup_finalize_last", __FILE__, __LINE__); }
-    // exclusive scan of the block totals on the host; the grand total is the claimed sum
-    QM31 run = q_zero();
-    for (u32 b = 0; b < n_blocks; b++) { QM31 t = q_load(&sums[4 * b]); q_store(&sums[4 * b], run); run = q_add(run, t); }
-    q_store(claimed_sum, run);
-    const QM31 shift = q_mul_m(run, m_inv(n % P));   // claimed_sum / N
-    e = hipMemcpyAsync(d_sums, sums.data(), sums.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    std::vector<Sec4> h(n_cols);
+    for (u32 k = 0; k < n_cols; k++) for (int q = 0; q < 4; q++) { if (!d_cols4[4 * k + q]) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: NULL column"); h[k].c[q] = d_cols4[4 * k + q]; }
+    uint8_t* blob = nullptr;
+    const size_t b_tab = ((size_t)n_cols * sizeof(Sec4) + 15) & ~(size_t)15, b_sums = (size_t)n_cols * n_blocks * 16, b_meta = (size_t)n_cols * 32;
+    NX_TRY(dev_alloc(ctx, b_tab + b_sums + b_meta, (void**)&blob));
+    const Sec4* d_tab = (const Sec4*)blob; u32* d_sums = (u32*)(blob + b_tab); u32* d_meta = (u32*)(blob + b_tab + b_sums);
+    hipError_t e = hipMemcpyAsync(blob, h.data(), (size_t)n_cols * sizeof(Sec4), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(logup_scan_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, col, (int)log_size, (const u32*)d_sums, shift);
+        hipLaunchKernelGGL(logup_scan_local_kernel, dim3(n_blocks, n_cols), dim3(SCAN_THREADS), 0, ctx->stream, d_tab, (int)log_size, d_sums);
+        hipLaunchKernelGGL(logup_scan_sums_kernel, dim3(n_cols), dim3(SCAN_THREADS), 0, ctx->stream, d_sums, n_blocks, (int)log_size, d_meta);
+        hipLaunchKernelGGL(logup_scan_fix_kernel, dim3((n + 255) / 256, n_cols), dim3(256), 0, ctx->stream, d_tab, (int)log_size, (const u32*)d_sums, n_blocks, (const u32*)d_meta);
         e = hipGetLastError();
     }
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);   // `sums` and d_sums must outlive the copy / kernel
-    dev_free(ctx, d_sums);
+    std::vector<u32> meta((size_t)n_cols * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(meta.data(), d_meta, meta.size() * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);   // `h`, `meta` and the blob must outlive the copies / kernels
+    dev_free(ctx, blob);
     if (e != hipSuccess) return hip_fail(ctx, e, "nx_logup_finalize_last", __FILE__, __LINE__);
     if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_logup_finalize_last(sync)", __FILE__, __LINE__);
+    for (u32 k = 0; k < n_cols; k++) memcpy(claimed_sums + 4 * k, &meta[8 * k], 16);
     return NX_OK;
+}
+
+int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_col4, uint32_t claimed_sum[4]) {
+    return nx_logup_finalize_last_batch(ctx, log_size, d_col4, 1, claimed_sum);
 }
 
 }  // extern "C"

@@ -775,6 +775,19 @@ def test_session_refuses_invalid_traces_and_misuse(be, nz, oracle):
         be.prover_session(cfg, 5).tree_begin([6])
 
 
+@pytest.mark.parametrize("log,k", [(4, 3), (12, 5), (13, 2), (17, 3)])
+def test_logup_finalize_last_batch_matches_oracle(be, oracle, log, k):
+    """Several secure columns finalised in one call (block scans, device scan of the block totals, fix-up) == the oracle's
+    finalize_last on each; sizes below, at and above one 4096-row scan block and across many blocks."""
+    rng = np.random.default_rng(log * 10 + k)
+    cols = [rng.integers(0, P, (4, 1 << log), dtype=np.uint32) for _ in range(k)]
+    dev = [be.columns_from_host(c) for c in cols]
+    claimed = be.logup_finalize_last_batch(dev)
+    for c, d, cs in zip(cols, dev, claimed):
+        ref_cols, ref_sum = oracle.logup_finalize_last([x.copy() for x in c])
+        assert np.array_equal(cs, ref_sum) and np.array_equal(d.to_cpu(), np.stack(ref_cols))
+
+
 @pytest.mark.parametrize("log", [6, 12])
 def test_session_end_to_end_with_device_logup(be, nz, oracle, log):
     """Ranks 1 + 2 + the session together, nothing but the main trace and the lookup elements on the host: the interaction column
