@@ -125,7 +125,12 @@ int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_co
 // channel on the device.
 constexpr int FRI_TAIL_LOG = 11, FRI_TAIL_MAX_LAYERS = 16;   // 2^12 and up: one CU is slower than the per-layer launches (measured)
 int tree_alloc(nx_ctx* ctx, uint32_t max_log, nx_tree** out);
-int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* evals, uint32_t* const* trees, int n_layers, int log0, uint32_t* h_state);
+// FRI channel state on the device: words [0,8) digest, [8] n_sent, then one record per committed layer at 9 + 12 j: root[8], alpha[4].
+constexpr int FRI_STATE_HEAD = 9, FRI_STATE_REC = 12;
+int fri_channel_step(nx_ctx* ctx, uint32_t* d_state, const uint32_t* d_root, int j);   // mix_root(root) + draw_secure_felt -> record j
+int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* evals, uint32_t* const* trees, int n_layers, int log0, uint32_t* d_state, int j0);
+int fold_circle_dev(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha);
+int fold_line_dev(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha, uint32_t* const* d_dst4);
 
 struct TreePipe {
     nx_tree* tree = nullptr;

@@ -329,13 +329,67 @@ struct FriTailArgs {
     u32* tree[FRI_TAIL_MAX_LAYERS];       // tree[j]: (2^(log0 - j + 1) - 1) nodes x 8 words, layer k at node offset 2^k - 1
     int n_layers, log0;
     const u32* itw; u32 tw_log;
-    u32* state;                           // in: digest[8]; out: digest[8], n_sent, then n_layers x (root[8], alpha[4])
+    u32* state;                           // device FRI channel state (internal.h): digest[8], n_sent, records (root[8], alpha[4])
+    int j0;                               // record index of this launch's first layer
 };
 
 __device__ __forceinline__ void b2s_init_std(u32 h[8]) {
 #pragma unroll
     for (int k = 0; k < 8; k++) h[k] = B2S_IV_D[k];
     h[0] ^= 0x01010020u;
+}
+
+// Blake2sChannel::mix_root(root) followed by draw_secure_felt, by the four lanes of quad 0.  chan (LDS): [0,8) digest (updated),
+// [8,24) scratch message block, [24,28) the drawn alpha.  root: 8 words (LDS or global).  Always standard Blake2s.
+__device__ __forceinline__ void channel_mix_draw_quad(const QuadLane& L, u32* chan, const u32* root, u32& n_sent) {
+    const u32 tid = threadIdx.x;
+    u32 lo, hi;
+    chan[8 + tid] = chan[tid]; chan[12 + tid] = chan[4 + tid]; chan[16 + tid] = root[tid]; chan[20 + tid] = root[4 + tid];
+    b2s_compress_quad<0>(L, chan + 8, 64, 0xFFFFFFFFu, lo, hi);      // digest = Blake2s(digest ‖ root)
+    chan[tid] = lo; chan[4 + tid] = hi;
+    n_sent = 0;
+    // draw_secure_felt: Blake2s(digest ‖ n_sent_le32 ‖ 29 zero bytes) until all 8 words are < 2P; the first 4, reduced
+    for (;;) {
+        chan[8 + tid] = lo; chan[12 + tid] = hi; chan[16 + tid] = tid == 0 ? n_sent : 0u; chan[20 + tid] = 0;
+        // two blocks: 64 bytes (not final), then 1 zero byte (final, t = 65), chained through the quad-distributed state
+        const u32 ha = L.iv_lo ^ (L.q == 0 ? 0x01010020u : 0u), hb = L.iv_hi;
+        u32 x = ha, y = hb, z = L.iv_lo, w = L.iv_hi ^ (L.q == 0 ? 64u : 0u);
+        quad_rounds(L, chan + 8, x, y, z, w);
+        const u32 h1a = ha ^ x ^ z, h1b = hb ^ y ^ w;
+        x = h1a; y = h1b; z = L.iv_lo; w = L.iv_hi ^ (L.q == 0 ? 65u : 0u) ^ (L.q == 2 ? 0xFFFFFFFFu : 0u);
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            B2S_G(x, y, z, w, 0u, 0u);
+            y = QROT(y, 0x39); z = QROT(z, 0x4E); w = QROT(w, 0x93);
+            B2S_G(x, y, z, w, 0u, 0u);
+            y = QROT(y, 0x93); z = QROT(z, 0x4E); w = QROT(w, 0x39);
+        }
+        const u32 g_lo = h1a ^ x ^ z, g_hi = h1b ^ y ^ w;
+        n_sent++;
+        int ok = (g_lo < 2u * P && g_hi < 2u * P) ? 1 : 0;           // all four lanes must agree: AND over the quad
+        ok &= __builtin_amdgcn_mov_dpp(ok, 0x39, 0xF, 0xF, true);
+        ok &= __builtin_amdgcn_mov_dpp(ok, 0x4E, 0xF, 0xF, true);
+        if (ok) { chan[24 + tid] = g_lo >= P ? g_lo - P : g_lo; break; }
+    }
+}
+
+// One FRI layer's channel step for the layers whose trees are built by ordinary launches: record j <- (root, alpha).
+__global__ __launch_bounds__(64) void fri_channel_kernel(u32* __restrict__ state, const u32* __restrict__ root, int j) {
+    __shared__ u32 chan[28];
+    __shared__ u32 rt[8];
+    QuadLane L;
+    quad_lane_init(L);
+    const u32 tid = threadIdx.x;
+    if (tid < 8) { chan[tid] = state[tid]; rt[tid] = root[tid]; }
+    __syncthreads();
+    if (tid < 4) {
+        u32 n_sent = 0;
+        channel_mix_draw_quad(L, chan, rt, n_sent);
+        u32* rec = state + FRI_STATE_HEAD + FRI_STATE_REC * j;
+        rec[tid] = rt[tid]; rec[4 + tid] = rt[4 + tid]; rec[8 + tid] = chan[24 + tid];
+        state[tid] = chan[tid]; state[4 + tid] = chan[4 + tid];
+        if (tid == 0) state[8] = n_sent;
+    }
 }
 
 template <int MODE>
@@ -372,42 +426,8 @@ __global__ __launch_bounds__(1024) void fri_tail_kernel(FriTailArgs a) {
         tree_levels_lds<MODE>(L, nodes, tree, l - 1);
         // the channel, on quad 0 (always standard Blake2s): mix_root, then draw_secure_felt
         if (tid < 4) {
-            u32 lo, hi;
-            // Blake2sChannel::mix_root: digest = Blake2s(digest ‖ root)
-            chan[8 + tid] = chan[tid]; chan[12 + tid] = chan[4 + tid]; chan[16 + tid] = nodes[tid]; chan[20 + tid] = nodes[4 + tid];
-            b2s_compress_quad<0>(L, chan + 8, 64, 0xFFFFFFFFu, lo, hi);
-            chan[tid] = lo; chan[4 + tid] = hi;
-            n_sent = 0;
-            // draw_secure_felt: Blake2s(digest ‖ n_sent_le32 ‖ 29 zero bytes) until all 8 words are < 2P; the first 4, reduced
-            for (;;) {
-                chan[8 + tid] = lo; chan[12 + tid] = hi; chan[16 + tid] = tid == 0 ? n_sent : 0u; chan[20 + tid] = 0;
-                u32 g_lo, g_hi;
-                {   // two blocks: 64 bytes (not final), then 1 zero byte (final, t = 65): chain through the quad state
-                    // block 1 on the standard initial state
-                    const u32 ha = L.iv_lo ^ (L.q == 0 ? 0x01010020u : 0u), hb = L.iv_hi;
-                    u32 x = ha, y = hb, z = L.iv_lo, w = L.iv_hi ^ (L.q == 0 ? 64u : 0u);
-                    quad_rounds(L, chan + 8, x, y, z, w);
-                    const u32 h1a = ha ^ x ^ z, h1b = hb ^ y ^ w;
-                    // block 2: all-zero message, t = 65, final
-                    x = h1a; y = h1b; z = L.iv_lo; w = L.iv_hi ^ (L.q == 0 ? 65u : 0u) ^ (L.q == 2 ? 0xFFFFFFFFu : 0u);
-#pragma unroll
-                    for (int r = 0; r < 10; r++) {
-                        B2S_G(x, y, z, w, 0u, 0u);
-                        y = QROT(y, 0x39); z = QROT(z, 0x4E); w = QROT(w, 0x93);
-                        B2S_G(x, y, z, w, 0u, 0u);
-                        y = QROT(y, 0x93); z = QROT(z, 0x4E); w = QROT(w, 0x39);
-                    }
-                    g_lo = h1a ^ x ^ z; g_hi = h1b ^ y ^ w;
-                }
-                n_sent++;
-                const bool mine = g_lo < 2u * P && g_hi < 2u * P;
-                // all four lanes must agree: AND over the quad
-                int ok = mine ? 1 : 0;
-                ok &= __builtin_amdgcn_mov_dpp(ok, 0x39, 0xF, 0xF, true);   // lane q & lane q+1
-                ok &= __builtin_amdgcn_mov_dpp(ok, 0x4E, 0xF, 0xF, true);   // ... & the pair two lanes over
-                if (ok) { chan[24 + tid] = g_lo >= P ? g_lo - P : g_lo; break; }
-            }
-            u32* rec = a.state + 9 + 12 * j;
+            channel_mix_draw_quad(L, chan, nodes, n_sent);
+            u32* rec = a.state + FRI_STATE_HEAD + FRI_STATE_REC * (a.j0 + j);
             rec[tid] = nodes[tid]; rec[4 + tid] = nodes[4 + tid]; rec[8 + tid] = chan[24 + tid];
         }
         __syncthreads();
@@ -442,36 +462,31 @@ int tree_alloc(nx_ctx* ctx, uint32_t max_log, nx_tree** out) {
     return NX_OK;
 }
 
-// Host side: h_state = digest[8] in; digest[8], n_sent, n_layers x (root[8], alpha[4]) out.  evals[j] / trees[j] are device buffers
-// the caller allocated (evals[0] = the input layer of log size log0; evals has n_layers + 1 entries).
-int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, u32* const* evals, u32* const* trees, int n_layers, int log0, u32* h_state) {
+// The last n_layers layers in one launch; d_state is the device channel state (the launch reads and updates it), j0 the record index
+// of the first of these layers.  evals[j] / trees[j]: device buffers the caller allocated (evals[0] = the input layer of log size
+// log0; evals has n_layers + 1 entries).  Asynchronous on the context's stream.
+int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, u32* const* evals, u32* const* trees, int n_layers, int log0, u32* d_state, int j0) {
     if (n_layers < 1 || n_layers > FRI_TAIL_MAX_LAYERS || log0 < n_layers || log0 > 11 || (u32)log0 > tw->log_half) return set_err(ctx, NX_ERR_ARG, "fri_tail: bad layer range");
     FriTailArgs a;
     for (int j = 0; j <= n_layers; j++) a.eval[j] = evals[j];
     for (int j = 0; j < n_layers; j++) a.tree[j] = trees[j];
-    a.n_layers = n_layers; a.log0 = log0; a.itw = tw->d_itw; a.tw_log = tw->log_half;
-    const size_t words = 9 + 12 * (size_t)n_layers;
-    u32* d_state = nullptr;
-    NX_TRY(dev_alloc(ctx, words * 4, (void**)&d_state));
-    a.state = d_state;
-    hipError_t e = hipMemcpyAsync(d_state, h_state, 32, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)fri_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)fri_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        const size_t lds = ((((size_t)2 << log0) - 1) * 8 + 32) * 4;
-        if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(fri_tail_kernel<0>, dim3(1), dim3(1024), lds, ctx->stream, a);
-        else hipLaunchKernelGGL(fri_tail_kernel<1>, dim3(1), dim3(1024), lds, ctx->stream, a);
-        e = hipGetLastError();
+    a.n_layers = n_layers; a.log0 = log0; a.itw = tw->d_itw; a.tw_log = tw->log_half; a.state = d_state; a.j0 = j0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        NX_HIP(ctx, hipFuncSetAttribute((const void*)fri_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        NX_HIP(ctx, hipFuncSetAttribute((const void*)fri_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(h_state, d_state, words * 4, hipMemcpyDeviceToHost, ctx->stream);
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    dev_free(ctx, d_state);
-    if (e != hipSuccess) return hip_fail(ctx, e, "fri_tail", __FILE__, __LINE__);
-    if (e2 != hipSuccess) return hip_fail(ctx, e2, "fri_tail(sync)", __FILE__, __LINE__);
+    const size_t lds = ((((size_t)2 << log0) - 1) * 8 + 32) * 4;
+    if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(fri_tail_kernel<0>, dim3(1), dim3(1024), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(fri_tail_kernel<1>, dim3(1), dim3(1024), lds, ctx->stream, a);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+int fri_channel_step(nx_ctx* ctx, u32* d_state, const u32* d_root, int j) {
+    hipLaunchKernelGGL(fri_channel_kernel, dim3(1), dim3(64), 0, ctx->stream, d_state, d_root, j);
+    NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
 

@@ -229,6 +229,54 @@ __global__ void fold_line_kernel(Sec4 dst, Sec4C src, int L, const u32* __restri
     dst.c[0][i] = o.a.a; dst.c[1][i] = o.a.b; dst.c[2][i] = o.b.a; dst.c[3][i] = o.b.b;
 }
 
+// The same folds with the folding alpha read from device memory (4 words): the FRI commit phase keeps the channel on the device
+// (merkle.hip: fri_channel_step / fri_tail), so the host never waits for a root to draw the next alpha.
+__global__ void fold_circle_dev_kernel(Sec4 dst, Sec4C src, int L, const u32* __restrict__ itw, u32 tw_log, const u32* __restrict__ alpha_ptr) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (L - 1))) return;
+    const QM31 alpha = qm(alpha_ptr[0], alpha_ptr[1], alpha_ptr[2], alpha_ptr[3]), alpha_sq = q_sqr(alpha);
+    u32 yi = circle_itw(itw, tw_log, L, i);
+    uint2 a = *reinterpret_cast<const uint2*>(src.c[0] + 2 * i), b = *reinterpret_cast<const uint2*>(src.c[1] + 2 * i);
+    uint2 c = *reinterpret_cast<const uint2*>(src.c[2] + 2 * i), d4 = *reinterpret_cast<const uint2*>(src.c[3] + 2 * i);
+    QM31 f0 = qm(a.x, b.x, c.x, d4.x), f1 = qm(a.y, b.y, c.y, d4.y);
+    QM31 s = q_add(f0, f1), t = q_mul_m(q_sub(f0, f1), yi);
+    QM31 fp = q_add(q_mul(alpha, t), s);
+    QM31 d = qm(dst.c[0][i], dst.c[1][i], dst.c[2][i], dst.c[3][i]);
+    d = q_add(q_mul(d, alpha_sq), fp);
+    dst.c[0][i] = d.a.a; dst.c[1][i] = d.a.b; dst.c[2][i] = d.b.a; dst.c[3][i] = d.b.b;
+}
+__global__ void fold_line_dev_kernel(Sec4 dst, Sec4C src, int L, const u32* __restrict__ itw, u32 tw_log, const u32* __restrict__ alpha_ptr) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (L - 1))) return;
+    const QM31 alpha = qm(alpha_ptr[0], alpha_ptr[1], alpha_ptr[2], alpha_ptr[3]);
+    u32 xi = itw[(1u << tw_log) - (1u << L) + i];
+    uint2 a = *reinterpret_cast<const uint2*>(src.c[0] + 2 * i), b = *reinterpret_cast<const uint2*>(src.c[1] + 2 * i);
+    uint2 c = *reinterpret_cast<const uint2*>(src.c[2] + 2 * i), d = *reinterpret_cast<const uint2*>(src.c[3] + 2 * i);
+    QM31 f0 = qm(a.x, b.x, c.x, d.x), f1 = qm(a.y, b.y, c.y, d.y);
+    QM31 s = q_add(f0, f1), t = q_mul_m(q_sub(f0, f1), xi);
+    QM31 o = q_add(s, q_mul(alpha, t));
+    dst.c[0][i] = o.a.a; dst.c[1][i] = o.a.b; dst.c[2][i] = o.b.a; dst.c[3][i] = o.b.b;
+}
+
+int fold_circle_dev(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha) {
+    if (src_log < 1 || (src_log >= 3 && src_log - 1 > tw->log_half)) return set_err(ctx, NX_ERR_ARG, "fold_circle_dev: bad log");
+    Sec4 d; Sec4C s;
+    for (int q = 0; q < 4; q++) { d.c[q] = d_dst4[q]; s.c[q] = d_src4[q]; }
+    uint32_t n = 1u << (src_log - 1);
+    hipLaunchKernelGGL(fold_circle_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, tw->d_itw, tw->log_half, d_alpha);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+int fold_line_dev(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha, uint32_t* const* d_dst4) {
+    if (src_log < 1 || src_log > tw->log_half) return set_err(ctx, NX_ERR_ARG, "fold_line_dev: domain not covered by the twiddle tree");
+    Sec4 d; Sec4C s;
+    for (int q = 0; q < 4; q++) { d.c[q] = d_dst4[q]; s.c[q] = d_src4[q]; }
+    uint32_t n = 1u << (src_log - 1);
+    hipLaunchKernelGGL(fold_line_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, tw->d_itw, tw->log_half, d_alpha);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
 }  // namespace nx
 
 using namespace nx;

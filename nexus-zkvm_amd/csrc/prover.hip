@@ -234,8 +234,92 @@ class FriProver {
         return nx_merkle_root(ctx, *tree, (uint8_t*)root->w);
     }
 
-    // FriProver::commit
+    // FriProver::commit.  The whole commit phase is enqueued without a host round trip: the Blake2s channel lives on the device
+    // (fri_channel_step after each tree, the folds read their alpha from the channel's records, fri_tail for the small layers);
+    // the host reads the roots and the channel state back once, before the last layer.  NX_FRI_DEVICE_CHANNEL=0: the per-layer
+    // host channel (same transcript; kept for A/B).
     int commit(Blake2sChannel& channel, std::vector<SecureColumn>&& cols) {
+        static const bool dev_channel = []() { const char* e = getenv("NX_FRI_DEVICE_CHANNEL"); return !e || atoi(e) != 0; }();
+        if (!dev_channel) return commit_host_channel(channel, std::move(cols));
+        columns = std::move(cols);
+        if (columns.empty()) return set_err(ctx, NX_ERR_ARG, "fri: no columns");
+        const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
+        uint32_t layer_log = columns[0].log - 1;
+        const uint32_t max_layers = layer_log > last_log ? layer_log - last_log : 0;
+        const size_t st_words = FRI_STATE_HEAD + FRI_STATE_REC * (size_t)(1 + max_layers);
+        DevBuf d_state; H_TRY(d_state.alloc(ctx, st_words));
+        auto rec_alpha = [&](int j) { return (const uint32_t*)(d_state.p + FRI_STATE_HEAD + FRI_STATE_REC * j + 8); };
+        {
+            std::vector<uint32_t> h(FRI_STATE_HEAD, 0);
+            memcpy(h.data(), channel.digest.w, 32);
+            void* staged = nullptr; H_TRY(stage(ctx, h.data(), h.size() * 4, &staged));
+            H_TRY(nx_copy(ctx, d_state.p, (const uint32_t*)staged, FRI_STATE_HEAD));
+        }
+        {   // first layer: every circle column in one mixed-degree tree
+            std::vector<const uint32_t*> p; std::vector<uint32_t> logs;
+            for (auto& c : columns) for (int k = 0; k < 4; k++) { p.push_back(c.c[k]); logs.push_back(c.log); }
+            H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), (uint32_t)p.size(), &first_merkle));
+            H_TRY(fri_channel_step(ctx, d_state.p, first_merkle->layers[0], 0));
+        }
+        int j_prev = 0;                         // record whose alpha is the current folding alpha
+        SecureColumn layer; H_TRY(layer.alloc(ctx, layer_log));
+        H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
+        size_t ci = 0;
+        static const bool use_tail = []() { const char* e = getenv("NX_FRI_TAIL"); return !e || atoi(e) != 0; }();
+        while (layer_log > last_log) {
+            const int j = (int)inner.size() + 1;   // record of the layer committed in this iteration
+            if (use_tail && ci == columns.size() && layer_log <= (uint32_t)FRI_TAIL_LOG && layer_log - last_log <= (uint32_t)FRI_TAIL_MAX_LAYERS) {
+                const int n = (int)(layer_log - last_log);
+                std::vector<FriLayer> tl(n);
+                std::vector<uint32_t*> evals(n + 1), trees(n);
+                tl[0].eval = std::move(layer);
+                for (int t = 0; t < n; t++) {
+                    if (t) H_TRY(tl[t].eval.alloc(ctx, layer_log - t));
+                    for (int k = 0; k < 4; k++) tl[t].eval.c[k] = tl[t].eval.buf.p + ((size_t)k << (layer_log - t));
+                    H_TRY(tree_alloc(ctx, layer_log - t, &tl[t].merkle));
+                    evals[t] = tl[t].eval.buf.p; trees[t] = tl[t].merkle->layers[0];
+                }
+                SecureColumn fin; H_TRY(fin.alloc(ctx, last_log));
+                evals[n] = fin.buf.p;
+                H_TRY(fri_tail(ctx, tw, evals.data(), trees.data(), n, (int)layer_log, d_state.p, j));
+                for (int t = 0; t < n; t++) inner.push_back(std::move(tl[t]));
+                layer = std::move(fin);
+                for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << last_log);
+                layer_log = last_log;
+                break;
+            }
+            while (ci < columns.size() && columns[ci].log - 1 == layer_log) {
+                const uint32_t* a = rec_alpha(cfg.fri_alpha_mode == NX_FRI_ALPHA_PREV ? j_prev : 0);
+                H_TRY(fold_circle_dev(ctx, tw, layer.c, (const uint32_t* const*)columns[ci].c, columns[ci].log, a));
+                ci++;
+            }
+            FriLayer L; L.eval = std::move(layer);
+            for (int k = 0; k < 4; k++) L.eval.c[k] = L.eval.buf.p + ((size_t)k << layer_log);
+            {
+                std::vector<const uint32_t*> p; std::vector<uint32_t> logs;
+                for (int k = 0; k < 4; k++) { p.push_back(L.eval.c[k]); logs.push_back(layer_log); }
+                H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), 4, &L.merkle));
+            }
+            H_TRY(fri_channel_step(ctx, d_state.p, L.merkle->layers[0], j));
+            SecureColumn next; H_TRY(next.alloc(ctx, layer_log - 1));
+            H_TRY(fold_line_dev(ctx, tw, (const uint32_t* const*)L.eval.c, layer_log, rec_alpha(j), next.c));
+            inner.push_back(std::move(L));
+            layer = std::move(next);
+            for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << (layer_log - 1));
+            layer_log--; j_prev = j;
+        }
+        {   // the one host round trip of the commit phase: channel state and every layer's root
+            std::vector<uint32_t> st(st_words);
+            H_TRY(nx_download(ctx, st.data(), d_state.p, FRI_STATE_HEAD + FRI_STATE_REC * (1 + inner.size())));
+            memcpy(channel.digest.w, st.data(), 32);
+            channel.n_challenges += (uint32_t)(1 + inner.size()); channel.n_sent = st[8];
+            memcpy(first_root.w, &st[FRI_STATE_HEAD], 32);
+            for (size_t i = 0; i < inner.size(); i++) memcpy(inner[i].root.w, &st[FRI_STATE_HEAD + FRI_STATE_REC * (i + 1)], 32);
+        }
+        return commit_last_layer(channel, layer, layer_log, ci);
+    }
+
+    int commit_host_channel(Blake2sChannel& channel, std::vector<SecureColumn>&& cols) {
         columns = std::move(cols);
         if (columns.empty()) return set_err(ctx, NX_ERR_ARG, "fri: no columns");
         { std::vector<const SecureColumn*> p; for (auto& c : columns) p.push_back(&c); H_TRY(commit_secure(ctx, p, &first_merkle, &first_root)); }
@@ -247,34 +331,7 @@ class FriProver {
         H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
         const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
         size_t ci = 0; uint32_t n_doublings = 0;
-        static const bool use_tail = []() { const char* e = getenv("NX_FRI_TAIL"); return !e || atoi(e) != 0; }();
         while (layer_log > last_log) {
-            if (use_tail && ci == columns.size() && layer_log <= (uint32_t)FRI_TAIL_LOG && layer_log - last_log <= (uint32_t)FRI_TAIL_MAX_LAYERS) {
-                // every circle column is folded in and the layers are small: the rest of the commit phase is one launch with the
-                // channel on the device (fri_tail, merkle.hip) — same trees, same transcript
-                const int n = (int)(layer_log - last_log);
-                std::vector<FriLayer> tl(n);
-                std::vector<uint32_t*> evals(n + 1), trees(n);
-                tl[0].eval = std::move(layer);
-                for (int j = 0; j < n; j++) {
-                    if (j) H_TRY(tl[j].eval.alloc(ctx, layer_log - j));
-                    for (int k = 0; k < 4; k++) tl[j].eval.c[k] = tl[j].eval.buf.p + ((size_t)k << (layer_log - j));
-                    H_TRY(tree_alloc(ctx, layer_log - j, &tl[j].merkle));
-                    evals[j] = tl[j].eval.buf.p; trees[j] = tl[j].merkle->layers[0];
-                }
-                SecureColumn fin; H_TRY(fin.alloc(ctx, last_log));
-                evals[n] = fin.buf.p;
-                std::vector<uint32_t> st(9 + 12 * (size_t)n);
-                memcpy(st.data(), channel.digest.w, 32);
-                H_TRY(fri_tail(ctx, tw, evals.data(), trees.data(), n, (int)layer_log, st.data()));
-                memcpy(channel.digest.w, st.data(), 32);
-                channel.n_challenges += (uint32_t)n; channel.n_sent = st[8];
-                for (int j = 0; j < n; j++) { memcpy(tl[j].root.w, &st[9 + 12 * j], 32); folding_alpha = q_load(&st[9 + 12 * j + 8]); inner.push_back(std::move(tl[j])); }
-                layer = std::move(fin);
-                for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << last_log);
-                n_doublings += (uint32_t)n; layer_log = last_log;
-                break;
-            }
             while (ci < columns.size() && columns[ci].log - 1 == layer_log) {
                 QM31 a = cfg.fri_alpha_mode == NX_FRI_ALPHA_PREV ? folding_alpha : first_alpha;
                 uint32_t aw[4]; q_store(aw, a);
@@ -295,6 +352,10 @@ class FriProver {
             for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << (layer_log - 1));
             layer_log--; n_doublings++;
         }
+        return commit_last_layer(channel, layer, layer_log, ci);
+    }
+
+    int commit_last_layer(Blake2sChannel& channel, SecureColumn& layer, uint32_t layer_log, size_t ci) {
         if (ci != columns.size()) return set_err(ctx, NX_ERR_PROTOCOL, "fri: first-layer columns not consumed (column smaller than the last layer)");
         // commit_last_layer: tiny — interpolate the line evaluation on the host
         size_t n = (size_t)1 << layer_log;
