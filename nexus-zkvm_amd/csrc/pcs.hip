@@ -229,6 +229,25 @@ __global__ void fold_line_kernel(Sec4 dst, Sec4C src, int L, const u32* __restri
     dst.c[0][i] = o.a.a; dst.c[1][i] = o.a.b; dst.c[2][i] = o.b.a; dst.c[3][i] = o.b.b;
 }
 
+// The evaluation tables of eval_at_point_kernel built on the device: entry j of a table is the product of the factors of the set
+// bits of j (factors [y, x, pi(x), pi^2(x), ...] of the point; low table: bits [0, L), coordinate-major; high table: bits [L, n),
+// 4 words per entry).  The host sends the <= 30 factors as a kernel argument instead of computing and copying 2^L + 2^(n-L) products.
+struct EvalFactors { QM31 f[30]; };
+__global__ __launch_bounds__(256) void eval_tables_kernel(EvalFactors F, int n, int L, u32* __restrict__ t_lo, u32* __restrict__ t_hi) {
+    const u32 n_lo = 1u << L, n_hi = 1u << (n - L);
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_lo) {
+        QM31 t = q_one();
+        for (int k = 0; k < L; k++) if ((i >> k) & 1) t = q_mul(t, F.f[k]);
+        t_lo[i] = t.a.a; t_lo[n_lo + i] = t.a.b; t_lo[2 * n_lo + i] = t.b.a; t_lo[3 * n_lo + i] = t.b.b;
+    } else if (i - n_lo < n_hi) {
+        const u32 j = i - n_lo;
+        QM31 t = q_one();
+        for (int k = L; k < n; k++) if ((j >> (k - L)) & 1) t = q_mul(t, F.f[k]);
+        t_hi[4 * j] = t.a.a; t_hi[4 * j + 1] = t.a.b; t_hi[4 * j + 2] = t.b.a; t_hi[4 * j + 3] = t.b.b;
+    }
+}
+
 // The same folds with the folding alpha read from device memory (4 words): the FRI commit phase keeps the channel on the device
 // (merkle.hip: fri_channel_step / fri_tail), so the host never waits for a root to draw the next alpha.
 __global__ void fold_circle_dev_kernel(Sec4 dst, Sec4C src, int L, const u32* __restrict__ itw, u32 tw_log, const u32* __restrict__ alpha_ptr) {
@@ -305,15 +324,7 @@ int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_
         std::vector<QM31> f(n);
         if (n > 0) f[0] = p.y;
         { QM31 x = p.x; for (int k = 1; k < n; k++) { f[k] = x; x = q_double_x(x); } }
-        std::vector<uint32_t> tlo(4 * (size_t)n_lo), thi(4 * (size_t)n_hi);
-        {
-            std::vector<QM31> t(n_lo); t[0] = q_one();
-            for (int k = 0; k < L; k++) for (uint32_t j = 0; j < (1u << k); j++) t[j + (1u << k)] = q_mul(t[j], f[k]);
-            for (uint32_t j = 0; j < n_lo; j++) { tlo[j] = t[j].a.a; tlo[n_lo + j] = t[j].a.b; tlo[2 * n_lo + j] = t[j].b.a; tlo[3 * n_lo + j] = t[j].b.b; }
-            std::vector<QM31> u(n_hi); u[0] = q_one();
-            for (int k = L; k < n; k++) for (uint32_t j = 0; j < (1u << (k - L)); j++) u[j + (1u << (k - L))] = q_mul(u[j], f[k]);
-            for (uint32_t j = 0; j < n_hi; j++) q_store(&thi[4 * j], u[j]);
-        }
+        const size_t tlo_words = 4 * (size_t)n_lo, thi_words = 4 * (size_t)n_hi;
         const uint32_t np = (uint32_t)groups[g].size();
         std::vector<const uint32_t*> sel(np);
         for (uint32_t i = 0; i < np; i++) sel[i] = d_polys[poly_idx[groups[g][i]]];
@@ -324,12 +335,14 @@ int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_
         uint32_t* const* d_tab = nullptr;
         size_t part_words = (size_t)np * n_chunks * 4;
         uint8_t* blob = nullptr;
-        size_t bytes = tlo.size() * 4 + thi.size() * 4 + part_words * 4 + (size_t)np * 8;
+        size_t bytes = tlo_words * 4 + thi_words * 4 + part_words * 4 + (size_t)np * 8;
         NX_TRY(dev_alloc(ctx, bytes, (void**)&blob));
-        d_lo = (uint32_t*)blob; d_hi = d_lo + tlo.size(); d_part = d_hi + thi.size();
-        d_tab = (uint32_t* const*)(blob + (tlo.size() + thi.size() + part_words) * 4);
-        hipError_t e = hipMemcpyAsync(d_lo, tlo.data(), tlo.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_hi, thi.data(), thi.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        d_lo = (uint32_t*)blob; d_hi = d_lo + tlo_words; d_part = d_hi + thi_words;
+        d_tab = (uint32_t* const*)(blob + (tlo_words + thi_words + part_words) * 4);
+        EvalFactors F;
+        for (int k = 0; k < 30; k++) F.f[k] = k < n ? f[k] : q_one();
+        hipLaunchKernelGGL(eval_tables_kernel, dim3((n_lo + n_hi + 255) / 256), dim3(256), 0, ctx->stream, F, n, L, d_lo, d_hi);
+        hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync((void*)d_tab, sel.data(), (size_t)np * 8, hipMemcpyHostToDevice, ctx->stream);
         std::vector<uint32_t> part(part_words);
         if (e == hipSuccess) {
