@@ -887,7 +887,7 @@ static int commit_sharded_tree(CommitmentSchemeProver& cs, const Shard& sh, int 
             const int prev = pos > 0 ? act[pos - 1] : -1, next = pos + 1 < act.size() ? act[pos + 1] : -1;
             const uint64_t n_rows = (uint64_t)1 << el;
             DevBuf st; H_TRY(st.alloc(ctx, (size_t)8 << el));
-            const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(8, n_rows);
+            const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, n_rows >> 10));   // up to 32 row chunks (>= 1024 rows each): fine-grained enough to keep seven hops busy
             for (uint32_t j = 0; j < n_chunks; j++) {
                 const uint64_t rb = n_rows * j / n_chunks, re = n_rows * (j + 1) / n_chunks;
                 uint32_t* sp = st.p + rb * 8;
