@@ -379,6 +379,7 @@ class HipBackend:
 
     def __init__(self, device=0):
         self.L = load_library()
+        self.device = int(device)
         self.ctx = C.c_void_p()
         rc = self.L.nx_ctx_create(int(device), C.byref(self.ctx))
         if rc != NX_OK:

@@ -53,6 +53,9 @@ class TorchComm:
         self.dist.broadcast(t, src)
         return t
 
+    def all_gather(self, out_list, t):
+        self.dist.all_gather(out_list, t)
+
     def device_sync(self):
         if self.device.type == "cuda":
             self.torch.cuda.synchronize(self.device)
@@ -75,6 +78,23 @@ class HipShardOps:
     def root_from_leaves(self, leaves, log_size):
         tree = self.be.merkle_from_leaves(leaves.data_ptr(), log_size)
         return tree, tree.root()
+
+    # transposed commit: rows [rb, re) of every local column as one torch tensor / a received block as columns
+    def export_rows(self, lde, rb, re):
+        import torch, ctypes as C
+        n = lde.n_cols
+        t = torch.empty((n, re - rb), dtype=torch.int32, device="cuda:%d" % self.be.device)
+        for k in range(n):
+            self.be._chk(self.be.L.nx_copy(self.be.ctx, C.c_void_p(t.data_ptr() + k * 4 * (re - rb)), C.c_void_p(lde.ptr.value + (k << lde.log_size) * 4 + 4 * rb),
+                                           C.c_size_t(re - rb)))
+        self.be.sync()
+        return t
+
+    def import_block(self, block):
+        from . import DeviceColumns
+        v = DeviceColumns.view(self.be, block.data_ptr(), block.shape[0], int(np.log2(block.shape[1])))
+        v.keep = block                                           # the tensor owns the memory
+        return v
 
 
 def sharded_commit(ops, comm, local_lde, col_range, total_cols, lde_log_size, n_row_chunks=8):
@@ -116,6 +136,62 @@ def sharded_commit(ops, comm, local_lde, col_range, total_cols, lde_log_size, n_
     comm.broadcast(root, active[-1])
     comm.device_sync()
     return root.cpu().numpy().view(np.uint32).copy(), tree
+
+
+# ---------------------------------------------------------------- the transposed commit (row shards after one all-to-all) ---
+# The chaining-state ring moves 32 B per row over every hop and serialises the hashing of a row over the ranks (DESIGN.md §7:
+# at config #4 it is the term that does not scale).  The alternative keeps ONLY the LDE column-parallel and then transposes once:
+# an all-to-all turns column shards into row shards — rank s receives rows [s M/W, (s+1) M/W) of every column — after which the
+# leaf hashing and the whole Merkle subtree over those rows are local; the W subtree roots are all-gathered and every rank
+# computes the top log2(W) levels itself ("all-gather only for Merkle roots", BASELINE north star).  Same tree, same root.
+
+def exchange_all_to_all(comm, send):
+    """send[s]: tensor for rank s (None = nothing).  Returns recv[q]: the tensor rank q addressed to this rank.  Pairwise
+    isend/irecv, so it runs on gloo (CPU tests) and nccl alike; shapes are (n_cols_of_sender, rows_per_rank), known to both sides."""
+    dist, torch = comm.dist, comm.torch
+    recv = [None] * comm.world
+    recv[comm.rank] = send[comm.rank]
+    for step in range(1, comm.world):
+        dst, src = (comm.rank + step) % comm.world, (comm.rank - step) % comm.world
+        ops = []
+        if send[dst] is not None and send[dst].numel():
+            ops.append(dist.P2POp(dist.isend, send[dst], dst))
+        shape = comm.recv_shape(src)
+        if shape[0]:
+            recv[src] = torch.empty(shape, dtype=torch.int32, device=comm.device)
+            ops.append(dist.P2POp(dist.irecv, recv[src], src))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+    return recv
+
+
+def transposed_commit(ops, comm, local_lde, col_ranges, lde_log_size, exchange=exchange_all_to_all):
+    """Commit one tree of equally sized LDE columns sharded by columns (col_ranges[r] = (begin, end) of rank r, any partition):
+    all-to-all to row shards, local leaf hashing + subtree, all-gather of the subtree roots, replicated top.  The world size must
+    be a power of two not larger than the column length.  Returns (root as 8 uint32 words, local subtree handle)."""
+    torch = comm.torch
+    W, rank = comm.world, comm.rank
+    assert W & (W - 1) == 0 and W <= (1 << lde_log_size)
+    log_w = W.bit_length() - 1
+    rows = (1 << lde_log_size) // W                       # rows per rank; a contiguous block in the (bit-reversed) row order
+    total_cols = col_ranges[-1][1]
+    lo, hi = col_ranges[rank]
+    comm.recv_shape = lambda q: (col_ranges[q][1] - col_ranges[q][0], rows)
+    send = [ops.export_rows(local_lde, s * rows, (s + 1) * rows) if hi > lo else None for s in range(W)]
+    recv = exchange(comm, send)
+    block = torch.cat([recv[q] for q in range(W) if recv[q] is not None and recv[q].shape[0]], dim=0).contiguous()   # [total_cols, rows]
+    assert block.shape == (total_cols, rows)
+    leaves = comm.empty_state(rows)
+    ops.leaf_chain(ops.import_block(block), 0, total_cols, None, leaves, 0, rows)
+    subtree, sub_root = ops.root_from_leaves(leaves, lde_log_size - log_w)
+    mine = torch.from_numpy(np.asarray(sub_root, dtype=np.uint32).view(np.int32).copy()).to(comm.device)
+    roots = [torch.empty(8, dtype=torch.int32, device=comm.device) for _ in range(W)]
+    comm.all_gather(roots, mine)
+    top = torch.stack(roots).contiguous()                 # the W subtree roots are level log2(W) of the tree
+    _, root = ops.root_from_leaves(top, log_w) if log_w else (None, sub_root)
+    comm.device_sync()
+    return np.asarray(root, dtype=np.uint32).copy(), subtree
 
 
 # ---------------------------------------------------------------- transports of the full sharded prove (nx_comm) ----------

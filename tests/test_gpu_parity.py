@@ -326,6 +326,66 @@ def test_large_prove_accepted_by_oracle_verifier(be, nz, oracle):
     assert stats["total"] > 0 and stats["lde_kernel_ms"] > 0
 
 
+@pytest.mark.parametrize("world,n_cols,log,mode", [(2, 21, 10, 0), (4, 70, 13, 0), (8, 33, 12, 1)])
+def test_transposed_commit_on_device_matches_single_commit(nz, world, n_cols, log, mode):
+    """The transposed commit (sharded.py) with HipShardOps: W ranks as threads, one context each on this GPU, tensors handed over in
+    process; every rank's root equals nx_merkle_commit of all the LDE columns on one context."""
+    import threading, torch
+    from nexus_zkvm_amd.sharded import HipShardOps, transposed_commit
+    dev = torch.device("cuda:0")
+    cols = np.random.default_rng(99).integers(0, P, (n_cols, 1 << log), dtype=np.uint32)
+    cuts = [n_cols * r // world for r in range(world + 1)]
+    if world > 2:
+        cuts[2] = cuts[1]                                              # rank 1 holds no columns
+    ranges = [(cuts[r], cuts[r + 1]) for r in range(world)]
+    ref_be = nz.HipBackend(0); ref_be.set_hash_mode(mode)
+    tw = ref_be.precompute_twiddles(log + 1)
+    full = ref_be.lde(tw, ref_be.columns_from_host(cols), 1)
+    expected = ref_be.merkle_commit([full]).root()
+    bar = threading.Barrier(world)
+    mail = {}
+    roots, errs = [None] * world, []
+
+    class Comm:
+        def __init__(self, rank):
+            self.rank, self.world, self.torch, self.device = rank, world, torch, dev
+        def empty_state(self, n_rows):
+            return torch.empty((n_rows, 8), dtype=torch.int32, device=dev)
+        def all_gather(self, out_list, t):
+            mail[("ag", self.rank)] = t
+            bar.wait()
+            for q in range(world):
+                out_list[q].copy_(mail[("ag", q)])
+            torch.cuda.synchronize(); bar.wait()
+        def device_sync(self):
+            torch.cuda.synchronize()
+
+    def exchange(comm, send):
+        for s_, t in enumerate(send):
+            mail[("a2a", comm.rank, s_)] = t
+        torch.cuda.synchronize(); bar.wait()
+        recv = [mail[("a2a", q, comm.rank)] for q in range(world)]
+        recv = [t.clone() if t is not None else None for t in recv]
+        torch.cuda.synchronize(); bar.wait()
+        return recv
+
+    def worker(rank):
+        try:
+            b = nz.HipBackend(0); b.set_hash_mode(mode)
+            ops = HipShardOps(b, b.precompute_twiddles(log + 1))
+            lo, hi = ranges[rank]
+            local = ops.lde(b.columns_from_host(cols[lo:hi]), 1) if hi > lo else b.columns(0, log + 1)
+            roots[rank], _ = transposed_commit(ops, Comm(rank), local, ranges, log + 1, exchange=exchange)
+        except Exception as e:                                          # surface the failure instead of dead-locking the barrier
+            errs.append(e); bar.abort()
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for r in range(world):
+        assert np.array_equal(roots[r], expected), r
+
+
 def test_headline_prove_verifies_and_the_session_reproduces_it(be, nz, oracle):
     """BASELINE config #3 at full size (2^22 rows, 27 + 347 + 64 columns): the proof the bench times is accepted by the oracle's
     verifier (a check whose cost does not grow with the trace), a tampered one is not, and the generic session — the same machine as

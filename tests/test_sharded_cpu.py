@@ -64,6 +64,12 @@ class OracleShardOps:
                     L.orc_blake2s_compress(O.ptr(h), O.ptr(m), 0, 0, 0, 0)
             state_out[r] = __import__("torch").from_numpy(h.view(np.int32))
 
+    def export_rows(self, lde, rb, re):
+        return __import__("torch").from_numpy(np.ascontiguousarray(lde[:, rb:re]).view(np.int32).copy())
+
+    def import_block(self, block):
+        return block.numpy().view(np.uint32)
+
     def root_from_leaves(self, leaves, log_size):
         L = O.lib()
         layer = leaves.numpy().view(np.uint32).copy()
@@ -103,6 +109,49 @@ def _worker(rank, world, port, n_cols, log_size, mode, n_chunks, result_dir):
             np.save(os.path.join(result_dir, "expected.npy"), O.merkle_commit(list(full), mode))
     finally:
         dist.destroy_process_group()
+
+
+def _transposed_worker(rank, world, port, n_cols, log_size, mode, uneven, result_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from nexus_zkvm_amd.sharded import TorchComm, transposed_commit
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = TorchComm(torch.device("cpu"))
+        cols = np.random.default_rng(4321).integers(0, P, (n_cols, 1 << log_size), dtype=np.uint32)   # same on every rank
+        # any column partition works (no 16-column alignment: the leaves are hashed whole after the transposition)
+        cuts = [0] + [min(n_cols, (n_cols * (r + 1)) // world + (3 if uneven and r == 0 else 0)) for r in range(world - 1)] + [n_cols]
+        if uneven and world > 2:
+            cuts[2] = cuts[1]                                      # a rank without columns
+        ranges = [(cuts[r], cuts[r + 1]) for r in range(world)]
+        lo, hi = ranges[rank]
+        ops = OracleShardOps(mode, log_size)
+        local = ops.lde(cols[lo:hi], 1) if hi > lo else np.zeros((0, 2 << log_size), np.uint32)
+        root, _ = transposed_commit(ops, comm, local, ranges, log_size + 1)
+        np.save(os.path.join(result_dir, f"root_{rank}.npy"), root)
+        if rank == 0:
+            np.save(os.path.join(result_dir, "expected.npy"), O.merkle_commit(list(ops.lde(cols, 1)), mode))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_cols,mode,uneven", [(2, 21, O.HASH_STD, False), (4, 37, O.HASH_STD, True), (2, 16, O.HASH_RAW0, True), (4, 5, O.HASH_RAW0, False)])
+def test_transposed_commit_matches_single_process_root(tmp_path, world, n_cols, mode, uneven):
+    """Column-parallel LDE, one all-to-all to row shards, local leaf hashing and subtrees, all-gather of the subtree roots, replicated
+    top: every rank ends with the single-process root (the plan DESIGN.md §7 proposes for 8 GPUs, protocol checked over gloo)."""
+    import torch.multiprocessing as mp
+    O.build_oracle()
+    mp.spawn(_transposed_worker, args=(world, _free_port(), n_cols, 4, mode, uneven, str(tmp_path)), nprocs=world, join=True)
+    expected = np.load(tmp_path / "expected.npy")
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"root_{r}.npy"), expected), (world, n_cols, mode, r)
 
 
 def _free_port():

@@ -1,8 +1,9 @@
 """BASELINE config #4 (commit phase): one 2^log-row trace, columns sharded over the GPUs of a node, LDE per shard and
 ONE Merkle tree through the chaining-state ring of nexus_zkvm_amd.sharded.  Launch with
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/sharded_commit.py --log-rows 24 --n-cols 347
-Rank 0 prints one JSON line (columns/s and ms per commit); with --check every rank also commits ALL columns alone
-(needs the memory for it) and compares the roots."""
+Rank 0 prints one JSON line (columns/s and ms per commit).  --mode transposed uses the other protocol of that module instead: LDE
+column-parallel, one all-to-all to row shards, local leaf hashing and subtrees, all-gather of the subtree roots (the
+plan that scales); both give the root of the single-GPU commit."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,19 +15,20 @@ def main():
     ap.add_argument("--n-cols", dest="cols", type=int, default=347)
     ap.add_argument("--chunks", type=int, default=8)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--mode", choices=("ring", "transposed"), default="ring")
+    ap.add_argument("--backend", default="nccl")
     a = ap.parse_args()
     import numpy as np
     import torch
     import torch.distributed as dist
     import nexus_zkvm_amd as nz
-    from nexus_zkvm_amd.sharded import HipShardOps, TorchComm, plan_column_shards, sharded_commit
+    from nexus_zkvm_amd.sharded import HipShardOps, TorchComm, plan_column_shards, sharded_commit, transposed_commit
     rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist.init_process_group(a.backend, rank=rank, world_size=world, **({"device_id": dev} if a.backend == "nccl" else {}))
     be = nz.HipBackend(local)
     tw = be.precompute_twiddles(a.log)
     comm = TorchComm(dev)
@@ -42,13 +44,16 @@ def main():
         lde = ops.lde(cols, 1) if cols is not None else None
         if lde is not None and lde.n_cols != hi - lo:
             lde.n_cols = hi - lo
-        root, _ = sharded_commit(ops, comm, lde, (lo, hi), a.cols, a.log + 1, n_row_chunks=a.chunks)
+        if a.mode == "ring":
+            root, _ = sharded_commit(ops, comm, lde, (lo, hi), a.cols, a.log + 1, n_row_chunks=a.chunks)
+        else:
+            root, _ = transposed_commit(ops, comm, lde if lde is not None else be.columns(0, a.log + 1), plan_column_shards(a.cols, world), a.log + 1)
         be.sync(); dist.barrier(); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if rep:
             best = min(best, dt)
     if rank == 0:
-        print(json.dumps({"workload": "config #4 commit phase: %d columns x 2^%d rows, blow-up 2, column-sharded over %d GPUs" % (a.cols, a.log, world),
+        print(json.dumps({"workload": "config #4 commit phase: %d columns x 2^%d rows, blow-up 2, column-sharded over %d GPUs" % (a.cols, a.log, world), "mode": a.mode,
                           "ms_per_commit": best * 1e3, "columns_per_s": a.cols / best, "root": [int(x) for x in root]}), flush=True)
     be.close()
     dist.barrier(); dist.destroy_process_group()
