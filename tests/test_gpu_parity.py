@@ -12,6 +12,8 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libnexus_hip.so: the wheel bundles its own ROCm runtime and whichever HIP runtime is loaded first serves
+#                 the whole process; loading /opt/rocm's first leaves torch without a device — only the multi-rank transport tests use torch)
 
 import oracle_lib as O
 
