@@ -4,11 +4,14 @@
 //  * a pass owns 13 index bits: K butterfly layers [lo, lo+K) plus B = 13-K low bits that only make
 //    the global accesses contiguous (runs of 2^B words, B = 0 for the pass that holds layers [0,13)).
 //    2^22 points = 2 passes (13 + 9 layers); each pass is one HBM round trip.
-//  * a block transforms the same 2^13-row tile of CB columns (1 or 2): with CB = 2 the LDS tile holds
-//    (col0, col1) pairs, every LDS access is 64-bit, twiddles and index arithmetic are paid once per pair.
-//  * RB layers per LDS round trip (radix-2^RB in registers, RB = 3 or 4); the pass's top layer is fused
-//    into the global<->LDS staging (its twiddle is uniform over the tile).
-//  * the twiddles of a round are requested one round ahead, so a round waits on LDS only.
+//  * a block transforms the same 2^13-row tile of CB columns: CB = 1 by default (34 KB of LDS, 58-70 VGPRs,
+//    3-4 blocks per CU); CB = 2 (NX_FFT_CB=2) holds (col0, col1) pairs, 64-bit LDS accesses, 2 blocks per CU.
+//  * 4 layers per LDS round trip (radix-16 in registers); the pass's top layer is fused into the
+//    global<->LDS staging (its twiddle is uniform over the tile); the layer count K is a template constant.
+//  * the twiddles of a round are requested one round ahead from DOUBLED tables (2t: what the doubled-factor
+//    product consumes), so a round waits on LDS only; all global accesses are address-space-1.
+//  * an LDE with blow-up 2 runs its middle (inverse last pass + forward first pass of both replicas) as ONE
+//    launch, lde_mid_kernel: the coefficients are written once and never re-read.
 //  * the trivial top layers of an LDE (inputs that are zero by construction) are not computed: the
 //    coefficient tile is replicated, each replica runs the remaining layers with its own twiddles.
 //  * blockIdx -> (tile, column group) keeps all column groups of a tile on one XCD (same twiddles,

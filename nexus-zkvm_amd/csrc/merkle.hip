@@ -9,6 +9,10 @@
 // coalesced access — with the 8-word chaining state and the 16-word block in VGPRs, the 10 rounds
 // fully unrolled with compile-time message schedule (rotates lower to v_alignbit_b32).  The kernel
 // is VALU-issue bound (≈1000 integer ops per block), not HBM bound.
+// Where a tree level has fewer nodes than the machine has lanes (the top of every tree, the small FRI layers) the LATENCY of
+// a compression is what counts: there one compression runs on a quad of lanes (b2s_compress_quad) and the nodes stay in LDS
+// (merkle_top_kernel); the last FRI layers are committed, mixed into the channel and folded in one launch (fri_tail_kernel),
+// the larger ones get their channel step from fri_channel_kernel — the FRI commit phase never waits for the host.
 #include "internal.h"
 #include <algorithm>
 #include <numeric>
