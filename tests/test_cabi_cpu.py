@@ -42,3 +42,15 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".hip", ".h", ".cuh", ".cpp", ".py", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "oracle_lib" not in text and "../oracle" not in text and "oracle/" not in text.replace("shares nothing with oracle/", "").replace("same as oracle/air.h", ""), os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c99_and_the_c_example_links(tmp_path):
+    """include/nexus_hip.h is the boundary a C / Rust-FFI caller sees: it must be valid C99 on its own, and examples/session_prove.c
+    (the prover session driven from plain C) must compile and link against the built library (run: the -m gpu test of the same name)."""
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    subprocess.run([gcc, "-x", "c", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", os.path.join(root, "include", "nexus_hip.h")], check=True)
+    lib_dir = os.path.join(root, "nexus-zkvm_amd")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "session_prove.c"),
+                    "-L" + lib_dir, "-lnexus_hip", "-Wl,-rpath," + lib_dir, "-o", str(tmp_path / "session_prove")], check=True)

@@ -894,6 +894,20 @@ def test_session_end_to_end_with_device_logup(be, nz, oracle, log):
     s.close()
 
 
+def test_c_example_proves_through_the_session(tmp_path):
+    """examples/session_prove.c: the session driven from plain C99 — proves, and refuses a trace that violates the constraint."""
+    import shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "nexus-zkvm_amd")
+    exe = str(tmp_path / "session_prove")
+    subprocess.run([shutil.which("gcc"), "-std=c99", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "session_prove.c"),
+                    "-L" + lib_dir, "-lnexus_hip", "-Wl,-rpath," + lib_dir, "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok ") and int(out.split()[1]) > 100
+    out = subprocess.run([exe, "bad"], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("refused:") and "ConstraintsNotSatisfied" in out
+
+
 # ---------------- "next" row R8: logup interaction trace on device --------------------------------------------------------
 
 @pytest.mark.parametrize("log", [4, 9, 13, 16])
