@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--n-inter", type=int, default=64)    # 16 logup columns x 4 base columns
     ap.add_argument("--pow-bits", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-rows", type=int, default=19)   # a bounded sample of the same machine: ~8-10 s of host work on the GPU box
+    ap.add_argument("--cpu-log-rows", type=int, default=20)   # a bounded sample of the same machine: ~10 s of host work on the GPU box
     ap.add_argument("--sharded", action="store_true",
                     help="N > 1: ONE proof per step with its columns sharded over the N GPUs (config #4 style, strong scaling) instead of one independent proof per GPU")
     args = ap.parse_args()

@@ -13,6 +13,7 @@
 // Blake2s-256 over (left ‖ right ‖ column values as LE u32); HASH_RAW0 = the older rule, raw
 // compression chaining from an all-zero state with t = f = 0 over 64-byte zero-padded blocks.
 #pragma once
+#include <thread>
 #include <vector>
 #include <map>
 #include <algorithm>
@@ -57,6 +58,9 @@ struct MerkleTree {
 };
 
 // MerkleProver::commit — columns in commit order; stable sort by size descending.
+// host threads used by merkle_commit for layers of >= 4096 nodes (set by the prove drivers; the result does not depend on it)
+static inline int& merkle_n_threads() { static int v = 1; return v; }
+
 static inline MerkleTree merkle_commit(std::vector<ColRef> cols, int mode) {
     MerkleTree t;
     if (cols.empty()) { t.layers.push_back({hash_node(nullptr, nullptr, nullptr, 0, mode)}); return t; }
@@ -71,11 +75,19 @@ static inline MerkleTree merkle_commit(std::vector<ColRef> cols, int mode) {
         size_t n = (size_t)1 << log;
         t.layers[log].resize(n);
         const std::vector<Hash>* prev = log < max_log ? &t.layers[log + 1] : nullptr;
-        vals.resize(lc.size());
-        for (size_t i = 0; i < n; i++) {
-            for (size_t c = 0; c < lc.size(); c++) vals[c] = lc[c][i];
-            t.layers[log][i] = hash_node(prev ? &(*prev)[2 * i] : nullptr, prev ? &(*prev)[2 * i + 1] : nullptr,
-                                         vals.data(), vals.size(), mode);
+        auto range = [&](size_t i0, size_t i1) {
+            std::vector<u32> v(lc.size());
+            for (size_t i = i0; i < i1; i++) {
+                for (size_t c = 0; c < lc.size(); c++) v[c] = lc[c][i];
+                t.layers[log][i] = hash_node(prev ? &(*prev)[2 * i] : nullptr, prev ? &(*prev)[2 * i + 1] : nullptr, v.data(), v.size(), mode);
+            }
+        };
+        const int nt = n >= 4096 ? merkle_n_threads() : 1;
+        if (nt <= 1) range(0, n);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < nt; k++) th.emplace_back(range, n * k / nt, n * (k + 1) / nt);
+            for (auto& x : th) x.join();
         }
     }
     return t;

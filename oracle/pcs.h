@@ -336,6 +336,7 @@ struct CommitmentSchemeProver {
         });
         std::vector<ColRef> refs;
         for (size_t i = 0; i < t.evals.size(); i++) refs.push_back({t.evals[i].data(), logs[i] + (int)cfg.log_blowup});
+        merkle_n_threads() = n_threads;
         t.merkle = merkle_commit(refs, cfg.hash_mode);
         ch.mix_root(t.merkle.root());
         trees.push_back(std::move(t));
