@@ -17,6 +17,7 @@
 //  * The zero-extension of the LDE ("extend") is folded into the first evaluate pass: source words
 //    at index >= 2^log_in read as zero, nothing is materialised.
 #include "internal.h"
+#include <atomic>
 #include <stdlib.h>
 #include <algorithm>
 
@@ -301,13 +302,13 @@ static int launch_pass(nx_ctx* ctx, bool inv, const FftPass& a) {
     dim3 grid(tiles * a.n_cols), block(threads);
     const bool first = a.lo == 0;
     if (lds_bytes > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
+        if (!(attr_set.load() & (1ull << (ctx->device & 63)))) {
             NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             NX_HIP(ctx, hipFuncSetAttribute((const void*)fft_pass_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            attr_set.fetch_or(1ull << (ctx->device & 63));
         }
     }
     if (inv && first) hipLaunchKernelGGL((fft_pass_kernel<true, true>), grid, block, lds_bytes, ctx->cur, a);

@@ -17,6 +17,7 @@
 //  * blockIdx -> (tile, column group) keeps all column groups of a tile on one XCD (same twiddles,
 //    neighbouring runs of the same cache lines) — for speed only, correctness never depends on it.
 #include "internal.h"
+#include <atomic>
 #include <algorithm>
 #include <stdlib.h>
 
@@ -579,11 +580,11 @@ static void shape_init() {
 
 template <bool INV, bool FIRST, int CB, int RB, int KT>
 static int launch13_t(nx_ctx* ctx, const Pass13& a) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
     const size_t lds_bytes = ((size_t)T13_ROWS + (T13_ROWS >> 4)) * 4 * CB;
-    if (!attr_set) {
+    if (!(attr_set.load() & (1ull << (ctx->device & 63)))) {
         NX_HIP(ctx, hipFuncSetAttribute((const void*)fft13_kernel<INV, FIRST, CB, RB, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.fetch_or(1ull << (ctx->device & 63));
     }
     dim3 grid(a.tiles * a.n_groups), block(T13_ROWS >> RB);
     hipLaunchKernelGGL((fft13_kernel<INV, FIRST, CB, RB, KT>), grid, block, lds_bytes, ctx->cur, a);
@@ -652,11 +653,11 @@ extern "C" int nx_fft13_trace_read(unsigned long long* out32, int reset) {
 
 template <int RB, int KT>
 static int launch_mid_t(nx_ctx* ctx, const PassMid& m) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
     const size_t lds_bytes = ((size_t)T13_ROWS + (T13_ROWS >> 4)) * 4 * 2;
-    if (!attr_set) {
+    if (!(attr_set.load() & (1ull << (ctx->device & 63)))) {
         NX_HIP(ctx, hipFuncSetAttribute((const void*)lde_mid_kernel<RB, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.fetch_or(1ull << (ctx->device & 63));
     }
     hipLaunchKernelGGL((lde_mid_kernel<RB, KT>), dim3(m.tiles * m.n_cols), dim3(T13_ROWS >> RB), lds_bytes, ctx->cur, m);
     NX_LAUNCH_CHECK(ctx);

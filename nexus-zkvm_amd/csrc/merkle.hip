@@ -14,6 +14,7 @@
 // (merkle_top_kernel); the last FRI layers are committed, mixed into the channel and folded in one launch (fri_tail_kernel),
 // the larger ones get their channel step from fri_channel_kernel — the FRI commit phase never waits for the host.
 #include "internal.h"
+#include <atomic>
 #include <algorithm>
 #include <numeric>
 #include <string.h>
@@ -308,11 +309,11 @@ __global__ __launch_bounds__(1024) void merkle_top_kernel(u32* __restrict__ base
 }
 
 static int launch_merkle_top(nx_ctx* ctx, u32* buf, int top) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
+    if (!(attr_set.load() & (1ull << (ctx->device & 63)))) {
         NX_HIP(ctx, hipFuncSetAttribute((const void*)merkle_top_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NX_HIP(ctx, hipFuncSetAttribute((const void*)merkle_top_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.fetch_or(1ull << (ctx->device & 63));
     }
     const size_t lds = (((size_t)4 << top) - 1) * 32;
     if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_top_kernel<0>, dim3(1), dim3(1024), lds, ctx->stream, buf, top);
@@ -475,11 +476,11 @@ int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, u32* const* evals, u32* const* 
     for (int j = 0; j <= n_layers; j++) a.eval[j] = evals[j];
     for (int j = 0; j < n_layers; j++) a.tree[j] = trees[j];
     a.n_layers = n_layers; a.log0 = log0; a.itw = tw->d_itw; a.tw_log = tw->log_half; a.state = d_state; a.j0 = j0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
+    if (!(attr_set.load() & (1ull << (ctx->device & 63)))) {
         NX_HIP(ctx, hipFuncSetAttribute((const void*)fri_tail_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         NX_HIP(ctx, hipFuncSetAttribute((const void*)fri_tail_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.fetch_or(1ull << (ctx->device & 63));
     }
     const size_t lds = ((((size_t)2 << log0) - 1) * 8 + 32) * 4;
     if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(fri_tail_kernel<0>, dim3(1), dim3(1024), lds, ctx->stream, a);
