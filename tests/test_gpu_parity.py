@@ -315,6 +315,22 @@ def test_config2_shape_lde_roundtrip_and_root_consistency(be):
     assert np.array_equal(t1, t2)
 
 
+def test_config2_lde_and_commit_bit_exact_vs_oracle_at_full_height(be, oracle):
+    """BASELINE config #2 at its full height (2^20 rows -> 2^21 LDE rows) on a column subset the oracle finishes in seconds: every
+    LDE value, every coefficient and the Blake2s Merkle root of nx_lde_commit equal the CPU oracle's."""
+    log, n_cols = 20, 12
+    vals = rand_cols(2021, n_cols, log)
+    tw = be.precompute_twiddles(log)
+    cols = be.columns_from_host(vals)
+    lde, root = be.lde_commit(tw, cols, 1)
+    otw = oracle.Twiddles(log + 1)
+    coeffs = [otw.interpolate(v) for v in vals]
+    ext = [otw.evaluate(c, log + 1) for c in coeffs]
+    assert np.array_equal(cols.to_cpu(), np.stack(coeffs))
+    assert np.array_equal(lde.to_cpu(), np.stack(ext))
+    assert np.array_equal(root, oracle.merkle_commit(ext))
+
+
 def test_large_prove_accepted_by_oracle_verifier(be, nz, oracle):
     """A 2^18-row synthetic prove (347 main / 27 preprocessed / 64 interaction columns): the oracle verifier
     must accept; tampering must be rejected."""
