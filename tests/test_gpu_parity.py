@@ -67,6 +67,24 @@ def test_interpolate_evaluate_match_oracle(be, oracle, log):
         lde.free()
 
 
+@pytest.mark.parametrize("log", [13, 14, 15, 16, 17, 18, 19, 20])
+def test_fused_lde_matches_oracle_at_every_pass_shape(be, oracle, log):
+    """nx_lde_batch with blow-up 2 takes the fused-middle route from 2^14 rows up (lde_mid_kernel with 1..7 layers here, 8 and 9 in
+    the large-transform test, the 3-pass plan at 2^23): coefficients and every LDE value against the oracle, an odd column count so
+    the batch tail is exercised too."""
+    n_cols = 3
+    vals = rand_cols(700 + log, n_cols, log)
+    tw = be.precompute_twiddles(log)
+    otw = oracle.Twiddles(log + 1)
+    cols = be.columns_from_host(vals)
+    lde = be.lde(tw, cols, 1)
+    coeffs = np.stack([otw.interpolate(v) for v in vals])
+    assert np.array_equal(cols.to_cpu(), coeffs)
+    got = lde.to_cpu()
+    for c in range(n_cols):
+        assert np.array_equal(got[c], otw.evaluate(coeffs[c], log + 1)), (log, c)
+
+
 @pytest.mark.parametrize("log", [21, 22, 23])
 def test_large_transforms_match_oracle_and_roundtrip(be, oracle, log):
     """2-pass (13+8, 13+9 layers) and 3-pass (13+5+5) schedules of the wide kernel: one column against the oracle,
