@@ -365,15 +365,24 @@ static int evaluate_cols(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n
     return NX_OK;
 }
 
+// Columns per launch: g_tune.batch_cols (2) is sized for 2^22-row columns — four of them in flight fill the Infinity Cache.  Smaller
+// columns get proportionally more per launch (the same bytes in flight): at 2^18 rows a 2-column launch is ~10 us of work behind
+// ~5 us of launch latency, and a 438-column tree needs 657 of them.
+static u32 batch_for(uint32_t log_size) {
+    const int shift = log_size < 22 ? (int)(22 - log_size) : 0;
+    return (u32)std::min<uint64_t>((uint64_t)g_tune.batch_cols << std::min(shift, 8), 256);
+}
+
 int fft_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size) {
     NX_TRY(check_tw(ctx, tw, (int)log_size));
     tune_init();
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * 8ull << log_size);
-    const int ns = n_cols > (u32)g_tune.batch_cols ? g_tune.streams : 1;
+    const u32 bc = batch_for(log_size);
+    const int ns = n_cols > bc ? g_tune.streams : 1;
     NX_TRY(streams_fork(ctx, ns));
     int rc = NX_OK;
-    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += g_tune.batch_cols, bi++) {
-        u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
+    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += bc, bi++) {
+        u32 nb = std::min<u32>(bc, n_cols - c0);
         streams_pick(ctx, (int)bi, ns);
         rc = interpolate_cols(ctx, tw, sub_colset(cols, c0), nb, (int)log_size);
     }
@@ -386,11 +395,12 @@ int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_co
     NX_TRY(check_tw(ctx, tw, n));
     tune_init();
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * ((4ull << log_size) + (4ull << n)));
-    const int ns = n_cols > (u32)g_tune.batch_cols ? g_tune.streams : 1;
+    const u32 bc = batch_for(log_size);
+    const int ns = n_cols > bc ? g_tune.streams : 1;
     NX_TRY(streams_fork(ctx, ns));
     int rc = NX_OK;
-    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += g_tune.batch_cols, bi++) {
-        u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
+    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += bc, bi++) {
+        u32 nb = std::min<u32>(bc, n_cols - c0);
         streams_pick(ctx, (int)bi, ns);
         rc = evaluate_cols(ctx, tw, sub_colset(polys, c0), nb, (int)log_size, n, sub_colset(out, c0));
     }
@@ -405,11 +415,12 @@ int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, ui
     tune_init();
     // algorithmic bytes: read N evals, write N coeffs, write M = 2^n LDE words
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * ((8ull << log_size) + (4ull << n)));
-    const int ns = n_cols > (u32)g_tune.batch_cols ? g_tune.streams : 1;
+    const u32 bc = batch_for(log_size);
+    const int ns = n_cols > bc ? g_tune.streams : 1;
     NX_TRY(streams_fork(ctx, ns));
     int rc = NX_OK;
-    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += g_tune.batch_cols, bi++) {
-        u32 nb = std::min<u32>(g_tune.batch_cols, n_cols - c0);
+    for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += bc, bi++) {
+        u32 nb = std::min<u32>(bc, n_cols - c0);
         streams_pick(ctx, (int)bi, ns);
         if (log_expand == 1 && log_size >= 14 && !g_tune.legacy && fft13_lde_fused_enabled()) {
             rc = fft13_lde(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, sub_colset(out, c0));   // middle passes fused (fft13.hip)
