@@ -726,7 +726,9 @@ int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t*
     uint8_t* d = nullptr;
     NX_TRY(dev_alloc(ctx, sizeof h, (void**)&d));
     hipError_t e = hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream);
-    const uint64_t batch = 1ull << 22;
+    // the first launch tries 64 x the expected number of nonces (2^pow_bits): enough with probability 1 - e^-64, ~10 us for the
+    // default 10 bits instead of the 108 us of a fixed 2^22 batch; later launches (never needed in practice) double up to 2^24
+    uint64_t batch = std::min<uint64_t>(1ull << 24, std::max<uint64_t>(1ull << 16, 64ull << std::min<uint32_t>(pow_bits, 18)));
     uint64_t base = 0;
     unsigned long long res = ~0ull;
     while (e == hipSuccess) {
@@ -737,6 +739,7 @@ int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t*
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (res != ~0ull) break;
         base += batch;
+        batch = std::min<uint64_t>(1ull << 24, batch * 2);
     }
     (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx, d);
