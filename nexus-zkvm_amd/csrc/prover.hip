@@ -161,27 +161,37 @@ int TreeBuilder::commit(Blake2sChannel& channel) {
     if (total_leaf_cols) H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp));
     std::vector<const uint32_t*> small_cols; std::vector<uint32_t> small_logs;
     const uint32_t G = pipe_group_cols();
-    for (auto& g : groups) {
-        uint32_t el = g.log + cs.cfg.log_blowup;
+    // consecutive groups of one size (the components of a prover2-style statement) are extended by ONE batch call: a tree of 55 small
+    // components is 6 calls, not 55 (each call forks/joins the FFT streams and is launch-bound below ~2^16 rows)
+    for (size_t g0 = 0; g0 < groups.size();) {
+        size_t g1 = g0 + 1;
+        while (g1 < groups.size() && groups[g1].log == groups[g0].log && groups[g1].is_evals == groups[g0].is_evals) g1++;
+        const uint32_t log = groups[g0].log, el = log + cs.cfg.log_blowup;
+        const bool is_evals = groups[g0].is_evals;
+        uint32_t n_run = 0;
+        for (size_t g = g0; g < g1; g++) n_run += groups[g].n_cols;
         DevBuf lde;
-        if (g.n_cols) {
-            H_TRY(lde.alloc(ctx, (size_t)g.n_cols << el));
-            auto in = col_ptrs(g.slab.p, g.n_cols, g.log), out = col_ptrs(lde.p, g.n_cols, el);
+        if (n_run) {
+            H_TRY(lde.alloc(ctx, (size_t)n_run << el));
+            std::vector<uint32_t*> in;
+            for (size_t g = g0; g < g1; g++) { auto p = col_ptrs(groups[g].slab.p, groups[g].n_cols, log); in.insert(in.end(), p.begin(), p.end()); }
+            auto out = col_ptrs(lde.p, n_run, el);
             const bool leaf = el == max_el;
-            const uint32_t step = leaf ? G : g.n_cols;
-            for (uint32_t c0 = 0; c0 < g.n_cols; c0 += step) {
-                const uint32_t nb = std::min(step, g.n_cols - c0);
-                if (g.is_evals) H_TRY(nx_lde_batch(ctx, cs.tw, in.data() + c0, nb, g.log, cs.cfg.log_blowup, out.data() + c0));   // K3 + K4
-                else H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)in.data() + c0, nb, g.log, cs.cfg.log_blowup, out.data() + c0));  // K4
+            const uint32_t step = leaf ? G : n_run;
+            for (uint32_t c0 = 0; c0 < n_run; c0 += step) {
+                const uint32_t nb = std::min(step, n_run - c0);
+                if (is_evals) H_TRY(nx_lde_batch(ctx, cs.tw, in.data() + c0, nb, log, cs.cfg.log_blowup, out.data() + c0));   // K3 + K4
+                else H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)in.data() + c0, nb, log, cs.cfg.log_blowup, out.data() + c0));  // K4
                 if (leaf) H_TRY(tree_pipe_absorb(ctx, &tp, (const uint32_t* const*)out.data() + c0, nb, false));                   // K5, leaf layer
             }
-            for (uint32_t i = 0; i < g.n_cols; i++) {
-                t.polys.push_back({in[i], g.log}); t.evals.push_back({out[i], el});
+            for (uint32_t i = 0; i < n_run; i++) {
+                t.polys.push_back({in[i], log}); t.evals.push_back({out[i], el});
                 if (!leaf) { small_cols.push_back(out[i]); small_logs.push_back(el); }
             }
         }
-        t.bufs.push_back(std::move(g.slab));
+        for (size_t g = g0; g < g1; g++) t.bufs.push_back(std::move(groups[g].slab));
         t.bufs.push_back(std::move(lde));
+        g0 = g1;
     }
     if (total_leaf_cols) H_TRY(tree_pipe_finish(ctx, &tp, small_cols.data(), small_logs.data(), (uint32_t)small_cols.size(), &t.merkle));   // K5, inner layers
     else H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &t.merkle));
