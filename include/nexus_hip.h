@@ -273,7 +273,8 @@ int nx_eval_constraint_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n
 /* The same program compiled into a gfx950 kernel at run time (hiprtc): straight-line code over VGPRs instead of an LDS
  * register file, ~3x faster than the interpreter; lookup elements and alpha powers stay run-time arguments, so one compilation
  * serves every proof of an AIR.  h_source_out (optional, may be the only output: then ctx may be NULL and no GPU is needed)
- * receives the generated HIP source (free with nx_free_host). */
+ * receives the generated HIP source (free with nx_free_host).  nx_air_eval is stream-ordered like the other kernels: it returns
+ * once the launch is enqueued (nx_sync or any later entry that reads the accumulator orders after it). */
 typedef struct nx_air_kernel nx_air_kernel;
 int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols,
                    uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out, char** h_source_out);

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <string.h>
 
 struct nx_air_kernel {
     nx_ctx* ctx;
@@ -199,23 +200,23 @@ int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_co
     const size_t b_cols = (size_t)k->n_cols * 8, b_ec = (size_t)k->n_econsts * 16, b_pw = (size_t)k->n_constraints * 16, b_den = (size_t)4 << (log_eval - log_size);
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_ec = al(b_cols), o_pw = o_ec + al(b_ec), o_den = o_pw + al(b_pw), total = o_den + al(b_den) + 16;
-    uint8_t* blob = nullptr;
-    NX_TRY(dev_alloc(ctx, total, (void**)&blob));
-    hipError_t er = hipSuccess;
-    auto up = [&](size_t off, const void* src, size_t bytes) { if (er == hipSuccess && bytes) er = hipMemcpyAsync(blob + off, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
-    up(0, d_cols, b_cols); up(o_ec, econsts, b_ec); up(o_pw, alpha_powers, b_pw); up(o_den, denom_inv, b_den);
-    if (er == hipSuccess) {
-        const void* p_cols = blob; const void* p_ec = blob + o_ec; const void* p_pw = blob + o_pw; const void* p_den = blob + o_den;
-        int ls = (int)log_size, le = (int)log_eval;
-        uint32_t* a0 = d_acc4[0]; uint32_t* a1 = d_acc4[1]; uint32_t* a2 = d_acc4[2]; uint32_t* a3 = d_acc4[3];
-        void* args[] = {&p_cols, &p_ec, &p_pw, &p_den, &ls, &le, &a0, &a1, &a2, &a3};
-        const uint32_t n = 1u << log_eval;
-        er = hipModuleLaunchKernel(k->fn, (n + 255) / 256, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
-    }
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    dev_free(ctx, blob);
+    // one stream-ordered copy through the context's pinned staging ring: no allocation, no synchronisation — a statement with
+    // dozens of components enqueues their kernels back to back
+    std::vector<uint8_t> host(total, 0);
+    if (b_cols) memcpy(host.data(), d_cols, b_cols);
+    if (b_ec) memcpy(host.data() + o_ec, econsts, b_ec);
+    if (b_pw) memcpy(host.data() + o_pw, alpha_powers, b_pw);
+    if (b_den) memcpy(host.data() + o_den, denom_inv, b_den);
+    void* staged = nullptr;
+    NX_TRY(stage(ctx, host.data(), total, &staged));
+    const uint8_t* blob = (const uint8_t*)staged;
+    const void* p_cols = blob; const void* p_ec = blob + o_ec; const void* p_pw = blob + o_pw; const void* p_den = blob + o_den;
+    int ls = (int)log_size, le = (int)log_eval;
+    uint32_t* a0 = d_acc4[0]; uint32_t* a1 = d_acc4[1]; uint32_t* a2 = d_acc4[2]; uint32_t* a3 = d_acc4[3];
+    void* args[] = {&p_cols, &p_ec, &p_pw, &p_den, &ls, &le, &a0, &a1, &a2, &a3};
+    const uint32_t n = 1u << log_eval;
+    hipError_t er = hipModuleLaunchKernel(k->fn, (n + 255) / 256, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
     if (er != hipSuccess) return hip_fail(ctx, er, "nx_air_eval", __FILE__, __LINE__);
-    if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_air_eval(sync)", __FILE__, __LINE__);
     return NX_OK;
 }
 

@@ -37,6 +37,21 @@ int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out) {
     return NX_OK;
 }
 
+// A pinned host region of the same ring (target of an asynchronous device-to-host copy); valid until the ring wraps.
+int pinned_reserve(nx_ctx* ctx, size_t bytes, void** h_out) {
+    size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > ctx->scratch_size) return set_err(ctx, NX_ERR_ARG, "pinned_reserve: request larger than scratch ring");
+    if (ctx->scratch_off + need > ctx->scratch_size) {
+        NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream));
+        for (int i = 0; i < 3; i++) NX_HIP(ctx, hipStreamSynchronize(ctx->side[i]));
+        ctx->scratch_off = 0;
+    }
+    *h_out = ctx->h_scratch + ctx->scratch_off;
+    ctx->scratch_off += need;
+    return NX_OK;
+}
+
 int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out) {
     out->base = nullptr; out->stride = 0; out->table = nullptr;
     if (n == 0) return NX_OK;

@@ -100,6 +100,13 @@ __device__ __forceinline__ void gst4(uint32_t* p, uint4 v) { nx_v4u32 w = {v.x, 
 int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out);
 // Stage arbitrary bytes into device scratch; returns device pointer (valid until the ring wraps).
 int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out);
+int pinned_reserve(nx_ctx* ctx, size_t bytes, void** h_out);   // pinned host region of the same ring (async D2H target)
+// nx_eval_at_points in two phases, so that a prover samples every tree and size with ONE synchronisation: enqueue launches the
+// kernels of one request and records where its partial sums will land; collect waits once and reduces them into the outputs.
+struct EvalJob { uint8_t* blob; const uint32_t* h_part; uint32_t np, n_chunks; std::vector<uint32_t> evals; uint32_t* h_out; };
+int eval_at_points_enqueue(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_size, const uint32_t* poly_idx, const uint32_t* h_points, uint32_t n_evals,
+                           uint32_t* h_out, std::vector<EvalJob>* jobs);
+int eval_at_points_collect(nx_ctx* ctx, std::vector<EvalJob>* jobs);
 // cached device allocation (bytes); dev_free returns the block to the cache (no device sync)
 int dev_alloc(nx_ctx* ctx, size_t bytes, void** out);
 void dev_free(nx_ctx* ctx, void* p);

@@ -304,6 +304,18 @@ extern "C" {
 
 int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_size, const uint32_t* poly_idx,
                       const uint32_t* h_points, uint32_t n_evals, uint32_t* h_out) {
+    std::vector<EvalJob> jobs;
+    int rc = eval_at_points_enqueue(ctx, d_polys, log_size, poly_idx, h_points, n_evals, h_out, &jobs);
+    int rc2 = eval_at_points_collect(ctx, &jobs);
+    return rc != NX_OK ? rc : rc2;
+}
+
+}  // extern "C"
+
+namespace nx {
+
+int eval_at_points_enqueue(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_size, const uint32_t* poly_idx, const uint32_t* h_points, uint32_t n_evals,
+                           uint32_t* h_out, std::vector<EvalJob>* jobs) {
     if (n_evals == 0) return NX_OK;
     if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_eval_at_points: log_size too large");
     const int n = (int)log_size;
@@ -321,52 +333,65 @@ int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_
     for (size_t g = 0; g < groups.size(); g++) {
         QPt p; p.x = q_load(gpts[g]); p.y = q_load(gpts[g] + 4);
         // factors for bit k of j: [y, x, pi(x), pi^2(x), ...]
-        std::vector<QM31> f(n);
-        if (n > 0) f[0] = p.y;
-        { QM31 x = p.x; for (int k = 1; k < n; k++) { f[k] = x; x = q_double_x(x); } }
+        EvalFactors F;
+        for (int k = 0; k < 30; k++) F.f[k] = q_one();
+        if (n > 0) F.f[0] = p.y;
+        { QM31 x = p.x; for (int k = 1; k < n; k++) { F.f[k] = x; x = q_double_x(x); } }
         const size_t tlo_words = 4 * (size_t)n_lo, thi_words = 4 * (size_t)n_hi;
         const uint32_t np = (uint32_t)groups[g].size();
         std::vector<const uint32_t*> sel(np);
         for (uint32_t i = 0; i < np; i++) sel[i] = d_polys[poly_idx[groups[g][i]]];
         uint32_t hi_per_block = std::max<uint32_t>(1, std::min<uint32_t>(n_hi, 128));
         uint32_t n_chunks = (n_hi + hi_per_block - 1) / hi_per_block;
-        // device buffers: tables + partials (+ pointer table when needed)
-        uint32_t *d_lo = nullptr, *d_hi = nullptr, *d_part = nullptr;
-        uint32_t* const* d_tab = nullptr;
-        size_t part_words = (size_t)np * n_chunks * 4;
-        uint8_t* blob = nullptr;
-        size_t bytes = tlo_words * 4 + thi_words * 4 + part_words * 4 + (size_t)np * 8;
-        NX_TRY(dev_alloc(ctx, bytes, (void**)&blob));
-        d_lo = (uint32_t*)blob; d_hi = d_lo + tlo_words; d_part = d_hi + thi_words;
-        d_tab = (uint32_t* const*)(blob + (tlo_words + thi_words + part_words) * 4);
-        EvalFactors F;
-        for (int k = 0; k < 30; k++) F.f[k] = k < n ? f[k] : q_one();
+        const size_t part_words = (size_t)np * n_chunks * 4;
+        // the ring must not wrap over partial sums that were not collected yet: drain the pending jobs first
+        if (!jobs->empty() && ctx->scratch_off + (size_t)np * 8 + part_words * 4 + 1024 > ctx->scratch_size) NX_TRY(eval_at_points_collect(ctx, jobs));
+        EvalJob job; job.blob = nullptr; job.np = np; job.n_chunks = n_chunks; job.evals = groups[g]; job.h_out = h_out;
+        NX_TRY(dev_alloc(ctx, (tlo_words + thi_words + part_words) * 4, (void**)&job.blob));
+        uint32_t* d_lo = (uint32_t*)job.blob; uint32_t* d_hi = d_lo + tlo_words; uint32_t* d_part = d_hi + thi_words;
+        void* d_tab = nullptr; void* h_part = nullptr;
+        int rc = stage(ctx, sel.data(), (size_t)np * 8, &d_tab);                       // pointer table through the pinned ring
+        if (rc == NX_OK) rc = pinned_reserve(ctx, part_words * 4, &h_part);
+        if (rc != NX_OK) { dev_free(ctx, job.blob); return rc; }
+        job.h_part = (const uint32_t*)h_part;
         hipLaunchKernelGGL(eval_tables_kernel, dim3((n_lo + n_hi + 255) / 256), dim3(256), 0, ctx->stream, F, n, L, d_lo, d_hi);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync((void*)d_tab, sel.data(), (size_t)np * 8, hipMemcpyHostToDevice, ctx->stream);
-        std::vector<uint32_t> part(part_words);
-        if (e == hipSuccess) {
-            ColSet cs; cs.base = nullptr; cs.stride = 0; cs.table = d_tab;
-            for (uint32_t p0 = 0; p0 < np && e == hipSuccess; p0 += 32768) {
-                uint32_t nb = std::min<uint32_t>(32768, np - p0);
-                ColSet sub = cs; sub.table = d_tab + p0;
-                hipLaunchKernelGGL(eval_at_point_kernel, dim3(n_chunks, nb), dim3(EVAL_THREADS), 0, ctx->stream, sub, n, d_lo, d_hi,
-                                   hi_per_block, d_part + (size_t)p0 * n_chunks * 4, n_chunks);
-                e = hipGetLastError();
-            }
+        for (uint32_t p0 = 0; p0 < np && e == hipSuccess; p0 += 32768) {
+            uint32_t nb = std::min<uint32_t>(32768, np - p0);
+            ColSet sub; sub.base = nullptr; sub.stride = 0; sub.table = (uint32_t* const*)d_tab + p0;
+            hipLaunchKernelGGL(eval_at_point_kernel, dim3(n_chunks, nb), dim3(EVAL_THREADS), 0, ctx->stream, sub, n, d_lo, d_hi,
+                               hi_per_block, d_part + (size_t)p0 * n_chunks * 4, n_chunks);
+            e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(part.data(), d_part, part_words * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        dev_free(ctx, blob);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_part, d_part, part_words * 4, hipMemcpyDeviceToHost, ctx->stream);   // pinned target: asynchronous
+        jobs->push_back(std::move(job));
         if (e != hipSuccess) return hip_fail(ctx, e, "nx_eval_at_points", __FILE__, __LINE__);
-        for (uint32_t i = 0; i < np; i++) {
-            uint32_t s[4] = {0, 0, 0, 0};
-            for (uint32_t c = 0; c < n_chunks; c++) for (int q = 0; q < 4; q++) s[q] = m_add(s[q], part[((size_t)i * n_chunks + c) * 4 + q]);
-            memcpy(h_out + 4 * (size_t)groups[g][i], s, 16);
-        }
     }
     return NX_OK;
 }
+
+int eval_at_points_collect(nx_ctx* ctx, std::vector<EvalJob>* jobs) {
+    if (jobs->empty()) return NX_OK;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    for (auto& j : *jobs) {
+        if (e == hipSuccess)
+            for (uint32_t i = 0; i < j.np; i++) {
+                u32 s4[4] = {0, 0, 0, 0};
+                for (uint32_t c = 0; c < j.n_chunks; c++) for (int q = 0; q < 4; q++) s4[q] = m_add(s4[q], j.h_part[((size_t)i * j.n_chunks + c) * 4 + q]);
+                memcpy(j.h_out + 4 * (size_t)j.evals[i], s4, 16);
+            }
+        dev_free(ctx, j.blob);
+    }
+    jobs->clear();
+    if (e != hipSuccess) return hip_fail(ctx, e, "nx_eval_at_points(sync)", __FILE__, __LINE__);
+    return NX_OK;
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
 
 // `entry_local` (NULL = all): which flattened (column, value) entries this GPU holds the column of; the others only advance
 // the alpha powers.  `include_line`: add the -(a·y + b) line terms of ALL entries (exactly one GPU of a column-sharded prove

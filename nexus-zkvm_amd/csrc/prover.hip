@@ -694,28 +694,39 @@ static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& c
     // ---------------- prove_values ----------------
     Proof proof;
     proof.sampled_values.resize(4);
-    for (int t = 0; t < 4; t++) {
-        auto& tr = cs.trees[t];
-        proof.sampled_values[t].resize(tr.polys.size());
-        std::map<uint32_t, std::vector<uint32_t>> by_log;  // poly log -> column indices
-        for (uint32_t c = 0; c < tr.polys.size(); c++) by_log[tr.polys[c].log].push_back(c);
-        for (auto& kv : by_log) {
-            std::vector<const uint32_t*> pp; std::vector<uint32_t> pidx, pts; std::vector<std::pair<uint32_t, uint32_t>> where;
-            for (uint32_t li = 0; li < kv.second.size(); li++) {
-                uint32_t c = kv.second[li];
-                pp.push_back(tr.polys[c].ptr);
-                for (uint32_t s = 0; s < points[t][c].size(); s++) {
-                    pidx.push_back(li);
-                    uint32_t w[8]; q_store(w, points[t][c][s].x); q_store(w + 4, points[t][c][s].y);
-                    pts.insert(pts.end(), w, w + 8);
-                    where.push_back({c, s});
+    {   // every tree and size is enqueued first; ONE synchronisation collects all the sampled values (K7)
+        struct Pending { std::vector<uint32_t> out; std::vector<std::pair<uint32_t, uint32_t>> where; int t; };
+        std::vector<Pending> pend; pend.reserve(64);
+        std::vector<EvalJob> jobs;
+        size_t n_req = 0;
+        for (int t = 0; t < 4; t++) { std::set<uint32_t> logs; for (auto& c : cs.trees[t].polys) logs.insert(c.log); n_req += logs.size(); }
+        pend.reserve(n_req);                                       // `out` buffers must not move while jobs point into them
+        for (int t = 0; t < 4; t++) {
+            auto& tr = cs.trees[t];
+            proof.sampled_values[t].resize(tr.polys.size());
+            std::map<uint32_t, std::vector<uint32_t>> by_log;  // poly log -> column indices
+            for (uint32_t c = 0; c < tr.polys.size(); c++) by_log[tr.polys[c].log].push_back(c);
+            for (auto& kv : by_log) {
+                std::vector<const uint32_t*> pp; std::vector<uint32_t> pidx, pts;
+                pend.emplace_back(); Pending& pd = pend.back(); pd.t = t;
+                for (uint32_t li = 0; li < kv.second.size(); li++) {
+                    uint32_t c = kv.second[li];
+                    pp.push_back(tr.polys[c].ptr);
+                    for (uint32_t s = 0; s < points[t][c].size(); s++) {
+                        pidx.push_back(li);
+                        uint32_t w[8]; q_store(w, points[t][c][s].x); q_store(w + 4, points[t][c][s].y);
+                        pts.insert(pts.end(), w, w + 8);
+                        pd.where.push_back({c, s});
+                    }
+                    proof.sampled_values[t][c].resize(points[t][c].size());
                 }
-                proof.sampled_values[t][c].resize(points[t][c].size());
+                pd.out.assign(4 * pidx.size(), 0);
+                H_TRY(eval_at_points_enqueue(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), pd.out.data(), &jobs));
             }
-            std::vector<uint32_t> out(4 * pidx.size());
-            H_TRY(nx_eval_at_points(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), out.data()));   // K7
-            for (size_t i = 0; i < where.size(); i++) proof.sampled_values[t][where[i].first][where[i].second] = q_load(&out[4 * i]);
         }
+        H_TRY(eval_at_points_collect(ctx, &jobs));
+        for (auto& pd : pend)
+            for (size_t i = 0; i < pd.where.size(); i++) proof.sampled_values[pd.t][pd.where[i].first][pd.where[i].second] = q_load(&pd.out[4 * i]);
     }
     { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); channel.mix_felts(flat); }
     lap(&st->oods);
