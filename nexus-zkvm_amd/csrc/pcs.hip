@@ -435,33 +435,29 @@ static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint3
         q_store(B.sum_a, sa); q_store(B.sum_b, sb); q_store(B.coeff, a_pow);
     }
     const size_t n_local = lidx.size();
-    // stage descriptors in one allocation that outlives the kernel
-    uint8_t* blob = nullptr;
+    // descriptors, column indices, coefficients and the column pointer table travel in ONE stream-ordered copy through the pinned
+    // staging ring (valid until the ring wraps, which synchronises): no allocation, no synchronisation per size group
     size_t bytes_b = hb.size() * sizeof(QBatchDev), bytes_i = n_local * 4, bytes_c = cks.size() * 4, bytes_t = (size_t)n_cols * 8;
     size_t off_i = (bytes_b + 15) & ~(size_t)15, off_c = off_i + ((bytes_i + 15) & ~(size_t)15), off_t = off_c + ((bytes_c + 15) & ~(size_t)15);
-    NX_TRY(dev_alloc(ctx, off_t + bytes_t + 16, (void**)&blob));
-    hipError_t e = hipMemcpyAsync(blob, hb.data(), bytes_b, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && n_local) e = hipMemcpyAsync(blob + off_i, lidx.data(), bytes_i, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && n_local) e = hipMemcpyAsync(blob + off_c, cks.data(), bytes_c, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && n_cols) e = hipMemcpyAsync(blob + off_t, d_cols, bytes_t, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        ColSet cs; cs.base = nullptr; cs.stride = 0; cs.table = (uint32_t* const*)(blob + off_t);
-        uint64_t alg = ((uint64_t)n_cols * 4 + 16) << log_size;
-        KTimer timer(ctx, NX_T_QUOT, alg);
-        uint32_t n = 1u << log_size;
-        if (log_size >= 2)
-            hipLaunchKernelGGL(quotient_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
-                               (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
-        else
-            hipLaunchKernelGGL(quotient_small_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
-                               (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
-        e = hipGetLastError();
-    }
-    // the pageable host vectors above die at return, and the blob must outlive the kernel: synchronise before freeing it
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    dev_free(ctx, blob);
-    if (e != hipSuccess) return hip_fail(ctx, e, "nx_accumulate_quotients", __FILE__, __LINE__);
-    if (e2 != hipSuccess) return hip_fail(ctx, e2, "nx_accumulate_quotients(sync)", __FILE__, __LINE__);
+    std::vector<uint8_t> host(off_t + bytes_t + 16, 0);
+    if (bytes_b) memcpy(host.data(), hb.data(), bytes_b);
+    if (bytes_i) memcpy(host.data() + off_i, lidx.data(), bytes_i);
+    if (bytes_c) memcpy(host.data() + off_c, cks.data(), bytes_c);
+    if (bytes_t) memcpy(host.data() + off_t, d_cols, bytes_t);
+    void* staged = nullptr;
+    NX_TRY(stage(ctx, host.data(), host.size(), &staged));
+    const uint8_t* blob = (const uint8_t*)staged;
+    ColSet cs; cs.base = nullptr; cs.stride = 0; cs.table = (uint32_t* const*)(blob + off_t);
+    uint64_t alg = ((uint64_t)n_cols * 4 + 16) << log_size;
+    KTimer timer(ctx, NX_T_QUOT, alg);
+    uint32_t n = 1u << log_size;
+    if (log_size >= 2)
+        hipLaunchKernelGGL(quotient_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
+                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+    else
+        hipLaunchKernelGGL(quotient_small_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
+                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+    NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
 
