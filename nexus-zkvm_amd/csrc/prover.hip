@@ -577,24 +577,35 @@ static int compute_composition(CommitmentSchemeProver& cs, const nx_component_sp
     std::vector<QM31> powers(total);
     { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
     std::map<uint32_t, SecureColumn> sub;  // evaluation-domain log size -> accumulation
-    size_t remaining = total;
+    // alpha powers and vanishing denominators of ALL components in one stream-ordered copy (a prover2-style statement has dozens of
+    // components: two staging calls each were most of their cost)
+    std::vector<uint32_t> params; std::vector<size_t> off_pw(n_comps), off_den(n_comps);
+    {
+        size_t remaining = total;
+        std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> den_cache;
+        for (uint32_t ci = 0; ci < n_comps; ci++) {
+            const nx_component_spec& c = comps[ci];
+            const uint32_t e = c.log_size + lcd;
+            const size_t nc = synth_n_constraints(c);
+            off_pw[ci] = params.size();
+            params.resize(params.size() + 4 * nc);   // this component takes the LAST nc remaining powers, reversed
+            for (size_t j = 0; j < nc; j++) q_store(&params[off_pw[ci] + 4 * j], powers[remaining - 1 - j]);
+            remaining -= nc;
+            auto key = std::make_pair(c.log_size, e);
+            if (!den_cache.count(key)) den_cache[key] = vanishing_denominators(c.log_size, e);
+            const auto& den = den_cache[key];
+            off_den[ci] = params.size();
+            params.insert(params.end(), den.begin(), den.end());
+            while (params.size() % 4) params.push_back(0);
+        }
+    }
+    void* d_params = nullptr;
+    if (!params.empty()) H_TRY(stage(ctx, params.data(), params.size() * 4, &d_params));
     for (uint32_t ci = 0; ci < n_comps; ci++) {
         const nx_component_spec& c = comps[ci];
         const uint32_t e = c.log_size + lcd;
-        const size_t nc = synth_n_constraints(c);
-        std::vector<uint32_t> pw(4 * nc);  // this component takes the LAST nc remaining powers, reversed
-        for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[remaining - 1 - j]);
-        remaining -= nc;
-        void* d_pw = nullptr; H_TRY(stage(ctx, pw.data(), pw.size() * 4, &d_pw));
-        // denominators: 1 / coset_vanishing(trace coset, eval_domain.at(i)), bit-reversed over log_expand bits
-        const uint32_t log_expand = e - c.log_size;
-        std::vector<uint32_t> den((size_t)1 << log_expand);
-        for (uint32_t i = 0; i < den.size(); i++) {
-            u32 x = pt_from_index(circle_domain_index((int)e, i)).x;
-            for (uint32_t k = 1; k < c.log_size; k++) x = m_double_x(x);
-            den[bitrev(i, (int)log_expand)] = m_inv(x);
-        }
-        void* d_den = nullptr; H_TRY(stage(ctx, den.data(), den.size() * 4, &d_den));
+        const u32* d_pw = (const u32*)d_params + off_pw[ci];
+        const u32* d_den = (const u32*)d_params + off_den[ci];
         // trace on the evaluation domain
         ColSet pre, mainc, inter;
         DevBuf ext;
@@ -618,7 +629,7 @@ static int compute_composition(CommitmentSchemeProver& cs, const nx_component_sp
         }
         if (!sub.count(e)) { H_TRY(sub[e].alloc(ctx, e)); H_TRY(nx_memset_zero(ctx, sub[e].buf.p, sub[e].buf.words)); }
         SynthRange rg{0, c.n_main, c.n_main, 0, c.n_inter, true};
-        H_TRY(synth_constraints(ctx, pre, mainc, inter, rg, (int)c.log_size, (int)e, (const u32*)d_pw, (const u32*)d_den, sub[e].c));
+        H_TRY(synth_constraints(ctx, pre, mainc, inter, rg, (int)c.log_size, (int)e, d_pw, d_den, sub[e].c));
     }
     return finalize_accumulation(cs, sub, out_polys, out_log);
 }
