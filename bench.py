@@ -126,6 +126,7 @@ def main():
                        "log_n_rows": args.log_rows, "parallelism": ("1 proof, columns sharded over %d GPUs" % world) if sharded else ("1 proof per GPU" if world > 1 else "1 GPU"),
                        "proof_words": int(len(words))},
             "roofline": {"bound": "hbm", "achieved": lde_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_gbs / HBM_PEAK_GBS,
+                         "frac_of_measured_copy": lde_gbs / 6290.0,   # MI355X_MICROARCH.md: 6.29 TB/s measured copy bandwidth
                          "traffic": traffic, "kernel": "nx::fft13_kernel<INV, FIRST, 1, 4, K> + nx::lde_mid_kernel<4, K> (Circle iFFT+FFT = LDE, all passes of one prove)",
                          "algorithmic_bytes": stats["lde_algorithmic_bytes"], "kernel_ms": stats["lde_kernel_ms"]},
             # the FFT is VALU-issue bound on gfx950, not HBM bound: butterflies of one prove's iFFT + LDE work
