@@ -24,5 +24,8 @@ int synth_fill_range(nx_ctx* ctx, const nx_component_spec& c, uint32_t ci, uint3
 int secure_accumulate(nx_ctx* ctx, u32* const dst4[4], const u32* const src4[4], u32 n);
 int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size, uint32_t log_expand, ColSet out);
 int merkle_layer(nx_ctx* ctx, ColSet cols, u32 n_cols, const u32* prev, u32* out, u32 log);
+// recorded AIR programs (air_jit.hip): bounds of every register / column / secure-constant index; counts the constraints
+int validate_air_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t* n_constraints_out);
+void air_kernel_shape(const nx_air_kernel* k, uint32_t* n_cols, uint32_t* n_econsts, uint32_t* n_constraints);
 
 }  // namespace nx

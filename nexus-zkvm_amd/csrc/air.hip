@@ -209,6 +209,7 @@ using namespace nx;
 
 extern "C" int nx_synth_fill_tree(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, uint32_t tree, uint64_t seed, uint64_t inter_seed,
                                   uint32_t* const* d_cols) {
+    NX_GUARD(ctx);
     if (tree > 2) return set_err(ctx, NX_ERR_ARG, "nx_synth_fill_tree: tree must be 0, 1 or 2");
     size_t first = 0;
     for (uint32_t ci = 0; ci < n_comps; ci++) {

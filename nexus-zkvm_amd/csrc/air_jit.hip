@@ -7,6 +7,7 @@
 // schedules the column loads.  Same semantics, same operand encoding, same accumulation as the interpreter; the lookup
 // elements (econsts) and alpha powers stay run-time arguments, so one compilation serves every proof of an AIR.
 #include "internal.h"
+#include "air.h"
 #include <hip/hiprtc.h>
 #include <algorithm>
 #include <string>
@@ -128,20 +129,18 @@ static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, 
 
 }  // namespace nx
 
-using namespace nx;
+namespace nx {
 
-extern "C" {
-
-// Validates like nx_eval_constraint_program, generates the source, compiles it for gfx950 and loads the module.
-// h_source_out (optional): receives a malloc'd copy of the generated source (free with nx_free_host) — also usable without a GPU.
-int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints,
-                   nx_air_kernel** out, char** h_source_out) {
-    if (!program || (!out && !h_source_out)) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: NULL argument");
-    if (n_regs == 0 || n_regs > 4096) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: register count out of range");
+// Shared by nx_air_compile, nx_eval_constraint_program's callers and the prover session (GenericAir::check): every register index
+// (dst, a, b and the +3 of the secure-field ops), column index and secure-constant index of a recorded program is inside the
+// announced bounds.  A caller mistake across the C ABI is NX_ERR_ARG, never an out-of-bounds access.
+int validate_air_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t* n_constraints_out) {
+    if (n_instr && !program) return set_err(ctx, NX_ERR_ARG, "recorded AIR: NULL program");
+    if (n_regs == 0 || n_regs > 4096) return set_err(ctx, NX_ERR_ARG, "recorded AIR: register count out of range");
     uint32_t n_c = 0;
     for (uint32_t i = 0; i < n_instr; i++) {
         const nx_cinstr& in = program[i];
-        auto reg_ok = [&](uint32_t rg, uint32_t width) { return rg + width <= n_regs; };
+        auto reg_ok = [&](uint32_t rg, uint32_t width) { return rg <= n_regs && width <= n_regs - rg; };
         bool ok = true;
         switch (in.op) {
         case NX_C_LOAD: ok = reg_ok(in.dst, 1) && in.a < n_cols; break;
@@ -151,13 +150,35 @@ int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint
         case NX_C_CONSTE: ok = reg_ok(in.dst, 4) && in.a < n_econsts; break;
         case NX_C_ADDE: case NX_C_SUBE: case NX_C_MULE: ok = reg_ok(in.dst, 4) && reg_ok(in.a, 4) && reg_ok(in.b, 4); break;
         case NX_C_MULEB: case NX_C_ADDEB: ok = reg_ok(in.dst, 4) && reg_ok(in.a, 4) && reg_ok(in.b, 1); break;
-        case NX_C_LOADE: ok = reg_ok(in.dst, 4) && in.a + 4 <= n_cols; break;
+        case NX_C_LOADE: ok = reg_ok(in.dst, 4) && in.a < n_cols && n_cols - in.a >= 4; break;
         case NX_C_CONSTRAINT_B: ok = reg_ok(in.a, 1); n_c++; break;
         case NX_C_CONSTRAINT_E: ok = reg_ok(in.a, 4); n_c++; break;
         default: ok = false;
         }
-        if (!ok) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: malformed instruction " + std::to_string(i));
+        if (!ok) return set_err(ctx, NX_ERR_ARG, "recorded AIR: malformed instruction " + std::to_string(i));
     }
+    if (n_constraints_out) *n_constraints_out = n_c;
+    return NX_OK;
+}
+// what a compiled kernel was built for (the prover session rejects a kernel that does not match its component)
+void air_kernel_shape(const nx_air_kernel* k, uint32_t* n_cols, uint32_t* n_econsts, uint32_t* n_constraints) {
+    *n_cols = k->n_cols; *n_econsts = k->n_econsts; *n_constraints = k->n_constraints;
+}
+
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+// Validates like nx_eval_constraint_program, generates the source, compiles it for gfx950 and loads the module.
+// h_source_out (optional): receives a malloc'd copy of the generated source (free with nx_free_host) — also usable without a GPU.
+int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints,
+                   nx_air_kernel** out, char** h_source_out) {
+    NX_GUARD(ctx);
+    if (!program || (!out && !h_source_out)) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: NULL argument");
+    uint32_t n_c = 0;
+    NX_TRY(validate_air_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, &n_c));
     if (n_c != n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: the program adds a different number of constraints than announced");
     const std::string src = generate_air_source(program, n_instr, n_regs);
     if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
@@ -188,6 +209,7 @@ int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint
 
 void nx_air_kernel_destroy(nx_air_kernel* k) {
     if (!k) return;
+    NX_GUARD(k->ctx);
     (void)hipStreamSynchronize(k->ctx->stream);
     (void)hipModuleUnload(k->module);
     delete k;
@@ -195,6 +217,7 @@ void nx_air_kernel_destroy(nx_air_kernel* k) {
 
 int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_cols, const uint32_t* econsts, const uint32_t* alpha_powers, const uint32_t* denom_inv,
                 uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4) {
+    NX_GUARD(ctx);
     if (!ctx || !k || !d_acc4 || (k->n_cols && !d_cols)) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: NULL argument");
     if (log_size < 1 || log_eval <= log_size || log_eval > 30) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: need 1 <= log_size < log_eval <= 30");
     const size_t b_cols = (size_t)k->n_cols * 8, b_ec = (size_t)k->n_econsts * 16, b_pw = (size_t)k->n_constraints * 16, b_den = (size_t)4 << (log_eval - log_size);

@@ -13,6 +13,8 @@
 // virtual registers live in LDS ([register][lane], conflict-free), the host allocates them (nexus-zkvm_amd/air_program.py);
 // runs of LOADs are issued 8 at a time so the column reads overlap.  The accumulator is 4 lazy 64-bit sums.
 #include "internal.h"
+#include "air.h"
+#include <atomic>
 #include <algorithm>
 
 namespace nx {
@@ -119,30 +121,13 @@ extern "C" int nx_eval_constraint_program(nx_ctx* ctx, const nx_cinstr* program,
                                           uint32_t n_cols, const uint32_t* econsts, uint32_t n_econsts, const uint32_t* alpha_powers,
                                           uint32_t n_constraints, const uint32_t* denom_inv, uint32_t log_size, uint32_t log_eval,
                                           uint32_t* const* d_acc4) {
+    NX_GUARD(ctx);
     if (!ctx || !program || !d_acc4 || (n_cols && !d_cols)) return set_err(ctx, NX_ERR_ARG, "nx_eval_constraint_program: NULL argument");
     if (log_size < 1 || log_eval <= log_size || log_eval > 30) return set_err(ctx, NX_ERR_ARG, "nx_eval_constraint_program: need 1 <= log_size < log_eval <= 30");
     if (n_regs == 0 || (size_t)n_regs * CP_THREADS * 4 > 160 * 1024) return set_err(ctx, NX_ERR_ARG, "nx_eval_constraint_program: register file does not fit the 160 KB LDS (max 160 registers)");
     // validate the program once on the host: register / column / constant / constraint indices in range
     uint32_t n_c = 0;
-    for (uint32_t i = 0; i < n_instr; i++) {
-        const nx_cinstr& in = program[i];
-        auto reg_ok = [&](uint32_t rg, uint32_t width) { return rg + width <= n_regs; };
-        bool ok = true;
-        switch (in.op) {
-        case NX_C_LOAD: ok = reg_ok(in.dst, 1) && in.a < n_cols; break;
-        case NX_C_CONST: ok = reg_ok(in.dst, 1) && in.a < P; break;
-        case NX_C_ADD: case NX_C_SUB: case NX_C_MUL: ok = reg_ok(in.dst, 1) && reg_ok(in.a, 1) && reg_ok(in.b, 1); break;
-        case NX_C_NEG: ok = reg_ok(in.dst, 1) && reg_ok(in.a, 1); break;
-        case NX_C_CONSTE: ok = reg_ok(in.dst, 4) && in.a < n_econsts; break;
-        case NX_C_ADDE: case NX_C_SUBE: case NX_C_MULE: ok = reg_ok(in.dst, 4) && reg_ok(in.a, 4) && reg_ok(in.b, 4); break;
-        case NX_C_MULEB: case NX_C_ADDEB: ok = reg_ok(in.dst, 4) && reg_ok(in.a, 4) && reg_ok(in.b, 1); break;
-        case NX_C_LOADE: ok = reg_ok(in.dst, 4) && in.a + 4 <= n_cols; break;
-        case NX_C_CONSTRAINT_B: ok = reg_ok(in.a, 1); n_c++; break;
-        case NX_C_CONSTRAINT_E: ok = reg_ok(in.a, 4); n_c++; break;
-        default: ok = false;
-        }
-        if (!ok) return set_err(ctx, NX_ERR_ARG, "nx_eval_constraint_program: malformed instruction " + std::to_string(i));
-    }
+    NX_TRY(validate_air_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, &n_c));
     if (n_c != n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_eval_constraint_program: the program adds a different number of constraints than alpha powers were given");
     const size_t b_prog = (size_t)n_instr * sizeof(nx_cinstr), b_cols = (size_t)n_cols * 8, b_ec = (size_t)n_econsts * 16, b_pw = (size_t)n_constraints * 16,
                  b_den = (size_t)4 << (log_eval - log_size);
@@ -154,8 +139,11 @@ extern "C" int nx_eval_constraint_program(nx_ctx* ctx, const nx_cinstr* program,
     auto up = [&](size_t off, const void* src, size_t bytes) { if (er == hipSuccess && bytes) er = hipMemcpyAsync(blob + off, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
     up(0, program, b_prog); up(o_cols, d_cols, b_cols); up(o_ec, econsts, b_ec); up(o_pw, alpha_powers, b_pw); up(o_den, denom_inv, b_den);
     if (er == hipSuccess) {
-        static bool attr = false;
-        if (!attr) { er = hipFuncSetAttribute((const void*)constraint_program_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
+        if (!(attr_set.load() & (1ull << (ctx->device & 63)))) {
+            er = hipFuncSetAttribute((const void*)constraint_program_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set.fetch_or(1ull << (ctx->device & 63));
+        }
         const uint32_t n = 1u << log_eval;
         if (er == hipSuccess) {
             hipLaunchKernelGGL(constraint_program_kernel, dim3((n + CP_THREADS - 1) / CP_THREADS), dim3(CP_THREADS), (size_t)n_regs * CP_THREADS * 4, ctx->stream,

@@ -37,19 +37,21 @@ int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out) {
     return NX_OK;
 }
 
-// A pinned host region of the same ring (target of an asynchronous device-to-host copy); valid until the ring wraps.
-int pinned_reserve(nx_ctx* ctx, size_t bytes, void** h_out) {
-    size_t need = (bytes + 255) & ~(size_t)255;
-    if (need > ctx->scratch_size) return set_err(ctx, NX_ERR_ARG, "pinned_reserve: request larger than scratch ring");
-    if (ctx->scratch_off + need > ctx->scratch_size) {
-        NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream));
-        for (int i = 0; i < 3; i++) NX_HIP(ctx, hipStreamSynchronize(ctx->side[i]));
-        ctx->scratch_off = 0;
-    }
-    *h_out = ctx->h_scratch + ctx->scratch_off;
-    ctx->scratch_off += need;
+int host_alloc(nx_ctx* ctx, size_t bytes, void** h_out) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = ctx->free_pinned.find(bytes);
+    if (it != ctx->free_pinned.end()) { *h_out = it->second; ctx->free_pinned.erase(it); ctx->live_pinned[*h_out] = bytes; return NX_OK; }
+    NX_HIP(ctx, hipHostMalloc(h_out, bytes, hipHostMallocDefault));
+    ctx->live_pinned[*h_out] = bytes;
     return NX_OK;
+}
+void host_free(nx_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx->live_pinned.find(p);
+    if (it == ctx->live_pinned.end()) return;
+    ctx->free_pinned.insert({it->second, p});
+    ctx->live_pinned.erase(it);
 }
 
 int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out) {
@@ -212,6 +214,7 @@ int nx_ctx_create(int device, nx_ctx** out) {
 }
 
 void nx_ctx_destroy(nx_ctx* ctx) {
+    NX_GUARD(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -221,6 +224,8 @@ void nx_ctx_destroy(nx_ctx* ctx) {
     for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    for (auto& kv : ctx->free_pinned) (void)hipHostFree(kv.second);
+    for (auto& kv : ctx->live_pinned) (void)hipHostFree(kv.first);
     for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(ctx->side[i]); (void)hipEventDestroy(ctx->join_ev[i]); }
     (void)hipEventDestroy(ctx->fork_ev);
     (void)hipStreamDestroy(ctx->hash_stream); (void)hipEventDestroy(ctx->hash_ev);
@@ -234,33 +239,39 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode) {
     return NX_OK;
 }
 
-int nx_sync(nx_ctx* ctx) { NX_HIP(ctx, hipStreamSynchronize(ctx->stream)); NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream)); return NX_OK; }
+int nx_sync(nx_ctx* ctx) { NX_GUARD(ctx); NX_HIP(ctx, hipStreamSynchronize(ctx->stream)); NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream)); return NX_OK; }
 void* nx_ctx_stream(nx_ctx* ctx) { return (void*)ctx->stream; }
 
 int nx_alloc(nx_ctx* ctx, size_t n_words, uint32_t** d_out) {
+    NX_GUARD(ctx);
     *d_out = nullptr;
     return dev_alloc(ctx, n_words * 4, (void**)d_out);
 }
 int nx_free(nx_ctx* ctx, uint32_t* d_ptr) {
+    NX_GUARD(ctx);
     dev_free(ctx, d_ptr);
     return NX_OK;
 }
 int nx_memset_zero(nx_ctx* ctx, uint32_t* d_ptr, size_t n_words) {
+    NX_GUARD(ctx);
     NX_HIP(ctx, hipMemsetAsync(d_ptr, 0, n_words * 4, ctx->stream));
     return NX_OK;
 }
 int nx_upload(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* h_src, size_t n_words) {
+    NX_GUARD(ctx);
     NX_HIP(ctx, hipMemcpyAsync(d_dst, h_src, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
     NX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_src may be pageable and reused by the caller
     return NX_OK;
 }
 int nx_download(nx_ctx* ctx, uint32_t* h_dst, const uint32_t* d_src, size_t n_words) {
+    NX_GUARD(ctx);
     NX_HIP(ctx, hipMemcpyAsync(h_dst, d_src, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NX_OK;
 }
 
 int nx_copy(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words) {
+    NX_GUARD(ctx);
     if (n_words == 0) return NX_OK;
     if ((n_words & 3) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_src & 15)) {
         NX_HIP(ctx, hipMemcpyAsync(d_dst, d_src, n_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -275,18 +286,21 @@ int nx_copy(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words)
 
 static unsigned stream_grid(nx_ctx* ctx, size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, (size_t)ctx->n_cus * 16); }
 int nx_m31_add_into(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words) {
+    NX_GUARD(ctx);
     if (!n_words) return NX_OK;
     hipLaunchKernelGGL(m31_add_into_kernel, dim3(stream_grid(ctx, n_words)), dim3(256), 0, ctx->stream, d_dst, d_src, n_words);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
 int nx_m31_widen(nx_ctx* ctx, uint64_t* d_dst, const uint32_t* d_src, size_t n_words) {
+    NX_GUARD(ctx);
     if (!n_words) return NX_OK;
     hipLaunchKernelGGL(m31_widen_kernel, dim3(stream_grid(ctx, n_words)), dim3(256), 0, ctx->stream, (u64*)d_dst, d_src, n_words);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
 int nx_m31_narrow(nx_ctx* ctx, uint32_t* d_dst, const uint64_t* d_src, size_t n_words) {
+    NX_GUARD(ctx);
     if (!n_words) return NX_OK;
     hipLaunchKernelGGL(m31_narrow_kernel, dim3(stream_grid(ctx, n_words)), dim3(256), 0, ctx->stream, d_dst, (const u64*)d_src, n_words);
     NX_LAUNCH_CHECK(ctx);
@@ -294,6 +308,7 @@ int nx_m31_narrow(nx_ctx* ctx, uint32_t* d_dst, const uint64_t* d_src, size_t n_
 }
 
 int nx_gather(nx_ctx* ctx, const uint32_t* const* d_ptrs, const uint64_t* index, size_t n, uint32_t* h_out) {
+    NX_GUARD(ctx);
     if (n == 0) return NX_OK;
     uint8_t* d = nullptr;
     size_t bytes = n * (8 + 8 + 4);

@@ -17,6 +17,7 @@
 //  * The zero-extension of the LDE ("extend") is folded into the first evaluate pass: source words
 //    at index >= 2^log_in read as zero, nothing is materialised.
 #include "internal.h"
+#include <mutex>
 #include <atomic>
 #include <stdlib.h>
 #include <algorithm>
@@ -236,20 +237,24 @@ __global__ void fft_tiny_kernel(ColSet src, ColSet dst, u32 n_cols, int n, int l
 // ---- planning ----
 struct FftTune { int smax, bmax, threads, batch_cols, legacy, streams; };
 static FftTune g_tune = {13, 5, 256, 2, 0, 2};   // 2 streams x 2 columns in flight: the working set of a batch (48 MiB per column at 2^22) stays in the 256 MiB Infinity Cache between its four passes
-static bool g_tune_init = false;
+static std::once_flag g_tune_once;
+// Read once per process, under std::call_once: contexts on several host threads (one per GPU, tools/concurrent_proves.py, ThreadGroup)
+// plan their first transform concurrently and must all see the fully clamped values.
 static void tune_init() {
-    if (g_tune_init) return;
-    g_tune_init = true;
-    if (const char* e = getenv("NX_FFT_SMAX")) g_tune.smax = atoi(e);
-    if (const char* e = getenv("NX_FFT_B")) g_tune.bmax = atoi(e);
-    if (const char* e = getenv("NX_FFT_THREADS")) g_tune.threads = atoi(e);
-    if (const char* e = getenv("NX_FFT_BATCH")) g_tune.batch_cols = atoi(e);
-    if (const char* e = getenv("NX_FFT_LEGACY")) g_tune.legacy = atoi(e);
-    if (const char* e = getenv("NX_FFT_STREAMS")) g_tune.streams = std::max(1, std::min(4, atoi(e)));
-    g_tune.smax = std::max(6, std::min(g_tune.smax, 15));
-    g_tune.bmax = std::max(2, std::min(g_tune.bmax, 6));
-    if (g_tune.threads != 128 && g_tune.threads != 256 && g_tune.threads != 512 && g_tune.threads != 1024) g_tune.threads = 256;
-    g_tune.batch_cols = std::max(1, g_tune.batch_cols);
+    std::call_once(g_tune_once, []() {
+        FftTune t = g_tune;
+        if (const char* e = getenv("NX_FFT_SMAX")) t.smax = atoi(e);
+        if (const char* e = getenv("NX_FFT_B")) t.bmax = atoi(e);
+        if (const char* e = getenv("NX_FFT_THREADS")) t.threads = atoi(e);
+        if (const char* e = getenv("NX_FFT_BATCH")) t.batch_cols = atoi(e);
+        if (const char* e = getenv("NX_FFT_LEGACY")) t.legacy = atoi(e);
+        if (const char* e = getenv("NX_FFT_STREAMS")) t.streams = std::max(1, std::min(4, atoi(e)));
+        t.smax = std::max(6, std::min(t.smax, 15));
+        t.bmax = std::max(2, std::min(t.bmax, 6));
+        if (t.threads != 128 && t.threads != 256 && t.threads != 512 && t.threads != 1024) t.threads = 256;
+        t.batch_cols = std::max(1, t.batch_cols);
+        g_tune = t;
+    });
 }
 
 struct PassPlan { int lo, hi, B; };
@@ -465,6 +470,7 @@ using namespace nx;
 extern "C" {
 
 int nx_twiddles_create(nx_ctx* ctx, uint32_t log_half_coset, nx_twiddles** out) {
+    NX_GUARD(ctx);
     if (!ctx || !out) return set_err(ctx, NX_ERR_ARG, "nx_twiddles_create: NULL argument");
     if (log_half_coset < 1 || log_half_coset > 28) return set_err(ctx, NX_ERR_ARG, "nx_twiddles_create: log_half_coset out of range [1,28]");
     nx_twiddles* t = new nx_twiddles();
@@ -486,17 +492,20 @@ int nx_twiddles_create(nx_ctx* ctx, uint32_t log_half_coset, nx_twiddles** out) 
 }
 
 void nx_twiddles_destroy(nx_twiddles* tw) {
+    NX_GUARD(tw ? tw->ctx : nullptr);
     if (!tw) return;
     dev_free(tw->ctx, tw->d_tw); dev_free(tw->ctx, tw->d_itw); dev_free(tw->ctx, tw->d_tw2); dev_free(tw->ctx, tw->d_itw2);
     delete tw;
 }
 
 int nx_twiddles_download(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* h_tw, uint32_t* h_itw) {
+    NX_GUARD(ctx);
     NX_TRY(nx_download(ctx, h_tw, tw->d_tw, (size_t)1 << tw->log_half));
     return nx_download(ctx, h_itw, tw->d_itw, (size_t)1 << tw->log_half);
 }
 
 int nx_interpolate_batch(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size) {
+    NX_GUARD(ctx);
     if (n_cols == 0) return NX_OK;
     ColSet cs; NX_TRY(make_colset(ctx, d_cols, n_cols, &cs));
     return fft_interpolate(ctx, tw, cs, n_cols, log_size);
@@ -504,6 +513,7 @@ int nx_interpolate_batch(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_
 
 int nx_evaluate_batch(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_polys, uint32_t n_cols, uint32_t log_size,
                       uint32_t log_expand, uint32_t* const* d_out) {
+    NX_GUARD(ctx);
     if (n_cols == 0) return NX_OK;
     ColSet p, o;
     NX_TRY(make_colset(ctx, d_polys, n_cols, &p));
@@ -512,6 +522,7 @@ int nx_evaluate_batch(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const*
 }
 
 int nx_bit_reverse(nx_ctx* ctx, uint32_t* d_col, uint32_t log_size) {
+    NX_GUARD(ctx);
     u32 n = 1u << log_size;
     hipLaunchKernelGGL(bit_reverse_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_col, (int)log_size);
     NX_LAUNCH_CHECK(ctx);
@@ -519,6 +530,7 @@ int nx_bit_reverse(nx_ctx* ctx, uint32_t* d_col, uint32_t log_size) {
 }
 
 int nx_finalize_columns(nx_ctx* ctx, const uint32_t* const* d_src_natural, uint32_t* const* d_dst, uint32_t n_cols, uint32_t log_size) {
+    NX_GUARD(ctx);
     if (n_cols == 0) return NX_OK;
     if (log_size < 1) return set_err(ctx, NX_ERR_ARG, "nx_finalize_columns: log_size < 1");
     ColSet s, d;
@@ -539,6 +551,7 @@ int nx_finalize_columns(nx_ctx* ctx, const uint32_t* const* d_src_natural, uint3
 // (or nothing, when the host already holds that order) behind it on the main stream, two columns in flight.  This replaces
 // the reference's per-column CPU passes (coset_order_to_circle_domain_order + from_iter + bit_reverse_column + clone).
 int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_cols, uint32_t log_size, uint32_t* const* d_cols, int coset_order) {
+    NX_GUARD(ctx);
     if (!ctx || (n_cols && (!h_cols || !d_cols))) return set_err(ctx, NX_ERR_ARG, "nx_upload_columns: NULL argument");
     if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_upload_columns: bad log_size");
     const size_t n = (size_t)1 << log_size, bytes = n * 4;
@@ -582,6 +595,7 @@ int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_col
 }
 
 int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst) {
+    NX_GUARD(ctx);
     uint32_t* d_tmp = nullptr;
     size_t n = (size_t)1 << log_size;
     NX_TRY(dev_alloc(ctx, n * 4, (void**)&d_tmp));

@@ -550,8 +550,7 @@ __global__ __launch_bounds__(T13_ROWS >> RB, 1) void lde_mid_kernel(PassMid m) {
 // ---- planning: layers [0, m) -> the FIRST pass [0, 13) plus passes of <= kmax layers (runs of 2^(13-kmax) words) ----
 struct Plan13 { int lo, K, B; };
 static int plan13_kmax() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("NX_FFT_KMAX"); v = e ? std::max(1, std::min(11, atoi(e))) : 9; }
+    static const int v = []() { const char* e = getenv("NX_FFT_KMAX"); return e ? std::max(1, std::min(11, atoi(e))) : 9; }();   // thread-safe (C++11 static init)
     return v;
 }
 static std::vector<Plan13> plan13(int m) {
@@ -570,12 +569,10 @@ static std::vector<Plan13> plan13(int m) {
 }
 
 struct Shape13 { int cb; };   // radix-8 rounds (RB = 3) measured slower in every shape and are no longer built
-static Shape13 g_shape = {1};  // one column per block: 34 KB tiles, 58-70 VGPRs -> 3-4 blocks per CU; measured 3 % faster than column pairs (2 blocks per CU)
-static bool g_shape_init = false;
-static void shape_init() {
-    if (g_shape_init) return;
-    g_shape_init = true;
-    if (const char* e = getenv("NX_FFT_CB")) g_shape.cb = atoi(e) == 1 ? 1 : 2;
+// one column per block: 34 KB tiles, 58-70 VGPRs -> 3-4 blocks per CU; measured 3 % faster than column pairs (2 blocks per CU)
+static const Shape13& shape13() {
+    static const Shape13 s = []() { Shape13 v = {1}; if (const char* e = getenv("NX_FFT_CB")) v.cb = atoi(e) == 1 ? 1 : 2; return v; }();   // thread-safe
+    return s;
 }
 
 template <bool INV, bool FIRST, int CB, int RB, int KT>
@@ -610,9 +607,7 @@ static int launch13_k(nx_ctx* ctx, bool first, const Pass13& a) {
 }
 
 static int launch13(nx_ctx* ctx, bool inv, bool first, Pass13 a) {
-    shape_init();
-
-    const int cb = a.n_cols == 1 ? 1 : g_shape.cb;
+    const int cb = a.n_cols == 1 ? 1 : shape13().cb;
     a.n_groups = (a.n_cols + cb - 1) / cb;
     if (cb == 2) return inv ? launch13_k<true, 2, 4>(ctx, first, a) : launch13_k<false, 2, 4>(ctx, first, a);
     return inv ? launch13_k<true, 1, 4>(ctx, first, a) : launch13_k<false, 1, 4>(ctx, first, a);
@@ -679,9 +674,8 @@ static int launch_mid(nx_ctx* ctx, const PassMid& m) {
 }
 
 bool fft13_lde_fused_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("NX_FFT_FUSED"); v = e ? (atoi(e) != 0) : 1; }
-    return v != 0;
+    static const bool v = []() { const char* e = getenv("NX_FFT_FUSED"); return e ? (atoi(e) != 0) : true; }();
+    return v;
 }
 
 // iFFT in place (coefficients stay in `cols`) + FFT onto 2^(n+1) points in `out`, n >= 14: every pass as in fft13_interpolate /

@@ -31,6 +31,10 @@ struct nx_ctx {
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live_blocks;
     size_t cached_bytes;
+    // pinned host blocks cached by exact size: targets of asynchronous device-to-host copies that must outlive later stage() calls
+    // (the partial sums of every OODS request of a proof are collected after ONE synchronisation)
+    std::multimap<size_t, void*> free_pinned;
+    std::map<void*, size_t> live_pinned;
     // kernel timing (HIP events on ctx->stream), resolved lazily by nx::timing_flush
     bool timing;
     struct Span { hipEvent_t e0, e1; int kind; };
@@ -74,6 +78,22 @@ int hip_fail(nx_ctx* ctx, hipError_t e, const char* what, const char* file, int 
     } while (0)
 #define NX_LAUNCH_CHECK(ctx) NX_HIP(ctx, hipGetLastError())
 
+// Every extern "C" entry that takes a context (or a handle that owns one) makes the context's device current for the call:
+// hipMalloc, hipHostRegister, hipFuncSetAttribute and kernel launches act on the CALLING THREAD's current device, which is 0 in a
+// fresh worker thread whatever device the context was created on.  The previous device is restored on return.
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(const nx_ctx* c) {
+        if (!c) return;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; }
+        if (prev != c->device) { switched = hipSetDevice(c->device) == hipSuccess && prev >= 0; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define NX_GUARD(ctxexpr) nx::DeviceGuard nx_device_guard__(ctxexpr)
+
 // A set of equally sized columns: either base + c*stride (words) or a device pointer table.
 struct ColSet {
     uint32_t* base;
@@ -100,7 +120,8 @@ __device__ __forceinline__ void gst4(uint32_t* p, uint4 v) { nx_v4u32 w = {v.x, 
 int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out);
 // Stage arbitrary bytes into device scratch; returns device pointer (valid until the ring wraps).
 int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out);
-int pinned_reserve(nx_ctx* ctx, size_t bytes, void** h_out);   // pinned host region of the same ring (async D2H target)
+int host_alloc(nx_ctx* ctx, size_t bytes, void** h_out);       // pinned host block owned by the caller until host_free (cached by size)
+void host_free(nx_ctx* ctx, void* p);
 // nx_eval_at_points in two phases, so that a prover samples every tree and size with ONE synchronisation: enqueue launches the
 // kernels of one request and records where its partial sums will land; collect waits once and reduces them into the outputs.
 struct EvalJob { uint8_t* blob; const uint32_t* h_part; uint32_t np, n_chunks; std::vector<uint32_t> evals; uint32_t* h_out; };

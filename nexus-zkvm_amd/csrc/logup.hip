@@ -191,6 +191,7 @@ extern "C" {
 
 int nx_logup_combine(nx_ctx* ctx, const uint32_t* const* d_tuple_cols, uint32_t n_cols, const uint32_t* alpha_powers, const uint32_t z[4], uint32_t log_size,
                      uint32_t* const* d_out4) {
+    NX_GUARD(ctx);
     if (!ctx || !d_out4 || !z || (n_cols && (!d_tuple_cols || !alpha_powers))) return set_err(ctx, NX_ERR_ARG, "nx_logup_combine: NULL argument");
     if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_combine: log_size too large");
     ColSet cs; NX_TRY(make_colset(ctx, d_tuple_cols, n_cols, &cs));
@@ -212,6 +213,7 @@ static LogupFrac make_frac(const uint32_t* d_mult, const uint32_t scale[4], cons
 int nx_logup_finalize_col(nx_ctx* ctx, uint32_t log_size, const uint32_t* d_mult_a, const uint32_t scale_a[4], const uint32_t* const* d_den_a4,
                           const uint32_t* d_mult_b, const uint32_t scale_b[4], const uint32_t* const* d_den_b4, const uint32_t* const* d_prev4,
                           uint32_t* const* d_out4) {
+    NX_GUARD(ctx);
     if (!ctx || !scale_a || !d_den_a4 || !d_out4) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_col: NULL argument");
     if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_col: log_size too large");
     const bool two = d_den_b4 != nullptr;
@@ -236,6 +238,7 @@ static int make_tuple_frac(nx_ctx* ctx, const nx_logup_frac* f, LogupTupleFrac* 
 }
 
 int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, const nx_logup_frac* frac_b, const uint32_t* const* d_prev4, uint32_t* const* d_out4) {
+    NX_GUARD(ctx);
     if (!ctx || !frac_a || !d_out4) return set_err(ctx, NX_ERR_ARG, "nx_logup_col: NULL argument");
     if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_col: log_size too large");
     LogupTupleFrac fa, fb;
@@ -253,6 +256,7 @@ int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, co
 // LogupTraceGenerator::finalize_last for n_cols secure columns of one size in three launches and ONE device-to-host copy (the
 // claimed sums): per-block scans, a one-block scan of the block totals per column, the fix-up.  d_cols4: n_cols x 4 pointers.
 int nx_logup_finalize_last_batch(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_cols4, uint32_t n_cols, uint32_t* claimed_sums) {
+    NX_GUARD(ctx);
     if (!ctx || !d_cols4 || !claimed_sums) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: NULL argument");
     if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: log_size too large");
     if (n_cols == 0) return NX_OK;
@@ -282,6 +286,7 @@ int nx_logup_finalize_last_batch(nx_ctx* ctx, uint32_t log_size, uint32_t* const
 }
 
 int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_col4, uint32_t claimed_sum[4]) {
+    NX_GUARD(ctx);
     return nx_logup_finalize_last_batch(ctx, log_size, d_col4, 1, claimed_sum);
 }
 

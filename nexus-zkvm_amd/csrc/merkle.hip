@@ -622,6 +622,7 @@ using namespace nx;
 extern "C" {
 
 int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t* log_sizes, uint32_t n_cols, nx_tree** out) {
+    NX_GUARD(ctx);
     if (!ctx || !out) return set_err(ctx, NX_ERR_ARG, "nx_merkle_commit: NULL argument");
     // stable sort by size, descending (MerkleProver::commit)
     std::vector<uint32_t> order(n_cols);
@@ -669,6 +670,7 @@ int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t*
 
 int nx_merkle_leaf_chain(nx_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size, uint32_t col_offset,
                          uint32_t total_cols, const uint32_t* d_state_in, uint32_t* d_state_out, uint64_t row_begin, uint64_t n_rows) {
+    NX_GUARD(ctx);
     if (!ctx || !d_state_out || (n_cols && !d_cols)) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: NULL argument");
     if (n_cols == 0 || col_offset + (uint64_t)n_cols > total_cols) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: empty shard or column range outside the layer");
     if (col_offset % 16) return set_err(ctx, NX_ERR_ARG, "nx_merkle_leaf_chain: col_offset must be a multiple of 16 (one Blake2s block)");
@@ -681,6 +683,7 @@ int nx_merkle_leaf_chain(nx_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_
 }
 
 int nx_merkle_from_leaves(nx_ctx* ctx, const uint32_t* d_leaf_digests, uint32_t log_size, nx_tree** out) {
+    NX_GUARD(ctx);
     if (!ctx || !out || !d_leaf_digests) return set_err(ctx, NX_ERR_ARG, "nx_merkle_from_leaves: NULL argument");
     if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_merkle_from_leaves: layer too large");
     nx_tree* t = new nx_tree();
@@ -707,18 +710,21 @@ int nx_merkle_from_leaves(nx_ctx* ctx, const uint32_t* d_leaf_digests, uint32_t 
 }
 
 int nx_merkle_root(nx_ctx* ctx, const nx_tree* tree, uint8_t root[32]) {
+    NX_GUARD(ctx);
     return nx_download(ctx, (uint32_t*)root, tree->layers[0], 8);
 }
 uint32_t nx_merkle_n_layers(const nx_tree* tree) { return (uint32_t)tree->layers.size(); }
 const uint32_t* nx_merkle_layer(const nx_tree* tree, uint32_t k) { return k < tree->layers.size() ? tree->layers[k] : nullptr; }
 
 void nx_tree_destroy(nx_tree* tree) {
+    NX_GUARD(tree ? tree->ctx : nullptr);
     if (!tree) return;
     if (!tree->layers.empty()) dev_free(tree->ctx, tree->layers[0]);
     delete tree;
 }
 
 int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce) {
+    NX_GUARD(ctx);
     if (pow_bits > 64) return set_err(ctx, NX_ERR_ARG, "nx_grind: pow_bits > 64");
     struct { uint32_t d[8]; unsigned long long res; } h;
     memcpy(h.d, digest, 32);

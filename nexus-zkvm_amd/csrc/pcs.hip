@@ -304,6 +304,7 @@ extern "C" {
 
 int nx_eval_at_points(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t log_size, const uint32_t* poly_idx,
                       const uint32_t* h_points, uint32_t n_evals, uint32_t* h_out) {
+    NX_GUARD(ctx);
     std::vector<EvalJob> jobs;
     int rc = eval_at_points_enqueue(ctx, d_polys, log_size, poly_idx, h_points, n_evals, h_out, &jobs);
     int rc2 = eval_at_points_collect(ctx, &jobs);
@@ -344,14 +345,12 @@ int eval_at_points_enqueue(nx_ctx* ctx, const uint32_t* const* d_polys, uint32_t
         uint32_t hi_per_block = std::max<uint32_t>(1, std::min<uint32_t>(n_hi, 128));
         uint32_t n_chunks = (n_hi + hi_per_block - 1) / hi_per_block;
         const size_t part_words = (size_t)np * n_chunks * 4;
-        // the ring must not wrap over partial sums that were not collected yet: drain the pending jobs first
-        if (!jobs->empty() && ctx->scratch_off + (size_t)np * 8 + part_words * 4 + 1024 > ctx->scratch_size) NX_TRY(eval_at_points_collect(ctx, jobs));
         EvalJob job; job.blob = nullptr; job.np = np; job.n_chunks = n_chunks; job.evals = groups[g]; job.h_out = h_out;
         NX_TRY(dev_alloc(ctx, (tlo_words + thi_words + part_words) * 4, (void**)&job.blob));
         uint32_t* d_lo = (uint32_t*)job.blob; uint32_t* d_hi = d_lo + tlo_words; uint32_t* d_part = d_hi + thi_words;
         void* d_tab = nullptr; void* h_part = nullptr;
         int rc = stage(ctx, sel.data(), (size_t)np * 8, &d_tab);                       // pointer table through the pinned ring
-        if (rc == NX_OK) rc = pinned_reserve(ctx, part_words * 4, &h_part);
+        if (rc == NX_OK) rc = host_alloc(ctx, part_words * 4, &h_part);   // owned by the job until collect: later stage() calls may wrap the ring
         if (rc != NX_OK) { dev_free(ctx, job.blob); return rc; }
         job.h_part = (const uint32_t*)h_part;
         hipLaunchKernelGGL(eval_tables_kernel, dim3((n_lo + n_hi + 255) / 256), dim3(256), 0, ctx->stream, F, n, L, d_lo, d_hi);
@@ -381,6 +380,7 @@ int eval_at_points_collect(nx_ctx* ctx, std::vector<EvalJob>* jobs) {
                 memcpy(j.h_out + 4 * (size_t)j.evals[i], s4, 16);
             }
         dev_free(ctx, j.blob);
+        host_free(ctx, (void*)j.h_part);
     }
     jobs->clear();
     if (e != hipSuccess) return hip_fail(ctx, e, "nx_eval_at_points(sync)", __FILE__, __LINE__);
@@ -464,18 +464,21 @@ static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint3
 int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
                             uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
                             const uint32_t* values, uint32_t* const* d_out4) {
+    NX_GUARD(ctx);
     return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, nullptr, 1, d_out4);
 }
 
 int nx_accumulate_quotients_partial(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
                                     uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
                                     const uint32_t* values, const uint8_t* entry_local, int include_line_terms, uint32_t* const* d_out4) {
+    NX_GUARD(ctx);
     return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, entry_local,
                                      include_line_terms, d_out4);
 }
 
 int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log,
                              const uint32_t alpha[4]) {
+    NX_GUARD(ctx);
     if (src_log < 1 || (src_log >= 3 && src_log - 1 > tw->log_half)) return set_err(ctx, NX_ERR_ARG, "nx_fold_circle_into_line: bad log");
     Sec4 d; Sec4C s;
     for (int q = 0; q < 4; q++) { d.c[q] = d_dst4[q]; s.c[q] = d_src4[q]; }
@@ -488,6 +491,7 @@ int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const
 
 int nx_fold_line(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, uint32_t n_doublings, const uint32_t alpha[4],
                  uint32_t* const* d_dst4) {
+    NX_GUARD(ctx);
     (void)n_doublings;  // half_odds(k).double() == half_odds(k-1): the domain of log size L is always half_odds(L)
     if (src_log < 1 || src_log > tw->log_half) return set_err(ctx, NX_ERR_ARG, "nx_fold_line: domain not covered by the twiddle tree");
     Sec4 d; Sec4C s;

@@ -140,13 +140,27 @@ static std::vector<uint32_t*> col_ptrs(uint32_t* base, uint32_t n, uint32_t log)
     return v;
 }
 
+// Host words -> a device buffer the caller owns, through the pinned staging ring in chunks: every staged chunk is consumed by the
+// copy enqueued right behind it, so — unlike a pointer into the ring — the result stays valid across any number of later stage()
+// calls (alpha powers and vanishing denominators of a whole statement live across every component's kernels).
+static int upload_owned(nx_ctx* ctx, const uint32_t* h, size_t n_words, DevBuf* out) {
+    H_TRY(out->alloc(ctx, std::max<size_t>(n_words, 4)));
+    const size_t chunk = (size_t)1 << 20;   // words (4 MiB of the 16 MiB ring)
+    for (size_t off = 0; off < n_words; off += chunk) {
+        const size_t n = std::min(chunk, n_words - off);
+        void* st = nullptr;
+        H_TRY(stage(ctx, h + off, n * 4, &st));
+        NX_HIP(ctx, hipMemcpyAsync(out->p + off, st, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return NX_OK;
+}
+
 // TreeBuilder::commit = CommitmentTreeProver::new (LDE of every polynomial) + MerkleProver::commit.  The leaf layer is one
 // Blake2s chain per row over the largest columns in commit order, so it is built incrementally: as soon as a group of
 // columns is extended, its 16-column blocks are absorbed on the hash stream while the main stream already extends the next
 // group (tree_pipe_* in merkle.hip).  Hashing is VALU-bound, the Circle FFT mostly waits on memory: they overlap well.
 static uint32_t pipe_group_cols() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("NX_PIPE_COLS"); v = e ? atoi(e) : 0; if (v < 16) v = 1 << 30; v = (v / 16) * 16; }
+    static const int v = []() { const char* e = getenv("NX_PIPE_COLS"); int x = e ? atoi(e) : 0; if (x < 16) x = 1 << 30; return (x / 16) * 16; }();   // thread-safe
     return (uint32_t)v;
 }
 
@@ -599,13 +613,13 @@ static int compute_composition(CommitmentSchemeProver& cs, const nx_component_sp
             while (params.size() % 4) params.push_back(0);
         }
     }
-    void* d_params = nullptr;
-    if (!params.empty()) H_TRY(stage(ctx, params.data(), params.size() * 4, &d_params));
+    DevBuf d_params;   // owned: read by every component's kernel while later components stage their own descriptors
+    H_TRY(upload_owned(ctx, params.data(), params.size(), &d_params));
     for (uint32_t ci = 0; ci < n_comps; ci++) {
         const nx_component_spec& c = comps[ci];
         const uint32_t e = c.log_size + lcd;
-        const u32* d_pw = (const u32*)d_params + off_pw[ci];
-        const u32* d_den = (const u32*)d_params + off_den[ci];
+        const u32* d_pw = d_params.p + off_pw[ci];
+        const u32* d_den = d_params.p + off_den[ci];
         // trace on the evaluation domain
         ColSet pre, mainc, inter;
         DevBuf ext;
@@ -1002,7 +1016,7 @@ static int prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint
         std::vector<uint32_t> pw(4 * nc);
         { QM31 a = q_one(); std::vector<QM31> powers(nc); for (size_t i = 0; i < nc; i++) { powers[i] = a; a = q_mul(a, random_coeff); }
           for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[nc - 1 - j]); }
-        void* d_pw = nullptr; H_TRY(stage(ctx, pw.data(), pw.size() * 4, &d_pw));
+        DevBuf d_pw_buf; H_TRY(upload_owned(ctx, pw.data(), pw.size(), &d_pw_buf)); const u32* d_pw = d_pw_buf.p;
         const uint32_t log_expand = e - c.log_size;
         std::vector<uint32_t> den((size_t)1 << log_expand);
         for (uint32_t i = 0; i < den.size(); i++) {
@@ -1010,7 +1024,7 @@ static int prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint
             for (uint32_t k = 1; k < c.log_size; k++) x = m_double_x(x);
             den[bitrev(i, (int)log_expand)] = m_inv(x);
         }
-        void* d_den = nullptr; H_TRY(stage(ctx, den.data(), den.size() * 4, &d_den));
+        DevBuf d_den_buf; H_TRY(upload_owned(ctx, den.data(), den.size(), &d_den_buf)); const u32* d_den = d_den_buf.p;
         auto slab_set = [](uint32_t* base, uint32_t log) { ColSet s; s.base = base; s.stride = (uint64_t)1 << log; s.table = nullptr; return s; };
         ColSet pre, mainc, inter;
         DevBuf ext;
@@ -1241,8 +1255,16 @@ struct GenericAir : AirProver {
                 for (int o : c.masks[k]) if (std::find(offs[t][i].begin(), offs[t][i].end(), o) == offs[t][i].end()) offs[t][i].push_back(o);
             }
             uint32_t n_c = 0;
+            // the full instruction validation of nx_air_compile, ALWAYS (a caller-supplied kernel skips the compilation, and the
+            // host interpreter of the OODS check indexes registers and secure constants with these fields)
+            H_TRY(validate_air_program(ctx, c.prog.data(), (uint32_t)c.prog.size(), c.n_regs, (uint32_t)c.cols.size(), (uint32_t)c.econsts.size() / 4, &n_c));
+            if (c.kernel) {
+                uint32_t kc = 0, ke = 0, kn = 0;
+                air_kernel_shape(c.kernel, &kc, &ke, &kn);
+                if (kc != c.cols.size() || ke != c.econsts.size() / 4 || kn != c.n_constraints)
+                    return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: the supplied kernel was compiled for a different column / constant / constraint count than the component");
+            }
             for (auto& in : c.prog) {
-                if (in.op == NX_C_CONSTRAINT_B || in.op == NX_C_CONSTRAINT_E) n_c++;
                 if (in.op == NX_C_LOAD || in.op == NX_C_LOADE) {
                     const uint32_t w = in.op == NX_C_LOADE ? 4 : 1;
                     for (uint32_t j = 0; j < w; j++) {
@@ -1366,6 +1388,7 @@ extern "C" {
 
 int nx_lde_batch(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size, uint32_t log_blowup,
                  uint32_t* const* d_lde) {
+    NX_GUARD(ctx);
     if (n_cols == 0) return NX_OK;
     ColSet c, o;
     NX_TRY(make_colset(ctx, d_cols, n_cols, &c));
@@ -1375,6 +1398,7 @@ int nx_lde_batch(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, ui
 
 int nx_lde_commit(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, uint32_t n_cols, uint32_t log_size, uint32_t log_blowup,
                   uint32_t* const* d_lde, uint8_t root[32]) {
+    NX_GUARD(ctx);
     NX_TRY(nx_lde_batch(ctx, tw, d_cols, n_cols, log_size, log_blowup, d_lde));
     std::vector<uint32_t> logs(n_cols, log_size + log_blowup);
     nx_tree* t = nullptr;
@@ -1386,6 +1410,7 @@ int nx_lde_commit(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, u
 
 int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
                            size_t ad_len, const nx_comm* comm, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    NX_GUARD(ctx);
     if (!ctx || !comps || !cfg || !proof_words || !n_words || !comm) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth_sharded: NULL argument");
     std::vector<uint32_t> w;
     int rc = nxhip::prove_synth_sharded(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
@@ -1400,6 +1425,7 @@ int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t
 
 int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
                    size_t ad_len, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    NX_GUARD(ctx);
     if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth: NULL argument");
     std::vector<uint32_t> w;
     int rc = nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, &w, stats);
@@ -1414,6 +1440,7 @@ int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps
 
 // ---------------------------------------------------------------- nx_prover session (recorded AIRs) --
 int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_size, nx_prover** out) {
+    NX_GUARD(ctx);
     if (!ctx || !cfg || !out) return set_err(ctx, NX_ERR_ARG, "nx_prover_create: NULL argument");
     if (cfg->log_blowup < 1 || cfg->log_constraint_degree < 1 || cfg->log_constraint_degree > 2 || max_log_size < 1 || max_log_size + cfg->log_constraint_degree + cfg->log_blowup > 31)
         return set_err(ctx, NX_ERR_ARG, "nx_prover_create: log_blowup >= 1, log_constraint_degree in {1,2}, 1 <= max_log_size required");
@@ -1429,6 +1456,7 @@ int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_siz
 }
 
 void nx_prover_destroy(nx_prover* p) {
+    NX_GUARD(p ? p->ctx : nullptr);
     if (!p) return;
     (void)nx_sync(p->ctx);
     p->pending.clear();
@@ -1457,6 +1485,7 @@ int nx_prover_channel_digest(const nx_prover* p, uint8_t digest[32]) {
 }
 
 int nx_prover_tree_begin(nx_prover* p, const uint32_t* log_sizes, uint32_t n_cols, uint32_t** d_cols_out) {
+    NX_GUARD(p ? p->ctx : nullptr);
     if (!p || (n_cols && (!log_sizes || !d_cols_out))) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_tree_begin: NULL argument");
     if (p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: the previous tree was not committed");
     if (p->cs->trees.size() >= 3) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: the three trace trees are already committed");
@@ -1476,6 +1505,7 @@ int nx_prover_tree_begin(nx_prover* p, const uint32_t* log_sizes, uint32_t n_col
 }
 
 int nx_prover_tree_commit(nx_prover* p, uint8_t root[32]) {
+    NX_GUARD(p ? p->ctx : nullptr);
     if (!p) return set_err(nullptr, NX_ERR_ARG, "nx_prover_tree_commit: NULL prover");
     if (!p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit: no tree was begun");
     nxhip::TreeBuilder tb = p->cs->tree_builder();
@@ -1487,6 +1517,7 @@ int nx_prover_tree_commit(nx_prover* p, uint8_t root[32]) {
 }
 
 int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comps, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    NX_GUARD(p ? p->ctx : nullptr);
     if (!p || !comps || !proof_words || !n_words) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_prove: NULL argument");
     nx_ctx* ctx = p->ctx;
     if (p->open) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: a tree is begun but not committed");
@@ -1494,6 +1525,7 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     for (uint32_t i = 0; i < n_comps; i++) {
         const nx_air_component& u = comps[i];
         if (!u.program || (u.n_cols && (!u.col_tree || !u.col_index || !u.mask_count)) || (u.n_econsts && !u.econsts)) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: NULL pointer in a component");
+        if (!u.mask_offsets) for (uint32_t k = 0; k < u.n_cols; k++) if (u.mask_count[k]) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: mask_offsets is NULL but a column has a nonzero mask_count");
         nxhip::GComponent g;
         g.log_size = u.log_size; g.n_regs = u.n_regs; g.n_constraints = u.n_constraints; g.kernel = u.kernel;
         g.prog.assign(u.program, u.program + u.n_instr);
