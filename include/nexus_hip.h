@@ -132,6 +132,21 @@ uint32_t nx_merkle_n_layers(const nx_tree* tree);
 const uint32_t* nx_merkle_layer(const nx_tree* tree, uint32_t k);
 void nx_tree_destroy(nx_tree* tree);
 
+/* MerkleOps<Blake2sMerkleHasher>::commit_on_layer itself — ONE layer: node i = H(prev[2i] ‖ prev[2i+1] ‖ cols[0][i] ‖ cols[1][i] ...);
+ * d_prev_layer: the 2^(log_size+1) nodes of the layer below (8 words each) or NULL for the leaf layer; d_cols: the columns of
+ * 2^log_size words injected at this layer (commit order); d_out: 2^log_size nodes.  Hash rule = nx_ctx_set_hash_mode.
+ * (MerkleProver::commit, the loop over layers, is nx_merkle_commit.) */
+int nx_merkle_commit_on_layer(nx_ctx* ctx, uint32_t log_size, const uint32_t* d_prev_layer, const uint32_t* const* d_cols, uint32_t n_cols,
+                              uint32_t* d_out);
+/* MerkleProver::decommit(queries_per_log_size, columns) (inside stwo::prover::prove, reference machine.rs:286-290): the values of
+ * `columns` (commit order, LDE log sizes) at the queried rows and the MerkleDecommitment {hash_witness, column_witness}.
+ * One (query_logs[i], query_counts[i]) pair per queried layer; `queries` holds every layer's sorted, distinct positions back to
+ * back.  Outputs are malloc'd (nx_free_host); hash_witness: 8 words per hash. */
+int nx_merkle_decommit(nx_ctx* ctx, const nx_tree* tree, const uint32_t* const* d_cols, const uint32_t* log_sizes, uint32_t n_cols,
+                       const uint32_t* query_logs, const uint32_t* query_counts, uint32_t n_query_logs, const uint64_t* queries,
+                       uint32_t** queried_values, size_t* n_queried_values, uint32_t** hash_witness, size_t* n_hashes,
+                       uint32_t** column_witness, size_t* n_column_witness);
+
 /* Column-sharded commitment (BASELINE config #4).  A tree leaf is one sequential Blake2s chain
  * over ALL columns of the tree (16 columns = one 64-byte block), so column shards of one tree are chained:
  * the GPU that owns columns [col_offset, col_offset + n_cols) of a layer with total_cols columns continues the
@@ -174,6 +189,24 @@ int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const
  * times (log size src_log) -> dst of log size src_log - 1. */
 int nx_fold_line(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log,
                  uint32_t n_doublings, const uint32_t alpha[4], uint32_t* const* d_dst4);
+
+/* ------------------------------------------- the rest of the Backend supertraits -------------------
+ * Called by stwo::prover::prove through `B: Backend` (reference machine.rs:286-290, prove.rs:124-128); not hot spots here (the
+ * composition accumulator and the logup kernels fuse what they need) but required for a per-op HipBackend to type-check. */
+/* AccumulationOps::accumulate: dst[k][i] += src[k][i] on 4 coordinate columns of 2^log_size words. */
+int nx_secure_accumulate(nx_ctx* ctx, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t log_size);
+/* AccumulationOps::generate_secure_powers: out = [1, felt, felt^2, ...] (host; 4 words each). */
+int nx_generate_secure_powers(const uint32_t felt[4], uint32_t n_powers, uint32_t* out);
+/* FieldOps<BaseField>::batch_inverse / FieldOps<SecureField>::batch_inverse: element-wise inverses (inputs must be non-zero,
+ * as Stwo requires); src and dst may alias. */
+int nx_batch_inverse_m31(nx_ctx* ctx, const uint32_t* d_src, uint32_t* d_dst, size_t n);
+int nx_batch_inverse_qm31(nx_ctx* ctx, const uint32_t* const* d_src4, uint32_t* const* d_dst4, size_t n);
+/* ColumnOps<SecureField>::bit_reverse_column (a SecureColumnByCoords is 4 base columns). */
+int nx_bit_reverse_secure(nx_ctx* ctx, uint32_t* const* d_col4, uint32_t log_size);
+/* FriOps::decompose(eval) -> (g, lambda): lambda = (sum of the first half - sum of the second half) / 2^log_size of the
+ * bit-reversed circle evaluation, g = eval -/+ lambda on the first / second half [upstream-recollection; not called by
+ * FriProver::commit at the pinned revision as far as the reference's use of it shows — exported for trait completeness]. */
+int nx_fri_decompose(nx_ctx* ctx, const uint32_t* const* d_src4, uint32_t log_size, uint32_t* const* d_g4, uint32_t lambda[4]);
 
 /* --------------------------------------------------------------- K10: GrindOps ------------- */
 /* GrindOps<Blake2sChannel>::grind: smallest nonce with >= pow_bits trailing zero bits of
@@ -298,6 +331,8 @@ void nx_prover_destroy(nx_prover* prover);
 int nx_prover_mix_u64(nx_prover* prover, uint64_t v);
 int nx_prover_mix_felts(nx_prover* prover, const uint32_t* felts, uint32_t n_felts); /* 4 words per QM31 */
 int nx_prover_draw_felt(nx_prover* prover, uint32_t out[4]);
+/* Channel::draw_felts(n): n secure felts from the base-felt stream (two per Blake2s draw) — LookupElements::draw's (z, alpha) */
+int nx_prover_draw_felts(nx_prover* prover, uint32_t n_felts, uint32_t* out /* 4 words each */);
 int nx_prover_channel_digest(const nx_prover* prover, uint8_t digest[32]);
 /* TreeBuilder::extend_evals + commit (machine.rs:208-263).  tree_begin allocates the tree's columns in the session (one slab per
  * run of equal log sizes) and returns their device addresses; the caller fills them with bit-reversed circle-domain evaluations

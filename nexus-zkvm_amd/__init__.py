@@ -156,6 +156,11 @@ class ProverSession:
         self.be._chk(self.be.L.nx_prover_draw_felt(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def draw_felts(self, n):
+        out = np.zeros((n, 4), np.uint32)
+        self.be._chk(self.be.L.nx_prover_draw_felts(self.h, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def digest(self):
         out = np.zeros(8, np.uint32)
         self.be._chk(self.be.L.nx_prover_channel_digest(self.h, out.ctypes.data_as(C.c_void_p)))
@@ -505,6 +510,74 @@ class HipBackend:
         h = C.c_void_p()
         self._chk(self.L.nx_merkle_from_leaves(self.ctx, C.c_void_p(leaf_ptr), log_size, C.byref(h)))
         return MerkleTree(self, h)
+
+
+    # ---- the remaining Backend supertraits: AccumulationOps, FieldOps::batch_inverse, per-layer MerkleOps,
+    #      MerkleProver::decommit, FriOps::decompose ----
+    def secure_accumulate(self, dst4, src4):
+        self._chk(self.L.nx_secure_accumulate(self.ctx, dst4.col_ptrs(), src4.col_ptrs(), dst4.log_size))
+        return dst4
+
+    def generate_secure_powers(self, felt, n):
+        out = np.zeros((n, 4), np.uint32)
+        f = _u32(felt)
+        self._chk(self.L.nx_generate_secure_powers(f.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def batch_inverse_m31(self, cols):
+        """Element-wise inverse of every word of a DeviceColumns (FieldOps<BaseField>::batch_inverse)."""
+        out = DeviceColumns(self, cols.n_cols, cols.log_size)
+        self._chk(self.L.nx_batch_inverse_m31(self.ctx, cols.ptr, out.ptr, C.c_size_t(cols.n_cols << cols.log_size)))
+        return out
+
+    def batch_inverse_qm31(self, cols4):
+        out = DeviceColumns(self, 4, cols4.log_size)
+        self._chk(self.L.nx_batch_inverse_qm31(self.ctx, cols4.col_ptrs(), out.col_ptrs(), C.c_size_t(1 << cols4.log_size)))
+        return out
+
+    def bit_reverse_secure(self, cols4):
+        self._chk(self.L.nx_bit_reverse_secure(self.ctx, cols4.col_ptrs(), cols4.log_size))
+        return cols4
+
+    def merkle_commit_on_layer(self, log_size, prev_layer_ptr, cols):
+        """One Merkle layer (MerkleOps::commit_on_layer): prev_layer_ptr = device address of the 2^(log_size+1) nodes below or None;
+        cols = DeviceColumns of 2^log_size rows injected here (or None).  Returns a DeviceColumns view-like buffer of 8 * 2^log_size words."""
+        out = DeviceColumns(self, 8, log_size)          # 2^log nodes x 8 words, node-major
+        n = cols.n_cols if cols is not None else 0
+        self._chk(self.L.nx_merkle_commit_on_layer(self.ctx, log_size, C.c_void_p(prev_layer_ptr) if prev_layer_ptr else None,
+                                                   cols.col_ptrs() if n else None, n, out.ptr))
+        return out
+
+    def merkle_decommit(self, tree, column_sets, queries_per_log):
+        """MerkleProver::decommit: queries_per_log = {log: sorted positions}.  Returns (queried_values, hash_witness[n, 8], column_witness)."""
+        ptrs, logs = [], []
+        for cs in column_sets:
+            stride = 4 << cs.log_size
+            for i in range(cs.n_cols):
+                ptrs.append(cs.ptr.value + i * stride)
+                logs.append(cs.log_size)
+        arr = (C.c_void_p * max(1, len(ptrs)))(*ptrs)
+        lg = _u32(logs)
+        qlogs = _u32(sorted(queries_per_log))
+        qcnt = _u32([len(queries_per_log[int(l)]) for l in qlogs])
+        qs = np.ascontiguousarray([q for l in qlogs for q in queries_per_log[int(l)]], dtype=np.uint64)
+        outs = [C.POINTER(C.c_uint32)() for _ in range(3)]
+        ns = [C.c_size_t(0) for _ in range(3)]
+        self._chk(self.L.nx_merkle_decommit(self.ctx, tree.h, arr, lg.ctypes.data_as(C.c_void_p), len(ptrs), qlogs.ctypes.data_as(C.c_void_p),
+                                            qcnt.ctypes.data_as(C.c_void_p), len(qlogs), qs.ctypes.data_as(C.c_void_p),
+                                            C.byref(outs[0]), C.byref(ns[0]), C.byref(outs[1]), C.byref(ns[1]), C.byref(outs[2]), C.byref(ns[2])))
+        res = []
+        for o, n, mul in zip(outs, ns, (1, 8, 1)):
+            a = np.ctypeslib.as_array(o, shape=(max(1, n.value * mul),))[:n.value * mul].copy()
+            self.L.nx_free_host(o)
+            res.append(a)
+        return res[0], res[1].reshape(-1, 8), res[2]
+
+    def fri_decompose(self, src4):
+        g = DeviceColumns(self, 4, src4.log_size)
+        lam = np.zeros(4, np.uint32)
+        self._chk(self.L.nx_fri_decompose(self.ctx, src4.col_ptrs(), src4.log_size, g.col_ptrs(), lam.ctypes.data_as(C.c_void_p)))
+        return g, lam
 
     # ---- QuotientOps ----
     def accumulate_quotients(self, cols, random_coeff, batches):

@@ -110,6 +110,16 @@ class Blake2sChannel {
         }
     }
     QM31 draw_secure_felt() { uint32_t f[8]; draw_base_felts(f); return nx::qm(f[0], f[1], f[2], f[3]); }
+    // Channel::draw_felts(n): chunks of 4 from the concatenated base-felt draws (two secure felts per draw) [upstream-recollection]
+    std::vector<QM31> draw_secure_felts(size_t n) {
+        std::vector<QM31> out;
+        while (out.size() < n) {
+            uint32_t f[8]; draw_base_felts(f);
+            out.push_back(nx::qm(f[0], f[1], f[2], f[3]));
+            if (out.size() < n) out.push_back(nx::qm(f[4], f[5], f[6], f[7]));
+        }
+        return out;
+    }
 };
 
 }  // namespace nxhip

@@ -1438,6 +1438,55 @@ int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps
     return NX_OK;
 }
 
+
+// MerkleProver::decommit(queries_per_log_size, columns) (inside stwo::prover::prove -> CommitmentSchemeProver::prove_values,
+// reference machine.rs:286-290): the values of `columns` (commit order, any sizes) at the queried rows, plus the witness a
+// verifier needs to recompute the root — sibling hashes not derivable from the queries and the column values of visited but
+// unqueried nodes.  query_logs ascending or not, one (log, count) pair per queried layer; `queries` holds the sorted, deduplicated
+// positions of every queried layer back to back.  All reads travel in ONE gather launch and one device-to-host copy.
+// Outputs are malloc'd (nx_free_host); hash_witness has 8 words per hash.
+int nx_merkle_decommit(nx_ctx* ctx, const nx_tree* tree, const uint32_t* const* d_cols, const uint32_t* log_sizes, uint32_t n_cols,
+                       const uint32_t* query_logs, const uint32_t* query_counts, uint32_t n_query_logs, const uint64_t* queries,
+                       uint32_t** queried_values, size_t* n_queried_values, uint32_t** hash_witness, size_t* n_hashes,
+                       uint32_t** column_witness, size_t* n_column_witness) {
+    NX_GUARD(ctx);
+    if (!ctx || !tree || (n_cols && (!d_cols || !log_sizes)) || (n_query_logs && (!query_logs || !query_counts || !queries)) || !queried_values ||
+        !n_queried_values || !hash_witness || !n_hashes || !column_witness || !n_column_witness)
+        return set_err(ctx, NX_ERR_ARG, "nx_merkle_decommit: NULL argument");
+    const uint32_t n_layers = nx_merkle_n_layers(tree);
+    std::map<uint32_t, std::vector<size_t>> qpl;
+    size_t off = 0;
+    for (uint32_t i = 0; i < n_query_logs; i++) {
+        if (query_logs[i] >= n_layers) return set_err(ctx, NX_ERR_ARG, "nx_merkle_decommit: queried layer outside the tree");
+        std::vector<size_t>& v = qpl[query_logs[i]];
+        for (uint32_t k = 0; k < query_counts[i]; k++) {
+            const uint64_t q = queries[off + k];
+            if (q >= ((uint64_t)1 << query_logs[i]) || (!v.empty() && q <= v.back())) return set_err(ctx, NX_ERR_ARG, "nx_merkle_decommit: queries must be sorted, distinct and inside their layer");
+            v.push_back((size_t)q);
+        }
+        off += query_counts[i];
+    }
+    std::vector<nxhip::ColumnRef> cols(n_cols);
+    for (uint32_t i = 0; i < n_cols; i++) {
+        if (log_sizes[i] >= n_layers || !d_cols[i]) return set_err(ctx, NX_ERR_ARG, "nx_merkle_decommit: column larger than the tree (or NULL)");
+        cols[i] = {const_cast<uint32_t*>(d_cols[i]), log_sizes[i]};
+    }
+    nxhip::GatherBatch gb;
+    nxhip::DecommitPlan plan = nxhip::merkle_decommit_plan(tree, qpl, cols, &gb);
+    NX_TRY(gb.run(ctx));
+    std::vector<uint32_t> qv; nxhip::MerkleDecommitment d;
+    nxhip::merkle_decommit_fill(plan, gb, &qv, &d);
+    auto dup = [](const uint32_t* src, size_t n_words) -> uint32_t* { uint32_t* p = (uint32_t*)malloc(std::max<size_t>(n_words, 1) * 4); if (p && n_words) memcpy(p, src, n_words * 4); return p; };
+    uint32_t* a = dup(qv.data(), qv.size());
+    uint32_t* b = dup(d.hash_witness.empty() ? nullptr : d.hash_witness[0].w, d.hash_witness.size() * 8);
+    uint32_t* c = dup(d.column_witness.data(), d.column_witness.size());
+    if (!a || !b || !c) { free(a); free(b); free(c); return set_err(ctx, NX_ERR_OOM, "nx_merkle_decommit: malloc failed"); }
+    *queried_values = a; *n_queried_values = qv.size();
+    *hash_witness = b; *n_hashes = d.hash_witness.size();
+    *column_witness = c; *n_column_witness = d.column_witness.size();
+    return NX_OK;
+}
+
 // ---------------------------------------------------------------- nx_prover session (recorded AIRs) --
 int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_size, nx_prover** out) {
     NX_GUARD(ctx);
@@ -1476,6 +1525,14 @@ int nx_prover_mix_felts(nx_prover* p, const uint32_t* felts, uint32_t n) {
 int nx_prover_draw_felt(nx_prover* p, uint32_t out[4]) {
     if (!p || !out) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_draw_felt: NULL argument");
     q_store(out, p->channel.draw_secure_felt());
+    return NX_OK;
+}
+// Channel::draw_felts(n): consecutive secure felts taken from the stream of base felts (8 per Blake2s draw, i.e. TWO secure felts
+// per draw) — what LookupElements::draw uses for (z, alpha) (reference machine.rs:239-240 draw_lookup_elements).
+int nx_prover_draw_felts(nx_prover* p, uint32_t n_felts, uint32_t* out) {
+    if (!p || (n_felts && !out)) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_draw_felts: NULL argument");
+    std::vector<QM31> v = p->channel.draw_secure_felts(n_felts);
+    for (uint32_t i = 0; i < n_felts; i++) q_store(out + 4 * (size_t)i, v[i]);
     return NX_OK;
 }
 int nx_prover_channel_digest(const nx_prover* p, uint8_t digest[32]) {

@@ -15,6 +15,7 @@
 #include "constraints.h"
 #include "air_generic.h"
 #include "logup.h"
+#include "backend_ops.h"
 
 using namespace orc;
 
@@ -166,6 +167,7 @@ void orc_lde_commit(void* tw, uint32_t** cols /*in: evals, out: coeffs*/, const 
         evaluate(cols[i], logs[i], evals_out[i], logs[i] + log_blowup, *T);
     });
     std::vector<ColRef> refs; for (int i = 0; i < ncols; i++) refs.push_back({evals_out[i], logs[i] + log_blowup});
+    merkle_n_threads() = n_threads;
     MerkleTree t = merkle_commit(refs, mode);
     memcpy(root_out, t.root().w, 32);
 }
@@ -251,6 +253,30 @@ void orc_logup_finalize_col(int log, const uint32_t* mult_a, const uint32_t* sca
     logup_finalize_col(log, fa, den_b4 ? &fb : nullptr, prev4, out4);
 }
 void orc_logup_finalize_last(int log, uint32_t** col4, uint32_t* claimed_sum) { logup_finalize_last(log, col4, claimed_sum); }
+
+// ---- the remaining Backend supertraits (backend_ops.h) ----
+void orc_batch_inverse_m31(const uint32_t* src, uint32_t* dst, size_t n) { batch_inverse_m31(src, dst, n); }
+void orc_batch_inverse_qm31(const uint32_t** src4, uint32_t** dst4, size_t n) { batch_inverse_qm31(src4, dst4, n); }
+void orc_secure_accumulate(uint32_t** dst4, const uint32_t** src4, size_t n) { secure_accumulate(dst4, src4, n); }
+void orc_generate_secure_powers(const uint32_t* felt, size_t n, uint32_t* out) { generate_secure_powers(qm31_load(felt), n, out); }
+void orc_fri_decompose(const uint32_t** src4, int log, uint32_t** g4, uint32_t* lambda) { qm31_store(lambda, fri_decompose(src4, log, g4)); }
+void orc_commit_on_layer(int log, const uint32_t* prev, const uint32_t** cols, size_t n_cols, int mode, uint32_t* out) { commit_on_layer(log, prev, cols, n_cols, mode, out); }
+void orc_channel_draw_secure_felts(void* c, size_t n, uint32_t* out) { std::vector<QM31> v = ((Channel*)c)->draw_secure_felts(n); for (size_t i = 0; i < n; i++) qm31_store(out + 4 * i, v[i]); }
+// MerkleProver::decommit over columns given in commit order; one (log, count) per queried layer, positions back to back.
+// Outputs: sizes in n_out[3] = {queried values, hashes, column witness words}; buffers must be large enough (call twice or over-allocate).
+void orc_merkle_decommit(const uint32_t** cols, const int* logs, int ncols, int mode, const int* qlogs, const int* qcounts, int nq, const uint64_t* queries,
+                         uint32_t* queried, uint32_t* hashes, uint32_t* colwit, size_t* n_out) {
+    std::vector<ColRef> refs; for (int i = 0; i < ncols; i++) refs.push_back({cols[i], logs[i]});
+    MerkleTree t = merkle_commit(refs, mode);
+    std::map<int, std::vector<size_t>> qpl; size_t off = 0;
+    for (int i = 0; i < nq; i++) { for (int k = 0; k < qcounts[i]; k++) qpl[qlogs[i]].push_back((size_t)queries[off + k]); off += qcounts[i]; }
+    std::vector<u32> qv; MerkleDecommitment d;
+    merkle_decommit(t, qpl, refs, qv, d);
+    n_out[0] = qv.size(); n_out[1] = d.hash_witness.size(); n_out[2] = d.column_witness.size();
+    if (queried) memcpy(queried, qv.data(), qv.size() * 4);
+    if (hashes) for (size_t i = 0; i < d.hash_witness.size(); i++) memcpy(hashes + 8 * i, d.hash_witness[i].w, 32);
+    if (colwit) memcpy(colwit, d.column_witness.data(), d.column_witness.size() * 4);
+}
 
 // Timed CPU baseline leg: one full prove, returns seconds (negative on error).
 double orc_time_prove_synth(const int* comps, int ncomp, const int* cfg, uint64_t seed, int n_threads) {

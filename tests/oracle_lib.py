@@ -159,6 +159,17 @@ def merkle_commit(cols, mode=HASH_STD, want_layers=False):
     return (root, layers) if want_layers else root
 
 
+def lde_commit(cols, log_blowup=1, mode=HASH_STD, threads=4, root_log=None):
+    """Reference of nx_lde_commit (config #2): interpolate + evaluate every column (in place: `cols` become the coefficients),
+    Blake2s Merkle root of the LDE columns.  Returns (lde columns, root)."""
+    logs = np.array([int(np.log2(len(c))) for c in cols], np.int32)
+    tw = Twiddles(int(logs.max()) + log_blowup if root_log is None else root_log)
+    ldes = [np.zeros(len(c) << log_blowup, np.uint32) for c in cols]
+    root = np.zeros(8, np.uint32)
+    lib().orc_lde_commit(tw.h, ptr_array(cols), ptr(logs), len(cols), log_blowup, mode, threads, ptr_array(ldes), ptr(root))
+    return ldes, root
+
+
 def synth_tree_columns(comps, tree, seed, inter_seed=0, threads=4):
     comps = comps_array(comps)
     outs = []

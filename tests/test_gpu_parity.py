@@ -1007,3 +1007,156 @@ def test_column_utilities(be):
     be._chk(be.L.nx_upload(be.ctx, wide.ptr, w8.view(np.uint32).ctypes.data_as(C.c_void_p), C.c_size_t(2 * n)))
     be._chk(be.L.nx_m31_narrow(be.ctx, dc.ptr, wide.ptr, C.c_size_t(n)))
     assert np.array_equal(dc.to_cpu().reshape(-1), (w8 % P).astype(np.uint32))
+
+
+# ---------------- the remaining Backend supertraits: each export against oracle/backend_ops.h -----------------
+
+def test_batch_inverse_matches_oracle(be, oracle):
+    L = oracle.lib()
+    for log in (0, 5, 13, 18):
+        vals = np.random.default_rng(log + 400).integers(1, P, (3, 1 << log), dtype=np.uint32)      # non-zero, as Stwo requires
+        got = be.batch_inverse_m31(be.columns_from_host(vals)).to_cpu()
+        ref = np.zeros_like(vals)
+        for c in range(3):
+            L.orc_batch_inverse_m31(O.ptr(np.ascontiguousarray(vals[c])), O.ptr(ref[c]), C.c_size_t(1 << log))
+        assert np.array_equal(got, ref), log
+        sec = np.random.default_rng(log + 500).integers(0, P, (4, 1 << log), dtype=np.uint32)
+        sec[0] |= 1                                                                                   # never the zero element
+        got4 = be.batch_inverse_qm31(be.columns_from_host(sec)).to_cpu()
+        ref4 = [np.zeros(1 << log, np.uint32) for _ in range(4)]
+        L.orc_batch_inverse_qm31(O.ptr_array([np.ascontiguousarray(c) for c in sec]), O.ptr_array(ref4), C.c_size_t(1 << log))
+        assert np.array_equal(got4, np.stack(ref4)), log
+
+
+def test_secure_accumulate_and_powers_match_oracle(be, oracle):
+    L = oracle.lib()
+    log = 11
+    a = rand_cols(1, 4, log); b = rand_cols(2, 4, log)
+    got = be.secure_accumulate(be.columns_from_host(a), be.columns_from_host(b)).to_cpu()
+    ref = [np.ascontiguousarray(c).copy() for c in a]
+    L.orc_secure_accumulate(O.ptr_array(ref), O.ptr_array([np.ascontiguousarray(c) for c in b]), C.c_size_t(1 << log))
+    assert np.array_equal(got, np.stack(ref))
+    _, _, felt = _random_point_and_alpha(oracle, 33)
+    pw = be.generate_secure_powers(felt, 37)
+    rp = np.zeros((37, 4), np.uint32)
+    L.orc_generate_secure_powers(O.ptr(felt), C.c_size_t(37), O.ptr(rp))
+    assert np.array_equal(pw, rp) and list(pw[0]) == [1, 0, 0, 0] and np.array_equal(pw[1], felt)
+
+
+def test_bit_reverse_secure(be):
+    log = 9
+    v = rand_cols(3, 4, log)
+    got = be.bit_reverse_secure(be.columns_from_host(v)).to_cpu()
+    idx = np.array([int(format(i, "0%db" % log)[::-1], 2) for i in range(1 << log)])
+    assert np.array_equal(got, v[:, idx])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_commit_on_layer_matches_oracle_and_whole_tree(be, oracle, mode):
+    """MerkleOps::commit_on_layer one layer at a time (leaf layer without a previous layer, inner layers with and without injected
+    columns) == the oracle's layer rule == the corresponding layer of nx_merkle_commit."""
+    L = oracle.lib()
+    be.set_hash_mode(mode)
+    try:
+        big, small = rand_cols(70, 19, 8), rand_cols(71, 3, 7)
+        d_big, d_small = be.columns_from_host(big), be.columns_from_host(small)
+        tree = be.merkle_commit([d_big, d_small])
+        leaf = be.merkle_commit_on_layer(8, None, d_big)
+        ref_leaf = np.zeros(8 << 8, np.uint32)
+        L.orc_commit_on_layer(8, None, O.ptr_array([np.ascontiguousarray(c) for c in big]), C.c_size_t(19), mode, O.ptr(ref_leaf))
+        assert np.array_equal(leaf.to_cpu().reshape(-1), ref_leaf)
+        assert np.array_equal(tree.layer(8).reshape(-1), ref_leaf)
+        l7 = be.merkle_commit_on_layer(7, leaf.ptr.value, d_small)
+        ref7 = np.zeros(8 << 7, np.uint32)
+        L.orc_commit_on_layer(7, O.ptr(ref_leaf), O.ptr_array([np.ascontiguousarray(c) for c in small]), C.c_size_t(3), mode, O.ptr(ref7))
+        assert np.array_equal(l7.to_cpu().reshape(-1), ref7) and np.array_equal(tree.layer(7).reshape(-1), ref7)
+        l6 = be.merkle_commit_on_layer(6, l7.ptr.value, None)
+        ref6 = np.zeros(8 << 6, np.uint32)
+        L.orc_commit_on_layer(6, O.ptr(ref7), None, C.c_size_t(0), mode, O.ptr(ref6))
+        assert np.array_equal(l6.to_cpu().reshape(-1), ref6) and np.array_equal(tree.layer(6).reshape(-1), ref6)
+    finally:
+        be.set_hash_mode(0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_merkle_decommit_matches_oracle(be, oracle, mode):
+    """MerkleProver::decommit on a mixed-degree tree with queries on two layers (the shape of a FRI first layer and of a
+    prover2-style trace tree): queried values, hash witness and column witness, word for word."""
+    L = oracle.lib()
+    be.set_hash_mode(mode)
+    try:
+        logs = [9] * 5 + [7] * 3 + [9] * 2 + [4]
+        host = [np.random.default_rng(900 + i).integers(0, P, 1 << l, dtype=np.uint32) for i, l in enumerate(logs)]
+        sets = [be.columns_from_host(h) for h in host]
+        tree = be.merkle_commit(sets)
+        queries = {9: [3, 4, 200, 201, 511], 7: [0, 50], 4: [7]}
+        qv, hw, cw = be.merkle_decommit(tree, sets, queries)
+        qlogs = np.array(sorted(queries), np.int32)
+        qcnt = np.array([len(queries[int(l)]) for l in qlogs], np.int32)
+        qs = np.array([q for l in qlogs for q in queries[int(l)]], np.uint64)
+        n_out = (C.c_size_t * 3)()
+        r_qv, r_hw, r_cw = np.zeros(4096, np.uint32), np.zeros(8 * 4096, np.uint32), np.zeros(4096, np.uint32)
+        L.orc_merkle_decommit(O.ptr_array(host), O.ptr(np.array(logs, np.int32)), len(logs), mode, O.ptr(qlogs), O.ptr(qcnt), len(qlogs), O.ptr(qs),
+                              O.ptr(r_qv), O.ptr(r_hw), O.ptr(r_cw), n_out)
+        assert len(qv) == n_out[0] and np.array_equal(qv, r_qv[:n_out[0]])
+        assert len(hw) == n_out[1] and np.array_equal(hw.reshape(-1), r_hw[:8 * n_out[1]])
+        assert len(cw) == n_out[2] and np.array_equal(cw, r_cw[:n_out[2]])
+        assert n_out[1] > 0 and n_out[2] > 0
+    finally:
+        be.set_hash_mode(0)
+
+
+def test_fri_decompose_matches_oracle(be, oracle):
+    L = oracle.lib()
+    for log in (1, 4, 12, 17):
+        src = rand_cols(log + 600, 4, log)
+        g, lam = be.fri_decompose(be.columns_from_host(src))
+        ref = [np.zeros(1 << log, np.uint32) for _ in range(4)]
+        rl = np.zeros(4, np.uint32)
+        L.orc_fri_decompose(O.ptr_array([np.ascontiguousarray(c) for c in src]), log, O.ptr_array(ref), O.ptr(rl))
+        assert np.array_equal(lam, rl), log
+        assert np.array_equal(g.to_cpu(), np.stack(ref)), log
+
+
+def test_session_draw_felts_matches_oracle_channel(be, nz, oracle):
+    """Channel::draw_felts(n) takes two secure felts from every Blake2s draw; n single draws take one each."""
+    L = oracle.lib()
+    s = be.prover_session(nz.default_config(), 6)
+    s.mix_u64(77)
+    got = s.draw_felts(5)
+    ch = C.c_void_p(L.orc_channel_new())
+    L.orc_channel_mix_u64(ch, 77)
+    ref = np.zeros((5, 4), np.uint32)
+    L.orc_channel_draw_secure_felts(ch, C.c_size_t(5), O.ptr(ref))
+    assert np.array_equal(got, ref)
+    nxt, rn = s.draw_felt(), np.zeros(4, np.uint32)
+    L.orc_channel_draw_secure_felt(ch, O.ptr(rn))
+    assert np.array_equal(nxt, rn)
+    L.orc_channel_free(ch)
+    s.close()
+
+
+def test_context_on_a_worker_thread_uses_its_own_device(nz):
+    """every entry makes the context's device current.  A context created on the main thread is driven from a fresh worker
+    thread (whose current device is whatever HIP defaults to) — with more than one GPU visible the context lives on the LAST device."""
+    import threading, torch
+    dev = torch.cuda.device_count() - 1
+    b = nz.HipBackend(dev)
+    vals = rand_cols(5, 3, 14)
+    ref_be = nz.HipBackend(0)
+    tw0 = ref_be.precompute_twiddles(14)
+    expect = ref_be.lde(tw0, ref_be.columns_from_host(vals), 1).to_cpu()
+    out, errs = [], []
+
+    def worker():
+        try:
+            tw = b.precompute_twiddles(14)
+            cols = b.columns_from_host(vals)
+            out.append(b.lde(tw, cols, 1).to_cpu())
+            out.append(b.merkle_commit([cols]).root())
+        except Exception as e:
+            errs.append(e)
+    t = threading.Thread(target=worker); t.start(); t.join()
+    assert not errs, errs
+    assert np.array_equal(out[0], expect)
+    b.close(); ref_be.close()

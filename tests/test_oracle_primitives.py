@@ -418,3 +418,61 @@ def test_golden_fixtures(oracle):
         ldes = [tw.evaluate(tw.interpolate(c), int(np.log2(len(c))) + 1) for c in cols]
         for mode, key in ((O.HASH_STD, "root_std"), (O.HASH_RAW0, "root_raw0")):
             assert [int(x) for x in oracle.merkle_commit(ldes, mode)] == case[key]
+
+
+# ---------------- oracle/backend_ops.h: pinned by the identities of the construction ----------------
+
+def test_oracle_batch_inverse_is_the_inverse(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    rng = np.random.default_rng(1234)
+    v = rng.integers(1, O.P, 1000, dtype=np.uint32)
+    inv = np.zeros_like(v)
+    L.orc_batch_inverse_m31(O.ptr(v), O.ptr(inv), C.c_size_t(len(v)))
+    assert all((int(a) * int(b)) % O.P == 1 for a, b in zip(v, inv))
+    q = [rng.integers(1, O.P, 64, dtype=np.uint32) for _ in range(4)]
+    qi = [np.zeros(64, np.uint32) for _ in range(4)]
+    L.orc_batch_inverse_qm31(O.ptr_array(q), O.ptr_array(qi), C.c_size_t(64))
+    for i in range(64):
+        a = np.array([c[i] for c in q], np.uint32); b = np.array([c[i] for c in qi], np.uint32)
+        out = np.zeros(4, np.uint32)
+        L.orc_qm31_mul(O.ptr(a), O.ptr(b), O.ptr(out))
+        assert list(out) == [1, 0, 0, 0]
+
+
+def test_oracle_fri_decompose_splits_off_the_sign_component(oracle):
+    """f = g + lambda * v_n with v_n = +1 / -1 on the halves, and g has no v_n component (its own decomposition coefficient is 0)."""
+    L = oracle.lib()
+    log = 6
+    rng = np.random.default_rng(5)
+    src = [rng.integers(0, O.P, 1 << log, dtype=np.uint32) for _ in range(4)]
+    g = [np.zeros(1 << log, np.uint32) for _ in range(4)]
+    lam = np.zeros(4, np.uint32)
+    L.orc_fri_decompose(O.ptr_array(src), log, O.ptr_array(g), O.ptr(lam))
+    half = 1 << (log - 1)
+    for q in range(4):
+        assert np.array_equal((g[q][:half].astype(np.uint64) + lam[q]) % O.P, src[q][:half])
+        assert np.array_equal((g[q][half:].astype(np.uint64) + O.P - lam[q]) % O.P, src[q][half:])
+    g2 = [np.zeros(1 << log, np.uint32) for _ in range(4)]
+    lam2 = np.ones(4, np.uint32)
+    L.orc_fri_decompose(O.ptr_array(g), log, O.ptr_array(g2), O.ptr(lam2))
+    assert not lam2.any()
+
+
+def test_oracle_commit_on_layer_rebuilds_the_committed_tree(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    rng = np.random.default_rng(9)
+    big = [rng.integers(0, O.P, 1 << 5, dtype=np.uint32) for _ in range(18)]
+    small = [rng.integers(0, O.P, 1 << 3, dtype=np.uint32) for _ in range(2)]
+    for mode in (0, 1):
+        root, layers = oracle.merkle_commit(big + small, mode, want_layers=True)
+        prev, off = None, 0
+        for log in range(5, -1, -1):
+            cols = big if log == 5 else small if log == 3 else []
+            out = np.zeros(8 << log, np.uint32)
+            L.orc_commit_on_layer(log, O.ptr(prev) if prev is not None else None, O.ptr_array(cols) if cols else None, C.c_size_t(len(cols)), mode, O.ptr(out))
+            assert np.array_equal(out, layers[off:off + (8 << log)]), (mode, log)
+            off += 8 << log
+            prev = out
+        assert np.array_equal(prev, root)
