@@ -1,14 +1,16 @@
 #!/usr/bin/env python
 """bench.py — RISC-V cycles proved / s on the synthetic 2^22-row trace (BASELINE.json config #3).
 
-One "step" = one full prove of the synthetic machine (trace fill on device -> 3 tree commits
-(Circle-FFT LDE + Blake2s Merkle) -> composition -> tree 4 -> OODS -> DEEP quotients -> FRI -> PoW ->
-decommit -> proof bytes on the host), everything resident in HBM (the trace is generated on device).
-`value` = 2^log_n_rows * steps * n_gpus / seconds (max over ranks).
+One "step" = one full prove of the reference-shaped synthetic machine (nx_prove_machine): trace fill on device -> preprocessed and
+main tree commits (Circle-FFT LDE + Blake2s Merkle) -> lookup elements -> REAL logup interaction trace on device -> claimed sums
+-> interaction tree commit -> composition (recorded AIR, JIT kernel) -> tree 4 -> OODS -> DEEP quotients -> FRI -> PoW ->
+decommit -> proof bytes on the host; everything resident in HBM (the trace is generated on device).
+`value` = 2^log_n_rows * steps / seconds (max over ranks).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 22] [--no-cpu-baseline]
-For N > 1 it is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-(one rank per GPU, RCCL); each rank proves its own trace (independent proofs — see DESIGN.md §multi-GPU).
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 22] [--no-cpu-baseline] [--no-v1-shaped] [--replicas]
+For N > 1 it is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL): by default the N GPUs prove ONE trace together (row-sharded prove, "scaling": "strong" — DESIGN.md §7); --replicas runs
+one independent proof per GPU instead (batch throughput, "weak").
 """
 import argparse
 import json
@@ -24,6 +26,30 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 
 
+def lde_roofline(stats, log_rows, n_cols_total):
+    """The Circle-FFT roofline block from one instrumented prove (HIP events around every FFT pass sequence, ctx.hip KTimer)."""
+    ms = stats["lde_kernel_ms"]
+    gbs = stats["lde_algorithmic_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, source = None, None
+    tpath = os.path.join(ROOT, "profiles", "fft_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("algorithmic_bytes_per_column") == float(16 << log_rows):
+                traffic = tj["hbm_bytes_per_column"] * (stats["lde_algorithmic_bytes"] / float(16 << log_rows))
+                source = "profiles/fft_traffic.json: separate --pmc passes of tools/pmc_traffic.py (FETCH_SIZE x2 + WRITE_SIZE, calibrated on a copy), per column at this size, scaled by this prove's column count; NOT re-measured inside this run"
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "frac_of_measured_copy": gbs / 6290.0,   # MI355X_MICROARCH.md: 6.29 TB/s measured copy bandwidth
+            "traffic": traffic, "traffic_source": source,
+            "kernel": "nx::fft13_kernel<INV, FIRST, 1, 4, K> + nx::lde_mid_kernel<4, K> (Circle iFFT+FFT = LDE, all passes of one prove)",
+            "algorithmic_bytes": stats["lde_algorithmic_bytes"], "kernel_ms": ms}
+
+
+STAGES = ("trace_gen", "commit", "interaction", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -32,21 +58,23 @@ def main():
     ap.add_argument("--log-rows", type=int, default=22)
     ap.add_argument("--n-pre", type=int, default=27)      # reference column.rs:617-664 (18 + 9)
     ap.add_argument("--n-main", type=int, default=347)    # reference column.rs:23-606
-    ap.add_argument("--n-inter", type=int, default=64)    # 16 logup columns x 4 base columns
+    ap.add_argument("--n-logup", type=int, default=16)    # 16 logup columns = 64 interaction base columns
     ap.add_argument("--pow-bits", type=int, default=10)
+    ap.add_argument("--hash-mode", type=int, default=0)   # 0 standard Blake2s-256 nodes, 1 zero-state raw compression chaining
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-rows", type=int, default=20)   # a bounded sample of the same machine: ~10 s of host work on the GPU box
-    ap.add_argument("--sharded", action="store_true",
-                    help="N > 1: ONE proof per step with its columns sharded over the N GPUs (config #4 style, strong scaling) instead of one independent proof per GPU")
+    ap.add_argument("--cpu-log-rows", type=int, default=20)   # a bounded sample of the same machine: ~10-20 s of host work on the GPU box
+    ap.add_argument("--no-v1-shaped", action="store_true", help="skip the second, reference-v1-shaped workload")
+    ap.add_argument("--v1-logup", type=int, default=250)      # ~250 logup columns ~ 1.0 k interaction base columns (SURVEY §8 preamble)
+    ap.add_argument("--replicas", action="store_true", help="N > 1: one independent proof per GPU (weak scaling) instead of ONE row-sharded proof")
+    ap.add_argument("--legacy-synth", action="store_true", help="prove the round-1 machine (synthetic interaction fill, hand-written constraint kernel)")
     args = ap.parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libnexus_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -59,8 +87,9 @@ def main():
 
     import nexus_zkvm_amd as nz
     be = nz.HipBackend(local_rank)
-    comps = [(args.log_rows, args.n_pre, args.n_main, args.n_inter)]
-    cfg = nz.default_config(pow_bits=args.pow_bits)
+    n_inter = 4 * args.n_logup
+    comps = [(args.log_rows, args.n_pre, args.n_main, n_inter)]
+    cfg = nz.default_config(pow_bits=args.pow_bits, hash_mode=args.hash_mode)
 
     def barrier():
         be.sync()
@@ -69,45 +98,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sharded = args.sharded and world > 1
+    sharded = world > 1 and not args.replicas
+    comm = None
     if sharded:
+        if world & (world - 1):
+            raise SystemExit("one row-sharded proof needs a power-of-two number of GPUs (use --replicas otherwise)")
         from nexus_zkvm_amd.sharded import TorchDistComm
         comm = nz.make_comm(rank, world, TorchDistComm(be, torch.device("cuda", local_rank)))
-        prove = lambda seed: be.prove_sharded(comps, comm, cfg, seed=seed)          # same seed on every rank: one proof
-    else:
-        prove = lambda seed: be.prove(comps, cfg, seed=seed + rank * 97)            # one independent proof per rank
-    for w in range(args.warmup):
-        prove(1000 + w)
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        prove(2000 + s)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # one extra instrumented step (outside the timed region) for the per-stage split and the FFT roofline:
-    # HIP events on the context's stream around every Circle-FFT pass sequence (nexus-zkvm_amd/csrc/ctx.hip KTimer)
-    words, stats = be.prove(comps, cfg, seed=4242 + rank, want_stats=True)
+    def prove(cs, cf, seed, want_stats=False):
+        sd = seed if sharded else seed + rank * 97            # one proof together, or one independent proof per rank
+        if args.legacy_synth:
+            return be.prove_sharded(cs, comm, cf, seed=sd, want_stats=want_stats) if sharded else be.prove(cs, cf, seed=sd, want_stats=want_stats)
+        return be.prove_machine(cs, cf, seed=sd, comm=comm, want_stats=want_stats)
+
+    def timed(cs, cf, steps, warmup):
+        for w in range(warmup):
+            prove(cs, cf, 1000 + w)
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            prove(cs, cf, 2000 + s)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed(comps, cfg, args.steps, args.warmup)
+    # one extra instrumented step (outside the timed region) for the per-stage split and the FFT roofline
+    words, stats = prove(comps, cfg, 4242, want_stats=True)
+
+    v1 = None
+    if not args.no_v1_shaped and world == 1 and not args.legacy_synth:
+        # The reference's v1 machine shape: LOG_CONSTRAINT_DEGREE = 2 (reference prover/src/components/mod.rs:12: the
+        # constraints are evaluated on a 2^(n+2) domain, every column re-evaluated there; twiddles for n+3, machine.rs:186-194),
+        # ~250 logup columns ~ 1.0 k interaction base columns (chips/range_check/range256.rs:271-288 et al.), 8 extension components
+        # of other sizes (machine.rs:82-91).  Reported next to the headline, not instead of it.
+        try:
+            v1_comps = [(args.log_rows, args.n_pre, args.n_main, 4 * args.v1_logup)] + [(8 + k, 2, 6 + k, 4) for k in range(8)]
+            v1_cfg = nz.default_config(pow_bits=args.pow_bits, hash_mode=args.hash_mode, log_constraint_degree=2)
+            v1_steps = max(1, min(2, args.steps))
+            v1_el = timed(v1_comps, v1_cfg, v1_steps, 1)
+            v1_words, v1_stats = prove(v1_comps, v1_cfg, 4243, want_stats=True)
+            n_cols = sum(c[1] + c[2] + c[3] for c in v1_comps)
+            v1 = {"workload": "v1-shaped: 2^%d rows, %d preprocessed + %d main + %d interaction columns (%d logup columns), log_constraint_degree 2, + 8 components of 2^8..2^15 rows"
+                  % (args.log_rows, args.n_pre, args.n_main, 4 * args.v1_logup, args.v1_logup),
+                  "value": (1 << args.log_rows) * v1_steps / v1_el, "unit": "cycles/s", "ms_per_step": 1e3 * v1_el / v1_steps, "steps": v1_steps,
+                  "n_columns": n_cols, "proof_words": int(len(v1_words)),
+                  "stages_ms": {k: round(v1_stats[k], 3) for k in STAGES},
+                  "roofline": lde_roofline(v1_stats, args.log_rows, n_cols),
+                  "merkle": {"kernel_ms": v1_stats["merkle_kernel_ms"], "algorithmic_bytes": v1_stats["merkle_algorithmic_bytes"]}}
+        except Exception as e:   # noqa: BLE001 — the headline line must still be printed
+            v1 = {"error": repr(e)[:300]}
+
     out = None
     if rank == 0:
         n_cycles = (1 << args.log_rows) * args.steps * (1 if sharded else world)
-        lde_gbs = stats["lde_algorithmic_bytes"] / (stats["lde_kernel_ms"] * 1e-3) / 1e9 if stats["lde_kernel_ms"] > 0 else 0.0
-        # HBM bytes of the same LDE work from the PMC passes of tools/pmc_traffic.py (FETCH_SIZE x2 + WRITE_SIZE, calibrated
-        # on a known copy as MI355X_MICROARCH.md prescribes), measured per column at the same log size and scaled to this
-        # prove's column count; null when the committed measurement is for another size
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "fft_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("algorithmic_bytes_per_column") == float(16 << args.log_rows):
-                    traffic = tj["hbm_bytes_per_column"] * (stats["lde_algorithmic_bytes"] / float(16 << args.log_rows))
-            except Exception:
-                traffic = None
+        n_cols_total = args.n_pre + args.n_main + n_inter
+        roof = lde_roofline(stats, args.log_rows, n_cols_total)
         out = {
             "metric": "RISC-V cycles proved/sec at log_n_rows=%d; achieved HBM GB/s on Circle-FFT" % args.log_rows,
             "value": n_cycles / elapsed,
@@ -117,38 +168,59 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak",
+            "scaling": "strong" if sharded or world == 1 else "weak",
             "vs_baseline": None,
             "dtype": "u32 (M31)",
             "data": "synthetic",
-            "config": {"workload": "synthetic 2^%d-row trace, full prove (LDE+quotient+FRI+Merkle), %d preprocessed + %d main + %d interaction columns, blowup 2, %d queries, pow_bits %d"
-                       % (args.log_rows, args.n_pre, args.n_main, args.n_inter, cfg.n_queries, cfg.pow_bits),
-                       "log_n_rows": args.log_rows, "parallelism": ("1 proof, columns sharded over %d GPUs" % world) if sharded else ("1 proof per GPU" if world > 1 else "1 GPU"),
+            "config": {"workload": "synthetic 2^%d-row trace, full prove (LDE+quotient+FRI+Merkle), %d preprocessed + %d main + %d interaction columns (%s), blowup 2, %d queries, pow_bits %d, %s Merkle nodes"
+                       % (args.log_rows, args.n_pre, args.n_main, n_inter,
+                          "synthetic interaction fill, hand-written constraint kernel" if args.legacy_synth else "%d real logup columns generated on device, recorded AIR" % args.n_logup,
+                          cfg.n_queries, cfg.pow_bits, "standard Blake2s-256" if args.hash_mode == 0 else "raw zero-state Blake2s compression"),
+                       "log_n_rows": args.log_rows,
+                       "parallelism": ("ONE proof on %d GPUs: column-parallel LDE, all-to-all into row blocks, local hashing / constraints / quotients / FRI folds" % world) if sharded
+                       else ("1 independent proof per GPU" if world > 1 else "1 GPU"),
                        "proof_words": int(len(words))},
-            "roofline": {"bound": "hbm", "achieved": lde_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_gbs / HBM_PEAK_GBS,
-                         "frac_of_measured_copy": lde_gbs / 6290.0,   # MI355X_MICROARCH.md: 6.29 TB/s measured copy bandwidth
-                         "traffic": traffic, "kernel": "nx::fft13_kernel<INV, FIRST, 1, 4, K> + nx::lde_mid_kernel<4, K> (Circle iFFT+FFT = LDE, all passes of one prove)",
-                         "algorithmic_bytes": stats["lde_algorithmic_bytes"], "kernel_ms": stats["lde_kernel_ms"]},
+            "roofline": roof,
             # the FFT is VALU-issue bound on gfx950, not HBM bound: butterflies of one prove's iFFT + LDE work
             # (n/2 * N per iFFT, n * N per 2x LDE: the trivial top layer is not computed) against the measured chip ceiling of the
             # butterfly instruction sequence itself (tools/ubench/bfly_rates.hip, variant B: 4.73e12 butterflies/s)
             "roofline_valu": (lambda nb: {"bound": "valu", "achieved": nb / (stats["lde_kernel_ms"] * 1e-3) / 1e12, "peak": 4.73, "unit": "T butterflies/s",
                                           "frac": nb / (stats["lde_kernel_ms"] * 1e-3) / 4.73e12, "butterflies": nb})(
-                (args.n_pre + args.n_main + args.n_inter) * 1.5 * args.log_rows * (1 << args.log_rows)
-                + 4 * ((args.log_rows + 1) / 2.0 + (args.log_rows + 1)) * (2 << args.log_rows)),
-            "stages_ms": {k: round(stats[k], 3) for k in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")},
+                ((n_cols_total * 1.5 * args.log_rows * (1 << args.log_rows)) / (world if sharded else 1)
+                 + 4 * ((args.log_rows + 1) / 2.0 + (args.log_rows + 1)) * (2 << args.log_rows))) if stats["lde_kernel_ms"] > 0 else None,
+            "stages_ms": {k: round(stats[k], 3) for k in STAGES},
             "merkle": {"kernel_ms": stats["merkle_kernel_ms"], "algorithmic_bytes": stats["merkle_algorithmic_bytes"],
                        "achieved_GBs": stats["merkle_algorithmic_bytes"] / (stats["merkle_kernel_ms"] * 1e-3) / 1e9 if stats["merkle_kernel_ms"] > 0 else 0.0},
         }
+        if sharded:
+            out["xgmi"] = {"bytes_sent_per_gpu_per_proof": int(stats["comm_bytes"]), "ms_in_collectives_per_proof": round(stats["comm_ms"], 3),
+                           "collectives": "one all-to-all per trace tree (LDE columns -> row blocks), all-gather of W subtree roots per tree, of the columns read at a non-zero mask offset, of the composition accumulator and of the FRI tail; sampled / queried values (KBs)"}
+        if v1 is not None:
+            out["config_v1_shaped"] = v1
         if not args.no_cpu_baseline and world == 1:
             import oracle_lib as O   # checker / baseline only — never part of the measured GPU path
+            import numpy as np
             O.build_oracle()
             cores = os.cpu_count() or 1
-            ccomps = [(args.cpu_log_rows, args.n_pre, args.n_main, args.n_inter)]
-            secs = O.time_prove_synth(ccomps, O.default_cfg(pow_bits=args.pow_bits), seed=7, threads=cores)
+            ccomps = [(args.cpu_log_rows, args.n_pre, args.n_main, n_inter)]
+            ocfg = O.default_cfg(pow_bits=args.pow_bits, hash_mode=args.hash_mode)
+            t0 = time.perf_counter()
+            if args.legacy_synth:
+                ref = O.prove_synth(ccomps, ocfg, seed=7, threads=cores)
+            else:
+                import machine_ref
+                ref = machine_ref.prove_machine(ccomps, ocfg, seed=7, threads=cores)
+            secs = time.perf_counter() - t0
+            # the same statement on the GPU: every proof word must agree (parity pinned at the sample size, not just verifier acceptance)
+            gpu = be.prove(ccomps, cfg, seed=7) if args.legacy_synth else be.prove_machine(ccomps, cfg, seed=7)
+            equal = bool(len(gpu) == len(ref) and np.array_equal(gpu, ref))
             out["cpu_baseline"] = {"value": (1 << args.cpu_log_rows) / secs, "unit": "cycles/s", "cores": cores, "kind": "port",
                                    "sample": "one full prove of the same machine at 2^%d rows (%.1f s) by the C++ oracle, %d threads; NOT Stwo SimdBackend"
-                                   % (args.cpu_log_rows, secs, cores)}
+                                   % (args.cpu_log_rows, secs, cores),
+                                   "proof_equal": equal, "proof_words": int(len(ref))}
+            if not equal:
+                print(json.dumps(out), flush=True)
+                raise SystemExit("bench.py: the GPU proof of the cpu_baseline sample differs from the oracle's proof")
         print(json.dumps(out), flush=True)
     be.close()
     if dist is not None:

@@ -233,6 +233,9 @@ typedef struct nx_prove_stats { /* milliseconds, device-synchronised stage bound
     uint64_t lde_algorithmic_bytes;
     double merkle_kernel_ms;
     uint64_t merkle_algorithmic_bytes;
+    double interaction;          /* logup interaction-trace generation (nx_prove_machine)         */
+    double comm_ms;              /* wall time inside nx_comm callbacks (one proof on several GPUs) */
+    uint64_t comm_bytes;         /* bytes this GPU sent to its peers                               */
 } nx_prove_stats;
 
 /* Fill tree `tree` (0 preprocessed / 1 main / 2 interaction) of the synthetic trace directly in
@@ -248,29 +251,49 @@ int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps
                    nx_prove_stats* stats);
 void nx_free_host(void* p);
 
-/* ------------------------------------------- one proof, columns sharded over the GPUs of a node (config #4) ---------
- * One process (or thread) per GPU calls nx_prove_synth_sharded with the same arguments and its own nx_comm.  Columns of
- * every trace tree are cut into contiguous 16-column-aligned blocks (rank r takes block r); LDE, OODS evaluation,
- * constraint and quotient partial sums are local; the exchanges are exactly: the Blake2s chaining state ring per tree
- * (send/recv, 32 B per row per hop), one modular all-reduce for the composition polynomial and one for the DEEP quotient
- * (allreduce_m31), the sampled / queried values (allgather of a few KB) and the roots and Merkle witnesses (broadcast).
- * FRI, proof of work and the composition tree are replicated.  Every rank returns the same proof, bit-identical to
- * nx_prove_synth on one GPU.  The transport is the caller's: RCCL over xGMI (nexus-zkvm_amd/sharded.py wraps
- * torch.distributed) or anything else; device-buffer calls must be complete when they return. */
+/* The reference-shaped machine: as nx_prove_synth, but the interaction tree is a REAL logup trace — lookup elements (z, alpha) drawn
+ * after the main commit (reference machine.rs:239-240), one fraction per logup column over main-trace columns
+ * (LogupTraceGenerator, reference traits.rs:124-145, chips/range_check/range256.rs:271-288: nx_logup_col per column, then
+ * nx_logup_finalize_last), claimed sums mixed before the commit (machine.rs:262) — and the AIR (transition, degree-2 and logup
+ * constraints with the [-1, 0] mask of the last logup column) is a recorded program compiled by nx_air_compile: the route a Rust
+ * shim takes for the reference's own AIR.  n_inter = 4 x (logup columns of the component).  comm: NULL = one GPU; otherwise ONE
+ * proof on the GPUs of the communicator (nx_comm below). */
+struct nx_comm;
+int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed,
+                     const uint8_t* ad, size_t ad_len, const struct nx_comm* comm, uint32_t** proof_words, size_t* n_words,
+                     nx_prove_stats* stats);
+
+/* ------------------------------------------- ONE proof on the GPUs of a node (BASELINE configs #4 / #5) ---------------
+ * One process (or thread) per GPU calls the prove entry with the same arguments and its own nx_comm; W must be a power of two.
+ * The LDE is column-parallel: every GPU transforms a contiguous share of each tree's columns.  One all-to-all per tree then turns
+ * column shards into ROW BLOCKS — GPU r holds rows [r M/W, (r+1) M/W) of every LDE column (a contiguous block of the bit-reversed
+ * domain = a subtree of the Merkle tree), so leaf hashing, constraint evaluation, DEEP quotients and the first FRI folds are
+ * local.  Besides the transposition only these cross the links: the W subtree roots of every tree (all-gather, 32 B each), the
+ * sampled and queried values (KBs), the columns read at a non-zero mask offset, the composition accumulator (all-gather of 4
+ * columns) and the small FRI tail.  Every GPU returns the same proof, bit-identical to the single-GPU proof.
+ * The transport is the caller's: RCCL over xGMI (nexus-zkvm_amd/sharded.py wraps torch.distributed) or anything else.  Device
+ * buffers handed to a callback are complete when it is called and must be complete when it returns.  Counts/offsets are in
+ * 32-bit words. */
 typedef struct nx_comm {
     int32_t rank, world;
     void* user;
-    int (*send)(void* user, int32_t dst, const uint32_t* d_buf, size_t n_words);          /* device buffer */
-    int (*recv)(void* user, int32_t src, uint32_t* d_buf, size_t n_words);                /* device buffer */
-    int (*allreduce_m31)(void* user, uint32_t* d_buf, size_t n_words);                    /* in place: sum over ranks mod p */
-    int (*allgather)(void* user, const void* h_send, size_t bytes, void* h_recv);         /* host: recv = world x bytes */
-    int (*broadcast)(void* user, void* h_buf, size_t bytes, int32_t root);                /* host */
+    int (*send)(void* user, int32_t dst, const uint32_t* d_buf, size_t n_words);          /* device buffer (ring commit protocol only) */
+    int (*recv)(void* user, int32_t src, uint32_t* d_buf, size_t n_words);                /* device buffer (ring commit protocol only) */
+    int (*allreduce_m31)(void* user, uint32_t* d_buf, size_t n_words);                    /* unused by the row-sharded prove          */
+    int (*allgather)(void* user, const void* h_send, size_t bytes, void* h_recv);         /* host: recv = world x bytes               */
+    int (*broadcast)(void* user, void* h_buf, size_t bytes, int32_t root);                /* host (unused by the row-sharded prove)   */
+    /* device all-to-all: words [send_off[r], send_off[r] + send_cnt[r]) of d_send go to rank r; what rank r sent lands at
+     * [recv_off[r], recv_off[r] + recv_cnt[r]) of d_recv (arrays of `world` entries; the own share is copied too) */
+    int (*alltoallv)(void* user, const uint32_t* d_send, const size_t* send_off, const size_t* send_cnt, uint32_t* d_recv,
+                     const size_t* recv_off, const size_t* recv_cnt);
+    /* device all-gather: d_recv = world x n_words, rank r's contribution at r * n_words */
+    int (*allgather_dev)(void* user, const uint32_t* d_send, size_t n_words, uint32_t* d_recv);
 } nx_comm;
+/* nx_prove_synth on the GPUs of `comm`. */
 int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg,
                            uint64_t seed, const uint8_t* ad, size_t ad_len, const nx_comm* comm, uint32_t** proof_words,
                            size_t* n_words, nx_prove_stats* stats);
-/* Building blocks for nx_comm.allreduce_m31 implementations: dst[i] = (dst[i] + src[i]) mod p;  widening to the 64-bit
- * lanes a sum-all-reduce needs (RCCL has no modular reduction) and the reduction back. */
+/* Modular add / widening helpers for transports that sum M31 buffers (RCCL has no modular reduction). */
 int nx_m31_add_into(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words);
 int nx_m31_widen(nx_ctx* ctx, uint64_t* d_dst, const uint32_t* d_src, size_t n_words);
 int nx_m31_narrow(nx_ctx* ctx, uint32_t* d_dst, const uint64_t* d_src, size_t n_words);
@@ -327,6 +350,9 @@ void nx_air_kernel_destroy(nx_air_kernel* kernel);
 typedef struct nx_prover nx_prover;
 int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_size, nx_prover** out);
 void nx_prover_destroy(nx_prover* prover);
+/* One proof on several GPUs: every GPU runs the same session calls with its own communicator (see nx_comm); nx_prover_tree_begin
+ * then hands each GPU only ITS columns (NULL for the others).  Call right after nx_prover_create. */
+int nx_prover_set_comm(nx_prover* prover, const nx_comm* comm);
 /* Blake2sChannel of the session */
 int nx_prover_mix_u64(nx_prover* prover, uint64_t v);
 int nx_prover_mix_felts(nx_prover* prover, const uint32_t* felts, uint32_t n_felts); /* 4 words per QM31 */

@@ -42,18 +42,23 @@ _RECV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t)
 _ALLREDUCE_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 _ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _BROADCAST_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32)
+_ALLTOALLV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
+_ALLGATHER_DEV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 class NxComm(C.Structure):
-    """nx_comm of include/nexus_hip.h: the transport callbacks of a column-sharded prove."""
+    """nx_comm of include/nexus_hip.h: the transport callbacks of one proof on several GPUs."""
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("send", _SEND_T), ("recv", _RECV_T),
-                ("allreduce_m31", _ALLREDUCE_T), ("allgather", _ALLGATHER_T), ("broadcast", _BROADCAST_T)]
+                ("allreduce_m31", _ALLREDUCE_T), ("allgather", _ALLGATHER_T), ("broadcast", _BROADCAST_T),
+                ("alltoallv", _ALLTOALLV_T), ("allgather_dev", _ALLGATHER_DEV_T)]
 
 
 def make_comm(rank, world, impl):
     """Wrap a Python object with send(dst, ptr, n_words) / recv(src, ptr, n_words) / allreduce_m31(ptr, n_words) /
-    allgather(bytes) -> list of bytes / broadcast(bytes_or_None, n, root) -> bytes into an NxComm.  Exceptions become a
-    non-zero return code (the library then fails the prove with NX_ERR_HIP)."""
+    allgather(bytes) -> list of bytes / broadcast(bytes_or_None, n, root) -> bytes /
+    alltoallv(send_ptr, send_off, send_cnt, recv_ptr, recv_off, recv_cnt) (lists of `world` word counts) /
+    allgather_dev(send_ptr, n_words, recv_ptr) into an NxComm.  Exceptions become a non-zero return code (the library then fails
+    the prove with NX_ERR_HIP)."""
     def guard(f):
         def g(*a):
             try:
@@ -73,8 +78,12 @@ def make_comm(rank, world, impl):
         data = impl.broadcast(C.string_at(h_buf, nbytes) if rank == root else None, nbytes, root)
         C.memmove(h_buf, data, nbytes)
 
+    def _alltoallv(_u, sp, soff, scnt, rp, roff, rcnt):
+        impl.alltoallv(sp, [soff[i] for i in range(world)], [scnt[i] for i in range(world)], rp, [roff[i] for i in range(world)], [rcnt[i] for i in range(world)])
+
     c = NxComm(rank, world, None, _SEND_T(guard(lambda _u, dst, p, n: impl.send(dst, p, n))), _RECV_T(guard(lambda _u, src, p, n: impl.recv(src, p, n))),
-               _ALLREDUCE_T(guard(lambda _u, p, n: impl.allreduce_m31(p, n))), _ALLGATHER_T(guard(_allgather)), _BROADCAST_T(guard(_broadcast)))
+               _ALLREDUCE_T(guard(lambda _u, p, n: impl.allreduce_m31(p, n))), _ALLGATHER_T(guard(_allgather)), _BROADCAST_T(guard(_broadcast)),
+               _ALLTOALLV_T(guard(_alltoallv)), _ALLGATHER_DEV_T(guard(lambda _u, sp, n, rp: impl.allgather_dev(sp, n, rp))))
     c._impl = impl   # keep the callbacks' target alive
     return c
 
@@ -144,6 +153,12 @@ class ProverSession:
         self.h = C.c_void_p()
         be._chk(be.L.nx_prover_create(be.ctx, C.byref(cfg), max_log_size, C.byref(self.h)))
 
+    def set_comm(self, comm):
+        """ONE proof on several GPUs: every rank runs the same session calls; tree_begin then returns None for the columns of
+        other ranks (nx_prover_set_comm).  Call before the first tree."""
+        self._comm = comm
+        self.be._chk(self.be.L.nx_prover_set_comm(self.h, C.byref(comm)))
+
     def mix_u64(self, v):
         self.be._chk(self.be.L.nx_prover_mix_u64(self.h, C.c_uint64(int(v))))
 
@@ -183,7 +198,8 @@ class ProverSession:
         cols = [_u32(c) for c in cols]
         ptrs = self.tree_begin([int(np.log2(len(c))) for c in cols])
         for c, d in zip(cols, ptrs):
-            self.be._chk(self.be.L.nx_upload(self.be.ctx, C.c_void_p(d), c.ctypes.data_as(C.c_void_p), C.c_size_t(len(c))))
+            if d:        # row-sharded prove: only this rank's columns are handed out
+                self.be._chk(self.be.L.nx_upload(self.be.ctx, C.c_void_p(d), c.ctypes.data_as(C.c_void_p), C.c_size_t(len(c))))
         return self.tree_commit()
 
     def prove(self, components, kernels=None, want_stats=False):
@@ -231,7 +247,7 @@ class LogupFrac(C.Structure):
 class ProveStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")] + \
                [("lde_kernel_ms", C.c_double), ("lde_algorithmic_bytes", C.c_uint64), ("merkle_kernel_ms", C.c_double),
-                ("merkle_algorithmic_bytes", C.c_uint64)]
+                ("merkle_algorithmic_bytes", C.c_uint64), ("interaction", C.c_double), ("comm_ms", C.c_double), ("comm_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -713,6 +729,19 @@ class HipBackend:
         adb = (C.c_uint8 * max(1, len(ad)))(*ad)
         self._chk(self.L.nx_prove_synth(self.ctx, self._comps(comps), len(comps), C.byref(cfg), C.c_uint64(seed), adb, C.c_size_t(len(ad)),
                                         C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
+        out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
+        self.L.nx_free_host(words)
+        return (out, stats.as_dict()) if want_stats else out
+
+    def prove_machine(self, comps, cfg=None, seed=1, ad=b"", want_stats=False, comm=None):
+        """nexus_vm_prover::prove analogue with a REAL logup interaction trace and a recorded AIR (nx_prove_machine); comps:
+        (log_size, n_pre, n_main, 4 x logup columns).  comm: an NxComm for ONE proof on several GPUs (every rank calls this)."""
+        cfg = cfg or default_config()
+        words, n = C.POINTER(C.c_uint32)(), C.c_size_t(0)
+        stats = ProveStats()
+        adb = (C.c_uint8 * max(1, len(ad)))(*ad)
+        self._chk(self.L.nx_prove_machine(self.ctx, self._comps(comps), len(comps), C.byref(cfg), C.c_uint64(seed), adb, C.c_size_t(len(ad)),
+                                          C.byref(comm) if comm is not None else None, C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
         out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
         self.L.nx_free_host(words)
         return (out, stats.as_dict()) if want_stats else out

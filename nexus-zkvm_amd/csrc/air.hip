@@ -21,14 +21,17 @@ __device__ __forceinline__ u32 synth_rand(u64 seed, u32 tree, u32 comp, u32 col,
     return v == P ? 0 : v;
 }
 
-// One lane per output position i (bit-reversed circle-domain order) -> natural row -> all columns
-// of the requested tree of one component.  Writes are coalesced per column.
-// `col_begin`: index (within the component's tree) of the first column of `cols` — a column shard starts at a multiple of
-// SYNTH_GROUP, where the two free columns of the group restart the (a, b) recurrence, so shards fill independently.
-__global__ __launch_bounds__(256) void synth_fill_kernel(ColSet cols, u32 log, u32 col_begin, u32 n_cols, u32 tree, u32 comp, u64 seed, u64 inter_seed) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+// One lane per output position i (bit-reversed circle-domain order) -> natural row -> the requested columns of one tree of one
+// component.  Writes are coalesced per column.
+// `col_begin`: index (within the component's tree) of the first column of `cols`.  The two free columns of every SYNTH_GROUP restart
+// the (a, b) recurrence, so a column range starting inside a group replays the group from its start (at most 15 columns) without
+// storing — any contiguous column range (a GPU's shard) and any position range [pos_begin, pos_begin + n_pos) (a GPU's row block;
+// cols then hold n_pos words each) fill independently.
+__global__ __launch_bounds__(256) void synth_fill_kernel(ColSet cols, u32 log, u32 col_begin, u32 n_cols, u32 tree, u32 comp, u64 seed, u64 inter_seed, u32 pos_begin, u32 n_pos) {
+    const u32 li = blockIdx.x * blockDim.x + threadIdx.x;
     u32 N = 1u << log;
-    if (i >= N) return;
+    if (li >= n_pos) return;
+    const u32 i = pos_begin + li;
     u32 d = bitrev(i, log);
     u32 row = d < N / 2 ? 2 * d : 2 * N - 1 - 2 * d;
     if (tree == 0) {
@@ -38,33 +41,27 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(ColSet cols, u32 log, u
             if (g == 0) v = row == 0;
             else if (g == 1) v = row == N - 1;
             else v = m_reduce64((u64)row * (u64)(g + 1) + 7ull * g);
-            cols.col(k)[i] = v;
+            cols.col(k)[li] = v;
         }
-    } else if (tree == 1) {
-        u32 a = 0, b = 0, k = 0;
-        if (col_begin == 0) {
-            u32 s0 = synth_rand(seed, 1, comp, 0, 0xFFFFFFFFu), s1 = synth_rand(seed, 1, comp, 1, 0xFFFFFFFFu);
-            a = m_add(s0, row);
-            u32 tri = (u32)((((u64)row * (u64)(row ? row - 1 : 0)) / 2) % P);
-            b = m_add(m_add(s1, m_mul(row, s0)), tri);
-            cols.col(0)[i] = a;
-            if (n_cols > 1) cols.col(1)[i] = b;
-            k = 2;
+        return;
+    }
+    const u32 g0 = col_begin - (col_begin % SYNTH_GROUP), g1 = col_begin + n_cols;
+    u32 a = 0, b = 0;
+    for (u32 g = g0; g < g1; g++) {
+        u32 v;
+        if (tree == 1 && g < 2) {
+            const u32 s0 = synth_rand(seed, 1, comp, 0, 0xFFFFFFFFu);
+            if (g == 0) v = m_add(s0, row);
+            else {
+                const u32 s1 = synth_rand(seed, 1, comp, 1, 0xFFFFFFFFu);
+                const u32 tri = (u32)((((u64)row * (u64)(row ? row - 1 : 0)) / 2) % P);
+                v = m_add(m_add(s1, m_mul(row, s0)), tri);
+            }
+        } else {
+            v = (g % SYNTH_GROUP) < 2 ? synth_rand(tree == 1 ? seed : inter_seed, tree, comp, g, row) : m_add(m_sqr(b), m_sqr(a));
         }
-        for (; k < n_cols; k++) {
-            const u32 g = col_begin + k;
-            u32 v = (g % SYNTH_GROUP) < 2 ? synth_rand(seed, 1, comp, g, row) : m_add(m_sqr(b), m_sqr(a));
-            cols.col(k)[i] = v;
-            a = b; b = v;
-        }
-    } else {
-        u32 a = 0, b = 0;
-        for (u32 k = 0; k < n_cols; k++) {
-            const u32 g = col_begin + k;
-            u32 v = (g % SYNTH_GROUP) < 2 ? synth_rand(inter_seed, 2, comp, g, row) : m_add(m_sqr(b), m_sqr(a));
-            cols.col(k)[i] = v;
-            a = b; b = v;
-        }
+        if (g >= col_begin) cols.col(g - col_begin)[li] = v;
+        a = b; b = v;
     }
 }
 
@@ -79,11 +76,12 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(ColSet cols, u32 log, u
 // preprocessed column 1 and therefore the two transition constraints.
 struct SynthShard { u32 main_begin, n_main, inter_begin, n_inter, j_main, j_inter, head; };
 
+// Rows [row_begin, row_end) of the evaluation domain (a GPU's row block; pointers biased by the caller so the GLOBAL row indexes them).
 __global__ __launch_bounds__(256) void synth_constraints_kernel(ColSet pre, ColSet mainc, ColSet inter, SynthShard sh, int log_size, int e,
                                                                 const u32* __restrict__ pw /*QM31 per constraint*/,
-                                                                const u32* __restrict__ denom_inv, u32* a0, u32* a1, u32* a2, u32* a3) {
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= (1u << e)) return;
+                                                                const u32* __restrict__ denom_inv, u32* a0, u32* a1, u32* a2, u32* a3, u32 row_begin, u32 row_end) {
+    u32 r = row_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= row_end) return;
     u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // lazy 64-bit accumulation, folded at least every 4 constraints
     u32 j = 0;
 #define ACC(val)                                                           \
@@ -169,8 +167,8 @@ __global__ void secure_accumulate_kernel(u32* d0, u32* d1, u32* d2, u32* d3, con
 }
 
 int synth_constraints(nx_ctx* ctx, ColSet pre, ColSet mainc, ColSet inter, const SynthRange& rg, int log_size, int e, const u32* d_pw,
-                      const u32* d_denom_inv, u32* const acc4[4]) {
-    u32 n = 1u << e;
+                      const u32* d_denom_inv, u32* const acc4[4], u32 row_begin, u32 n) {
+    if (!n) return NX_OK;
     SynthShard sh;
     sh.main_begin = rg.main_begin; sh.n_main = rg.n_main; sh.inter_begin = rg.inter_begin; sh.n_inter = rg.n_inter;
     sh.head = rg.main_begin == 0 && rg.n_main >= 2 && rg.has_pre1;
@@ -179,7 +177,7 @@ int synth_constraints(nx_ctx* ctx, ColSet pre, ColSet mainc, ColSet inter, const
     sh.j_main = 2 + count_free(2, std::max<u32>(2, rg.main_begin));
     sh.j_inter = 2 + count_free(2, rg.n_main_total) + count_free(0, rg.inter_begin);
     hipLaunchKernelGGL(synth_constraints_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, pre, mainc, inter, sh, log_size, e,
-                       d_pw, d_denom_inv, acc4[0], acc4[1], acc4[2], acc4[3]);
+                       d_pw, d_denom_inv, acc4[0], acc4[1], acc4[2], acc4[3], row_begin, row_begin + n);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
@@ -192,13 +190,12 @@ int secure_accumulate(nx_ctx* ctx, u32* const dst4[4], const u32* const src4[4],
 }
 
 int synth_fill_range(nx_ctx* ctx, const nx_component_spec& c, uint32_t ci, uint32_t tree, uint64_t seed, uint64_t inter_seed, uint32_t col_begin,
-                     uint32_t n_cols, uint32_t* const* d_cols) {
+                     uint32_t n_cols, uint32_t* const* d_cols, uint32_t pos_begin, uint32_t n_pos) {
     if (c.n_pre < 2 || c.n_main < 2 || c.log_size < 1 || c.log_size > 28) return set_err(ctx, NX_ERR_ARG, "synthetic component needs n_pre >= 2, n_main >= 2, 1 <= log_size <= 28");
-    if (n_cols == 0) return NX_OK;
-    if (col_begin % SYNTH_GROUP) return set_err(ctx, NX_ERR_ARG, "synthetic fill: a column range must start at a multiple of 16");
+    if (n_cols == 0 || n_pos == 0) return NX_OK;
+    if ((uint64_t)pos_begin + n_pos > ((uint64_t)1 << c.log_size)) return set_err(ctx, NX_ERR_ARG, "synthetic fill: position range outside the column");
     ColSet cs; NX_TRY(make_colset(ctx, d_cols, n_cols, &cs));
-    uint32_t N = 1u << c.log_size;
-    hipLaunchKernelGGL(synth_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, cs, c.log_size, col_begin, n_cols, tree, ci, seed, inter_seed);
+    hipLaunchKernelGGL(synth_fill_kernel, dim3((n_pos + 255) / 256), dim3(256), 0, ctx->stream, cs, c.log_size, col_begin, n_cols, tree, ci, seed, inter_seed, pos_begin, n_pos);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
@@ -216,7 +213,7 @@ extern "C" int nx_synth_fill_tree(nx_ctx* ctx, const nx_component_spec* comps, u
         const nx_component_spec& c = comps[ci];
         uint32_t n = tree == 0 ? c.n_pre : tree == 1 ? c.n_main : c.n_inter;
         if (c.n_pre < 2 || c.n_main < 2 || c.log_size < 1 || c.log_size > 28) return set_err(ctx, NX_ERR_ARG, "synthetic component needs n_pre >= 2, n_main >= 2, 1 <= log_size <= 28");
-        NX_TRY(synth_fill_range(ctx, c, ci, tree, seed, inter_seed, 0, n, d_cols + first));
+        NX_TRY(synth_fill_range(ctx, c, ci, tree, seed, inter_seed, 0, n, d_cols + first, 0, 1u << c.log_size));
         first += n;
     }
     return NX_OK;

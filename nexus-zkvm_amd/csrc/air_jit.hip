@@ -65,8 +65,8 @@ FI u32 row_offset(u32 r, int log_size, int e, int offset) {
 static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs) {
     std::string s = AIR_PRELUDE;
     s += "extern \"C\" __attribute__((global)) __attribute__((amdgpu_flat_work_group_size(256, 256))) void air_kernel(const u32* const* __restrict__ cols, const u32* __restrict__ econst, const u32* __restrict__ pw,\n"
-         "    const u32* __restrict__ denom_inv, int log_size, int e, u32* a0, u32* a1, u32* a2, u32* a3) {\n"
-         "  const u32 r = __builtin_amdgcn_workgroup_id_x() * 256 + __builtin_amdgcn_workitem_id_x();\n  if (r >= (1u << e)) return;\n"
+         "    const u32* __restrict__ denom_inv, int log_size, int e, u32* a0, u32* a1, u32* a2, u32* a3, u32 row_begin, u32 row_end) {\n"
+         "  const u32 r = row_begin + __builtin_amdgcn_workgroup_id_x() * 256 + __builtin_amdgcn_workitem_id_x();\n  if (r >= row_end) return;\n"
          "  u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;\n";
     // which row offsets occur
     std::vector<int> offs;
@@ -215,11 +215,18 @@ void nx_air_kernel_destroy(nx_air_kernel* k) {
     delete k;
 }
 
-int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_cols, const uint32_t* econsts, const uint32_t* alpha_powers, const uint32_t* denom_inv,
-                uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4) {
-    NX_GUARD(ctx);
+}  // extern "C"
+
+namespace nx {
+// Rows [row_begin, row_begin + n_rows) of the evaluation domain.  The generated kernel indexes columns and accumulators with the
+// GLOBAL row: in a row-sharded prove the caller passes block pointers moved back by the block's first row (bias_rows) — columns read
+// at a non-zero mask offset must be whole (their neighbour rows live in other blocks).
+int air_eval_rows(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_cols, const uint32_t* econsts, const uint32_t* alpha_powers, const uint32_t* denom_inv,
+                  uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4, uint32_t row_begin, uint32_t n_rows) {
     if (!ctx || !k || !d_acc4 || (k->n_cols && !d_cols)) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: NULL argument");
     if (log_size < 1 || log_eval <= log_size || log_eval > 30) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: need 1 <= log_size < log_eval <= 30");
+    if ((uint64_t)row_begin + n_rows > ((uint64_t)1 << log_eval)) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: row block outside the evaluation domain");
+    if (!n_rows) return NX_OK;
     const size_t b_cols = (size_t)k->n_cols * 8, b_ec = (size_t)k->n_econsts * 16, b_pw = (size_t)k->n_constraints * 16, b_den = (size_t)4 << (log_eval - log_size);
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_ec = al(b_cols), o_pw = o_ec + al(b_ec), o_den = o_pw + al(b_pw), total = o_den + al(b_den) + 16;
@@ -236,11 +243,21 @@ int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_co
     const void* p_cols = blob; const void* p_ec = blob + o_ec; const void* p_pw = blob + o_pw; const void* p_den = blob + o_den;
     int ls = (int)log_size, le = (int)log_eval;
     uint32_t* a0 = d_acc4[0]; uint32_t* a1 = d_acc4[1]; uint32_t* a2 = d_acc4[2]; uint32_t* a3 = d_acc4[3];
-    void* args[] = {&p_cols, &p_ec, &p_pw, &p_den, &ls, &le, &a0, &a1, &a2, &a3};
-    const uint32_t n = 1u << log_eval;
-    hipError_t er = hipModuleLaunchKernel(k->fn, (n + 255) / 256, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+    uint32_t rb = row_begin, re = row_begin + n_rows;
+    void* args[] = {&p_cols, &p_ec, &p_pw, &p_den, &ls, &le, &a0, &a1, &a2, &a3, &rb, &re};
+    hipError_t er = hipModuleLaunchKernel(k->fn, (n_rows + 255) / 256, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
     if (er != hipSuccess) return hip_fail(ctx, er, "nx_air_eval", __FILE__, __LINE__);
     return NX_OK;
+}
+}  // namespace nx
+
+extern "C" {
+
+int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_cols, const uint32_t* econsts, const uint32_t* alpha_powers, const uint32_t* denom_inv,
+                uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4) {
+    NX_GUARD(ctx);
+    if (log_eval > 30) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: need 1 <= log_size < log_eval <= 30");
+    return air_eval_rows(ctx, k, d_cols, econsts, alpha_powers, denom_inv, log_size, log_eval, d_acc4, 0, 1u << log_eval);
 }
 
 }  // extern "C"

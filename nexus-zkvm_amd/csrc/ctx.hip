@@ -169,7 +169,30 @@ __global__ __launch_bounds__(256) void m31_narrow_kernel(u32* __restrict__ dst, 
 
 __global__ void gather_kernel(const uint32_t* const* ptrs, const uint64_t* index, size_t n, uint32_t* out) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) out[i] = ptrs[i][index[i]];
+    if (i < n) out[i] = ptrs[i] ? ptrs[i][index[i]] : 0u;   // NULL: a word another GPU of a row-sharded prove supplies
+}
+
+// Column shard <-> row block transposition around an all-to-all.  `full` holds n_cols columns of `rows` words (column stride col_stride);
+// `blocks` is [world][n_cols][rows / world]: block d = rows [d * rows/world, (d+1) * rows/world) of every column, i.e. what GPU d
+// receives (pack) or what came from GPU d (unpack).  16 bytes per lane; rows / world is a multiple of 4.
+__global__ __launch_bounds__(256) void transpose_blocks_kernel(uint32_t* full, uint64_t col_stride, uint32_t* blocks, uint32_t n_cols, uint64_t rows, uint32_t world, int unpack) {
+    const uint64_t rb4 = rows / world / 4, total = (uint64_t)n_cols * world * rb4;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t x = i % rb4, cd = i / rb4;
+        const uint32_t c = (uint32_t)(cd % n_cols), d = (uint32_t)(cd / n_cols);
+        uint4* f = reinterpret_cast<uint4*>(full + (uint64_t)c * col_stride) + (uint64_t)d * rb4 + x;
+        uint4* b = reinterpret_cast<uint4*>(blocks) + ((uint64_t)d * n_cols + c) * rb4 + x;
+        if (unpack) *f = *b; else *b = *f;
+    }
+}
+int transpose_blocks(nx_ctx* ctx, uint32_t* full, uint64_t col_stride, uint32_t* blocks, uint32_t n_cols, uint64_t rows, uint32_t world, bool unpack) {
+    if (!n_cols || !rows) return NX_OK;
+    if ((rows / world) % 4 || rows % world || col_stride % 4) return set_err(ctx, NX_ERR_ARG, "transpose_blocks: the row block must be a multiple of 4 words");
+    const uint64_t total = (uint64_t)n_cols * rows / 4;
+    hipLaunchKernelGGL(transpose_blocks_kernel, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, (uint64_t)ctx->n_cus * 32)), dim3(256), 0, ctx->stream, full, col_stride, blocks, n_cols,
+                       rows, world, unpack ? 1 : 0);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
 }
 
 }  // namespace nx
@@ -218,6 +241,7 @@ void nx_ctx_destroy(nx_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    nxhip::machine_kernels_release(ctx);
     timing_flush(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     dev_cache_release(ctx);

@@ -59,6 +59,8 @@ struct nx_tree {
     std::vector<uint32_t*> layers;  // layers[k]: 2^k nodes x 8 words, device
 };
 
+namespace nxhip { void machine_kernels_release(nx_ctx* ctx); }   // machine.hip: compiled AIR kernels cached per context
+
 namespace nx {
 
 extern thread_local std::string g_last_error;
@@ -115,6 +117,10 @@ __device__ __forceinline__ void gst(uint32_t* p, uint32_t v) { *(NX_GLOBAL_AS ui
 __device__ __forceinline__ void gst4(uint32_t* p, uint4 v) { nx_v4u32 w = {v.x, v.y, v.z, v.w}; *(NX_GLOBAL_AS nx_v4u32*)p = w; }
 #endif
 
+// Row-sharded proves (one contiguous block of the bit-reversed rows per GPU): kernels index every column with the GLOBAL row, the
+// host hands them the block pointer moved back by the block's first row.  Only addresses p[row_begin ...] are ever dereferenced.
+template <class T> static inline T* bias_rows(T* p, uint64_t row_begin) { return p ? (T*)((uintptr_t)p - row_begin * sizeof(T)) : p; }
+
 // Builds a ColSet from a host array of device pointers: constant stride is detected, otherwise the
 // table is staged into the context's device scratch ring (stream-ordered).
 int make_colset(nx_ctx* ctx, const uint32_t* const* h_ptrs, uint32_t n, ColSet* out);
@@ -132,6 +138,8 @@ int eval_at_points_collect(nx_ctx* ctx, std::vector<EvalJob>* jobs);
 int dev_alloc(nx_ctx* ctx, size_t bytes, void** out);
 void dev_free(nx_ctx* ctx, void* p);
 void dev_cache_release(nx_ctx* ctx);
+
+int transpose_blocks(nx_ctx* ctx, uint32_t* full, uint64_t col_stride, uint32_t* blocks, uint32_t n_cols, uint64_t rows, uint32_t world, bool unpack);
 
 // Event-pair span on ctx->stream, recorded only when ctx->timing is on; resolved by timing_flush.
 struct KTimer {
@@ -159,6 +167,11 @@ int fri_channel_step(nx_ctx* ctx, uint32_t* d_state, const uint32_t* d_root, int
 int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* evals, uint32_t* const* trees, int n_layers, int log0, uint32_t* d_state, int j0);
 int fold_circle_dev(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha);
 int fold_line_dev(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha, uint32_t* const* d_dst4);
+int fold_circle_rows(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t alpha[4], uint32_t i0, uint32_t n);
+int fold_line_rows(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t alpha[4], uint32_t* const* d_dst4, uint32_t i0, uint32_t n);
+int accumulate_quotients_rows(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4], uint32_t n_batches,
+                              const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx, const uint32_t* values, uint32_t* const* d_out4,
+                              uint64_t row_begin, uint64_t n_rows);
 
 struct TreePipe {
     nx_tree* tree = nullptr;

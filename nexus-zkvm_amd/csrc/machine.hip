@@ -1,0 +1,501 @@
+// The synthetic machines the bench and the parity suite prove: callers of the commitment scheme / prover of prover.h that play the
+// role of `Machine::prove_with_extensions` (reference prover/src/machine.rs:130-297) for a synthetic wide-Fibonacci-style trace
+// (SURVEY.md §8(d)): channel seeding (:197-206), preprocessed / main / interaction tree commits (:208-263), stwo::prover::prove
+// (:286-290).
+//   nx_prove_synth    the three trace trees are filled by a generator, the constraints are a hand-written kernel (air.hip)
+//   nx_prove_machine  the reference's shape end to end: lookup elements drawn after the main commit (:239-240), the interaction trace
+//                     is a REAL logup trace generated on the device from main-trace columns (LogupTraceGenerator: one fraction per
+//                     column, finalize_col, finalize_last — reference traits.rs:124-145, chips/range_check/range256.rs:271-288),
+//                     the claimed sums are mixed (:262), and the AIR — transition + degree-2 + logup constraints — is a RECORDED
+//                     program compiled by nx_air_compile, i.e. the path a Rust shim takes for the reference's own AIR
+// Both run on one GPU or as ONE proof on the GPUs of an nx_comm (row-sharded, prover.h).
+#include "prover.h"
+#include <mutex>
+
+namespace nxhip {
+
+struct Loc { size_t pre0, main0, inter0; };
+
+static std::vector<Loc> locations(const nx_component_spec* comps, uint32_t n_comps, uint32_t* max_log) {
+    std::vector<Loc> locs; size_t a = 0, b = 0, c = 0; *max_log = 0;
+    for (uint32_t i = 0; i < n_comps; i++) { locs.push_back({a, b, c}); a += comps[i].n_pre; b += comps[i].n_main; c += comps[i].n_inter; *max_log = std::max(*max_log, comps[i].log_size); }
+    return locs;
+}
+
+// ---------------------------------------------------------------- nx_prove_synth: hand-written constraint kernel ----------
+// eval_composition_polynomial_at_point (the prover's OODS sanity check, stwo prover/mod.rs::prove)
+static QM31 synth_eval_composition_at_point(const nx_component_spec* comps, uint32_t n_comps, const std::vector<Loc>& locs, QPt point,
+                                            const SampledValues& sv, QM31 random_coeff) {
+    QM31 acc = q_zero();
+    for (uint32_t ci = 0; ci < n_comps; ci++) {
+        const nx_component_spec& c = comps[ci];
+        QM31 di = q_inv(coset_vanishing_q(c.log_size, point));
+        auto add = [&](QM31 v) { acc = q_add(q_mul(acc, random_coeff), q_mul(di, v)); };
+        auto M = [&](uint32_t k, int s = 0) { return sv[1][locs[ci].main0 + k][s]; };
+        auto I = [&](uint32_t k) { return sv[2][locs[ci].inter0 + k][0]; };
+        QM31 not_last = q_sub(q_one(), sv[0][locs[ci].pre0 + 1][0]);
+        add(q_mul(q_sub(q_sub(M(0, 1), M(0)), q_one()), not_last));
+        add(q_mul(q_sub(q_sub(M(1, 1), M(1)), M(0)), not_last));
+        for (uint32_t k = 2; k < c.n_main; k++) if (!synth_col_is_free(k)) add(q_sub(q_sub(M(k), q_sqr(M(k - 1))), q_sqr(M(k - 2))));
+        for (uint32_t k = 0; k < c.n_inter; k++) if (!synth_col_is_free(k)) add(q_sub(q_sub(I(k), q_sqr(I(k - 1))), q_sqr(I(k - 2))));
+    }
+    return acc;
+}
+
+struct SynthAir : AirProver {
+    const nx_component_spec* comps; uint32_t n_comps; const std::vector<Loc>& locs;
+    SynthAir(const nx_component_spec* c, uint32_t n, const std::vector<Loc>& l) : comps(c), n_comps(n), locs(l) {}
+
+    // ComponentProvers::compute_composition_polynomial for the synthetic machine
+    int compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) override {
+        nx_ctx* ctx = cs.ctx;
+        const uint32_t lcd = cs.cfg.log_constraint_degree;
+        size_t total = 0;
+        for (uint32_t i = 0; i < n_comps; i++) total += synth_n_constraints(comps[i]);
+        std::vector<QM31> powers(total);
+        { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
+        std::map<uint32_t, SecureColumn> sub;  // evaluation-domain log size -> accumulation
+        // alpha powers and vanishing denominators of ALL components in one owned upload (a prover2-style statement has dozens of components)
+        std::vector<uint32_t> params; std::vector<size_t> off_pw(n_comps), off_den(n_comps);
+        {
+            size_t remaining = total;
+            std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> den_cache;
+            for (uint32_t ci = 0; ci < n_comps; ci++) {
+                const nx_component_spec& c = comps[ci];
+                const uint32_t e = c.log_size + lcd;
+                const size_t nc = synth_n_constraints(c);
+                off_pw[ci] = params.size();
+                params.resize(params.size() + 4 * nc);   // this component takes the LAST nc remaining powers, reversed
+                for (size_t j = 0; j < nc; j++) q_store(&params[off_pw[ci] + 4 * j], powers[remaining - 1 - j]);
+                remaining -= nc;
+                auto key = std::make_pair(c.log_size, e);
+                if (!den_cache.count(key)) den_cache[key] = vanishing_denominators(c.log_size, e);
+                const auto& den = den_cache[key];
+                off_den[ci] = params.size();
+                params.insert(params.end(), den.begin(), den.end());
+                while (params.size() % 4) params.push_back(0);
+            }
+        }
+        DevBuf d_params;   // owned: read by every component's kernel while later components stage their own descriptors
+        H_TRY(upload_owned(ctx, params.data(), params.size(), &d_params));
+        for (uint32_t ci = 0; ci < n_comps; ci++) {
+            const nx_component_spec& c = comps[ci];
+            const uint32_t e = c.log_size + lcd;
+            std::vector<std::pair<uint32_t, uint32_t>> cc;
+            for (uint32_t k = 0; k < c.n_pre; k++) cc.push_back({0u, (uint32_t)locs[ci].pre0 + k});
+            for (uint32_t k = 0; k < c.n_main; k++) cc.push_back({1u, (uint32_t)locs[ci].main0 + k});
+            for (uint32_t k = 0; k < c.n_inter; k++) cc.push_back({2u, (uint32_t)locs[ci].inter0 + k});
+            std::vector<char> masked(cc.size(), 0);
+            masked[c.n_pre] = masked[c.n_pre + 1] = 1;                 // main columns 0 and 1 are read at the next row
+            EvalDomainCols cols;
+            H_TRY(columns_on_eval_domain(cs, cc, c.log_size, e, masked, &cols));
+            ColSet pre, mainc, inter;
+            H_TRY(make_colset(ctx, cols.ptrs.data(), c.n_pre, &pre));
+            H_TRY(make_colset(ctx, cols.ptrs.data() + c.n_pre, c.n_main, &mainc));
+            H_TRY(make_colset(ctx, cols.ptrs.data() + c.n_pre + c.n_main, c.n_inter, &inter));
+            SecureColumn* acc = nullptr;
+            H_TRY(composition_accumulator(cs, sub, e, &acc));
+            const uint64_t rb = cs.dist.on() ? cs.dist.begin(e) : 0;
+            u32* a4[4]; for (int k = 0; k < 4; k++) a4[k] = bias_rows(acc->c[k], rb);
+            SynthRange rg{0, c.n_main, c.n_main, 0, c.n_inter, true};
+            H_TRY(synth_constraints(ctx, pre, mainc, inter, rg, (int)c.log_size, (int)e, d_params.p + off_pw[ci], d_params.p + off_den[ci], a4, (u32)rb, (u32)acc->rows));
+        }
+        return finalize_accumulation(cs, sub, out_polys, out_log);
+    }
+    void mask_points(QPt oods, MaskPoints* points) override {
+        points->assign(3, {});
+        for (uint32_t i = 0; i < n_comps; i++) {
+            QPt step; { Pt s = pt_from_index(1u << (31 - comps[i].log_size)); step.x = q_from_m(s.x); step.y = q_from_m(s.y); }
+            for (uint32_t k = 0; k < comps[i].n_pre; k++) (*points)[0].push_back({oods});
+            for (uint32_t k = 0; k < comps[i].n_main; k++) { if (k < 2) (*points)[1].push_back({oods, qpt_add(oods, step)}); else (*points)[1].push_back({oods}); }
+            for (uint32_t k = 0; k < comps[i].n_inter; k++) (*points)[2].push_back({oods});
+        }
+    }
+    QM31 eval_composition_at_point(QPt point, const SampledValues& sv, QM31 rc) override { return synth_eval_composition_at_point(comps, n_comps, locs, point, sv, rc); }
+};
+
+static int check_components(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg) {
+    if (n_comps == 0) return set_err(ctx, NX_ERR_ARG, "prove: no components");
+    if (ucfg->log_blowup < 1 || ucfg->log_constraint_degree < 1 || ucfg->log_constraint_degree > 2) return set_err(ctx, NX_ERR_ARG, "prove: log_blowup >= 1 and log_constraint_degree in {1,2} required");
+    for (uint32_t i = 0; i < n_comps; i++)
+        if (comps[i].n_pre < 2 || comps[i].n_main < 2 || comps[i].log_size < 1 || comps[i].log_size > 28) return set_err(ctx, NX_ERR_ARG, "synthetic component needs n_pre >= 2, n_main >= 2, 1 <= log_size <= 28");
+    return NX_OK;
+}
+
+// one synthetic tree: every GPU fills and hands over its share of each component's columns (all of them on one GPU)
+static int fill_and_extend(CommitmentSchemeProver& cs, TreeBuilder& tb, const nx_component_spec* comps, uint32_t n_comps, uint32_t tree, uint64_t seed, uint64_t inter_seed) {
+    nx_ctx* ctx = cs.ctx;
+    std::vector<std::pair<uint32_t, uint32_t>> groups, local;
+    for (uint32_t i = 0; i < n_comps; i++) groups.push_back({tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter, comps[i].log_size});
+    plan_local_columns(groups, cs.dist, &local);
+    for (uint32_t i = 0; i < n_comps; i++) {
+        const uint32_t lo = local[i].first, hi = local[i].second, log = comps[i].log_size;
+        DevBuf slab;
+        if (hi > lo) {
+            H_TRY(slab.alloc(ctx, (size_t)(hi - lo) << log));
+            auto p = col_ptrs(slab.p, hi - lo, log);
+            H_TRY(synth_fill_range(ctx, comps[i], i, tree, seed, inter_seed, lo, hi - lo, p.data(), 0, 1u << log));
+        }
+        tb.extend_evals_local(std::move(slab), groups[i].first, log, lo, hi);
+    }
+    return NX_OK;
+}
+
+static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
+                       size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st) {
+    PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
+    H_TRY(check_components(ctx, comps, n_comps, ucfg));
+    H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
+    uint32_t max_log = 0;
+    std::vector<Loc> locs = locations(comps, n_comps, &max_log);
+    const bool timed = st != nullptr;
+    nx_prove_stats local_stats;
+    if (!st) st = &local_stats;
+    memset(st, 0, sizeof *st);
+    if (timed) { ctx->timing = true; timing_reset(ctx); }
+    double t_start = 0;
+    Lap lap{ctx, timed, 0};
+    if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = now_ms(); }
+
+    // machine.rs:184-194 — twiddles for CanonicCoset(max_log + LOG_CONSTRAINT_DEGREE + log_blowup).half_coset
+    nx_twiddles* tw = nullptr;
+    H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));
+    struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
+    Blake2sChannel channel;
+    for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
+    CommitmentSchemeProver cs(ctx, tw, cfg);                                          // machine.rs:202-203
+    if (comm) { H_TRY(dist_init(ctx, comm, &cs.dist)); cs.dist.comm_ms = &st->comm_ms; cs.dist.comm_bytes = &st->comm_bytes; }
+    for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
+    lap(&st->commit);
+
+    auto fill_and_commit = [&](uint32_t tree, uint64_t inter_seed) -> int {
+        TreeBuilder tb = cs.tree_builder();
+        H_TRY(fill_and_extend(cs, tb, comps, n_comps, tree, seed, inter_seed));
+        lap(&st->trace_gen);
+        H_TRY(tb.commit(channel));
+        lap(&st->commit);
+        return NX_OK;
+    };
+    H_TRY(fill_and_commit(0, 0));                                                     // machine.rs:208-228
+    H_TRY(fill_and_commit(1, 0));                                                     // machine.rs:230-237
+    QM31 z = channel.draw_secure_felt();                                              // machine.rs:239-240 (lookup elements)
+    uint64_t inter_seed = ((u64)z.a.a << 32) ^ (u64)z.a.b ^ ((u64)z.b.a << 16) ^ ((u64)z.b.b << 48);
+    channel.mix_felts(std::vector<QM31>(n_comps, q_zero()));                          // machine.rs:262 (claimed sums)
+    H_TRY(fill_and_commit(2, inter_seed));                                            // machine.rs:249-263
+
+    SynthAir air(comps, n_comps, locs);
+    H_TRY(prove_core(ctx, cs, channel, cfg, tw, air, words, st, lap));
+    if (timed) finish_stats(ctx, st, t_start);
+    return NX_OK;
+}
+
+// ================================================================ nx_prove_machine: real logup + recorded AIR ===========
+// Component (log_size, n_pre, n_main, n_inter = 4 L): L logup columns.  Fraction j of a row:
+//   den_j = main[a_j] - z                       (j even: a one-element tuple, like the reference's check_bytes limb, range256.rs:281-284)
+//         = main[a_j] + alpha main[b_j] - z     (j odd: a two-element tuple)
+//   num_j = 1,  or  -main[m_j] when j % 3 == 2  (the table side of a lookup: a negated multiplicity column)
+//   a_j = (3 + 7 j) % n_main, b_j = (5 + 11 j) % n_main, m_j = (2 + 13 j) % n_main
+// Logup column j holds sum_{i <= j} fraction_i(row) (LogupColGenerator::finalize_col); the last one is finalised by
+// LogupTraceGenerator::finalize_last (claimed sum; prefix sum over the rows of value - claimed / N).
+// Constraints, in declaration order: the two transition constraints and the degree-2 constraints of the synthetic main trace (as
+// nx_prove_synth), then per logup column stwo-constraint-framework's finalize_logup_batched with one fraction per batch:
+//   (S_j - S_{j-1}) den_j - num_j                                             j < L - 1
+//   (S_j(row) - S_j(row - 1) - S_{j-1}(row) + claimed / N) den_j - num_j      j = L - 1 (mask [-1, 0] on the last column)
+static void logup_cols(uint32_t j, uint32_t n_main, uint32_t* a, uint32_t* b, uint32_t* m) { *a = (3 + 7 * j) % n_main; *b = (5 + 11 * j) % n_main; *m = (2 + 13 * j) % n_main; }
+
+struct ProgEmit {
+    std::vector<nx_cinstr> p;
+    void op(uint32_t o, uint32_t d, uint32_t a = 0, uint32_t b = 0) { p.push_back(nx_cinstr{o, d, a, b}); }
+};
+
+// econsts of a component: [z, alpha, claimed / N, 0]
+static GComponent machine_component(const nx_component_spec& c, const Loc& loc) {
+    GComponent g;
+    g.log_size = c.log_size;
+    const uint32_t L = c.n_inter / 4, PRE = 0, MAIN = c.n_pre, INT = c.n_pre + c.n_main;
+    for (uint32_t k = 0; k < c.n_pre; k++) { g.cols.push_back({0u, (uint32_t)loc.pre0 + k}); g.masks.push_back({0}); }
+    for (uint32_t k = 0; k < c.n_main; k++) { g.cols.push_back({1u, (uint32_t)loc.main0 + k}); g.masks.push_back(k < 2 ? std::vector<int>{0, 1} : std::vector<int>{0}); }
+    for (uint32_t k = 0; k < c.n_inter; k++) { g.cols.push_back({2u, (uint32_t)loc.inter0 + k}); g.masks.push_back(k / 4 + 1 == L ? std::vector<int>{-1, 0} : std::vector<int>{0}); }
+    // registers: B 0..7; E quads from 8: SA, SB (rolling S_{j-1} / S_j), DEN, T, Z, ALPHA, SHIFT, NEGZ, PR (previous row)
+    enum { T0 = 0, T1 = 1, T2 = 2, T3 = 3, R0 = 4 /* R0..R2: rolling main values */, ESA = 8, ESB = 12, EDEN = 16, ET = 20, EZ = 24, EAL = 28, ESH = 32, ENZ = 36, EPR = 40, NREGS = 44 };
+    g.n_regs = NREGS;
+    ProgEmit e;
+    uint32_t nc = 0;
+    // (main0' - main0 - 1)(1 - is_last), (main1' - main1 - main0)(1 - is_last)
+    e.op(NX_C_LOAD, R0 + 0, MAIN + 0, 0); e.op(NX_C_LOAD, R0 + 1, MAIN + 1, 0);
+    e.op(NX_C_CONST, T2, 1); e.op(NX_C_LOAD, T3, PRE + 1, 0); e.op(NX_C_SUB, T3, T2, T3);
+    e.op(NX_C_LOAD, T0, MAIN + 0, 1); e.op(NX_C_SUB, T0, T0, R0 + 0); e.op(NX_C_SUB, T0, T0, T2); e.op(NX_C_MUL, T0, T0, T3); e.op(NX_C_CONSTRAINT_B, 0, T0); nc++;
+    e.op(NX_C_LOAD, T0, MAIN + 1, 1); e.op(NX_C_SUB, T0, T0, R0 + 1); e.op(NX_C_SUB, T0, T0, R0 + 0); e.op(NX_C_MUL, T0, T0, T3); e.op(NX_C_CONSTRAINT_B, 0, T0); nc++;
+    for (uint32_t k = 2; k < c.n_main; k++) {
+        const uint32_t rv = R0 + k % 3, rb = R0 + (k - 1) % 3, ra = R0 + (k - 2) % 3;
+        e.op(NX_C_LOAD, rv, MAIN + k, 0);
+        if (!synth_col_is_free(k)) {
+            e.op(NX_C_MUL, T0, rb, rb); e.op(NX_C_MUL, T1, ra, ra); e.op(NX_C_SUB, T2, rv, T0); e.op(NX_C_SUB, T2, T2, T1); e.op(NX_C_CONSTRAINT_B, 0, T2); nc++;
+        }
+    }
+    if (L) {
+        e.op(NX_C_CONSTE, EZ, 0); e.op(NX_C_CONSTE, EAL, 1); e.op(NX_C_CONSTE, ESH, 2); e.op(NX_C_CONSTE, ENZ, 3); e.op(NX_C_SUBE, ENZ, ENZ, EZ);   // -z
+        for (uint32_t j = 0; j < L; j++) {
+            uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m);
+            const uint32_t cur = (j & 1) ? ESB : ESA, prev = (j & 1) ? ESA : ESB;
+            e.op(NX_C_LOAD, T0, MAIN + a, 0);
+            if (j & 1) { e.op(NX_C_LOAD, T1, MAIN + b, 0); e.op(NX_C_MULEB, EDEN, EAL, T1); e.op(NX_C_ADDEB, EDEN, EDEN, T0); e.op(NX_C_ADDE, EDEN, EDEN, ENZ); }
+            else e.op(NX_C_ADDEB, EDEN, ENZ, T0);
+            e.op(NX_C_LOADE, cur, INT + 4 * j, 0);
+            if (j + 1 < L) {
+                if (j == 0) e.op(NX_C_MULE, ET, cur, EDEN);
+                else { e.op(NX_C_SUBE, ET, cur, prev); e.op(NX_C_MULE, ET, ET, EDEN); }
+            } else {
+                e.op(NX_C_LOADE, EPR, INT + 4 * j, (uint32_t)-1);
+                e.op(NX_C_SUBE, ET, cur, EPR);
+                if (j > 0) e.op(NX_C_SUBE, ET, ET, prev);
+                e.op(NX_C_ADDE, ET, ET, ESH);
+                e.op(NX_C_MULE, ET, ET, EDEN);
+            }
+            if (j % 3 == 2) e.op(NX_C_LOAD, T2, MAIN + m, 0);   // - num = + main[m]
+            else e.op(NX_C_CONST, T2, P - 1);                     // - num = - 1
+            e.op(NX_C_ADDEB, ET, ET, T2);
+            e.op(NX_C_CONSTRAINT_E, 0, ET); nc++;
+        }
+    }
+    g.prog = std::move(e.p);
+    g.n_constraints = nc;
+    g.econsts.assign(16, 0);
+    return g;
+}
+
+// compiled kernels are cached per context and per program text: one compilation serves every proof of an AIR
+struct KernelCache { std::mutex mu; std::map<std::pair<nx_ctx*, std::string>, nx_air_kernel*> map; };
+static KernelCache& kernel_cache() { static KernelCache c; return c; }
+static int cached_kernel(nx_ctx* ctx, const GComponent& g, const nx_air_kernel** out) {
+    std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
+    key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs);
+    KernelCache& kc = kernel_cache();
+    std::lock_guard<std::mutex> lk(kc.mu);
+    auto it = kc.map.find({ctx, key});
+    if (it == kc.map.end()) {
+        nx_air_kernel* k = nullptr;
+        H_TRY(nx_air_compile(ctx, g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), (uint32_t)g.econsts.size() / 4, g.n_constraints, &k, nullptr));
+        it = kc.map.insert({{ctx, key}, k}).first;
+    }
+    *out = it->second;
+    return NX_OK;
+}
+void machine_kernels_release(nx_ctx* ctx) {   // nx_ctx_destroy: the modules belong to the context's device
+    KernelCache& kc = kernel_cache();
+    std::lock_guard<std::mutex> lk(kc.mu);
+    for (auto it = kc.map.begin(); it != kc.map.end();) { if (it->first.first == ctx) { nx_air_kernel_destroy(it->second); it = kc.map.erase(it); } else ++it; }
+}
+
+// The logup interaction trace of one component from the main-trace columns `mainv` (evaluations, bit-reversed circle-domain order;
+// whole columns, or this GPU's row block of n_rows = 2^log_rows rows): inter = 4 L coordinate columns of n_rows words.
+static int logup_columns(nx_ctx* ctx, const nx_component_spec& c, uint32_t log_rows, const std::map<uint32_t, const uint32_t*>& mainv, const uint32_t z[4], const uint32_t alpha[4],
+                         uint32_t* const* inter) {
+    const uint32_t L = c.n_inter / 4;
+    const uint32_t one[4] = {1, 0, 0, 0}, minus_one[4] = {P - 1, 0, 0, 0};
+    uint32_t ap[8] = {1, 0, 0, 0, alpha[0], alpha[1], alpha[2], alpha[3]};     // LookupElements alpha powers [1, alpha]
+    for (uint32_t j = 0; j < L; j++) {
+        uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m);
+        const uint32_t* tuple[2] = {mainv.at(a), (j & 1) ? mainv.at(b) : nullptr};
+        nx_logup_frac f;
+        f.d_tuple_cols = tuple; f.n_tuple_cols = (j & 1) ? 2 : 1; f.alpha_powers = ap; f.z = z;
+        f.d_mult = j % 3 == 2 ? mainv.at(m) : nullptr; f.scale = j % 3 == 2 ? minus_one : one;
+        H_TRY(nx_logup_col(ctx, log_rows, &f, nullptr, j ? (const uint32_t* const*)(inter + 4 * (j - 1)) : nullptr, inter + 4 * j));
+    }
+    return NX_OK;
+}
+static std::set<uint32_t> logup_main_columns(const nx_component_spec& c) {
+    std::set<uint32_t> s;
+    for (uint32_t j = 0; j < c.n_inter / 4; j++) { uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m); s.insert(a); if (j & 1) s.insert(b); if (j % 3 == 2) s.insert(m); }
+    return s;
+}
+
+static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
+                         size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st) {
+    PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
+    H_TRY(check_components(ctx, comps, n_comps, ucfg));
+    for (uint32_t i = 0; i < n_comps; i++) if (comps[i].n_inter % 4) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: n_inter = 4 x (number of logup columns)");
+    H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
+    uint32_t max_log = 0;
+    std::vector<Loc> locs = locations(comps, n_comps, &max_log);
+    const bool timed = st != nullptr;
+    nx_prove_stats local_stats;
+    if (!st) st = &local_stats;
+    memset(st, 0, sizeof *st);
+    if (timed) { ctx->timing = true; timing_reset(ctx); }
+    double t_start = 0;
+    Lap lap{ctx, timed, 0};
+    if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = now_ms(); }
+
+    nx_twiddles* tw = nullptr;
+    H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));      // machine.rs:184-194
+    struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
+    Blake2sChannel channel;
+    for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
+    CommitmentSchemeProver cs(ctx, tw, cfg);                                          // machine.rs:202-203
+    if (comm) { H_TRY(dist_init(ctx, comm, &cs.dist)); cs.dist.comm_ms = &st->comm_ms; cs.dist.comm_bytes = &st->comm_bytes; }
+    const Dist& D = cs.dist;
+    for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
+    lap(&st->commit);
+
+    { TreeBuilder tb = cs.tree_builder(); H_TRY(fill_and_extend(cs, tb, comps, n_comps, 0, seed, 0)); lap(&st->trace_gen); H_TRY(tb.commit(channel)); lap(&st->commit); }   // :208-228
+
+    // The main trace is consumed by its commitment (the columns become coefficients), and the interaction trace needs its
+    // evaluations afterwards: the reference clones the whole finalized trace (machine.rs:232); here only the columns the logup
+    // fractions read are kept.  One GPU: clones of the filled columns (nx_copy).  Row-sharded: the logup is row-wise, so every GPU
+    // needs ITS ROWS of those columns — for this synthetic trace the generator fills that block directly.
+    std::vector<DevBuf> kept(n_comps);
+    std::vector<std::map<uint32_t, const uint32_t*>> kept_ptr(n_comps);
+    {
+        TreeBuilder tb = cs.tree_builder();
+        std::vector<std::pair<uint32_t, uint32_t>> groups, local;
+        for (uint32_t i = 0; i < n_comps; i++) groups.push_back({comps[i].n_main, comps[i].log_size});
+        plan_local_columns(groups, D, &local);
+        for (uint32_t i = 0; i < n_comps; i++) {
+            const nx_component_spec& c = comps[i];
+            const uint32_t lo = local[i].first, hi = local[i].second, log = c.log_size;
+            DevBuf slab;
+            if (hi > lo) {
+                H_TRY(slab.alloc(ctx, (size_t)(hi - lo) << log));
+                auto p = col_ptrs(slab.p, hi - lo, log);
+                H_TRY(synth_fill_range(ctx, c, i, 1, seed, 0, lo, hi - lo, p.data(), 0, 1u << log));
+            }
+            const std::set<uint32_t> need = logup_main_columns(c);
+            if (!need.empty()) {
+                if (D.on() && log < (uint32_t)D.log_w + 2) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: every trace column needs at least 4 rows per GPU");
+                const uint64_t nb = D.on() ? D.block(log) : ((uint64_t)1 << log);
+                H_TRY(kept[i].alloc(ctx, need.size() * (size_t)nb));
+                size_t q = 0;
+                for (uint32_t k : need) {
+                    uint32_t* dst = kept[i].p + q * (size_t)nb;
+                    if (!D.on()) H_TRY(nx_copy(ctx, dst, slab.p + ((size_t)k << log), (size_t)nb));            // Column::clone (R4)
+                    else { uint32_t* one[1] = {dst}; H_TRY(synth_fill_range(ctx, c, i, 1, seed, 0, k, 1, one, (uint32_t)D.begin(log), (uint32_t)nb)); }
+                    kept_ptr[i][k] = dst; q++;
+                }
+            }
+            tb.extend_evals_local(std::move(slab), c.n_main, log, lo, hi);
+        }
+        lap(&st->trace_gen);
+        H_TRY(tb.commit(channel));                                                    // machine.rs:230-237
+        lap(&st->commit);
+    }
+
+    // machine.rs:239-247: draw_lookup_elements, generate_interaction_trace
+    uint32_t z[4], alpha[4];
+    { std::vector<QM31> za = channel.draw_secure_felts(2); q_store(z, za[0]); q_store(alpha, za[1]); }
+    std::vector<QM31> claimed(n_comps, q_zero());
+    TreeBuilder tb2 = cs.tree_builder();
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> groups, local;
+        for (uint32_t i = 0; i < n_comps; i++) groups.push_back({comps[i].n_inter, comps[i].log_size});
+        plan_local_columns(groups, D, &local);
+        for (uint32_t i = 0; i < n_comps; i++) {
+            const nx_component_spec& c = comps[i];
+            const uint32_t log = c.log_size, L = c.n_inter / 4, lo = local[i].first, hi = local[i].second;
+            DevBuf slab;
+            if (L) {
+                const uint32_t log_rows = D.on() ? log - (uint32_t)D.log_w : log;
+                const uint64_t nb = (uint64_t)1 << log_rows;
+                DevBuf rows; H_TRY(rows.alloc(ctx, (size_t)c.n_inter * nb));                  // every logup column, this GPU's rows
+                std::vector<uint32_t*> ip(c.n_inter);
+                for (uint32_t k = 0; k < c.n_inter; k++) ip[k] = rows.p + (size_t)k * nb;
+                H_TRY(logup_columns(ctx, c, log_rows, kept_ptr[i], z, alpha, ip.data()));
+                uint32_t cs4[4];
+                if (!D.on()) {
+                    H_TRY(nx_logup_finalize_last(ctx, log, ip.data() + 4 * (L - 1), cs4));
+                    slab = std::move(rows);
+                } else {
+                    // finalize_last is a prefix sum over ALL rows in natural order: the last column is all-gathered and finalised by
+                    // everyone (the claimed sum enters the transcript); the other columns go back to column shards by one all-to-all
+                    DevBuf last; H_TRY(last.alloc(ctx, (size_t)4 << log));
+                    uint32_t* lp[4];
+                    for (int q = 0; q < 4; q++) { lp[q] = last.p + ((size_t)q << log); H_TRY(D.allgather_dev(ctx, ip[4 * (L - 1) + q], (size_t)nb, lp[q])); }
+                    H_TRY(nx_logup_finalize_last(ctx, log, lp, cs4));
+                    const uint32_t n_loc = hi - lo;
+                    DevBuf recv; H_TRY(recv.alloc(ctx, (size_t)std::max<uint32_t>(n_loc, 1) << log));
+                    std::vector<size_t> soff(D.world), scnt(D.world), roff(D.world), rcnt(D.world);
+                    {
+                        // the share of component i's interaction columns each GPU transforms (the same plan on every GPU)
+                        for (int r = 0; r < D.world; r++) {
+                            Dist dr = D; dr.rank = r;
+                            std::vector<std::pair<uint32_t, uint32_t>> lr; plan_local_columns(groups, dr, &lr);
+                            soff[r] = (size_t)lr[i].first * nb; scnt[r] = (size_t)(lr[i].second - lr[i].first) * nb;
+                            roff[r] = (size_t)r * n_loc * nb; rcnt[r] = (size_t)n_loc * nb;
+                        }
+                    }
+                    H_TRY(D.alltoallv(ctx, rows.p, soff.data(), scnt.data(), recv.p, roff.data(), rcnt.data()));
+                    if (n_loc) {
+                        H_TRY(slab.alloc(ctx, (size_t)n_loc << log));
+                        H_TRY(transpose_blocks(ctx, slab.p, (uint64_t)1 << log, recv.p, n_loc, (uint64_t)1 << log, (uint32_t)D.world, true));
+                        for (uint32_t k = std::max(lo, 4 * (L - 1)); k < hi; k++)       // the finalised last column, for the GPUs that transform its coordinates
+                            H_TRY(nx_copy(ctx, slab.p + ((size_t)(k - lo) << log), lp[k - 4 * (L - 1)], (size_t)1 << log));
+                        H_TRY(nx_sync(ctx));   // `last` is released below
+                    }
+                }
+                claimed[i] = q_load(cs4);
+            }
+            tb2.extend_evals_local(std::move(slab), c.n_inter, log, lo, hi);
+        }
+    }
+    kept.clear();
+    lap(&st->interaction);
+    channel.mix_felts(claimed);                                                       // machine.rs:262
+    H_TRY(tb2.commit(channel));                                                       // machine.rs:263
+    lap(&st->commit);
+
+    // machine.rs:265-285: the components (recorded programs; lookup elements and claimed-sum shifts are run-time constants)
+    GenericAir air; air.ctx = ctx;
+    for (uint32_t i = 0; i < n_comps; i++) {
+        GComponent g = machine_component(comps[i], locs[i]);
+        const QM31 shift = q_mul_m(claimed[i], m_inv((1u << comps[i].log_size) % P));
+        memcpy(&g.econsts[0], z, 16); memcpy(&g.econsts[4], alpha, 16); q_store(&g.econsts[8], shift);
+        H_TRY(cached_kernel(ctx, g, &g.kernel));
+        air.comps.push_back(std::move(g));
+    }
+    H_TRY(air.check(cs));
+    H_TRY(prove_core(ctx, cs, channel, cfg, tw, air, words, st, lap));               // machine.rs:286-290
+    if (timed) finish_stats(ctx, st, t_start);
+    return NX_OK;
+}
+
+}  // namespace nxhip
+
+using namespace nx;
+
+static int hand_out(nx_ctx* ctx, int rc, std::vector<uint32_t>& w, uint32_t** proof_words, size_t* n_words, const char* who) {
+    ctx->timing = false;
+    if (rc != NX_OK) return rc;
+    uint32_t* out = (uint32_t*)malloc(std::max<size_t>(w.size(), 1) * 4);
+    if (!out) return set_err(ctx, NX_ERR_OOM, std::string(who) + ": malloc failed");
+    memcpy(out, w.data(), w.size() * 4);
+    *proof_words = out; *n_words = w.size();
+    return NX_OK;
+}
+
+extern "C" {
+
+int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
+                   size_t ad_len, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    NX_GUARD(ctx);
+    if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth: NULL argument");
+    std::vector<uint32_t> w;
+    return hand_out(ctx, nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, nullptr, &w, stats), w, proof_words, n_words, "nx_prove_synth");
+}
+
+int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
+                           size_t ad_len, const nx_comm* comm, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    NX_GUARD(ctx);
+    if (!ctx || !comps || !cfg || !proof_words || !n_words || !comm) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth_sharded: NULL argument");
+    std::vector<uint32_t> w;
+    return hand_out(ctx, nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats), w, proof_words, n_words, "nx_prove_synth_sharded");
+}
+
+int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
+                     size_t ad_len, const nx_comm* comm, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
+    NX_GUARD(ctx);
+    if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: NULL argument");
+    std::vector<uint32_t> w;
+    return hand_out(ctx, nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats), w, proof_words, n_words, "nx_prove_machine");
+}
+
+}  // extern "C"

@@ -97,11 +97,13 @@ struct QBatchDev {       // one ColumnSampleBatch, device-resident description
 // Each lane owns 4 consecutive rows (one 16-byte read per column: 1 KB contiguous per wave and column instead of 256 B, which
 // is what lets ~440 concurrent column streams run near HBM speed).  In bit-reversed order the 4 domain points of rows
 // 4j..4j+3 are (x, y), (x, -y), (-x, -y), (-x, y): one scalar-multiple walk for all four.
-__global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, const QBatchDev* __restrict__ batches, u32 n_batches,
+// Rows [4 j0, 4 j1) of the domain: a GPU of a row-sharded prove owns one contiguous block of the (bit-reversed) rows; column and
+// output pointers are biased by the caller so that indexing with the GLOBAL row works (single GPU: j0 = 0, j1 = 2^(log-2)).
+__global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, u32 j0, u32 j1, const QBatchDev* __restrict__ batches, u32 n_batches,
                                                        const u32* __restrict__ col_idx, const u32* __restrict__ cks /*4 per entry*/,
-                                                       u32* __restrict__ o0, u32* __restrict__ o1, u32* __restrict__ o2, u32* __restrict__ o3) {
-    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (1u << (log - 2))) return;
+                                                       u32* o0, u32* o1, u32* o2, u32* o3) {
+    const u32 j = j0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= j1) return;
     const u32 r = 4 * j;
     Pt dp[4];
     dp[0] = pt_from_index(circle_domain_index(log, bitrev(r, log)));
@@ -163,10 +165,10 @@ __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, con
 }
 
 // log_size < 2: one lane per row
-__global__ void quotient_small_kernel(ColSet cols, int log, const QBatchDev* __restrict__ batches, u32 n_batches, const u32* __restrict__ col_idx,
-                                      const u32* __restrict__ cks, u32* __restrict__ o0, u32* __restrict__ o1, u32* __restrict__ o2, u32* __restrict__ o3) {
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= (1u << log)) return;
+__global__ void quotient_small_kernel(ColSet cols, int log, u32 r0, u32 r1, const QBatchDev* __restrict__ batches, u32 n_batches, const u32* __restrict__ col_idx,
+                                      const u32* __restrict__ cks, u32* o0, u32* o1, u32* o2, u32* o3) {
+    u32 r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r1) return;
     Pt dp = pt_from_index(circle_domain_index(log, bitrev(r, log)));
     QM31 acc = q_zero();
     for (u32 b = 0; b < n_batches; b++) {
@@ -199,9 +201,11 @@ __device__ __forceinline__ u32 circle_itw(const u32* itw, u32 tw_log, int L, u32
 struct Sec4 { u32* c[4]; };
 struct Sec4C { const u32* c[4]; };
 
-__global__ void fold_circle_kernel(Sec4 dst, Sec4C src, int L, const u32* __restrict__ itw, u32 tw_log, QM31 alpha, QM31 alpha_sq) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (1u << (L - 1))) return;
+// The fold kernels work on outputs [i0, i1) (a row block of a row-sharded prove; pointers biased by the caller so that the GLOBAL
+// index addresses them; single GPU: i0 = 0, i1 = 2^(L-1)).
+__global__ void fold_circle_kernel(Sec4 dst, Sec4C src, int L, u32 i0, u32 i1, const u32* __restrict__ itw, u32 tw_log, QM31 alpha, QM31 alpha_sq) {
+    u32 i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= i1) return;
     u32 yi = circle_itw(itw, tw_log, L, i);
     QM31 f0, f1;
     {
@@ -217,9 +221,9 @@ __global__ void fold_circle_kernel(Sec4 dst, Sec4C src, int L, const u32* __rest
 }
 
 // line domain of log size L is Coset::half_odds(L); 1/x at bitrev_L(2i) is itwiddle layer (H-L), entry i
-__global__ void fold_line_kernel(Sec4 dst, Sec4C src, int L, const u32* __restrict__ itw, u32 tw_log, QM31 alpha) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (1u << (L - 1))) return;
+__global__ void fold_line_kernel(Sec4 dst, Sec4C src, int L, u32 i0, u32 i1, const u32* __restrict__ itw, u32 tw_log, QM31 alpha) {
+    u32 i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= i1) return;
     u32 xi = itw[(1u << tw_log) - (1u << L) + i];
     uint2 a = *reinterpret_cast<const uint2*>(src.c[0] + 2 * i), b = *reinterpret_cast<const uint2*>(src.c[1] + 2 * i);
     uint2 c = *reinterpret_cast<const uint2*>(src.c[2] + 2 * i), d = *reinterpret_cast<const uint2*>(src.c[3] + 2 * i);
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void eval_tables_kernel(EvalFactors F, int n, 
 // The same folds with the folding alpha read from device memory (4 words): the FRI commit phase keeps the channel on the device
 // (merkle.hip: fri_channel_step / fri_tail), so the host never waits for a root to draw the next alpha.
 __global__ void fold_circle_dev_kernel(Sec4 dst, Sec4C src, int L, const u32* __restrict__ itw, u32 tw_log, const u32* __restrict__ alpha_ptr) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;   // device-channel path: single GPU, whole layer
     if (i >= (1u << (L - 1))) return;
     const QM31 alpha = qm(alpha_ptr[0], alpha_ptr[1], alpha_ptr[2], alpha_ptr[3]), alpha_sq = q_sqr(alpha);
     u32 yi = circle_itw(itw, tw_log, L, i);
@@ -296,6 +300,28 @@ int fold_line_dev(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_s
     return NX_OK;
 }
 
+
+// Row-block forms for a row-sharded prove: dst holds outputs [i0, i0 + n) of the folded layer, src the matching 2n inputs
+// [2 i0, 2 i0 + 2n) (pairs are adjacent in bit-reversed order, so a fold never leaves its block).
+int fold_circle_rows(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t alpha[4], uint32_t i0, uint32_t n) {
+    if (src_log < 1 || (src_log >= 3 && src_log - 1 > tw->log_half) || (uint64_t)i0 + n > ((uint64_t)1 << (src_log - 1))) return set_err(ctx, NX_ERR_ARG, "fold_circle_rows: bad range");
+    if (!n) return NX_OK;
+    Sec4 d; Sec4C s;
+    for (int q = 0; q < 4; q++) { d.c[q] = bias_rows(d_dst4[q], i0); s.c[q] = bias_rows(d_src4[q], 2 * (uint64_t)i0); }
+    const QM31 a = q_load(alpha);
+    hipLaunchKernelGGL(fold_circle_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, i0, i0 + n, tw->d_itw, tw->log_half, a, q_sqr(a));
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+int fold_line_rows(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t alpha[4], uint32_t* const* d_dst4, uint32_t i0, uint32_t n) {
+    if (src_log < 1 || src_log > tw->log_half || (uint64_t)i0 + n > ((uint64_t)1 << (src_log - 1))) return set_err(ctx, NX_ERR_ARG, "fold_line_rows: bad range");
+    if (!n) return NX_OK;
+    Sec4 d; Sec4C s;
+    for (int q = 0; q < 4; q++) { d.c[q] = bias_rows(d_dst4[q], i0); s.c[q] = bias_rows(d_src4[q], 2 * (uint64_t)i0); }
+    hipLaunchKernelGGL(fold_line_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, i0, i0 + n, tw->d_itw, tw->log_half, q_load(alpha));
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
 }  // namespace nx
 
 using namespace nx;
@@ -396,10 +422,14 @@ extern "C" {
 // `entry_local` (NULL = all): which flattened (column, value) entries this GPU holds the column of; the others only advance
 // the alpha powers.  `include_line`: add the -(a·y + b) line terms of ALL entries (exactly one GPU of a column-sharded prove
 // does, so that the partial accumulations of the GPUs sum to the full quotient).
+// row_begin / n_rows: the block of (bit-reversed) rows this call computes — the whole domain on one GPU, one contiguous block per GPU
+// in a row-sharded prove; d_cols and d_out4 then point at the BLOCK (n_rows words each).
 static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
                                      uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
-                                     const uint32_t* values, const uint8_t* entry_local, int include_line, uint32_t* const* d_out4) {
+                                     const uint32_t* values, const uint8_t* entry_local, int include_line, uint32_t* const* d_out4,
+                                     uint64_t row_begin, uint64_t n_rows) {
     if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: bad log_size");
+    if (row_begin + n_rows > ((uint64_t)1 << log_size) || (log_size >= 2 && ((row_begin | n_rows) & 3))) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: row block outside the domain or not a multiple of 4 rows");
     QM31 alpha = q_load(random_coeff);
     size_t total = 0;
     for (uint32_t b = 0; b < n_batches; b++) total += batch_counts[b];
@@ -443,29 +473,40 @@ static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint3
     if (bytes_b) memcpy(host.data(), hb.data(), bytes_b);
     if (bytes_i) memcpy(host.data() + off_i, lidx.data(), bytes_i);
     if (bytes_c) memcpy(host.data() + off_c, cks.data(), bytes_c);
-    if (bytes_t) memcpy(host.data() + off_t, d_cols, bytes_t);
+    for (uint32_t c = 0; c < n_cols; c++) { const uint32_t* biased = bias_rows(d_cols[c], row_begin); memcpy(host.data() + off_t + 8 * (size_t)c, &biased, 8); }   // kernels index with the global row
     void* staged = nullptr;
     NX_TRY(stage(ctx, host.data(), host.size(), &staged));
     const uint8_t* blob = (const uint8_t*)staged;
     ColSet cs; cs.base = nullptr; cs.stride = 0; cs.table = (uint32_t* const*)(blob + off_t);
-    uint64_t alg = ((uint64_t)n_cols * 4 + 16) << log_size;
+    uint64_t alg = ((uint64_t)n_cols * 4 + 16) * n_rows;
     KTimer timer(ctx, NX_T_QUOT, alg);
-    uint32_t n = 1u << log_size;
+    if (n_rows == 0) return NX_OK;
+    u32* o[4]; for (int q = 0; q < 4; q++) o[q] = bias_rows(d_out4[q], row_begin);
     if (log_size >= 2)
-        hipLaunchKernelGGL(quotient_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
-                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+        hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((n_rows / 4 + 255) / 256)), dim3(256), 0, ctx->stream, cs, (int)log_size, (u32)(row_begin / 4), (u32)((row_begin + n_rows) / 4),
+                           (const QBatchDev*)blob, n_batches, (const u32*)(blob + off_i), (const u32*)(blob + off_c), o[0], o[1], o[2], o[3]);
     else
-        hipLaunchKernelGGL(quotient_small_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, (int)log_size, (const QBatchDev*)blob, n_batches,
-                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+        hipLaunchKernelGGL(quotient_small_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, (int)log_size, (u32)row_begin, (u32)(row_begin + n_rows), (const QBatchDev*)blob, n_batches,
+                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), o[0], o[1], o[2], o[3]);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
+
+}  // extern "C"
+namespace nx {
+int accumulate_quotients_rows(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4], uint32_t n_batches,
+                              const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx, const uint32_t* values, uint32_t* const* d_out4,
+                              uint64_t row_begin, uint64_t n_rows) {
+    return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, nullptr, 1, d_out4, row_begin, n_rows);
+}
+}  // namespace nx
+extern "C" {
 
 int nx_accumulate_quotients(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
                             uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
                             const uint32_t* values, uint32_t* const* d_out4) {
     NX_GUARD(ctx);
-    return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, nullptr, 1, d_out4);
+    return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, nullptr, 1, d_out4, 0, (uint64_t)1 << log_size);
 }
 
 int nx_accumulate_quotients_partial(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
@@ -473,7 +514,7 @@ int nx_accumulate_quotients_partial(nx_ctx* ctx, uint32_t log_size, const uint32
                                     const uint32_t* values, const uint8_t* entry_local, int include_line_terms, uint32_t* const* d_out4) {
     NX_GUARD(ctx);
     return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, entry_local,
-                                     include_line_terms, d_out4);
+                                     include_line_terms, d_out4, 0, (uint64_t)1 << log_size);
 }
 
 int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log,
@@ -484,7 +525,7 @@ int nx_fold_circle_into_line(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const
     for (int q = 0; q < 4; q++) { d.c[q] = d_dst4[q]; s.c[q] = d_src4[q]; }
     QM31 a = q_load(alpha);
     uint32_t n = 1u << (src_log - 1);
-    hipLaunchKernelGGL(fold_circle_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, tw->d_itw, tw->log_half, a, q_sqr(a));
+    hipLaunchKernelGGL(fold_circle_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, 0u, n, tw->d_itw, tw->log_half, a, q_sqr(a));
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }
@@ -497,7 +538,7 @@ int nx_fold_line(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_sr
     Sec4 d; Sec4C s;
     for (int q = 0; q < 4; q++) { d.c[q] = d_dst4[q]; s.c[q] = d_src4[q]; }
     uint32_t n = 1u << (src_log - 1);
-    hipLaunchKernelGGL(fold_line_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, tw->d_itw, tw->log_half, q_load(alpha));
+    hipLaunchKernelGGL(fold_line_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d, s, (int)src_log, 0u, n, tw->d_itw, tw->log_half, q_load(alpha));
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
 }

@@ -1,67 +1,111 @@
-// Host driver of the device prover: the C++ mirror of the Stwo objects the reference instantiates
-//   CommitmentSchemeProver / TreeBuilder   (reference prover/src/machine.rs:202-263)
-//   stwo::prover::prove                     (reference prover/src/machine.rs:286-290)
-//   FriProver, prove_values, decommit       (inside prove)
-// written against the C ABI of include/nexus_hip.h (plus the synthetic machine's own kernels), so
-// that everything a Rust `HipBackend` shim needs is exercised through the same entry points.
-// The reference's toolchain (Rust nightly) is absent from this image, hence C++ (task rule ②).
-#include "internal.h"
-#include "air.h"
-#include "host/channel.h"
-#include <algorithm>
+// Host driver of the device prover: CommitmentSchemeProver / TreeBuilder (reference prover/src/machine.rs:202-263),
+// stwo::prover::prove, FriProver, prove_values, decommit (reference prover/src/machine.rs:286-290) and the nx_prover session over
+// recorded AIRs — see prover.h for the objects and for how one proof is spread over the GPUs of a node.
+#include "prover.h"
 #include <chrono>
-#include <map>
-#include <set>
+#include <numeric>
 #include <tuple>
-#include <string.h>
-#include <stdlib.h>
 
 namespace nxhip {
 
-using namespace nx;
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-#define H_TRY(call) do { int rc__ = (call); if (rc__ != NX_OK) return rc__; } while (0)
+#define C_TRY(call) do { if ((call) != 0) return set_err(ctx, NX_ERR_HIP, "nx_comm callback failed: " #call); } while (0)
 
-struct DevBuf {  // owned device allocation
-    nx_ctx* ctx = nullptr; uint32_t* p = nullptr; size_t words = 0;
-    DevBuf() {}
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept { ctx = o.ctx; p = o.p; words = o.words; o.p = nullptr; }
-    DevBuf& operator=(DevBuf&& o) noexcept { release(); ctx = o.ctx; p = o.p; words = o.words; o.p = nullptr; return *this; }
-    int alloc(nx_ctx* c, size_t w) { release(); ctx = c; words = w; return nx_alloc(c, w, &p); }
-    void release() { if (p) { (void)nx_free(ctx, p); p = nullptr; } }
-    ~DevBuf() { release(); }
-};
+// ---------------------------------------------------------------- Dist: the transport of a row-sharded prove ----------
+int dist_init(nx_ctx* ctx, const nx_comm* comm, Dist* out) {
+    if (!comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world) return set_err(ctx, NX_ERR_ARG, "nx_comm: bad rank / world");
+    int lw = 0; while ((1 << lw) < comm->world) lw++;
+    if ((1 << lw) != comm->world) return set_err(ctx, NX_ERR_ARG, "nx_comm: the number of GPUs of one proof must be a power of two (row blocks are subtrees)");
+    if (comm->world > 1 && (!comm->allgather || !comm->alltoallv || !comm->allgather_dev)) return set_err(ctx, NX_ERR_ARG, "nx_comm: allgather, alltoallv and allgather_dev are required");
+    out->comm = comm; out->rank = comm->rank; out->world = comm->world; out->log_w = lw;
+    return NX_OK;
+}
+struct CommClock { const Dist& d; double t0; CommClock(const Dist& x) : d(x), t0(now_ms()) {} ~CommClock() { if (d.comm_ms) *d.comm_ms += now_ms() - t0; } };
+int Dist::allgather_host(nx_ctx* ctx, const void* send, size_t bytes, void* recv) const {
+    CommClock clk(*this);
+    C_TRY(comm->allgather(comm->user, send, bytes, recv));
+    if (comm_bytes) *comm_bytes += bytes * (size_t)(world - 1);
+    return NX_OK;
+}
+int Dist::allgather_dev(nx_ctx* ctx, const uint32_t* d_send, size_t words, uint32_t* d_recv) const {
+    H_TRY(nx_sync(ctx));                      // the peers read this buffer: it must be complete
+    CommClock clk(*this);
+    C_TRY(comm->allgather_dev(comm->user, d_send, words, d_recv));
+    if (comm_bytes) *comm_bytes += words * 4 * (size_t)(world - 1);
+    return NX_OK;
+}
+int Dist::alltoallv(nx_ctx* ctx, const uint32_t* d_send, const size_t* soff, const size_t* scnt, uint32_t* d_recv, const size_t* roff, const size_t* rcnt) const {
+    H_TRY(nx_sync(ctx));
+    CommClock clk(*this);
+    C_TRY(comm->alltoallv(comm->user, d_send, soff, scnt, d_recv, roff, rcnt));
+    if (comm_bytes) for (int r = 0; r < world; r++) if (r != rank) *comm_bytes += scnt[r] * 4;
+    return NX_OK;
+}
 
-struct ColumnRef { uint32_t* ptr; uint32_t log; };
+// node = H(left ‖ right) with no column values: the levels above the subtree roots of a row-sharded tree
+static Blake2sHash hash_pair(int mode, const Blake2sHash& l, const Blake2sHash& r) {
+    Blake2sHash h;
+    if (mode == NX_HASH_BLAKE2S) { Blake2sState s; s.update(l.w, 32); s.update(r.w, 32); s.finalize((uint8_t*)h.w); }
+    else { uint8_t block[64]; memcpy(block, l.w, 32); memcpy(block + 32, r.w, 32); memset(h.w, 0, 32); Blake2sState::compress(h.w, block, 0, false); }
+    return h;
+}
 
-struct PcsConfig { uint32_t pow_bits, log_blowup, n_queries, log_last_layer_degree_bound, fri_alpha_mode, log_constraint_degree; };
-
-struct MerkleDecommitment { std::vector<Blake2sHash> hash_witness; std::vector<uint32_t> column_witness; };
+int merkle_commit_any(nx_ctx* ctx, const Dist& dist, const uint32_t* const* d_cols, const uint32_t* logs, uint32_t n_cols, TreeRef* out) {
+    TreeRef t;
+    uint32_t max_log = 0;
+    for (uint32_t i = 0; i < n_cols; i++) max_log = std::max(max_log, logs[i]);
+    t.n_layers = max_log + 1;
+    if (!dist.on() || n_cols == 0) {   // a tree without columns is the hash of nothing on every GPU
+        H_TRY(nx_merkle_commit(ctx, d_cols, logs, n_cols, &t.local));
+        H_TRY(nx_merkle_root(ctx, t.local, (uint8_t*)t.root.w));
+        *out = std::move(t);
+        return NX_OK;
+    }
+    std::vector<uint32_t> ll(n_cols);
+    for (uint32_t i = 0; i < n_cols; i++) {
+        if (logs[i] < (uint32_t)dist.log_w + 2) return set_err(ctx, NX_ERR_ARG, "row-sharded commit: every column needs at least 4 rows per GPU");
+        ll[i] = logs[i] - (uint32_t)dist.log_w;
+    }
+    H_TRY(nx_merkle_commit(ctx, d_cols, ll.data(), n_cols, &t.local));
+    Blake2sHash mine;
+    H_TRY(nx_merkle_root(ctx, t.local, (uint8_t*)mine.w));
+    t.log_w = dist.log_w;
+    t.top.resize(dist.log_w + 1);
+    t.top[dist.log_w].resize(dist.world);
+    H_TRY(dist.allgather_host(ctx, mine.w, 32, t.top[dist.log_w].data()));
+    for (int k = dist.log_w - 1; k >= 0; k--) {
+        t.top[k].resize((size_t)1 << k);
+        for (size_t i = 0; i < t.top[k].size(); i++) t.top[k][i] = hash_pair(ctx->hash_mode, t.top[k + 1][2 * i], t.top[k + 1][2 * i + 1]);
+    }
+    t.root = t.top[0][0];
+    *out = std::move(t);
+    return NX_OK;
+}
 
 // ---------------------------------------------------------------- MerkleProver::decommit ------
-// Every word a decommitment needs depends only on the query positions and the layer structure, so all decommitments of a
-// proof (4 trees + every FRI layer + the FRI witness values) first record their reads in one GatherBatch, ONE nx_gather
-// fetches them (one kernel, one device->host copy, one synchronisation), then each plan picks its words up.
-struct GatherBatch {
-    std::vector<const uint32_t*> ptrs; std::vector<uint64_t> idx; std::vector<uint32_t> vals;
-    size_t add(const uint32_t* p, uint64_t i) { ptrs.push_back(p); idx.push_back(i); return ptrs.size() - 1; }
-    int run(nx_ctx* ctx) { vals.resize(ptrs.size()); return nx_gather(ctx, ptrs.data(), idx.data(), ptrs.size(), vals.data()); }
-};
-struct DecommitPlan { size_t first = 0; std::vector<uint8_t> kind; };  // kind: 0 hash word, 1 queried value, 2 column witness
+int GatherBatch::run(nx_ctx* ctx) {
+    vals.assign(ptrs.size(), 0);
+    H_TRY(nx_gather(ctx, ptrs.data(), idx.data(), ptrs.size(), vals.data()));
+    if (dist && dist->on() && !vals.empty()) {
+        std::vector<uint32_t> all(vals.size() * (size_t)dist->world);
+        H_TRY(dist->allgather_host(ctx, vals.data(), vals.size() * 4, all.data()));
+        for (size_t i = 0; i < vals.size(); i++) if (owner[i] >= 0) vals[i] = all[(size_t)owner[i] * vals.size() + i];
+    }
+    for (auto& iv : imm) vals[iv.first] = iv.second;
+    return NX_OK;
+}
 
-static DecommitPlan merkle_decommit_plan(const nx_tree* tree, const std::map<uint32_t, std::vector<size_t>>& queries_per_log, std::vector<ColumnRef> cols,
-                                         GatherBatch* gb) {
+DecommitPlan merkle_decommit_plan(const TreeRef& tree, const std::map<uint32_t, std::vector<size_t>>& queries_per_log, std::vector<ColumnRef> cols, GatherBatch* gb) {
     std::stable_sort(cols.begin(), cols.end(), [](const ColumnRef& a, const ColumnRef& b) { return a.log > b.log; });
     DecommitPlan plan; plan.first = gb->ptrs.size();
     size_t ci = 0;
     std::vector<size_t> last;
-    uint32_t n_layers = nx_merkle_n_layers(tree);
+    const uint32_t n_layers = tree.n_layers;
     for (int log = (int)n_layers - 1; log >= 0; log--) {
-        std::vector<const uint32_t*> lc;
-        while (ci < cols.size() && cols[ci].log == (uint32_t)log) lc.push_back(cols[ci++].ptr);
-        const uint32_t* prev = (uint32_t)(log + 1) < n_layers ? nx_merkle_layer(tree, log + 1) : nullptr;
+        std::vector<ColumnRef> lc;
+        while (ci < cols.size() && cols[ci].log == (uint32_t)log) lc.push_back(cols[ci++]);
+        const bool has_prev = (uint32_t)(log + 1) < n_layers;
         static const std::vector<size_t> none;
         auto it = queries_per_log.find((uint32_t)log);
         const std::vector<size_t>& lq = it == queries_per_log.end() ? none : it->second;
@@ -72,22 +116,23 @@ static DecommitPlan merkle_decommit_plan(const nx_tree* tree, const std::map<uin
             if (pi < last.size() && qi < lq.size()) node = std::min(last[pi] / 2, lq[qi]);
             else if (pi < last.size()) node = last[pi] / 2;
             else node = lq[qi];
-            if (prev) {
+            if (has_prev) {
                 for (size_t child = 2 * node; child <= 2 * node + 1; child++) {
                     if (pi < last.size() && last[pi] == child) { pi++; continue; }
-                    for (int w = 0; w < 8; w++) { gb->add(prev, child * 8 + w); plan.kind.push_back(0); }
+                    gb->add_node(tree, (uint32_t)log + 1, child);
+                    for (int w = 0; w < 8; w++) plan.kind.push_back(0);
                 }
             }
             uint8_t k = 2;
             if (qi < lq.size() && lq[qi] == node) { qi++; k = 1; }
-            for (auto c : lc) { gb->add(c, node); plan.kind.push_back(k); }
+            for (auto& c : lc) { gb->add_column(c, node); plan.kind.push_back(k); }
             total.push_back(node);
         }
         last.swap(total);
     }
     return plan;
 }
-static void merkle_decommit_fill(const DecommitPlan& plan, const GatherBatch& gb, std::vector<uint32_t>* queried_values, MerkleDecommitment* d) {
+void merkle_decommit_fill(const DecommitPlan& plan, const GatherBatch& gb, std::vector<uint32_t>* queried_values, MerkleDecommitment* d) {
     Blake2sHash cur; int hw = 0;
     for (size_t i = 0; i < plan.kind.size(); i++) {
         const uint32_t v = gb.vals[plan.first + i];
@@ -98,43 +143,7 @@ static void merkle_decommit_fill(const DecommitPlan& plan, const GatherBatch& gb
 }
 
 // ---------------------------------------------------------------- commitment scheme ----------
-struct CommitmentTreeProver {
-    std::vector<ColumnRef> polys;  // coefficients, commit order
-    std::vector<ColumnRef> evals;  // LDE (log = poly log + log_blowup)
-    std::vector<DevBuf> bufs;
-    nx_tree* merkle = nullptr;
-    Blake2sHash root;
-    CommitmentTreeProver() {}
-    CommitmentTreeProver(CommitmentTreeProver&& o) noexcept
-        : polys(std::move(o.polys)), evals(std::move(o.evals)), bufs(std::move(o.bufs)), merkle(o.merkle), root(o.root) { o.merkle = nullptr; }
-    CommitmentTreeProver(const CommitmentTreeProver&) = delete;
-    ~CommitmentTreeProver() { if (merkle) nx_tree_destroy(merkle); }
-};
-
-class CommitmentSchemeProver;
-
-// TreeBuilder::{extend_evals, extend_polys, commit}
-class TreeBuilder {
-    struct Group { DevBuf slab; uint32_t n_cols, log; bool is_evals; };
-    CommitmentSchemeProver& cs;
-    std::vector<Group> groups;
-  public:
-    explicit TreeBuilder(CommitmentSchemeProver& c) : cs(c) {}
-    // slab: n_cols contiguous columns of 2^log words (bit-reversed evaluations on CanonicCoset(log).circle_domain())
-    void extend_evals(DevBuf&& slab, uint32_t n_cols, uint32_t log) { Group g; g.slab = std::move(slab); g.n_cols = n_cols; g.log = log; g.is_evals = true; groups.push_back(std::move(g)); }
-    void extend_polys(DevBuf&& slab, uint32_t n_cols, uint32_t log) { Group g; g.slab = std::move(slab); g.n_cols = n_cols; g.log = log; g.is_evals = false; groups.push_back(std::move(g)); }
-    int commit(Blake2sChannel& channel);
-};
-
-class CommitmentSchemeProver {
-  public:
-    nx_ctx* ctx; const nx_twiddles* tw; PcsConfig cfg;
-    std::vector<CommitmentTreeProver> trees;
-    CommitmentSchemeProver(nx_ctx* c, const nx_twiddles* t, PcsConfig f) : ctx(c), tw(t), cfg(f) {}
-    TreeBuilder tree_builder() { return TreeBuilder(*this); }
-};
-
-static std::vector<uint32_t*> col_ptrs(uint32_t* base, uint32_t n, uint32_t log) {
+std::vector<uint32_t*> col_ptrs(uint32_t* base, uint32_t n, uint32_t log) {
     std::vector<uint32_t*> v(n);
     for (uint32_t i = 0; i < n; i++) v[i] = base + ((size_t)i << log);
     return v;
@@ -143,7 +152,7 @@ static std::vector<uint32_t*> col_ptrs(uint32_t* base, uint32_t n, uint32_t log)
 // Host words -> a device buffer the caller owns, through the pinned staging ring in chunks: every staged chunk is consumed by the
 // copy enqueued right behind it, so — unlike a pointer into the ring — the result stays valid across any number of later stage()
 // calls (alpha powers and vanishing denominators of a whole statement live across every component's kernels).
-static int upload_owned(nx_ctx* ctx, const uint32_t* h, size_t n_words, DevBuf* out) {
+int upload_owned(nx_ctx* ctx, const uint32_t* h, size_t n_words, DevBuf* out) {
     H_TRY(out->alloc(ctx, std::max<size_t>(n_words, 4)));
     const size_t chunk = (size_t)1 << 20;   // words (4 MiB of the 16 MiB ring)
     for (size_t off = 0; off < n_words; off += chunk) {
@@ -155,21 +164,42 @@ static int upload_owned(nx_ctx* ctx, const uint32_t* h, size_t n_words, DevBuf* 
     return NX_OK;
 }
 
+void plan_local_columns(const std::vector<std::pair<uint32_t, uint32_t>>& groups, const Dist& dist, std::vector<std::pair<uint32_t, uint32_t>>* out) {
+    out->assign(groups.size(), {0u, 0u});
+    for (size_t g0 = 0; g0 < groups.size();) {
+        size_t g1 = g0 + 1;
+        while (g1 < groups.size() && groups[g1].second == groups[g0].second) g1++;
+        uint32_t n_run = 0;
+        for (size_t g = g0; g < g1; g++) n_run += groups[g].first;
+        const uint32_t lo = Dist::cut(n_run, dist.rank, dist.world), hi = Dist::cut(n_run, dist.rank + 1, dist.world);
+        uint32_t off = 0;
+        for (size_t g = g0; g < g1; g++) {
+            const uint32_t a = std::max(lo, off), b = std::min(hi, off + groups[g].first);
+            (*out)[g] = a < b ? std::make_pair(a - off, b - off) : std::make_pair(0u, 0u);
+            off += groups[g].first;
+        }
+        g0 = g1;
+    }
+}
+
 // TreeBuilder::commit = CommitmentTreeProver::new (LDE of every polynomial) + MerkleProver::commit.  The leaf layer is one
 // Blake2s chain per row over the largest columns in commit order, so it is built incrementally: as soon as a group of
 // columns is extended, its 16-column blocks are absorbed on the hash stream while the main stream already extends the next
-// group (tree_pipe_* in merkle.hip).  Hashing is VALU-bound, the Circle FFT mostly waits on memory: they overlap well.
+// group (tree_pipe_* in merkle.hip).
 static uint32_t pipe_group_cols() {
     static const int v = []() { const char* e = getenv("NX_PIPE_COLS"); int x = e ? atoi(e) : 0; if (x < 16) x = 1 << 30; return (x / 16) * 16; }();   // thread-safe
     return (uint32_t)v;
 }
 
-int TreeBuilder::commit(Blake2sChannel& channel) {
+int TreeBuilder::commit(Blake2sChannel& channel) { return cs.dist.on() ? commit_dist(channel) : commit_single(channel); }
+
+int TreeBuilder::commit_single(Blake2sChannel& channel) {
     nx_ctx* ctx = cs.ctx;
     CommitmentTreeProver t;
     uint32_t max_el = 0, total_leaf_cols = 0;
     for (auto& g : groups) if (g.n_cols) max_el = std::max(max_el, g.log + cs.cfg.log_blowup);
     for (auto& g : groups) if (g.n_cols && g.log + cs.cfg.log_blowup == max_el) total_leaf_cols += g.n_cols;
+    for (auto& g : groups) if (g.lo != 0 || g.hi != g.n_cols) return set_err(ctx, NX_ERR_ARG, "TreeBuilder: a column shard was handed to a single-GPU commitment scheme");
     TreePipe tp;
     struct PipeGuard { nx_ctx* c; TreePipe* p; ~PipeGuard() { if (p->tree) { (void)nx_sync(c); nx_tree_destroy(p->tree); p->tree = nullptr; } } } guard{ctx, &tp};
     if (total_leaf_cols) H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp));
@@ -199,7 +229,7 @@ int TreeBuilder::commit(Blake2sChannel& channel) {
                 if (leaf) H_TRY(tree_pipe_absorb(ctx, &tp, (const uint32_t* const*)out.data() + c0, nb, false));                   // K5, leaf layer
             }
             for (uint32_t i = 0; i < n_run; i++) {
-                t.polys.push_back({in[i], log}); t.evals.push_back({out[i], el});
+                t.polys.push_back({in[i], log, false}); t.evals.push_back({out[i], el, false}); t.owner.push_back(-1);
                 if (!leaf) { small_cols.push_back(out[i]); small_logs.push_back(el); }
             }
         }
@@ -207,21 +237,108 @@ int TreeBuilder::commit(Blake2sChannel& channel) {
         t.bufs.push_back(std::move(lde));
         g0 = g1;
     }
-    if (total_leaf_cols) H_TRY(tree_pipe_finish(ctx, &tp, small_cols.data(), small_logs.data(), (uint32_t)small_cols.size(), &t.merkle));   // K5, inner layers
-    else H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &t.merkle));
-    H_TRY(nx_merkle_root(ctx, t.merkle, (uint8_t*)t.root.w));
+    t.merkle.n_layers = max_el + 1;
+    if (total_leaf_cols) H_TRY(tree_pipe_finish(ctx, &tp, small_cols.data(), small_logs.data(), (uint32_t)small_cols.size(), &t.merkle.local));   // K5, inner layers
+    else H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &t.merkle.local));
+    H_TRY(nx_merkle_root(ctx, t.merkle.local, (uint8_t*)t.root.w));
+    t.merkle.root = t.root;
     channel.mix_root(t.root);                                                                // K6
     cs.trees.push_back(std::move(t));
     groups.clear();
     return NX_OK;
 }
 
+// One proof on W GPUs: every GPU extends its share of each run of equally sized columns (iFFT + FFT need whole columns), one
+// all-to-all per run turns the column shards into row blocks, the Merkle subtree over the block is local, the W subtree roots are
+// all-gathered and the top log2 W levels computed by everyone.  Coefficients stay with the GPU that transformed them (OODS sampling
+// is per column).  Polynomials handed in by extend_polys are on every GPU already: everyone evaluates them and keeps its rows.
+int TreeBuilder::commit_dist(Blake2sChannel& channel) {
+    nx_ctx* ctx = cs.ctx;
+    const Dist& D = cs.dist;
+    const uint32_t blow = cs.cfg.log_blowup;
+    CommitmentTreeProver t;
+    std::vector<const uint32_t*> all_cols; std::vector<uint32_t> all_logs;
+    for (size_t g0 = 0; g0 < groups.size();) {
+        size_t g1 = g0 + 1;
+        while (g1 < groups.size() && groups[g1].log == groups[g0].log && groups[g1].is_evals == groups[g0].is_evals) g1++;
+        const uint32_t log = groups[g0].log, el = log + blow;
+        const bool is_evals = groups[g0].is_evals;
+        uint32_t n_run = 0;
+        for (size_t g = g0; g < g1; g++) n_run += groups[g].n_cols;
+        if (n_run && el < (uint32_t)D.log_w + 2) return set_err(ctx, NX_ERR_ARG, "row-sharded commit: every LDE column needs at least 4 rows per GPU");
+        const uint64_t mb = D.block(el);
+        if (n_run && !is_evals) {
+            // replicated coefficients: the whole LDE everywhere, this GPU's rows are a window into it
+            DevBuf lde; H_TRY(lde.alloc(ctx, (size_t)n_run << el));
+            std::vector<uint32_t*> in;
+            for (size_t g = g0; g < g1; g++) {
+                if (groups[g].lo != 0 || groups[g].hi != groups[g].n_cols) return set_err(ctx, NX_ERR_ARG, "TreeBuilder::extend_polys: the polynomials must be on every GPU");
+                auto p = col_ptrs(groups[g].slab.p, groups[g].n_cols, log); in.insert(in.end(), p.begin(), p.end());
+            }
+            auto out = col_ptrs(lde.p, n_run, el);
+            H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)in.data(), n_run, log, blow, out.data()));
+            for (uint32_t i = 0; i < n_run; i++) {
+                t.polys.push_back({in[i], log, false}); t.owner.push_back(-1);
+                t.evals.push_back({out[i] + D.begin(el), el, true});
+                all_cols.push_back(out[i] + D.begin(el)); all_logs.push_back(el);
+            }
+            for (size_t g = g0; g < g1; g++) t.bufs.push_back(std::move(groups[g].slab));
+            t.bufs.push_back(std::move(lde));
+        } else if (n_run) {
+            // this GPU's range of the run, as the caller planned it (plan_local_columns)
+            const uint32_t lo = Dist::cut(n_run, D.rank, D.world), hi = Dist::cut(n_run, D.rank + 1, D.world), n_loc = hi - lo;
+            std::vector<uint32_t*> in;
+            {
+                uint32_t off = 0;
+                for (size_t g = g0; g < g1; g++) {
+                    const uint32_t a = std::max(lo, off), b = std::min(hi, off + groups[g].n_cols);
+                    const uint32_t glo = a < b ? a - off : 0, ghi = a < b ? b - off : 0;
+                    if (groups[g].lo != glo || groups[g].hi != ghi) return set_err(ctx, NX_ERR_ARG, "TreeBuilder: the column shard does not match plan_local_columns");
+                    auto p = col_ptrs(groups[g].slab.p, ghi - glo, log); in.insert(in.end(), p.begin(), p.end());
+                    off += groups[g].n_cols;
+                }
+            }
+            DevBuf rows; H_TRY(rows.alloc(ctx, (size_t)n_run * mb));
+            {
+                DevBuf lde, send;
+                if (n_loc) {
+                    H_TRY(lde.alloc(ctx, (size_t)n_loc << el));
+                    auto out = col_ptrs(lde.p, n_loc, el);
+                    H_TRY(nx_lde_batch(ctx, cs.tw, in.data(), n_loc, log, blow, out.data()));                                   // K3 + K4, column-parallel
+                    H_TRY(send.alloc(ctx, (size_t)n_loc << el));
+                    H_TRY(transpose_blocks(ctx, lde.p, (uint64_t)1 << el, send.p, n_loc, (uint64_t)1 << el, (uint32_t)D.world, false));
+                }
+                std::vector<size_t> soff(D.world), scnt(D.world), roff(D.world), rcnt(D.world);
+                for (int r = 0; r < D.world; r++) {
+                    soff[r] = (size_t)r * n_loc * mb; scnt[r] = (size_t)n_loc * mb;
+                    const uint32_t rlo = Dist::cut(n_run, r, D.world), rhi = Dist::cut(n_run, r + 1, D.world);
+                    roff[r] = (size_t)rlo * mb; rcnt[r] = (size_t)(rhi - rlo) * mb;
+                }
+                H_TRY(D.alltoallv(ctx, send.p, soff.data(), scnt.data(), rows.p, roff.data(), rcnt.data()));                     // the transposition
+            }
+            for (uint32_t c = 0; c < n_run; c++) {
+                const bool local = c >= lo && c < hi;
+                int own = 0; while (!(c >= Dist::cut(n_run, own, D.world) && c < Dist::cut(n_run, own + 1, D.world))) own++;
+                t.polys.push_back({local ? in[c - lo] : nullptr, log, false}); t.owner.push_back(own);
+                uint32_t* blk = rows.p + (size_t)c * mb;
+                t.evals.push_back({blk, el, true});
+                all_cols.push_back(blk); all_logs.push_back(el);
+            }
+            for (size_t g = g0; g < g1; g++) t.bufs.push_back(std::move(groups[g].slab));
+            t.bufs.push_back(std::move(rows));
+        }
+        g0 = g1;
+    }
+    H_TRY(merkle_commit_any(ctx, D, all_cols.data(), all_logs.data(), (uint32_t)all_cols.size(), &t.merkle));                        // K5: local subtree + W roots
+    t.root = t.merkle.root;
+    channel.mix_root(t.root);
+    cs.trees.push_back(std::move(t));
+    groups.clear();
+    return NX_OK;
+}
+
 // ---------------------------------------------------------------- FRI ------------------------
-struct SecureColumn {  // SecureColumnByCoords on device
-    DevBuf buf; uint32_t log = 0; uint32_t* c[4] = {nullptr, nullptr, nullptr, nullptr};
-    int alloc(nx_ctx* ctx, uint32_t l) { log = l; H_TRY(buf.alloc(ctx, (size_t)4 << l)); for (int k = 0; k < 4; k++) c[k] = buf.p + ((size_t)k << l); return NX_OK; }
-};
-struct FriLayer { SecureColumn eval; nx_tree* merkle = nullptr; Blake2sHash root; };
+struct FriLayer { SecureColumn eval; TreeRef merkle; Blake2sHash root; };
 struct FriLayerProof { std::vector<QM31> fri_witness; MerkleDecommitment decommitment; Blake2sHash commitment; };
 
 struct Proof {
@@ -241,30 +358,39 @@ static std::vector<size_t> queries_fold(const std::vector<size_t>& q, uint32_t n
     return r;
 }
 
+// all-gather a row-sharded secure column into a whole one (the FRI tail, the composition accumulator)
+static int gather_secure(nx_ctx* ctx, const Dist& D, const SecureColumn& blk, SecureColumn* whole) {
+    H_TRY(whole->alloc(ctx, blk.log));
+    for (int k = 0; k < 4; k++) H_TRY(D.allgather_dev(ctx, blk.c[k], (size_t)blk.rows, whole->c[k]));
+    return NX_OK;
+}
+
 class FriProver {
   public:
-    nx_ctx* ctx; const nx_twiddles* tw; PcsConfig cfg;
-    std::vector<SecureColumn> columns;  // first layer, decreasing size
-    nx_tree* first_merkle = nullptr; Blake2sHash first_root;
+    nx_ctx* ctx; const nx_twiddles* tw; PcsConfig cfg; const Dist& D;
+    std::vector<SecureColumn> columns;  // first layer, decreasing size (row blocks when the prove is row-sharded)
+    TreeRef first_merkle; Blake2sHash first_root;
     std::vector<FriLayer> inner;
     std::vector<QM31> last_layer_poly;
-    FriProver(nx_ctx* c, const nx_twiddles* t, PcsConfig f) : ctx(c), tw(t), cfg(f) {}
-    ~FriProver() { if (first_merkle) nx_tree_destroy(first_merkle); for (auto& l : inner) if (l.merkle) nx_tree_destroy(l.merkle); }
+    FriProver(nx_ctx* c, const nx_twiddles* t, PcsConfig f, const Dist& d) : ctx(c), tw(t), cfg(f), D(d) {}
 
-    static int commit_secure(nx_ctx* ctx, const std::vector<const SecureColumn*>& cols, nx_tree** tree, Blake2sHash* root) {
+    static int commit_secure(nx_ctx* ctx, const Dist& D, const std::vector<const SecureColumn*>& cols, TreeRef* tree, Blake2sHash* root) {
         std::vector<const uint32_t*> p; std::vector<uint32_t> logs;
-        for (auto s : cols) for (int k = 0; k < 4; k++) { p.push_back(s->c[k]); logs.push_back(s->log); }
-        H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), (uint32_t)p.size(), tree));
-        return nx_merkle_root(ctx, *tree, (uint8_t*)root->w);
+        const Dist single;
+        bool blocks = false;
+        for (auto s : cols) { blocks = blocks || s->block; for (int k = 0; k < 4; k++) { p.push_back(s->c[k]); logs.push_back(s->log); } }
+        H_TRY(merkle_commit_any(ctx, blocks ? D : single, p.data(), logs.data(), (uint32_t)p.size(), tree));
+        *root = tree->root;
+        return NX_OK;
     }
 
-    // FriProver::commit.  The whole commit phase is enqueued without a host round trip: the Blake2s channel lives on the device
-    // (fri_channel_step after each tree, the folds read their alpha from the channel's records, fri_tail for the small layers);
-    // the host reads the roots and the channel state back once, before the last layer.  NX_FRI_DEVICE_CHANNEL=0: the per-layer
-    // host channel (same transcript; kept for A/B).
+    // FriProver::commit.  Single GPU: the whole commit phase is enqueued without a host round trip — the Blake2s channel lives on the
+    // device (fri_channel_step after each tree, the folds read their alpha from the channel's records, fri_tail for the small layers);
+    // the host reads the roots and the channel state back once, before the last layer.  NX_FRI_DEVICE_CHANNEL=0: the per-layer host
+    // channel (same transcript; kept for A/B).  Row-sharded: every layer's root needs the W subtree roots, so the host channel.
     int commit(Blake2sChannel& channel, std::vector<SecureColumn>&& cols) {
         static const bool dev_channel = []() { const char* e = getenv("NX_FRI_DEVICE_CHANNEL"); return !e || atoi(e) != 0; }();
-        if (!dev_channel) return commit_host_channel(channel, std::move(cols));
+        if (D.on() || !dev_channel) return commit_host_channel(channel, std::move(cols));
         columns = std::move(cols);
         if (columns.empty()) return set_err(ctx, NX_ERR_ARG, "fri: no columns");
         const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
@@ -282,8 +408,9 @@ class FriProver {
         {   // first layer: every circle column in one mixed-degree tree
             std::vector<const uint32_t*> p; std::vector<uint32_t> logs;
             for (auto& c : columns) for (int k = 0; k < 4; k++) { p.push_back(c.c[k]); logs.push_back(c.log); }
-            H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), (uint32_t)p.size(), &first_merkle));
-            H_TRY(fri_channel_step(ctx, d_state.p, first_merkle->layers[0], 0));
+            H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), (uint32_t)p.size(), &first_merkle.local));
+            first_merkle.n_layers = columns[0].log + 1;
+            H_TRY(fri_channel_step(ctx, d_state.p, first_merkle.local->layers[0], 0));
         }
         int j_prev = 0;                         // record whose alpha is the current folding alpha
         SecureColumn layer; H_TRY(layer.alloc(ctx, layer_log));
@@ -299,16 +426,15 @@ class FriProver {
                 tl[0].eval = std::move(layer);
                 for (int t = 0; t < n; t++) {
                     if (t) H_TRY(tl[t].eval.alloc(ctx, layer_log - t));
-                    for (int k = 0; k < 4; k++) tl[t].eval.c[k] = tl[t].eval.buf.p + ((size_t)k << (layer_log - t));
-                    H_TRY(tree_alloc(ctx, layer_log - t, &tl[t].merkle));
-                    evals[t] = tl[t].eval.buf.p; trees[t] = tl[t].merkle->layers[0];
+                    H_TRY(tree_alloc(ctx, layer_log - t, &tl[t].merkle.local));
+                    tl[t].merkle.n_layers = layer_log - t + 1;
+                    evals[t] = tl[t].eval.buf.p; trees[t] = tl[t].merkle.local->layers[0];
                 }
                 SecureColumn fin; H_TRY(fin.alloc(ctx, last_log));
                 evals[n] = fin.buf.p;
                 H_TRY(fri_tail(ctx, tw, evals.data(), trees.data(), n, (int)layer_log, d_state.p, j));
                 for (int t = 0; t < n; t++) inner.push_back(std::move(tl[t]));
                 layer = std::move(fin);
-                for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << last_log);
                 layer_log = last_log;
                 break;
             }
@@ -318,18 +444,17 @@ class FriProver {
                 ci++;
             }
             FriLayer L; L.eval = std::move(layer);
-            for (int k = 0; k < 4; k++) L.eval.c[k] = L.eval.buf.p + ((size_t)k << layer_log);
             {
                 std::vector<const uint32_t*> p; std::vector<uint32_t> logs;
                 for (int k = 0; k < 4; k++) { p.push_back(L.eval.c[k]); logs.push_back(layer_log); }
-                H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), 4, &L.merkle));
+                H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), 4, &L.merkle.local));
+                L.merkle.n_layers = layer_log + 1;
             }
-            H_TRY(fri_channel_step(ctx, d_state.p, L.merkle->layers[0], j));
+            H_TRY(fri_channel_step(ctx, d_state.p, L.merkle.local->layers[0], j));
             SecureColumn next; H_TRY(next.alloc(ctx, layer_log - 1));
             H_TRY(fold_line_dev(ctx, tw, (const uint32_t* const*)L.eval.c, layer_log, rec_alpha(j), next.c));
             inner.push_back(std::move(L));
             layer = std::move(next);
-            for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << (layer_log - 1));
             layer_log--; j_prev = j;
         }
         {   // the one host round trip of the commit phase: channel state and every layer's root
@@ -337,45 +462,67 @@ class FriProver {
             H_TRY(nx_download(ctx, st.data(), d_state.p, FRI_STATE_HEAD + FRI_STATE_REC * (1 + inner.size())));
             memcpy(channel.digest.w, st.data(), 32);
             channel.n_challenges += (uint32_t)(1 + inner.size()); channel.n_sent = st[8];
-            memcpy(first_root.w, &st[FRI_STATE_HEAD], 32);
-            for (size_t i = 0; i < inner.size(); i++) memcpy(inner[i].root.w, &st[FRI_STATE_HEAD + FRI_STATE_REC * (i + 1)], 32);
+            memcpy(first_root.w, &st[FRI_STATE_HEAD], 32); first_merkle.root = first_root;
+            for (size_t i = 0; i < inner.size(); i++) { memcpy(inner[i].root.w, &st[FRI_STATE_HEAD + FRI_STATE_REC * (i + 1)], 32); inner[i].merkle.root = inner[i].root; }
         }
         return commit_last_layer(channel, layer, layer_log, ci);
     }
 
+    // The per-layer host channel.  Row-sharded: the first-layer columns and the line layers are row blocks — trees are subtree + W
+    // roots, folds are local (pairs are adjacent) — until a layer has fewer than 2^FRI_DIST_MIN_LOCAL rows per GPU: then the layer
+    // and the remaining circle columns are all-gathered and the tail runs replicated on every GPU.
+    static constexpr uint32_t FRI_DIST_MIN_LOCAL = 10;
     int commit_host_channel(Blake2sChannel& channel, std::vector<SecureColumn>&& cols) {
         columns = std::move(cols);
         if (columns.empty()) return set_err(ctx, NX_ERR_ARG, "fri: no columns");
-        { std::vector<const SecureColumn*> p; for (auto& c : columns) p.push_back(&c); H_TRY(commit_secure(ctx, p, &first_merkle, &first_root)); }
+        { std::vector<const SecureColumn*> p; for (auto& c : columns) p.push_back(&c); H_TRY(commit_secure(ctx, D, p, &first_merkle, &first_root)); }
         channel.mix_root(first_root);
         QM31 folding_alpha = channel.draw_secure_felt();
         const QM31 first_alpha = folding_alpha;
         uint32_t layer_log = columns[0].log - 1;
-        SecureColumn layer; H_TRY(layer.alloc(ctx, layer_log));
+        bool sharded = D.on();
+        SecureColumn layer;
+        if (sharded) H_TRY(layer.alloc_rows(ctx, layer_log, D.block(layer_log), true)); else H_TRY(layer.alloc(ctx, layer_log));
         H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
         const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
         size_t ci = 0; uint32_t n_doublings = 0;
+        std::vector<SecureColumn> gathered;   // whole copies of the circle columns folded in after the switch to the replicated tail
         while (layer_log > last_log) {
+            if (sharded && layer_log < (uint32_t)D.log_w + FRI_DIST_MIN_LOCAL) {
+                SecureColumn whole; H_TRY(gather_secure(ctx, D, layer, &whole));
+                layer = std::move(whole);
+                gathered.resize(columns.size());
+                for (size_t k = ci; k < columns.size(); k++) H_TRY(gather_secure(ctx, D, columns[k], &gathered[k]));
+                sharded = false;
+            }
             while (ci < columns.size() && columns[ci].log - 1 == layer_log) {
                 QM31 a = cfg.fri_alpha_mode == NX_FRI_ALPHA_PREV ? folding_alpha : first_alpha;
                 uint32_t aw[4]; q_store(aw, a);
-                H_TRY(nx_fold_circle_into_line(ctx, tw, layer.c, (const uint32_t* const*)columns[ci].c, columns[ci].log, aw));
+                if (sharded) H_TRY(fold_circle_rows(ctx, tw, layer.c, (const uint32_t* const*)columns[ci].c, columns[ci].log, aw, (uint32_t)D.begin(layer_log), (uint32_t)D.block(layer_log)));
+                else {
+                    const SecureColumn& src = columns[ci].block && D.on() ? gathered[ci] : columns[ci];
+                    H_TRY(nx_fold_circle_into_line(ctx, tw, layer.c, (const uint32_t* const*)src.c, src.log, aw));
+                }
                 ci++;
             }
             FriLayer L; L.eval = std::move(layer);
-            for (int k = 0; k < 4; k++) L.eval.c[k] = L.eval.buf.p + ((size_t)k << layer_log);
-            { std::vector<const SecureColumn*> p{&L.eval}; H_TRY(commit_secure(ctx, p, &L.merkle, &L.root)); }
+            { std::vector<const SecureColumn*> p{&L.eval}; H_TRY(commit_secure(ctx, D, p, &L.merkle, &L.root)); }
             channel.mix_root(L.root);
             folding_alpha = channel.draw_secure_felt();
-            SecureColumn next; H_TRY(next.alloc(ctx, layer_log - 1));
+            SecureColumn next;
             uint32_t aw[4]; q_store(aw, folding_alpha);
-            H_TRY(nx_fold_line(ctx, tw, (const uint32_t* const*)L.eval.c, layer_log, n_doublings, aw, next.c));
+            if (sharded) {
+                H_TRY(next.alloc_rows(ctx, layer_log - 1, D.block(layer_log - 1), true));
+                H_TRY(fold_line_rows(ctx, tw, (const uint32_t* const*)L.eval.c, layer_log, aw, next.c, (uint32_t)D.begin(layer_log - 1), (uint32_t)D.block(layer_log - 1)));
+            } else {
+                H_TRY(next.alloc(ctx, layer_log - 1));
+                H_TRY(nx_fold_line(ctx, tw, (const uint32_t* const*)L.eval.c, layer_log, n_doublings, aw, next.c));
+            }
             inner.push_back(std::move(L));
-            // moved FriLayer: fix coordinate pointers (buffer address is unchanged by the move)
             layer = std::move(next);
-            for (int k = 0; k < 4; k++) layer.c[k] = layer.buf.p + ((size_t)k << (layer_log - 1));
             layer_log--; n_doublings++;
         }
+        if (sharded) { SecureColumn whole; H_TRY(gather_secure(ctx, D, layer, &whole)); layer = std::move(whole); }
         return commit_last_layer(channel, layer, layer_log, ci);
     }
 
@@ -429,9 +576,10 @@ class FriProver {
         }
     }
     struct SecurePlan { size_t first, count; };
+    static ColumnRef coord_ref(const SecureColumn& col, int k) { return ColumnRef{col.c[k], col.log, col.block}; }
     static SecurePlan plan_secure(const SecureColumn& col, const std::vector<size_t>& pos, GatherBatch* gb) {
         SecurePlan p{gb->ptrs.size(), pos.size()};
-        for (size_t q : pos) for (int k = 0; k < 4; k++) gb->add(col.c[k], q);
+        for (size_t q : pos) for (int k = 0; k < 4; k++) gb->add_column(coord_ref(col, k), q);
         return p;
     }
     static void fill_secure(const SecurePlan& p, const GatherBatch& gb, std::vector<QM31>* out) {
@@ -465,7 +613,7 @@ class FriProver {
                 decommit_positions(queries_fold(queries, max_log - c.log), &pos, &wpos);
                 lp.witness.push_back(plan_secure(c, wpos, gb));
                 pos_by_log[c.log] = pos;
-                for (int k = 0; k < 4; k++) refs.push_back({c.c[k], c.log});
+                for (int k = 0; k < 4; k++) refs.push_back(coord_ref(c, k));
             }
             lp.merkle = merkle_decommit_plan(first_merkle, pos_by_log, refs, gb);
             plans.push_back(std::move(lp));
@@ -477,7 +625,7 @@ class FriProver {
             decommit_positions(lq, &pos, &wpos);
             lp.witness.push_back(plan_secure(L.eval, wpos, gb));
             std::map<uint32_t, std::vector<size_t>> pos_by_log; pos_by_log[L.eval.log] = pos;
-            std::vector<ColumnRef> refs; for (int k = 0; k < 4; k++) refs.push_back({L.eval.c[k], L.eval.log});
+            std::vector<ColumnRef> refs; for (int k = 0; k < 4; k++) refs.push_back(coord_ref(L.eval, k));
             lp.merkle = merkle_decommit_plan(L.merkle, pos_by_log, refs, gb);
             plans.push_back(std::move(lp));
             lq = queries_fold(lq, 1);
@@ -527,23 +675,107 @@ static std::vector<uint32_t> serialize(const Proof& p, const PcsConfig& cfg) {
     return o;
 }
 
-// ---------------------------------------------------------------- synthetic machine ----------
-struct Loc { size_t pre0, main0, inter0; };
-
-static QPt get_random_point(Blake2sChannel& ch) {  // CirclePoint::get_random_point
+// ---------------------------------------------------------------- composition polynomial helpers ----------
+QPt get_random_point(Blake2sChannel& ch) {  // CirclePoint::get_random_point
     QM31 t = ch.draw_secure_felt(), t2 = q_sqr(t);
     QM31 inv = q_inv(q_add(t2, q_one()));
     QPt p; p.x = q_mul(q_sub(q_one(), t2), inv); p.y = q_mul(q_add(t, t), inv);
     return p;
 }
-static QM31 coset_vanishing_q(uint32_t n, QPt p) { QM31 x = p.x; for (uint32_t i = 1; i < n; i++) x = q_double_x(x); return x; }
+QM31 coset_vanishing_q(uint32_t n, QPt p) { QM31 x = p.x; for (uint32_t i = 1; i < n; i++) x = q_double_x(x); return x; }
+
+// 1 / coset_vanishing(trace coset, eval_domain.at(i)) over the 2^(e - log_size) cosets of the evaluation domain, bit-reversed
+std::vector<uint32_t> vanishing_denominators(uint32_t log_size, uint32_t e) {
+    const uint32_t log_expand = e - log_size;
+    std::vector<uint32_t> den((size_t)1 << log_expand);
+    for (uint32_t i = 0; i < den.size(); i++) {
+        u32 x = pt_from_index(circle_domain_index((int)e, i)).x;
+        for (uint32_t k = 1; k < log_size; k++) x = m_double_x(x);
+        den[bitrev(i, (int)log_expand)] = m_inv(x);
+    }
+    return den;
+}
+
+int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pair<uint32_t, uint32_t>>& comp_cols, uint32_t log_size, uint32_t e,
+                           const std::vector<char>& masked, EvalDomainCols* out) {
+    nx_ctx* ctx = cs.ctx;
+    const Dist& D = cs.dist;
+    const size_t n = comp_cols.size();
+    out->ptrs.assign(n, nullptr);
+    const bool committed = e == log_size + cs.cfg.log_blowup;
+    if (!D.on()) {
+        if (committed) { for (size_t k = 0; k < n; k++) out->ptrs[k] = cs.trees[comp_cols[k].first].evals[comp_cols[k].second].ptr; return NX_OK; }
+        DevBuf ext; H_TRY(ext.alloc(ctx, std::max<size_t>(n, 1) << e));                 // "need_to_extend": re-evaluate the polynomials on the constraint domain
+        std::vector<const uint32_t*> src(n);
+        for (size_t k = 0; k < n; k++) src[k] = cs.trees[comp_cols[k].first].polys[comp_cols[k].second].ptr;
+        auto dst = col_ptrs(ext.p, (uint32_t)n, e);
+        if (n) H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), (uint32_t)n, log_size, e - log_size, dst.data()));
+        for (size_t k = 0; k < n; k++) out->ptrs[k] = dst[k];
+        out->keep.push_back(std::move(ext));
+        return NX_OK;
+    }
+    if (e < (uint32_t)D.log_w + 2) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: the constraint domain needs at least 4 rows per GPU");
+    const uint64_t mb = D.block(e), rb = D.begin(e);
+    std::vector<uint32_t*> blk(n, nullptr);
+    if (committed) {
+        for (size_t k = 0; k < n; k++) blk[k] = cs.trees[comp_cols[k].first].evals[comp_cols[k].second].ptr;
+    } else {
+        // every GPU re-evaluates the polynomials it holds; one all-to-all hands out the rows.  Receive layout: by source GPU, the
+        // source's columns in the component's column order.
+        std::vector<int> own(n); std::vector<uint32_t> pos(n); std::vector<uint32_t> cnt(D.world, 0);
+        for (size_t k = 0; k < n; k++) {
+            own[k] = cs.trees[comp_cols[k].first].owner[comp_cols[k].second];
+            if (own[k] < 0) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: a trace column is not column-sharded");
+            pos[k] = cnt[own[k]]++;
+        }
+        const uint32_t n_loc = cnt[D.rank];
+        DevBuf ext, send, rows;
+        H_TRY(rows.alloc(ctx, std::max<size_t>(n, 1) * mb));
+        if (n_loc) {
+            H_TRY(ext.alloc(ctx, (size_t)n_loc << e));
+            std::vector<const uint32_t*> src;
+            for (size_t k = 0; k < n; k++) if (own[k] == D.rank) src.push_back(cs.trees[comp_cols[k].first].polys[comp_cols[k].second].ptr);
+            auto dst = col_ptrs(ext.p, n_loc, e);
+            H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), n_loc, log_size, e - log_size, dst.data()));
+            H_TRY(send.alloc(ctx, (size_t)n_loc << e));
+            H_TRY(transpose_blocks(ctx, ext.p, (uint64_t)1 << e, send.p, n_loc, (uint64_t)1 << e, (uint32_t)D.world, false));
+        }
+        std::vector<size_t> soff(D.world), scnt(D.world), roff(D.world), rcnt(D.world);
+        size_t acc = 0;
+        for (int r = 0; r < D.world; r++) { soff[r] = (size_t)r * n_loc * mb; scnt[r] = (size_t)n_loc * mb; roff[r] = acc; rcnt[r] = (size_t)cnt[r] * mb; acc += rcnt[r]; }
+        H_TRY(D.alltoallv(ctx, send.p, soff.data(), scnt.data(), rows.p, roff.data(), rcnt.data()));
+        for (size_t k = 0; k < n; k++) blk[k] = rows.p + roff[own[k]] + (size_t)pos[k] * mb;
+        out->keep.push_back(std::move(rows));
+    }
+    for (size_t k = 0; k < n; k++) {
+        if (k < masked.size() && masked[k]) {       // neighbour rows live in other blocks: the whole column
+            DevBuf whole; H_TRY(whole.alloc(ctx, (size_t)1 << e));
+            H_TRY(D.allgather_dev(ctx, blk[k], (size_t)mb, whole.p));
+            out->ptrs[k] = whole.p;
+            out->keep.push_back(std::move(whole));
+        } else out->ptrs[k] = bias_rows(blk[k], rb);
+    }
+    return NX_OK;
+}
+
+int composition_accumulator(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, uint32_t e, SecureColumn** out) {
+    if (!sub.count(e)) {
+        SecureColumn& s = sub[e];
+        if (cs.dist.on()) H_TRY(s.alloc_rows(cs.ctx, e, cs.dist.block(e), true)); else H_TRY(s.alloc(cs.ctx, e));
+        H_TRY(nx_memset_zero(cs.ctx, s.buf.p, s.buf.words));
+    }
+    *out = &sub[e];
+    return NX_OK;
+}
 
 // DomainEvaluationAccumulator::finalize — ascending size: lift the running polynomial, add, interpolate
-static int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, DevBuf* out_polys, uint32_t* out_log) {
+int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, DevBuf* out_polys, uint32_t* out_log) {
     nx_ctx* ctx = cs.ctx;
     DevBuf cur; uint32_t cur_log = 0; bool have = false;
     for (auto& kv : sub) {
-        uint32_t log = kv.first; SecureColumn& values = kv.second;
+        uint32_t log = kv.first;
+        if (kv.second.block) { SecureColumn whole; H_TRY(gather_secure(ctx, cs.dist, kv.second, &whole)); kv.second = std::move(whole); }
+        SecureColumn& values = kv.second;
         if (have) {
             DevBuf lifted; H_TRY(lifted.alloc(ctx, (size_t)4 << log));
             auto src = col_ptrs(cur.p, 4, cur_log), dst = col_ptrs(lifted.p, 4, log);
@@ -559,137 +791,7 @@ static int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, 
     return NX_OK;
 }
 
-// 1 / coset_vanishing(trace coset, eval_domain.at(i)) over the 2^(e - log_size) cosets of the evaluation domain, bit-reversed
-static std::vector<uint32_t> vanishing_denominators(uint32_t log_size, uint32_t e) {
-    const uint32_t log_expand = e - log_size;
-    std::vector<uint32_t> den((size_t)1 << log_expand);
-    for (uint32_t i = 0; i < den.size(); i++) {
-        u32 x = pt_from_index(circle_domain_index((int)e, i)).x;
-        for (uint32_t k = 1; k < log_size; k++) x = m_double_x(x);
-        den[bitrev(i, (int)log_expand)] = m_inv(x);
-    }
-    return den;
-}
-
-// What stwo::prover::prove needs from the components (ComponentProvers): the synthetic machine and recorded AIRs provide it.
-typedef std::vector<std::vector<std::vector<QM31>>> SampledValues;   // tree -> column -> mask
-typedef std::vector<std::vector<std::vector<QPt>>> MaskPoints;
-struct AirProver {
-    virtual ~AirProver() {}
-    virtual int compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) = 0;
-    virtual void mask_points(QPt oods, MaskPoints* points) = 0;          // the three trace trees
-    virtual QM31 eval_composition_at_point(QPt point, const SampledValues& sv, QM31 random_coeff) = 0;
-};
-
-// ComponentProvers::compute_composition_polynomial for the synthetic machine.
-static int compute_composition(CommitmentSchemeProver& cs, const nx_component_spec* comps, uint32_t n_comps, const std::vector<Loc>& locs,
-                               QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) {
-    nx_ctx* ctx = cs.ctx;
-    const uint32_t lcd = cs.cfg.log_constraint_degree, blow = cs.cfg.log_blowup;
-    size_t total = 0;
-    for (uint32_t i = 0; i < n_comps; i++) total += synth_n_constraints(comps[i]);
-    std::vector<QM31> powers(total);
-    { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
-    std::map<uint32_t, SecureColumn> sub;  // evaluation-domain log size -> accumulation
-    // alpha powers and vanishing denominators of ALL components in one stream-ordered copy (a prover2-style statement has dozens of
-    // components: two staging calls each were most of their cost)
-    std::vector<uint32_t> params; std::vector<size_t> off_pw(n_comps), off_den(n_comps);
-    {
-        size_t remaining = total;
-        std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> den_cache;
-        for (uint32_t ci = 0; ci < n_comps; ci++) {
-            const nx_component_spec& c = comps[ci];
-            const uint32_t e = c.log_size + lcd;
-            const size_t nc = synth_n_constraints(c);
-            off_pw[ci] = params.size();
-            params.resize(params.size() + 4 * nc);   // this component takes the LAST nc remaining powers, reversed
-            for (size_t j = 0; j < nc; j++) q_store(&params[off_pw[ci] + 4 * j], powers[remaining - 1 - j]);
-            remaining -= nc;
-            auto key = std::make_pair(c.log_size, e);
-            if (!den_cache.count(key)) den_cache[key] = vanishing_denominators(c.log_size, e);
-            const auto& den = den_cache[key];
-            off_den[ci] = params.size();
-            params.insert(params.end(), den.begin(), den.end());
-            while (params.size() % 4) params.push_back(0);
-        }
-    }
-    DevBuf d_params;   // owned: read by every component's kernel while later components stage their own descriptors
-    H_TRY(upload_owned(ctx, params.data(), params.size(), &d_params));
-    for (uint32_t ci = 0; ci < n_comps; ci++) {
-        const nx_component_spec& c = comps[ci];
-        const uint32_t e = c.log_size + lcd;
-        const u32* d_pw = d_params.p + off_pw[ci];
-        const u32* d_den = d_params.p + off_den[ci];
-        // trace on the evaluation domain
-        ColSet pre, mainc, inter;
-        DevBuf ext;
-        auto slab_set = [](uint32_t* base, uint32_t log) { ColSet s; s.base = base; s.stride = (uint64_t)1 << log; s.table = nullptr; return s; };
-        if (e == c.log_size + blow) {
-            pre = slab_set(cs.trees[0].evals[locs[ci].pre0].ptr, e);
-            mainc = slab_set(cs.trees[1].evals[locs[ci].main0].ptr, e);
-            inter = slab_set(c.n_inter ? cs.trees[2].evals[locs[ci].inter0].ptr : nullptr, e);
-        } else {  // "need_to_extend": re-evaluate the polynomials on the constraint domain
-            uint32_t ncols = c.n_pre + c.n_main + c.n_inter;
-            H_TRY(ext.alloc(ctx, (size_t)ncols << e));
-            std::vector<const uint32_t*> src;
-            for (uint32_t k = 0; k < c.n_pre; k++) src.push_back(cs.trees[0].polys[locs[ci].pre0 + k].ptr);
-            for (uint32_t k = 0; k < c.n_main; k++) src.push_back(cs.trees[1].polys[locs[ci].main0 + k].ptr);
-            for (uint32_t k = 0; k < c.n_inter; k++) src.push_back(cs.trees[2].polys[locs[ci].inter0 + k].ptr);
-            auto dst = col_ptrs(ext.p, ncols, e);
-            H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), ncols, c.log_size, e - c.log_size, dst.data()));
-            pre = slab_set(ext.p, e);
-            mainc = slab_set(ext.p + ((size_t)c.n_pre << e), e);
-            inter = slab_set(ext.p + ((size_t)(c.n_pre + c.n_main) << e), e);
-        }
-        if (!sub.count(e)) { H_TRY(sub[e].alloc(ctx, e)); H_TRY(nx_memset_zero(ctx, sub[e].buf.p, sub[e].buf.words)); }
-        SynthRange rg{0, c.n_main, c.n_main, 0, c.n_inter, true};
-        H_TRY(synth_constraints(ctx, pre, mainc, inter, rg, (int)c.log_size, (int)e, d_pw, d_den, sub[e].c));
-    }
-    return finalize_accumulation(cs, sub, out_polys, out_log);
-}
-
-// eval_composition_polynomial_at_point (the prover's OODS sanity check, stwo prover/mod.rs::prove)
-static QM31 eval_composition_at_point(const nx_component_spec* comps, uint32_t n_comps, const std::vector<Loc>& locs, QPt point,
-                                      const std::vector<std::vector<std::vector<QM31>>>& sv, QM31 random_coeff) {
-    QM31 acc = q_zero();
-    for (uint32_t ci = 0; ci < n_comps; ci++) {
-        const nx_component_spec& c = comps[ci];
-        QM31 di = q_inv(coset_vanishing_q(c.log_size, point));
-        auto add = [&](QM31 v) { acc = q_add(q_mul(acc, random_coeff), q_mul(di, v)); };
-        auto M = [&](uint32_t k, int s = 0) { return sv[1][locs[ci].main0 + k][s]; };
-        auto I = [&](uint32_t k) { return sv[2][locs[ci].inter0 + k][0]; };
-        QM31 not_last = q_sub(q_one(), sv[0][locs[ci].pre0 + 1][0]);
-        add(q_mul(q_sub(q_sub(M(0, 1), M(0)), q_one()), not_last));
-        add(q_mul(q_sub(q_sub(M(1, 1), M(1)), M(0)), not_last));
-        for (uint32_t k = 2; k < c.n_main; k++) if (!synth_col_is_free(k)) add(q_sub(q_sub(M(k), q_sqr(M(k - 1))), q_sqr(M(k - 2))));
-        for (uint32_t k = 0; k < c.n_inter; k++) if (!synth_col_is_free(k)) add(q_sub(q_sub(I(k), q_sqr(I(k - 1))), q_sqr(I(k - 2))));
-    }
-    return acc;
-}
-
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-struct SynthAir : AirProver {
-    const nx_component_spec* comps; uint32_t n_comps; const std::vector<Loc>& locs;
-    SynthAir(const nx_component_spec* c, uint32_t n, const std::vector<Loc>& l) : comps(c), n_comps(n), locs(l) {}
-    int compute_composition(CommitmentSchemeProver& cs, QM31 rc, DevBuf* out, uint32_t* out_log) override { return nxhip::compute_composition(cs, comps, n_comps, locs, rc, out, out_log); }
-    void mask_points(QPt oods, MaskPoints* points) override {
-        points->assign(3, {});
-        for (uint32_t i = 0; i < n_comps; i++) {
-            QPt step; { Pt s = pt_from_index(1u << (31 - comps[i].log_size)); step.x = q_from_m(s.x); step.y = q_from_m(s.y); }
-            for (uint32_t k = 0; k < comps[i].n_pre; k++) (*points)[0].push_back({oods});
-            for (uint32_t k = 0; k < comps[i].n_main; k++) { if (k < 2) (*points)[1].push_back({oods, qpt_add(oods, step)}); else (*points)[1].push_back({oods}); }
-            for (uint32_t k = 0; k < comps[i].n_inter; k++) (*points)[2].push_back({oods});
-        }
-    }
-    QM31 eval_composition_at_point(QPt point, const SampledValues& sv, QM31 rc) override { return nxhip::eval_composition_at_point(comps, n_comps, locs, point, sv, rc); }
-};
-
-struct Lap {   // per-stage wall clock of nx_prove_stats (only when the caller asked for stats)
-    nx_ctx* ctx; bool timed; double t0;
-    void operator()(double* slot) { if (!timed) return; (void)nx_sync(ctx); double t = now_ms(); *slot += t - t0; t0 = t; }
-};
-static void finish_stats(nx_ctx* ctx, nx_prove_stats* st, double t_start) {
+void finish_stats(nx_ctx* ctx, nx_prove_stats* st, double t_start) {
     (void)nx_sync(ctx);
     st->total = now_ms() - t_start;
     timing_flush(ctx);
@@ -700,8 +802,9 @@ static void finish_stats(nx_ctx* ctx, nx_prove_stats* st, double t_start) {
 
 // stwo::prover::prove from the point where the three trace trees are committed: composition polynomial, OODS sampling, DEEP
 // quotients, FRI, proof of work, decommitment.
-static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel, const PcsConfig& cfg, const nx_twiddles* tw, AirProver& air,
-                      std::vector<uint32_t>* words, nx_prove_stats* st, Lap& lap) {
+int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel, const PcsConfig& cfg, const nx_twiddles* tw, AirProver& air,
+               std::vector<uint32_t>* words, nx_prove_stats* st, Lap& lap) {
+    const Dist& D = cs.dist;
     // ---------------- stwo::prover::prove ----------------
     QM31 random_coeff = channel.draw_secure_felt();
     DevBuf comp_polys; uint32_t clog = 0;
@@ -719,9 +822,10 @@ static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& c
     // ---------------- prove_values ----------------
     Proof proof;
     proof.sampled_values.resize(4);
-    {   // every tree and size is enqueued first; ONE synchronisation collects all the sampled values (K7)
+    {   // every tree and size is enqueued first; ONE synchronisation collects all the sampled values (K7).  Row-sharded: each GPU
+        // samples the polynomials it holds; the values (KBs) are all-gathered.
         struct Pending { std::vector<uint32_t> out; std::vector<std::pair<uint32_t, uint32_t>> where; int t; };
-        std::vector<Pending> pend; pend.reserve(64);
+        std::vector<Pending> pend;
         std::vector<EvalJob> jobs;
         size_t n_req = 0;
         for (int t = 0; t < 4; t++) { std::set<uint32_t> logs; for (auto& c : cs.trees[t].polys) logs.insert(c.log); n_req += logs.size(); }
@@ -729,8 +833,9 @@ static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& c
         for (int t = 0; t < 4; t++) {
             auto& tr = cs.trees[t];
             proof.sampled_values[t].resize(tr.polys.size());
-            std::map<uint32_t, std::vector<uint32_t>> by_log;  // poly log -> column indices
-            for (uint32_t c = 0; c < tr.polys.size(); c++) by_log[tr.polys[c].log].push_back(c);
+            for (uint32_t c = 0; c < tr.polys.size(); c++) proof.sampled_values[t][c].assign(points[t][c].size(), q_zero());
+            std::map<uint32_t, std::vector<uint32_t>> by_log;  // poly log -> column indices held by this GPU
+            for (uint32_t c = 0; c < tr.polys.size(); c++) if (tr.polys[c].ptr) by_log[tr.polys[c].log].push_back(c);
             for (auto& kv : by_log) {
                 std::vector<const uint32_t*> pp; std::vector<uint32_t> pidx, pts;
                 pend.emplace_back(); Pending& pd = pend.back(); pd.t = t;
@@ -743,7 +848,6 @@ static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& c
                         pts.insert(pts.end(), w, w + 8);
                         pd.where.push_back({c, s});
                     }
-                    proof.sampled_values[t][c].resize(points[t][c].size());
                 }
                 pd.out.assign(4 * pidx.size(), 0);
                 H_TRY(eval_at_points_enqueue(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), pd.out.data(), &jobs));
@@ -752,6 +856,17 @@ static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& c
         H_TRY(eval_at_points_collect(ctx, &jobs));
         for (auto& pd : pend)
             for (size_t i = 0; i < pd.where.size(); i++) proof.sampled_values[pd.t][pd.where[i].first][pd.where[i].second] = q_load(&pd.out[4 * i]);
+        if (D.on()) {
+            std::vector<uint32_t> mine;
+            for (int t = 0; t < 4; t++) for (auto& col : proof.sampled_values[t]) for (auto& v : col) { uint32_t w[4]; q_store(w, v); mine.insert(mine.end(), w, w + 4); }
+            std::vector<uint32_t> everyone(mine.size() * (size_t)D.world);
+            H_TRY(D.allgather_host(ctx, mine.data(), mine.size() * 4, everyone.data()));
+            size_t slot = 0;
+            for (int t = 0; t < 4; t++) for (uint32_t c = 0; c < proof.sampled_values[t].size(); c++) {
+                const int r = cs.trees[t].owner[c];
+                for (auto& v : proof.sampled_values[t][c]) { if (r >= 0) v = q_load(&everyone[(size_t)r * mine.size() + 4 * slot]); slot++; }
+            }
+        }
     }
     { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); channel.mix_felts(flat); }
     lap(&st->oods);
@@ -783,16 +898,17 @@ static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& c
             counts.push_back((uint32_t)bcols[b].size());
             for (auto& cv : bcols[b]) { cidx.push_back(cv.first); uint32_t q[4]; q_store(q, cv.second); vals.insert(vals.end(), q, q + 4); }
         }
-        SecureColumn qc; H_TRY(qc.alloc(ctx, all[i].log));
+        const uint32_t L = all[i].log;
+        SecureColumn qc;
+        if (D.on()) H_TRY(qc.alloc_rows(ctx, L, D.block(L), true)); else H_TRY(qc.alloc(ctx, L));
         uint32_t aw[4]; q_store(aw, q_coeff);
-        H_TRY(nx_accumulate_quotients(ctx, all[i].log, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(),
-                                      cidx.data(), vals.data(), qc.c));                                                              // K8
+        H_TRY(accumulate_quotients_rows(ctx, L, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(), cidx.data(), vals.data(), qc.c,
+                                        D.on() ? D.begin(L) : 0, qc.rows));                                                            // K8
         quotients.push_back(std::move(qc));
-        for (int k = 0; k < 4; k++) quotients.back().c[k] = quotients.back().buf.p + ((size_t)k << quotients.back().log);
         i = j;
     }
     lap(&st->quotients);
-    FriProver fri(ctx, tw, cfg);
+    FriProver fri(ctx, tw, cfg, D);
     H_TRY(fri.commit(channel, std::move(quotients)));                                                                                 // K9
     lap(&st->fri);
     H_TRY(nx_grind(ctx, (const uint8_t*)channel.digest.w, cfg.pow_bits, &proof.proof_of_work));                                       // K10
@@ -800,7 +916,7 @@ static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& c
     lap(&st->pow);
     std::map<uint32_t, std::vector<size_t>> qpos;
     fri.draw_queries(channel, &qpos);
-    GatherBatch gb;
+    GatherBatch gb; gb.dist = &D;
     fri.decommit_plan(&gb);
     DecommitPlan tree_plans[4];
     for (int t = 0; t < 4; t++) tree_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, cs.trees[t].evals, &gb);
@@ -821,565 +937,136 @@ static int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& c
     return NX_OK;
 }
 
-static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
-                       size_t ad_len, std::vector<uint32_t>* words, nx_prove_stats* st) {
-    PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
-    if (n_comps == 0) return set_err(ctx, NX_ERR_ARG, "prove: no components");
-    if (cfg.log_blowup < 1 || cfg.log_constraint_degree < 1 || cfg.log_constraint_degree > 2) return set_err(ctx, NX_ERR_ARG, "prove: log_blowup >= 1 and log_constraint_degree in {1,2} required");
-    H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
-    uint32_t max_log = 0;
-    std::vector<Loc> locs; { size_t a = 0, b = 0, c = 0; for (uint32_t i = 0; i < n_comps; i++) { locs.push_back({a, b, c}); a += comps[i].n_pre; b += comps[i].n_main; c += comps[i].n_inter; max_log = std::max(max_log, comps[i].log_size); } }
-    const bool timed = st != nullptr;
-    nx_prove_stats local_stats;
-    if (!st) st = &local_stats;
-    memset(st, 0, sizeof *st);
-    if (timed) { ctx->timing = true; timing_reset(ctx); }
-    double t_start = 0;
-    Lap lap{ctx, timed, 0};
-    if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = now_ms(); }
-
-    // machine.rs:184-194 — twiddles for CanonicCoset(max_log + LOG_CONSTRAINT_DEGREE + log_blowup).half_coset
-    nx_twiddles* tw = nullptr;
-    H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));
-    struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
-    Blake2sChannel channel;
-    for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
-    CommitmentSchemeProver cs(ctx, tw, cfg);                                          // machine.rs:202-203
-    for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
-    lap(&st->commit);
-
-    auto fill_and_commit = [&](uint32_t tree, uint64_t inter_seed) -> int {
-        TreeBuilder tb = cs.tree_builder();
-        std::vector<uint32_t*> all;
-        std::vector<DevBuf> slabs(n_comps);
-        for (uint32_t i = 0; i < n_comps; i++) {
-            uint32_t n = tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter;
-            if (n) H_TRY(slabs[i].alloc(ctx, (size_t)n << comps[i].log_size));
-            auto p = col_ptrs(slabs[i].p, n, comps[i].log_size);
-            all.insert(all.end(), p.begin(), p.end());
-        }
-        H_TRY(nx_synth_fill_tree(ctx, comps, n_comps, tree, seed, inter_seed, all.data()));
-        lap(&st->trace_gen);
-        for (uint32_t i = 0; i < n_comps; i++) {
-            uint32_t n = tree == 0 ? comps[i].n_pre : tree == 1 ? comps[i].n_main : comps[i].n_inter;
-            tb.extend_evals(std::move(slabs[i]), n, comps[i].log_size);
-        }
-        H_TRY(tb.commit(channel));
-        lap(&st->commit);
-        return NX_OK;
-    };
-    H_TRY(fill_and_commit(0, 0));                                                     // machine.rs:208-228
-    H_TRY(fill_and_commit(1, 0));                                                     // machine.rs:230-237
-    QM31 z = channel.draw_secure_felt();                                              // machine.rs:239-240 (lookup elements)
-    uint64_t inter_seed = ((u64)z.a.a << 32) ^ (u64)z.a.b ^ ((u64)z.b.a << 16) ^ ((u64)z.b.b << 48);
-    channel.mix_felts(std::vector<QM31>(n_comps, q_zero()));                          // machine.rs:262 (claimed sums)
-    H_TRY(fill_and_commit(2, inter_seed));                                            // machine.rs:249-263
-
-    SynthAir air(comps, n_comps, locs);
-    H_TRY(prove_core(ctx, cs, channel, cfg, tw, air, words, st, lap));
-    if (timed) finish_stats(ctx, st, t_start);
-    return NX_OK;
-}
-
-// ================================================================ one proof, columns sharded over the GPUs of a node ===
-// SURVEY.md §8(e), BASELINE config #4.  Same protocol, same transcript, same proof bytes as prove_synth; every rank holds a
-// contiguous 16-column-aligned block of each trace tree.  What crosses the links (nx_comm): the Blake2s chaining state of
-// the leaf layers (ring, 32 B per row per hop), two modular all-reduces (composition accumulator, DEEP quotient), the
-// sampled and queried values (KBs) and roots / Merkle witnesses (broadcast).  FRI, grinding and the 4-column composition
-// tree are replicated.  Restricted to one component (the shape of config #4).
-struct Shard {
-    const nx_comm* comm; int rank, world;
-    uint32_t total[3];
-    std::vector<std::pair<uint32_t, uint32_t>> ranges[3];   // per tree, per rank: [lo, hi)
-    uint32_t lo(int t) const { return ranges[t][rank].first; }
-    uint32_t hi(int t) const { return ranges[t][rank].second; }
-    uint32_t n_local(int t) const { return hi(t) - lo(t); }
-    int owner(int t, uint32_t c) const { for (int r = 0; r < world; r++) if (c >= ranges[t][r].first && c < ranges[t][r].second) return r; return -1; }
-    std::vector<int> active(int t) const { std::vector<int> a; for (int r = 0; r < world; r++) if (ranges[t][r].second > ranges[t][r].first) a.push_back(r); return a; }
-};
-static void plan_column_shards(uint32_t n_cols, int world, std::vector<std::pair<uint32_t, uint32_t>>* out) {   // == nexus_zkvm_amd.sharded.plan_column_shards
-    uint32_t blocks = (n_cols + 15) / 16, per = blocks / world, extra = blocks % world, b = 0;
-    out->clear();
-    for (int r = 0; r < world; r++) {
-        uint32_t nb = per + ((uint32_t)r < extra ? 1 : 0);
-        out->push_back({std::min(n_cols, 16 * b), std::min(n_cols, 16 * (b + nb))});
-        b += nb;
-    }
-}
-#define C_TRY(call) do { if ((call) != 0) return set_err(ctx, NX_ERR_HIP, "nx_comm callback failed: " #call); } while (0)
-
-// TreeBuilder::commit of one sharded trace tree: local LDE, chaining-state ring over row chunks, inner layers on the last
-// active rank, root to everybody.
-static int commit_sharded_tree(CommitmentSchemeProver& cs, const Shard& sh, int t, DevBuf&& slab, uint32_t log, Blake2sChannel& channel) {
-    nx_ctx* ctx = cs.ctx;
-    const uint32_t el = log + cs.cfg.log_blowup, n_local = sh.n_local(t);
-    CommitmentTreeProver tr;
-    DevBuf lde;
-    std::vector<uint32_t*> out;
-    if (n_local) {
-        H_TRY(lde.alloc(ctx, (size_t)n_local << el));
-        auto in = col_ptrs(slab.p, n_local, log); out = col_ptrs(lde.p, n_local, el);
-        H_TRY(nx_lde_batch(ctx, cs.tw, in.data(), n_local, log, cs.cfg.log_blowup, out.data()));
-        for (uint32_t i = 0; i < n_local; i++) { tr.polys.push_back({in[i], log}); tr.evals.push_back({out[i], el}); }
-    }
-    const std::vector<int> act = sh.active(t);
-    if (act.empty()) {   // a tree without columns: every rank commits the empty tree
-        H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &tr.merkle));
-        H_TRY(nx_merkle_root(ctx, tr.merkle, (uint8_t*)tr.root.w));
-    } else {
-        const int last = act.back();
-        if (n_local) {
-            size_t pos = std::find(act.begin(), act.end(), sh.rank) - act.begin();
-            const int prev = pos > 0 ? act[pos - 1] : -1, next = pos + 1 < act.size() ? act[pos + 1] : -1;
-            const uint64_t n_rows = (uint64_t)1 << el;
-            DevBuf st; H_TRY(st.alloc(ctx, (size_t)8 << el));
-            const uint32_t n_chunks = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, n_rows >> 10));   // up to 32 row chunks (>= 1024 rows each): fine-grained enough to keep seven hops busy
-            for (uint32_t j = 0; j < n_chunks; j++) {
-                const uint64_t rb = n_rows * j / n_chunks, re = n_rows * (j + 1) / n_chunks;
-                uint32_t* sp = st.p + rb * 8;
-                if (prev >= 0) C_TRY(sh.comm->recv(sh.comm->user, prev, sp, (size_t)(re - rb) * 8));
-                H_TRY(nx_merkle_leaf_chain(ctx, (const uint32_t* const*)out.data(), n_local, el, sh.lo(t), sh.total[t], prev >= 0 ? sp : nullptr, sp, rb, re - rb));
-                if (next >= 0) { H_TRY(nx_sync(ctx)); C_TRY(sh.comm->send(sh.comm->user, next, sp, (size_t)(re - rb) * 8)); }
-            }
-            if (sh.rank == last) {
-                H_TRY(nx_merkle_from_leaves(ctx, st.p, el, &tr.merkle));
-                H_TRY(nx_merkle_root(ctx, tr.merkle, (uint8_t*)tr.root.w));
-            }
-        }
-        C_TRY(sh.comm->broadcast(sh.comm->user, tr.root.w, 32, last));
-    }
-    tr.bufs.push_back(std::move(slab));
-    tr.bufs.push_back(std::move(lde));
-    channel.mix_root(tr.root);
-    cs.trees.push_back(std::move(tr));
-    return NX_OK;
-}
-
-static int prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
-                               size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st) {
-    PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
-    if (n_comps != 1) return set_err(ctx, NX_ERR_ARG, "sharded prove: exactly one component (BASELINE config #4 shape)");
-    if (cfg.log_blowup < 1 || cfg.log_constraint_degree < 1 || cfg.log_constraint_degree > 2) return set_err(ctx, NX_ERR_ARG, "prove: log_blowup >= 1 and log_constraint_degree in {1,2} required");
-    if (!comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || !comm->send || !comm->recv || !comm->allreduce_m31 || !comm->allgather || !comm->broadcast)
-        return set_err(ctx, NX_ERR_ARG, "sharded prove: incomplete nx_comm");
-    const nx_component_spec& c = comps[0];
-    if (c.n_pre < 2 || c.n_main < 2 || c.log_size < 1 || c.log_size > 28) return set_err(ctx, NX_ERR_ARG, "synthetic component needs n_pre >= 2, n_main >= 2, 1 <= log_size <= 28");
-    H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
-    Shard sh; sh.comm = comm; sh.rank = comm->rank; sh.world = comm->world;
-    sh.total[0] = c.n_pre; sh.total[1] = c.n_main; sh.total[2] = c.n_inter;
-    for (int t = 0; t < 3; t++) plan_column_shards(sh.total[t], sh.world, &sh.ranges[t]);
-    std::vector<Loc> locs{{0, 0, 0}};
-    const bool timed = st != nullptr;
-    nx_prove_stats local_stats;
-    if (!st) st = &local_stats;
-    memset(st, 0, sizeof *st);
-    if (timed) { ctx->timing = true; timing_reset(ctx); }
-    double t_start = 0, t0 = 0;
-    auto lap = [&](double* slot) { if (!timed) return; (void)nx_sync(ctx); double t = now_ms(); *slot += t - t0; t0 = t; };
-    if (timed) { (void)nx_sync(ctx); t_start = t0 = now_ms(); }
-
-    nx_twiddles* tw = nullptr;
-    H_TRY(nx_twiddles_create(ctx, c.log_size + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));
-    struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
-    Blake2sChannel channel;
-    for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);
-    CommitmentSchemeProver cs(ctx, tw, cfg);
-    channel.mix_u64(c.log_size);
-    lap(&st->commit);
-
-    auto fill_and_commit = [&](uint32_t tree, uint64_t inter_seed) -> int {
-        const uint32_t n_local = sh.n_local((int)tree);
-        DevBuf slab;
-        if (n_local) {
-            H_TRY(slab.alloc(ctx, (size_t)n_local << c.log_size));
-            auto p = col_ptrs(slab.p, n_local, c.log_size);
-            H_TRY(synth_fill_range(ctx, c, 0, tree, seed, inter_seed, sh.lo((int)tree), n_local, p.data()));
-        }
-        lap(&st->trace_gen);
-        H_TRY(commit_sharded_tree(cs, sh, (int)tree, std::move(slab), c.log_size, channel));
-        lap(&st->commit);
-        return NX_OK;
-    };
-    H_TRY(fill_and_commit(0, 0));
-    H_TRY(fill_and_commit(1, 0));
-    QM31 z = channel.draw_secure_felt();
-    uint64_t inter_seed = ((u64)z.a.a << 32) ^ (u64)z.a.b ^ ((u64)z.b.a << 16) ^ ((u64)z.b.b << 48);
-    channel.mix_felts(std::vector<QM31>(1, q_zero()));
-    H_TRY(fill_and_commit(2, inter_seed));
-
-    // ---------------- composition polynomial: local constraints, one modular all-reduce, replicated interpolation ----------------
-    QM31 random_coeff = channel.draw_secure_felt();
-    const uint32_t lcd = cfg.log_constraint_degree, blow = cfg.log_blowup, e = c.log_size + lcd;
-    DevBuf comp_polys;
-    {
-        const size_t nc = synth_n_constraints(c);
-        std::vector<uint32_t> pw(4 * nc);
-        { QM31 a = q_one(); std::vector<QM31> powers(nc); for (size_t i = 0; i < nc; i++) { powers[i] = a; a = q_mul(a, random_coeff); }
-          for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[nc - 1 - j]); }
-        DevBuf d_pw_buf; H_TRY(upload_owned(ctx, pw.data(), pw.size(), &d_pw_buf)); const u32* d_pw = d_pw_buf.p;
-        const uint32_t log_expand = e - c.log_size;
-        std::vector<uint32_t> den((size_t)1 << log_expand);
-        for (uint32_t i = 0; i < den.size(); i++) {
-            u32 x = pt_from_index(circle_domain_index((int)e, i)).x;
-            for (uint32_t k = 1; k < c.log_size; k++) x = m_double_x(x);
-            den[bitrev(i, (int)log_expand)] = m_inv(x);
-        }
-        DevBuf d_den_buf; H_TRY(upload_owned(ctx, den.data(), den.size(), &d_den_buf)); const u32* d_den = d_den_buf.p;
-        auto slab_set = [](uint32_t* base, uint32_t log) { ColSet s; s.base = base; s.stride = (uint64_t)1 << log; s.table = nullptr; return s; };
-        ColSet pre, mainc, inter;
-        DevBuf ext;
-        const uint32_t np = sh.n_local(0), nm = sh.n_local(1), ni = sh.n_local(2);
-        if (e == c.log_size + blow) {
-            pre = slab_set(np ? cs.trees[0].evals[0].ptr : nullptr, e);
-            mainc = slab_set(nm ? cs.trees[1].evals[0].ptr : nullptr, e);
-            inter = slab_set(ni ? cs.trees[2].evals[0].ptr : nullptr, e);
-        } else {
-            const uint32_t ncols = np + nm + ni;
-            H_TRY(ext.alloc(ctx, (size_t)std::max<uint32_t>(ncols, 1) << e));
-            std::vector<const uint32_t*> src;
-            for (int t = 0; t < 3; t++) for (auto& p : cs.trees[t].polys) src.push_back(p.ptr);
-            auto dst = col_ptrs(ext.p, ncols, e);
-            if (ncols) H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), ncols, c.log_size, e - c.log_size, dst.data()));
-            pre = slab_set(ext.p, e);
-            mainc = slab_set(ext.p + ((size_t)np << e), e);
-            inter = slab_set(ext.p + ((size_t)(np + nm) << e), e);
-        }
-        SecureColumn acc; H_TRY(acc.alloc(ctx, e)); H_TRY(nx_memset_zero(ctx, acc.buf.p, acc.buf.words));
-        SynthRange rg{sh.lo(1), nm, c.n_main, sh.lo(2), ni, sh.lo(0) == 0 && sh.hi(0) >= 2};
-        if (nm || ni) H_TRY(synth_constraints(ctx, pre, mainc, inter, rg, (int)c.log_size, (int)e, (const u32*)d_pw, (const u32*)d_den, acc.c));
-        H_TRY(nx_sync(ctx));
-        C_TRY(comm->allreduce_m31(comm->user, acc.buf.p, acc.buf.words));
-        H_TRY(nx_interpolate_batch(ctx, cs.tw, acc.c, 4, e));
-        comp_polys = std::move(acc.buf);
-    }
-    lap(&st->composition);
-    { TreeBuilder tb = cs.tree_builder(); tb.extend_polys(std::move(comp_polys), 4, e); H_TRY(tb.commit(channel)); }   // replicated
-    lap(&st->commit);
-    QPt oods = get_random_point(channel);
-
-    // mask points per GLOBAL column
-    std::vector<std::vector<std::vector<QPt>>> points(4);
-    {
-        QPt step; { Pt s0 = pt_from_index(1u << (31 - c.log_size)); step.x = q_from_m(s0.x); step.y = q_from_m(s0.y); }
-        for (uint32_t k = 0; k < c.n_pre; k++) points[0].push_back({oods});
-        for (uint32_t k = 0; k < c.n_main; k++) { if (k < 2) points[1].push_back({oods, qpt_add(oods, step)}); else points[1].push_back({oods}); }
-        for (uint32_t k = 0; k < c.n_inter; k++) points[2].push_back({oods});
-        for (int k = 0; k < 4; k++) points[3].push_back({oods});
-    }
-    // ---------------- prove_values: local columns, then an all-gather of the (few KB of) sampled values ----------------
-    Proof proof;
-    proof.sampled_values.resize(4);
-    for (int t = 0; t < 4; t++) { proof.sampled_values[t].resize(points[t].size()); for (size_t k = 0; k < points[t].size(); k++) proof.sampled_values[t][k].assign(points[t][k].size(), q_zero()); }
-    for (int t = 0; t < 4; t++) {
-        auto& tr = cs.trees[t];
-        const uint32_t g0 = t < 3 ? sh.lo(t) : 0;
-        if (tr.polys.empty()) continue;
-        std::vector<const uint32_t*> pp; std::vector<uint32_t> pidx, pts; std::vector<std::pair<uint32_t, uint32_t>> where;
-        for (uint32_t li = 0; li < tr.polys.size(); li++) {
-            const uint32_t g = g0 + li;
-            pp.push_back(tr.polys[li].ptr);
-            for (uint32_t s2 = 0; s2 < points[t][g].size(); s2++) {
-                pidx.push_back(li);
-                uint32_t w[8]; q_store(w, points[t][g][s2].x); q_store(w + 4, points[t][g][s2].y);
-                pts.insert(pts.end(), w, w + 8);
-                where.push_back({g, s2});
-            }
-        }
-        std::vector<uint32_t> out(4 * pidx.size());
-        H_TRY(nx_eval_at_points(ctx, pp.data(), tr.polys[0].log, pidx.data(), pts.data(), (uint32_t)pidx.size(), out.data()));
-        for (size_t i = 0; i < where.size(); i++) proof.sampled_values[t][where[i].first][where[i].second] = q_load(&out[4 * i]);
-    }
-    {   // exchange trees 0..2: every rank contributes the slots of its columns
-        std::vector<uint32_t> mine;
-        for (int t = 0; t < 3; t++) for (auto& col : proof.sampled_values[t]) for (auto& v : col) { uint32_t w[4]; q_store(w, v); mine.insert(mine.end(), w, w + 4); }
-        std::vector<uint32_t> everyone(mine.size() * (size_t)sh.world);
-        C_TRY(comm->allgather(comm->user, mine.data(), mine.size() * 4, everyone.data()));
-        size_t slot = 0;
-        for (int t = 0; t < 3; t++) for (uint32_t g = 0; g < proof.sampled_values[t].size(); g++) {
-            const int r = sh.owner(t, g);
-            for (auto& v : proof.sampled_values[t][g]) { v = q_load(&everyone[(size_t)r * mine.size() + 4 * slot]); slot++; }
-        }
-    }
-    { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& col : t) for (auto& v : col) flat.push_back(v); channel.mix_felts(flat); }
-    lap(&st->oods);
-    QM31 q_coeff = channel.draw_secure_felt();
-    // ---------------- DEEP quotients: size groups over the GLOBAL column list; sharded groups = partial sums + all-reduce ----------------
-    struct Flat { const uint32_t* ptr; uint32_t log; int t; uint32_t c; };
-    std::vector<Flat> all;
-    for (int t = 0; t < 3; t++) for (uint32_t g = 0; g < sh.total[t]; g++) {
-        const bool local = g >= sh.lo(t) && g < sh.hi(t);
-        all.push_back({local ? cs.trees[t].evals[g - sh.lo(t)].ptr : nullptr, c.log_size + blow, t, g});
-    }
-    for (uint32_t g = 0; g < 4; g++) all.push_back({cs.trees[3].evals[g].ptr, cs.trees[3].evals[g].log, 3, g});
-    std::stable_sort(all.begin(), all.end(), [](const Flat& a, const Flat& b) { return a.log > b.log; });
-    std::vector<SecureColumn> quotients;
-    for (size_t i = 0; i < all.size();) {
-        size_t j = i; while (j < all.size() && all[j].log == all[i].log) j++;
-        std::vector<QPt> bpts; std::vector<std::vector<std::tuple<uint32_t, QM31, bool>>> bcols;
-        std::vector<const uint32_t*> gcols;
-        bool sharded_group = false;   // decided by the group's CONTENT (trace-tree columns), identically on every rank
-        for (size_t k = i; k < j; k++) {
-            const bool local = all[k].ptr != nullptr;
-            uint32_t lidx = 0;
-            if (local) { lidx = (uint32_t)gcols.size(); gcols.push_back(all[k].ptr); }
-            if (all[k].t < 3) sharded_group = true;
-            const auto& ps = points[all[k].t][all[k].c];
-            for (size_t s2 = 0; s2 < ps.size(); s2++) {
-                size_t b = 0;
-                for (; b < bpts.size(); b++) if (q_eq(bpts[b].x, ps[s2].x) && q_eq(bpts[b].y, ps[s2].y)) break;
-                if (b == bpts.size()) { bpts.push_back(ps[s2]); bcols.emplace_back(); }
-                bcols[b].push_back(std::make_tuple(lidx, proof.sampled_values[all[k].t][all[k].c][s2], local));
-            }
-        }
-        std::vector<uint32_t> fpts, counts, cidx, vals; std::vector<uint8_t> is_local;
-        for (size_t b = 0; b < bpts.size(); b++) {
-            uint32_t w[8]; q_store(w, bpts[b].x); q_store(w + 4, bpts[b].y); fpts.insert(fpts.end(), w, w + 8);
-            counts.push_back((uint32_t)bcols[b].size());
-            for (auto& cv : bcols[b]) { cidx.push_back(std::get<0>(cv)); uint32_t q[4]; q_store(q, std::get<1>(cv)); vals.insert(vals.end(), q, q + 4); is_local.push_back(std::get<2>(cv) ? 1 : 0); }
-        }
-        SecureColumn qc; H_TRY(qc.alloc(ctx, all[i].log));
-        uint32_t aw[4]; q_store(aw, q_coeff);
-        if (sharded_group) {
-            H_TRY(nx_accumulate_quotients_partial(ctx, all[i].log, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(),
-                                                  cidx.data(), vals.data(), is_local.data(), sh.rank == 0 ? 1 : 0, qc.c));
-            H_TRY(nx_sync(ctx));
-            C_TRY(comm->allreduce_m31(comm->user, qc.buf.p, qc.buf.words));
-        } else {
-            H_TRY(nx_accumulate_quotients(ctx, all[i].log, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(),
-                                          cidx.data(), vals.data(), qc.c));
-        }
-        quotients.push_back(std::move(qc));
-        for (int k = 0; k < 4; k++) quotients.back().c[k] = quotients.back().buf.p + ((size_t)k << quotients.back().log);
-        i = j;
-    }
-    lap(&st->quotients);
-    FriProver fri(ctx, tw, cfg);
-    H_TRY(fri.commit(channel, std::move(quotients)));                    // replicated
-    lap(&st->fri);
-    H_TRY(nx_grind(ctx, (const uint8_t*)channel.digest.w, cfg.pow_bits, &proof.proof_of_work));
-    channel.mix_u64(proof.proof_of_work);
-    lap(&st->pow);
-    // ---------------- decommit ----------------
-    std::map<uint32_t, std::vector<size_t>> qpos;
-    fri.draw_queries(channel, &qpos);
-    GatherBatch gb;
-    fri.decommit_plan(&gb);
-    const std::vector<size_t>& tq = qpos[c.log_size + blow];             // query positions of the trace trees' single column size
-    size_t value_first[3];
-    for (int t = 0; t < 3; t++) { value_first[t] = gb.ptrs.size(); for (size_t q : tq) for (auto& ev : cs.trees[t].evals) gb.add(ev.ptr, q); }
-    DecommitPlan hash_plans[4];
-    for (int t = 0; t < 3; t++) if (cs.trees[t].merkle) hash_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, std::vector<ColumnRef>(), &gb);
-    hash_plans[3] = merkle_decommit_plan(cs.trees[3].merkle, qpos, cs.trees[3].evals, &gb);
-    H_TRY(gb.run(ctx));
-    fri.decommit_fill(gb, &proof);
-    proof.decommitments.resize(4); proof.queried_values.resize(4);
-    for (int t = 0; t < 3; t++) {
-        // queried values: [query][global column]; every rank contributes its columns
-        const uint32_t nl = sh.n_local(t), tot = sh.total[t];
-        uint32_t max_local = 0; for (int r = 0; r < sh.world; r++) max_local = std::max(max_local, sh.ranges[t][r].second - sh.ranges[t][r].first);
-        std::vector<uint32_t> mine(std::max<size_t>(1, tq.size() * (size_t)max_local), 0);
-        for (size_t qi = 0; qi < tq.size(); qi++) for (uint32_t l = 0; l < nl; l++) mine[qi * max_local + l] = gb.vals[value_first[t] + qi * nl + l];
-        std::vector<uint32_t> everyone(mine.size() * (size_t)sh.world);
-        C_TRY(comm->allgather(comm->user, mine.data(), mine.size() * 4, everyone.data()));
-        for (size_t qi = 0; qi < tq.size(); qi++) for (uint32_t g = 0; g < tot; g++) {
-            const int r = sh.owner(t, g);
-            proof.queried_values[t].push_back(everyone[(size_t)r * mine.size() + qi * max_local + (g - sh.ranges[t][r].first)]);
-        }
-        // hash witness: from the rank that holds the tree (the last active one; rank 0 for an empty tree, which is replicated)
-        const std::vector<int> act = sh.active(t);
-        const int holder = act.empty() ? 0 : act.back();
-        std::vector<uint32_t> wit;
-        if (sh.rank == holder) {
-            MerkleDecommitment d; merkle_decommit_fill(hash_plans[t], gb, nullptr, &d);
-            for (auto& h : d.hash_witness) wit.insert(wit.end(), h.w, h.w + 8);
-        }
-        uint32_t n_wit = (uint32_t)wit.size();
-        C_TRY(comm->broadcast(comm->user, &n_wit, 4, holder));
-        wit.resize(n_wit);
-        if (n_wit) C_TRY(comm->broadcast(comm->user, wit.data(), (size_t)n_wit * 4, holder));
-        for (uint32_t k = 0; k + 8 <= n_wit; k += 8) { Blake2sHash h; memcpy(h.w, &wit[k], 32); proof.decommitments[t].hash_witness.push_back(h); }
-        proof.commitments.push_back(cs.trees[t].root);
-    }
-    merkle_decommit_fill(hash_plans[3], gb, &proof.queried_values[3], &proof.decommitments[3]);
-    proof.commitments.push_back(cs.trees[3].root);
-    lap(&st->decommit);
-    QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
-    QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
-    if (!q_eq(lhs, eval_composition_at_point(comps, n_comps, locs, oods, proof.sampled_values, random_coeff)))
-        return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
-    *words = serialize(proof, cfg);
-    if (timed) {
-        (void)nx_sync(ctx);
-        st->total = now_ms() - t_start;
-        timing_flush(ctx);
-        st->lde_kernel_ms = ctx->kind_ms[NX_T_LDE]; st->lde_algorithmic_bytes = ctx->kind_bytes[NX_T_LDE];
-        st->merkle_kernel_ms = ctx->kind_ms[NX_T_MERKLE]; st->merkle_algorithmic_bytes = ctx->kind_bytes[NX_T_MERKLE];
-        ctx->timing = false;
-    }
-    return NX_OK;
-}
-
-
 // ================================================================ recorded AIRs: the nx_prover session ================
-// The generic counterpart of prove_synth: components are RECORDED constraint programs (include/nexus_hip.h, nx_air_component —
-// what FrameworkComponent<E> is to Stwo, reference prover/src/components/mod.rs:15-57), the caller drives the transcript
-// prefix (reference machine.rs:198-263) through the session and nx_prover_prove runs stwo::prover::prove on the device.
-struct GComponent {
-    uint32_t log_size = 0, n_regs = 0, n_constraints = 0;
-    std::vector<nx_cinstr> prog;
-    std::vector<uint32_t> econsts;
-    std::vector<std::pair<uint32_t, uint32_t>> cols;     // component column -> (tree, column in tree)
-    std::vector<std::vector<int>> masks;                 // component column -> row offsets sampled
-    const nx_air_kernel* kernel = nullptr; nx_air_kernel* owned = nullptr;
-};
+// The generic counterpart of the synthetic machines: components are RECORDED constraint programs (include/nexus_hip.h,
+// nx_air_component — what FrameworkComponent<E> is to Stwo, reference prover/src/components/mod.rs:15-57), the caller drives the
+// transcript prefix (reference machine.rs:198-263) through the session and nx_prover_prove runs stwo::prover::prove on the device.
 
-struct GenericAir : AirProver {
-    nx_ctx* ctx; std::vector<GComponent> comps;
-    std::vector<std::vector<std::vector<int>>> offs;     // tree -> column -> union of sampled offsets (first-appearance order)
-    std::vector<std::vector<uint32_t>> tree_logs;
-    ~GenericAir() override { for (auto& c : comps) if (c.owned) nx_air_kernel_destroy(c.owned); }
-
-    // the consistency rules of oracle-side gair_check: every committed column claimed, sizes agree, loads inside the masks
-    int check(const CommitmentSchemeProver& cs) {
-        if (cs.trees.size() != 3) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: exactly three trace trees (preprocessed, main, interaction) must be committed first");
-        if (comps.empty()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: no components");
-        tree_logs.assign(3, {}); offs.assign(3, {});
-        std::vector<std::vector<char>> claimed(3);
-        for (int t = 0; t < 3; t++) { for (auto& c : cs.trees[t].polys) tree_logs[t].push_back(c.log); claimed[t].assign(tree_logs[t].size(), 0); offs[t].resize(tree_logs[t].size()); }
-        for (auto& c : comps) {
-            for (size_t k = 0; k < c.cols.size(); k++) {
-                const uint32_t t = c.cols[k].first, i = c.cols[k].second;
-                if (t > 2 || i >= tree_logs[t].size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column outside the committed trees");
-                if (tree_logs[t][i] != c.log_size) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column of a different log size than the component");
-                claimed[t][i] = 1;
-                for (int o : c.masks[k]) if (std::find(offs[t][i].begin(), offs[t][i].end(), o) == offs[t][i].end()) offs[t][i].push_back(o);
-            }
-            uint32_t n_c = 0;
-            // the full instruction validation of nx_air_compile, ALWAYS (a caller-supplied kernel skips the compilation, and the
-            // host interpreter of the OODS check indexes registers and secure constants with these fields)
-            H_TRY(validate_air_program(ctx, c.prog.data(), (uint32_t)c.prog.size(), c.n_regs, (uint32_t)c.cols.size(), (uint32_t)c.econsts.size() / 4, &n_c));
-            if (c.kernel) {
-                uint32_t kc = 0, ke = 0, kn = 0;
-                air_kernel_shape(c.kernel, &kc, &ke, &kn);
-                if (kc != c.cols.size() || ke != c.econsts.size() / 4 || kn != c.n_constraints)
-                    return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: the supplied kernel was compiled for a different column / constant / constraint count than the component");
-            }
-            for (auto& in : c.prog) {
-                if (in.op == NX_C_LOAD || in.op == NX_C_LOADE) {
-                    const uint32_t w = in.op == NX_C_LOADE ? 4 : 1;
-                    for (uint32_t j = 0; j < w; j++) {
-                        if (in.a + j >= c.cols.size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: LOAD of a column the component does not claim");
-                        const auto& m = c.masks[in.a + j];
-                        if (std::find(m.begin(), m.end(), (int)in.b) == m.end()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: LOAD at an offset missing from the column's mask");
-                    }
-                }
-            }
-            if (n_c != c.n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: constraint count mismatch");
+// the consistency rules of oracle-side gair_check: every committed column claimed, sizes agree, loads inside the masks
+int GenericAir::check(const CommitmentSchemeProver& cs) {
+    if (cs.trees.size() != 3) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: exactly three trace trees (preprocessed, main, interaction) must be committed first");
+    if (comps.empty()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: no components");
+    tree_logs.assign(3, {}); offs.assign(3, {});
+    std::vector<std::vector<char>> claimed(3);
+    for (int t = 0; t < 3; t++) { for (auto& c : cs.trees[t].polys) tree_logs[t].push_back(c.log); claimed[t].assign(tree_logs[t].size(), 0); offs[t].resize(tree_logs[t].size()); }
+    for (auto& c : comps) {
+        if (c.masks.size() != c.cols.size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: one mask list per component column required");
+        for (size_t k = 0; k < c.cols.size(); k++) {
+            const uint32_t t = c.cols[k].first, i = c.cols[k].second;
+            if (t > 2 || i >= tree_logs[t].size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column outside the committed trees");
+            if (tree_logs[t][i] != c.log_size) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column of a different log size than the component");
+            claimed[t][i] = 1;
+            for (int o : c.masks[k]) if (std::find(offs[t][i].begin(), offs[t][i].end(), o) == offs[t][i].end()) offs[t][i].push_back(o);
         }
-        for (int t = 0; t < 3; t++) for (char x : claimed[t]) if (!x) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: a committed column is claimed by no component");
-        return NX_OK;
-    }
-
-    int compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) override {
-        const uint32_t lcd = cs.cfg.log_constraint_degree, blow = cs.cfg.log_blowup;
-        size_t total = 0;
-        for (auto& c : comps) total += c.n_constraints;
-        std::vector<QM31> powers(total);
-        { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
-        std::map<uint32_t, SecureColumn> sub;
-        size_t remaining = total;
-        for (auto& c : comps) {
-            const uint32_t e = c.log_size + lcd;
-            const size_t nc = c.n_constraints;
-            std::vector<uint32_t> pw(4 * nc);          // the LAST nc remaining powers, reversed (accumulator.columns())
-            for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[remaining - 1 - j]);
-            remaining -= nc;
-            const std::vector<uint32_t> den = vanishing_denominators(c.log_size, e);
-            std::vector<const uint32_t*> ptrs(c.cols.size());
-            DevBuf ext;
-            if (e == c.log_size + blow) {
-                for (size_t k = 0; k < c.cols.size(); k++) ptrs[k] = cs.trees[c.cols[k].first].evals[c.cols[k].second].ptr;
-            } else {                                   // "need_to_extend": re-evaluate the polynomials on the constraint domain
-                H_TRY(ext.alloc(ctx, c.cols.size() << e));
-                std::vector<const uint32_t*> src(c.cols.size());
-                for (size_t k = 0; k < c.cols.size(); k++) src[k] = cs.trees[c.cols[k].first].polys[c.cols[k].second].ptr;
-                auto dst = col_ptrs(ext.p, (uint32_t)c.cols.size(), e);
-                H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), (uint32_t)c.cols.size(), c.log_size, e - c.log_size, dst.data()));
-                for (size_t k = 0; k < c.cols.size(); k++) ptrs[k] = dst[k];
-            }
-            if (!sub.count(e)) { H_TRY(sub[e].alloc(ctx, e)); H_TRY(nx_memset_zero(ctx, sub[e].buf.p, sub[e].buf.words)); }
-            if (!c.kernel) {
-                H_TRY(nx_air_compile(ctx, c.prog.data(), (uint32_t)c.prog.size(), c.n_regs, (uint32_t)c.cols.size(), (uint32_t)c.econsts.size() / 4, c.n_constraints, &c.owned, nullptr));
-                c.kernel = c.owned;
-            }
-            H_TRY(nx_air_eval(ctx, c.kernel, ptrs.data(), c.econsts.data(), pw.data(), den.data(), c.log_size, e, sub[e].c));
+        uint32_t n_c = 0;
+        // the full instruction validation of nx_air_compile, ALWAYS (a caller-supplied kernel skips the compilation, and the
+        // host interpreter of the OODS check indexes registers and secure constants with these fields)
+        H_TRY(validate_air_program(ctx, c.prog.data(), (uint32_t)c.prog.size(), c.n_regs, (uint32_t)c.cols.size(), (uint32_t)c.econsts.size() / 4, &n_c));
+        if (c.kernel) {
+            uint32_t kc = 0, ke = 0, kn = 0;
+            air_kernel_shape(c.kernel, &kc, &ke, &kn);
+            if (kc != c.cols.size() || ke != c.econsts.size() / 4 || kn != c.n_constraints)
+                return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: the supplied kernel was compiled for a different column / constant / constraint count than the component");
         }
-        return finalize_accumulation(cs, sub, out_polys, out_log);
-    }
-
-    void mask_points(QPt oods, MaskPoints* points) override {
-        points->assign(3, {});
-        for (int t = 0; t < 3; t++)
-            for (size_t c = 0; c < offs[t].size(); c++) {
-                std::vector<QPt> pts;
-                for (int o : offs[t][c]) {
-                    if (o == 0) { pts.push_back(oods); continue; }
-                    const int64_t idx = ((int64_t)o * ((int64_t)1 << (31 - tree_logs[t][c]))) & 0x7fffffffLL;
-                    Pt s = pt_from_index((u32)idx);
-                    QPt step; step.x = q_from_m(s.x); step.y = q_from_m(s.y);
-                    pts.push_back(qpt_add(oods, step));
-                }
-                points->at(t).push_back(pts);
-            }
-    }
-
-    // the recorded program over QM31: every register holds the value of its expression at the OODS point
-    QM31 eval_composition_at_point(QPt point, const SampledValues& sv, QM31 rc) override {
-        QM31 acc = q_zero();
-        for (auto& c : comps) {
-            const QM31 di = q_inv(coset_vanishing_q(c.log_size, point));
-            std::vector<QM31> R(c.n_regs, q_zero());
-            auto sampled = [&](uint32_t col, int off) {
-                const uint32_t t = c.cols[col].first, i = c.cols[col].second;
-                const size_t k = std::find(offs[t][i].begin(), offs[t][i].end(), off) - offs[t][i].begin();
-                return sv[t][i][k];
-            };
-            for (auto& in : c.prog) {
-                switch (in.op) {
-                case NX_C_LOAD: R[in.dst] = sampled(in.a, (int)in.b); break;
-                case NX_C_CONST: R[in.dst] = q_from_m(in.a); break;
-                case NX_C_ADD: case NX_C_ADDE: case NX_C_ADDEB: R[in.dst] = q_add(R[in.a], R[in.b]); break;
-                case NX_C_SUB: case NX_C_SUBE: R[in.dst] = q_sub(R[in.a], R[in.b]); break;
-                case NX_C_MUL: case NX_C_MULE: case NX_C_MULEB: R[in.dst] = q_mul(R[in.a], R[in.b]); break;
-                case NX_C_NEG: R[in.dst] = q_sub(q_zero(), R[in.a]); break;
-                case NX_C_CONSTE: R[in.dst] = q_load(&c.econsts[4 * in.a]); break;
-                case NX_C_LOADE: {
-                    QM31 v = sampled(in.a, (int)in.b);
-                    v = q_add(v, q_mul(sampled(in.a + 1, (int)in.b), qm(0, 1, 0, 0)));
-                    v = q_add(v, q_mul(sampled(in.a + 2, (int)in.b), qm(0, 0, 1, 0)));
-                    v = q_add(v, q_mul(sampled(in.a + 3, (int)in.b), qm(0, 0, 0, 1)));
-                    R[in.dst] = v; break;
-                }
-                case NX_C_CONSTRAINT_B: case NX_C_CONSTRAINT_E: acc = q_add(q_mul(acc, rc), q_mul(di, R[in.a])); break;
-                default: break;
+        for (auto& in : c.prog) {
+            if (in.op == NX_C_LOAD || in.op == NX_C_LOADE) {
+                const uint32_t w = in.op == NX_C_LOADE ? 4 : 1;
+                for (uint32_t j = 0; j < w; j++) {
+                    if (in.a + j >= c.cols.size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: LOAD of a column the component does not claim");
+                    const auto& m = c.masks[in.a + j];
+                    if (std::find(m.begin(), m.end(), (int)in.b) == m.end()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: LOAD at an offset missing from the column's mask");
                 }
             }
         }
-        return acc;
+        if (n_c != c.n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: constraint count mismatch");
     }
-};
+    for (int t = 0; t < 3; t++) for (char x : claimed[t]) if (!x) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: a committed column is claimed by no component");
+    return NX_OK;
+}
 
-}  // namespace nxhip
+int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) {
+    const uint32_t lcd = cs.cfg.log_constraint_degree;
+    size_t total = 0;
+    for (auto& c : comps) total += c.n_constraints;
+    std::vector<QM31> powers(total);
+    { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
+    std::map<uint32_t, SecureColumn> sub;
+    size_t remaining = total;
+    for (auto& c : comps) {
+        const uint32_t e = c.log_size + lcd;
+        const size_t nc = c.n_constraints;
+        std::vector<uint32_t> pw(4 * nc);          // the LAST nc remaining powers, reversed (accumulator.columns())
+        for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[remaining - 1 - j]);
+        remaining -= nc;
+        const std::vector<uint32_t> den = vanishing_denominators(c.log_size, e);
+        std::vector<char> masked(c.cols.size(), 0);
+        for (size_t k = 0; k < c.cols.size(); k++) for (int o : c.masks[k]) if (o != 0) masked[k] = 1;
+        EvalDomainCols cols;
+        H_TRY(columns_on_eval_domain(cs, c.cols, c.log_size, e, masked, &cols));
+        SecureColumn* acc = nullptr;
+        H_TRY(composition_accumulator(cs, sub, e, &acc));
+        if (!c.kernel) {
+            H_TRY(nx_air_compile(ctx, c.prog.data(), (uint32_t)c.prog.size(), c.n_regs, (uint32_t)c.cols.size(), (uint32_t)c.econsts.size() / 4, c.n_constraints, &c.owned, nullptr));
+            c.kernel = c.owned;
+        }
+        const uint64_t rb = cs.dist.on() ? cs.dist.begin(e) : 0;
+        uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = bias_rows(acc->c[k], rb);
+        H_TRY(air_eval_rows(ctx, c.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), c.log_size, e, a4, (uint32_t)rb, (uint32_t)acc->rows));
+    }
+    return finalize_accumulation(cs, sub, out_polys, out_log);
+}
 
-struct nx_prover {
-    nx_ctx* ctx; nx_pcs_config ucfg; nxhip::PcsConfig cfg; nx_twiddles* tw = nullptr; uint32_t max_log;
-    nxhip::Blake2sChannel channel;
-    nxhip::CommitmentSchemeProver* cs = nullptr;
-    struct Run { nxhip::DevBuf slab; uint32_t n_cols, log; };
-    std::vector<Run> pending; bool open = false;
-};
+void GenericAir::mask_points(QPt oods, MaskPoints* points) {
+    points->assign(3, {});
+    for (int t = 0; t < 3; t++)
+        for (size_t c = 0; c < offs[t].size(); c++) {
+            std::vector<QPt> pts;
+            for (int o : offs[t][c]) {
+                if (o == 0) { pts.push_back(oods); continue; }
+                const int64_t idx = ((int64_t)o * ((int64_t)1 << (31 - tree_logs[t][c]))) & 0x7fffffffLL;
+                Pt s = pt_from_index((u32)idx);
+                QPt step; step.x = q_from_m(s.x); step.y = q_from_m(s.y);
+                pts.push_back(qpt_add(oods, step));
+            }
+            points->at(t).push_back(pts);
+        }
+}
 
-namespace nxhip {
+// the recorded program over QM31: every register holds the value of its expression at the OODS point
+QM31 GenericAir::eval_composition_at_point(QPt point, const SampledValues& sv, QM31 rc) {
+    QM31 acc = q_zero();
+    for (auto& c : comps) {
+        const QM31 di = q_inv(coset_vanishing_q(c.log_size, point));
+        std::vector<QM31> R(c.n_regs, q_zero());
+        auto sampled = [&](uint32_t col, int off) {
+            const uint32_t t = c.cols[col].first, i = c.cols[col].second;
+            const size_t k = std::find(offs[t][i].begin(), offs[t][i].end(), off) - offs[t][i].begin();
+            return sv[t][i][k];
+        };
+        for (auto& in : c.prog) {
+            switch (in.op) {
+            case NX_C_LOAD: R[in.dst] = sampled(in.a, (int)in.b); break;
+            case NX_C_CONST: R[in.dst] = q_from_m(in.a); break;
+            case NX_C_ADD: case NX_C_ADDE: case NX_C_ADDEB: R[in.dst] = q_add(R[in.a], R[in.b]); break;
+            case NX_C_SUB: case NX_C_SUBE: R[in.dst] = q_sub(R[in.a], R[in.b]); break;
+            case NX_C_MUL: case NX_C_MULE: case NX_C_MULEB: R[in.dst] = q_mul(R[in.a], R[in.b]); break;
+            case NX_C_NEG: R[in.dst] = q_sub(q_zero(), R[in.a]); break;
+            case NX_C_CONSTE: R[in.dst] = q_load(&c.econsts[4 * in.a]); break;
+            case NX_C_LOADE: {
+                QM31 v = sampled(in.a, (int)in.b);
+                v = q_add(v, q_mul(sampled(in.a + 1, (int)in.b), qm(0, 1, 0, 0)));
+                v = q_add(v, q_mul(sampled(in.a + 2, (int)in.b), qm(0, 0, 1, 0)));
+                v = q_add(v, q_mul(sampled(in.a + 3, (int)in.b), qm(0, 0, 0, 1)));
+                R[in.dst] = v; break;
+            }
+            case NX_C_CONSTRAINT_B: case NX_C_CONSTRAINT_E: acc = q_add(q_mul(acc, rc), q_mul(di, R[in.a])); break;
+            default: break;
+            }
+        }
+    }
+    return acc;
+}
+
 }  // namespace nxhip
 
 using namespace nx;
@@ -1408,42 +1095,11 @@ int nx_lde_commit(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_cols, u
     return rc;
 }
 
-int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
-                           size_t ad_len, const nx_comm* comm, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
-    NX_GUARD(ctx);
-    if (!ctx || !comps || !cfg || !proof_words || !n_words || !comm) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth_sharded: NULL argument");
-    std::vector<uint32_t> w;
-    int rc = nxhip::prove_synth_sharded(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
-    ctx->timing = false;
-    if (rc != NX_OK) return rc;
-    uint32_t* out = (uint32_t*)malloc(w.size() * 4);
-    if (!out) return set_err(ctx, NX_ERR_OOM, "nx_prove_synth_sharded: malloc failed");
-    memcpy(out, w.data(), w.size() * 4);
-    *proof_words = out; *n_words = w.size();
-    return NX_OK;
-}
-
-int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
-                   size_t ad_len, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
-    NX_GUARD(ctx);
-    if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth: NULL argument");
-    std::vector<uint32_t> w;
-    int rc = nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, &w, stats);
-    ctx->timing = false;
-    if (rc != NX_OK) return rc;
-    uint32_t* out = (uint32_t*)malloc(w.size() * 4);
-    if (!out) return set_err(ctx, NX_ERR_OOM, "nx_prove_synth: malloc failed");
-    memcpy(out, w.data(), w.size() * 4);
-    *proof_words = out; *n_words = w.size();
-    return NX_OK;
-}
-
-
 // MerkleProver::decommit(queries_per_log_size, columns) (inside stwo::prover::prove -> CommitmentSchemeProver::prove_values,
 // reference machine.rs:286-290): the values of `columns` (commit order, any sizes) at the queried rows, plus the witness a
 // verifier needs to recompute the root — sibling hashes not derivable from the queries and the column values of visited but
-// unqueried nodes.  query_logs ascending or not, one (log, count) pair per queried layer; `queries` holds the sorted, deduplicated
-// positions of every queried layer back to back.  All reads travel in ONE gather launch and one device-to-host copy.
+// unqueried nodes.  One (log, count) pair per queried layer; `queries` holds the sorted, deduplicated positions of every queried
+// layer back to back.  All reads travel in ONE gather launch and one device-to-host copy.
 // Outputs are malloc'd (nx_free_host); hash_witness has 8 words per hash.
 int nx_merkle_decommit(nx_ctx* ctx, const nx_tree* tree, const uint32_t* const* d_cols, const uint32_t* log_sizes, uint32_t n_cols,
                        const uint32_t* query_logs, const uint32_t* query_counts, uint32_t n_query_logs, const uint64_t* queries,
@@ -1469,10 +1125,12 @@ int nx_merkle_decommit(nx_ctx* ctx, const nx_tree* tree, const uint32_t* const* 
     std::vector<nxhip::ColumnRef> cols(n_cols);
     for (uint32_t i = 0; i < n_cols; i++) {
         if (log_sizes[i] >= n_layers || !d_cols[i]) return set_err(ctx, NX_ERR_ARG, "nx_merkle_decommit: column larger than the tree (or NULL)");
-        cols[i] = {const_cast<uint32_t*>(d_cols[i]), log_sizes[i]};
+        cols[i] = {const_cast<uint32_t*>(d_cols[i]), log_sizes[i], false};
     }
+    nxhip::TreeRef ref; ref.local = const_cast<nx_tree*>(tree); ref.n_layers = n_layers;
+    struct Release { nxhip::TreeRef& r; ~Release() { r.local = nullptr; } } release{ref};   // borrowed: the caller owns the tree
     nxhip::GatherBatch gb;
-    nxhip::DecommitPlan plan = nxhip::merkle_decommit_plan(tree, qpl, cols, &gb);
+    nxhip::DecommitPlan plan = nxhip::merkle_decommit_plan(ref, qpl, cols, &gb);
     NX_TRY(gb.run(ctx));
     std::vector<uint32_t> qv; nxhip::MerkleDecommitment d;
     nxhip::merkle_decommit_fill(plan, gb, &qv, &d);
@@ -1502,6 +1160,16 @@ int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_siz
     p->cs = new nxhip::CommitmentSchemeProver(ctx, p->tw, p->cfg);
     *out = p;
     return NX_OK;
+}
+
+// One proof on several GPUs: every GPU runs the same session (same transcript calls, same trees) with its own communicator; it
+// fills only the columns nx_prover_tree_begin hands it (NULL for the others).  Call before the first tree.
+int nx_prover_set_comm(nx_prover* p, const nx_comm* comm) {
+    NX_GUARD(p ? p->ctx : nullptr);
+    if (!p || !comm) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_set_comm: NULL argument");
+    if (!p->cs->trees.empty() || p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_set_comm: must be called before the first tree");
+    p->comm_copy = *comm; p->has_comm = true;
+    return nxhip::dist_init(p->ctx, &p->comm_copy, &p->cs->dist);
 }
 
 void nx_prover_destroy(nx_prover* p) {
@@ -1548,12 +1216,14 @@ int nx_prover_tree_begin(nx_prover* p, const uint32_t* log_sizes, uint32_t n_col
     if (p->cs->trees.size() >= 3) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: the three trace trees are already committed");
     for (uint32_t i = 0; i < n_cols; i++) if (log_sizes[i] < 1 || log_sizes[i] > p->max_log) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: column log size outside [1, max_log_size]");
     p->pending.clear();
-    for (uint32_t i = 0; i < n_cols;) {             // one slab per run of equal sizes (TreeBuilder::extend_evals groups)
+    const nxhip::Dist& D = p->cs->dist;
+    for (uint32_t i = 0; i < n_cols;) {             // one slab per run of equal sizes (TreeBuilder::extend_evals groups); row-sharded: this GPU's range of the run
         uint32_t j = i; while (j < n_cols && log_sizes[j] == log_sizes[i]) j++;
         nx_prover::Run r; r.n_cols = j - i; r.log = log_sizes[i];
-        int rc = r.slab.alloc(p->ctx, (size_t)r.n_cols << r.log);
+        r.lo = nxhip::Dist::cut(r.n_cols, D.rank, D.world); r.hi = nxhip::Dist::cut(r.n_cols, D.rank + 1, D.world);
+        int rc = r.slab.alloc(p->ctx, (size_t)std::max<uint32_t>(r.hi - r.lo, 1) << r.log);
         if (rc != NX_OK) { p->pending.clear(); return rc; }
-        for (uint32_t k = 0; k < r.n_cols; k++) d_cols_out[i + k] = r.slab.p + ((size_t)k << r.log);
+        for (uint32_t k = 0; k < r.n_cols; k++) d_cols_out[i + k] = (k >= r.lo && k < r.hi) ? r.slab.p + ((size_t)(k - r.lo) << r.log) : nullptr;
         p->pending.push_back(std::move(r));
         i = j;
     }
@@ -1566,7 +1236,7 @@ int nx_prover_tree_commit(nx_prover* p, uint8_t root[32]) {
     if (!p) return set_err(nullptr, NX_ERR_ARG, "nx_prover_tree_commit: NULL prover");
     if (!p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit: no tree was begun");
     nxhip::TreeBuilder tb = p->cs->tree_builder();
-    for (auto& r : p->pending) tb.extend_evals(std::move(r.slab), r.n_cols, r.log);
+    for (auto& r : p->pending) tb.extend_evals_local(std::move(r.slab), r.n_cols, r.log, r.lo, r.hi);
     p->pending.clear(); p->open = false;
     NX_TRY(tb.commit(p->channel));
     if (root) memcpy(root, p->cs->trees.back().root.w, 32);
@@ -1602,6 +1272,7 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     nx_prove_stats* st = stats ? stats : &local;
     memset(st, 0, sizeof *st);
     if (timed) { ctx->timing = true; timing_reset(ctx); }
+    p->cs->dist.comm_ms = &st->comm_ms; p->cs->dist.comm_bytes = &st->comm_bytes;
     nxhip::Lap lap{ctx, timed, 0};
     double t_start = 0;
     if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = nxhip::now_ms(); }
@@ -1609,6 +1280,7 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     int rc = nxhip::prove_core(ctx, *p->cs, p->channel, p->cfg, p->tw, air, &w, st, lap);
     if (timed) nxhip::finish_stats(ctx, st, t_start);
     ctx->timing = false;
+    p->cs->dist.comm_ms = nullptr; p->cs->dist.comm_bytes = nullptr;
     if (rc != NX_OK) return rc;
     uint32_t* out = (uint32_t*)malloc(w.size() * 4);
     if (!out) return set_err(ctx, NX_ERR_OOM, "nx_prover_prove: malloc failed");

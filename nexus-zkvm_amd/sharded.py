@@ -271,6 +271,38 @@ class _ThreadComm:
         g.barrier.wait()
         return out
 
+    def _copy(self, dst, src, n):
+        import ctypes as C
+        if n:
+            self.be._chk(self.be.L.nx_copy(self.be.ctx, C.c_void_p(dst), C.c_void_p(src), C.c_size_t(n)))
+
+    def alltoallv(self, send_ptr, soff, scnt, recv_ptr, roff, rcnt):
+        g = self.g
+        g.slots[self.rank] = (send_ptr, soff, scnt)
+        g.barrier.wait()
+        for src in range(g.world):
+            sp, so, sc = g.slots[src]
+            assert sc[self.rank] == rcnt[src], (src, self.rank, sc[self.rank], rcnt[src])
+            self._copy(recv_ptr + 4 * roff[src], sp + 4 * so[self.rank], rcnt[src])
+        self.be.sync()
+        g.barrier.wait()
+
+    def allgather_dev(self, send_ptr, n, recv_ptr):
+        g = self.g
+        g.slots[self.rank] = send_ptr
+        g.barrier.wait()
+        for src in range(g.world):
+            self._copy(recv_ptr + 4 * n * src, g.slots[src], n)
+        self.be.sync()
+        g.barrier.wait()
+
+
+class _DevView:
+    """A raw device pointer as a zero-copy torch tensor (int32 words) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
 
 class TorchDistComm:
     """One process per GPU over torch.distributed (backend 'nccl' = RCCL over xGMI).  Device buffers of the library are
@@ -330,3 +362,47 @@ class TorchDistComm:
         t = self._bytes_tensor(data, nbytes)
         self.dist.broadcast(t, root)
         return bytes(t[:nbytes].cpu().numpy().tobytes())
+
+    # ---- the device collectives of the row-sharded prove: RCCL works directly on the library's buffers (zero-copy views)
+    def _view(self, ptr, n):
+        return self.torch.as_tensor(_DevView(ptr, max(int(n), 1)), device=self.device)[:int(n)]
+
+    def alltoallv(self, send_ptr, soff, scnt, recv_ptr, roff, rcnt):
+        W = self.world
+        contiguous = all(soff[r + 1] == soff[r] + scnt[r] for r in range(W - 1)) and all(roff[r + 1] == roff[r] + rcnt[r] for r in range(W - 1))
+        staged = self.dist.get_backend() != "nccl"       # gloo (tests): through host memory
+        if contiguous and sum(scnt) + sum(rcnt) > 0:
+            src = self._view(send_ptr + 4 * soff[0], sum(scnt))
+            dst = self._view(recv_ptr + 4 * roff[0], sum(rcnt))
+            if staged:
+                out = self.torch.empty(sum(rcnt), dtype=self.torch.int32)
+                self.dist.all_to_all_single(out, src.cpu(), list(rcnt), list(scnt))
+                dst.copy_(out.to(self.device))
+            else:
+                self.dist.all_to_all_single(dst, src, list(rcnt), list(scnt))
+        else:
+            ops, keep = [], []
+            for r in range(W):
+                if scnt[r]:
+                    t = self._view(send_ptr + 4 * soff[r], scnt[r]); t = t.cpu() if staged else t
+                    keep.append(t); ops.append(self.dist.P2POp(self.dist.isend, t, r))
+                if rcnt[r]:
+                    d = self._view(recv_ptr + 4 * roff[r], rcnt[r]); t = self.torch.empty(rcnt[r], dtype=self.torch.int32) if staged else d
+                    keep.append((d, t)); ops.append(self.dist.P2POp(self.dist.irecv, t, r))
+            for w in self.dist.batch_isend_irecv(ops) if ops else []:
+                w.wait()
+            if staged:
+                for k in keep:
+                    if isinstance(k, tuple):
+                        k[0].copy_(k[1].to(self.device))
+        self.torch.cuda.synchronize(self.device)
+
+    def allgather_dev(self, send_ptr, n, recv_ptr):
+        src, dst = self._view(send_ptr, n), self._view(recv_ptr, n * self.world)
+        if self.dist.get_backend() != "nccl":
+            out = self.torch.empty(n * self.world, dtype=self.torch.int32)
+            self.dist.all_gather_into_tensor(out, src.cpu())
+            dst.copy_(out.to(self.device))
+        else:
+            self.dist.all_gather_into_tensor(dst, src)
+        self.torch.cuda.synchronize(self.device)

@@ -10,25 +10,39 @@
 //                              bit-reversed circle-domain storage order, scan, redo it.
 #pragma once
 #include <vector>
+#include <thread>
 #include "poly.h"
 
 namespace orc {
 
+// rows are independent in combine / finalize_col: the CPU baseline runs them on every host core (the result does not depend on it)
+static inline int& logup_n_threads() { static int v = 1; return v; }
+template <class F> static inline void logup_rows(u32 n, F f) {
+    const int nt = n >= 4096 ? logup_n_threads() : 1;
+    if (nt <= 1) { f(0u, n); return; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < nt; k++) th.emplace_back(f, (u32)((u64)n * k / nt), (u32)((u64)n * (k + 1) / nt));
+    for (auto& x : th) x.join();
+}
+
 static inline void logup_combine(const u32* const* cols, u32 n_cols, const u32* alpha_powers, const u32* z, int log, u32* const out4[4]) {
-    for (u32 r = 0; r < (1u << log); r++) {
+    logup_rows(1u << log, [&](u32 r0, u32 r1) {
+    for (u32 r = r0; r < r1; r++) {
         QM31 s = qm31_zero();
         for (u32 k = 0; k < n_cols; k++) s = qm31_add(s, qm31_mul_m31(qm31_load(alpha_powers + 4 * k), cols[k][r]));
         s = qm31_sub(s, qm31_load(z));
         u32 w[4]; qm31_store(w, s);
         for (int q = 0; q < 4; q++) out4[q][r] = w[q];
     }
+    });
 }
 
 struct LogupFrac { const u32* mult; QM31 scale; const u32* den[4]; };
 static inline QM31 frac_num(const LogupFrac& f, u32 r) { return f.mult ? qm31_mul_m31(f.scale, f.mult[r]) : f.scale; }
 
 static inline void logup_finalize_col(int log, const LogupFrac& fa, const LogupFrac* fb, const u32* const* prev4, u32* const out4[4]) {
-    for (u32 r = 0; r < (1u << log); r++) {
+    logup_rows(1u << log, [&](u32 r0, u32 r1) {
+    for (u32 r = r0; r < r1; r++) {
         QM31 num = frac_num(fa, r), den = qm31(fa.den[0][r], fa.den[1][r], fa.den[2][r], fa.den[3][r]);
         if (fb) {
             QM31 c = frac_num(*fb, r), d = qm31(fb->den[0][r], fb->den[1][r], fb->den[2][r], fb->den[3][r]);
@@ -40,6 +54,7 @@ static inline void logup_finalize_col(int log, const LogupFrac& fa, const LogupF
         u32 w[4]; qm31_store(w, v);
         for (int q = 0; q < 4; q++) out4[q][r] = w[q];
     }
+    });
 }
 
 static inline void logup_finalize_last(int log, u32* const col4[4], u32* claimed_sum) {

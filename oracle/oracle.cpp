@@ -253,6 +253,7 @@ void orc_logup_finalize_col(int log, const uint32_t* mult_a, const uint32_t* sca
     logup_finalize_col(log, fa, den_b4 ? &fb : nullptr, prev4, out4);
 }
 void orc_logup_finalize_last(int log, uint32_t** col4, uint32_t* claimed_sum) { logup_finalize_last(log, col4, claimed_sum); }
+void orc_logup_set_threads(int n) { logup_n_threads() = n < 1 ? 1 : n; }
 
 // ---- the remaining Backend supertraits (backend_ops.h) ----
 void orc_batch_inverse_m31(const uint32_t* src, uint32_t* dst, size_t n) { batch_inverse_m31(src, dst, n); }

@@ -1,0 +1,117 @@
+"""The reference-shaped synthetic machine of nx_prove_machine (nexus-zkvm_amd/csrc/machine.hip), restated on the CPU oracle.
+
+TEST INFRASTRUCTURE (checker / cpu_baseline only).  An independent statement of the same machine: the AIR is recorded with the
+Python ProgramBuilder (nexus_zkvm_amd.air_program — a different recorder, register allocation and instruction order than the C++
+emitter of machine.hip), the trace and the logup interaction trace come from the oracle (oracle/air.h, oracle/logup.h), the
+transcript follows reference prover/src/machine.rs:197-290 through the oracle's prover session (oracle/air_generic.h).  The
+proof must equal nx_prove_machine's word for word.
+
+Component (log_size, n_pre, n_main, 4 L).  Fraction j of a row: den_j = main[a_j] - z (j even) or main[a_j] + alpha main[b_j] - z
+(j odd); num_j = 1, or -main[m_j] when j % 3 == 2; a_j = (3 + 7 j) % n_main, b_j = (5 + 11 j) % n_main, m_j = (2 + 13 j) % n_main.
+"""
+import os
+
+import numpy as np
+
+import oracle_lib as O
+
+P = O.P
+
+
+def logup_cols(j, n_main):
+    return (3 + 7 * j) % n_main, (5 + 11 * j) % n_main, (2 + 13 * j) % n_main
+
+
+def machine_component(ap, comp, loc, z, alpha, shift):
+    """The component's AIR through the recording evaluator: what `add_constraints` of a FrameworkEval would declare."""
+    log, n_pre, n_main, n_inter = comp
+    L = n_inter // 4
+    pre0, main0, inter0 = loc
+    pb = ap.ProgramBuilder()
+    PRE, MAIN, INT = 0, n_pre, n_pre + n_main
+    m0, m0n = pb.next_trace_mask(MAIN + 0, (0, 1))
+    m1, m1n = pb.next_trace_mask(MAIN + 1, (0, 1))
+    (is_last,) = pb.next_trace_mask(PRE + 1)
+    not_last = 1 - is_last
+    pb.add_constraint((m0n - m0 - 1) * not_last)
+    pb.add_constraint((m1n - m1 - m0) * not_last)
+    main = [m0, m1] + [pb.next_trace_mask(MAIN + k)[0] for k in range(2, n_main)]
+    for k in range(2, n_main):
+        if k % 16 >= 2:
+            pb.add_constraint(main[k] - main[k - 1] * main[k - 1] - main[k - 2] * main[k - 2])
+    if L:
+        ze, al, sh = pb.econst(z), pb.econst(alpha), pb.econst(shift)
+        prev = None
+        for j in range(L):
+            a, b, m = logup_cols(j, n_main)
+            den = (al * main[b] + main[a] - ze) if j & 1 else (main[a] - ze)          # E arithmetic: B - E lowers to (-E) + B
+            if j + 1 < L:
+                (cur,) = pb.next_secure_mask(INT + 4 * j)
+                diff = cur if prev is None else cur - prev
+            else:
+                prow, cur = pb.next_secure_mask(INT + 4 * j, (-1, 0))
+                diff = cur - prow
+                if prev is not None:
+                    diff = diff - prev
+                diff = diff + sh
+            num_neg = main[m] if j % 3 == 2 else pb.const(P - 1)                      # - num
+            pb.add_constraint(diff * den + num_neg)
+            prev = cur
+    cols = [(0, pre0 + k) for k in range(n_pre)] + [(1, main0 + k) for k in range(n_main)] + [(2, inter0 + k) for k in range(n_inter)]
+    prog = pb.build()
+    # mask lists exactly as the machine declares them (columns the program happens not to load are still sampled at offset 0)
+    masks = [[0]] * n_pre + [[0, 1], [0, 1]] + [[0]] * (n_main - 2) + [([-1, 0] if k // 4 + 1 == L else [0]) for k in range(n_inter)]
+    return ap.Component(log, prog, cols, masks)
+
+
+def interaction_trace(comp, main_cols, z, alpha):
+    """LogupTraceGenerator as the reference drives it (one fraction per column, finalize_col, finalize_last) on the oracle.
+    main_cols: the component's finalized main-trace columns.  Returns (4 L coordinate columns, claimed sum)."""
+    log, n_pre, n_main, n_inter = comp
+    L = n_inter // 4
+    if L == 0:
+        return [], np.zeros(4, np.uint32)
+    ap = np.array([[1, 0, 0, 0], list(alpha)], np.uint32)
+    cols, prev = [], None
+    for j in range(L):
+        a, b, m = logup_cols(j, n_main)
+        tup = [main_cols[a], main_cols[b]] if j & 1 else [main_cols[a]]
+        den = O.logup_combine(tup, ap[:len(tup)], z)
+        if j % 3 == 2:
+            col = O.logup_finalize_col(den, scale_a=(P - 1, 0, 0, 0), mult_a=main_cols[m], prev=prev)
+        else:
+            col = O.logup_finalize_col(den, prev=prev)
+        cols.append(col); prev = col
+    cols[-1], claimed = O.logup_finalize_last(cols[-1])
+    return [c for col in cols for c in col], claimed
+
+
+def prove_machine(comps, cfg, seed=1, ad=b"", threads=None):
+    """nexus_vm_prover::prove for the machine, on the CPU oracle: returns the NXP1 proof words."""
+    import nexus_zkvm_amd.air_program as ap
+    threads = threads or max(4, os.cpu_count() or 4)
+    O.lib().orc_logup_set_threads(threads)
+    comps = [tuple(int(x) for x in c) for c in comps]
+    s = O.ProverSession(cfg, max(c[0] for c in comps), threads)
+    for byte in ad:
+        s.mix_u64(byte)                                       # machine.rs:198-200
+    for c in comps:
+        s.mix_u64(c[0])                                       # machine.rs:204-206
+    s.commit(O.synth_tree_columns(comps, 0, seed, threads=threads))            # :208-228
+    main = O.synth_tree_columns(comps, 1, seed, threads=threads)
+    s.commit(main)                                            # :230-237 (the session copies: `main` keeps the evaluations, like the reference's clone)
+    z, alpha = s.draw_felts(2)                                # :239-240
+    inter, claimed, shifts, off = [], [], [], 0
+    for c in comps:
+        cols, cs = interaction_trace(c, main[off:off + c[2]], z, alpha)
+        off += c[2]
+        inter += cols; claimed.append(cs)
+        n_inv = pow((1 << c[0]) % P, P - 2, P)
+        shifts.append(np.array([(int(x) * n_inv) % P for x in cs], np.uint32))
+    s.mix_felts(np.array(claimed, np.uint32))                 # :262
+    s.commit(inter)                                           # :263
+    locs, a, b, d = [], 0, 0, 0
+    for c in comps:
+        locs.append((a, b, d)); a += c[1]; b += c[2]; d += c[3]
+    components = [machine_component(ap, c, l, z, alpha, sh) for c, l, sh in zip(comps, locs, shifts)]
+    return s.prove(components)                                # :286-290

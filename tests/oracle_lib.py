@@ -266,6 +266,11 @@ class _SessionChannel:
         lib().orc_channel_draw_secure_felt(self.h, ptr(out))
         return out
 
+    def draw_felts(self, n):
+        out = np.zeros((n, 4), np.uint32)
+        lib().orc_channel_draw_secure_felts(self.h, C.c_size_t(n), ptr(out))
+        return out
+
     def digest(self):
         out = np.zeros(8, np.uint32)
         lib().orc_channel_digest(self.h, ptr(out))

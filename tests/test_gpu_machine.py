@@ -1,0 +1,152 @@
+"""GPU parity of the reference-shaped machine (-m gpu): nx_prove_machine — lookup elements drawn after the main commit, a real logup
+interaction trace generated on the device (nx_logup_col per column, nx_logup_finalize_last), claimed sums mixed, a recorded AIR
+compiled by nx_air_compile — against the same machine stated independently on the CPU oracle (tests/machine_ref.py), word for word;
+then the same proof from 2 / 4 / 8 ranks (row-sharded), and the generic session driven by several ranks."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (HIP runtime load order, see test_gpu_parity.py)
+
+import machine_ref as M
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+P = O.P
+THREADS = max(4, os.cpu_count() or 4)
+
+
+@pytest.fixture(scope="module")
+def be():
+    import nexus_zkvm_amd as nz
+    b = nz.HipBackend(0)
+    yield b
+    b.close()
+
+
+@pytest.fixture(scope="module")
+def nz():
+    import nexus_zkvm_amd
+    return nexus_zkvm_amd
+
+
+def _same(ref, words):
+    assert len(ref) == len(words), (len(ref), len(words))
+    if not np.array_equal(ref, words):
+        bad = int(np.nonzero(ref != words)[0][0])
+        pytest.fail(f"first differing proof word {bad} of {len(ref)} (roots are words 6..37)")
+
+
+MACHINE_CASES = [
+    ([(8, 3, 20, 8)], dict(pow_bits=6)),
+    ([(10, 27, 40, 12), (6, 2, 5, 4)], dict(pow_bits=8)),
+    ([(9, 4, 18, 4)], dict(pow_bits=5, log_constraint_degree=2)),                               # one logup column: the [-1, 0] column is the only one
+    ([(8, 3, 20, 24), (8, 2, 3, 0), (5, 2, 2, 8)], dict(pow_bits=6, hash_mode=1, fri_alpha_mode=1)),   # a component without logup columns
+    ([(12, 27, 347, 64)], dict(pow_bits=10)),                                                    # the bench's machine, small
+    ([(14, 5, 35, 16), (13, 3, 17, 8), (7, 2, 6, 4)], dict(pow_bits=7, log_constraint_degree=2)),
+]
+
+
+@pytest.mark.parametrize("comps,kw", MACHINE_CASES)
+def test_machine_prove_bit_exact_vs_oracle(be, nz, oracle, comps, kw):
+    words, stats = be.prove_machine(comps, nz.default_config(**kw), seed=0xBEEF, ad=b"\x01\x02", want_stats=True)
+    ref = M.prove_machine(comps, O.default_cfg(**kw), seed=0xBEEF, ad=b"\x01\x02", threads=THREADS)
+    _same(ref, words)
+    assert stats["total"] > 0 and (stats["interaction"] > 0 or all(c[3] == 0 for c in comps))
+    # a second prove reuses the cached kernels and gives the same bytes
+    _same(ref, be.prove_machine(comps, nz.default_config(**kw), seed=0xBEEF, ad=b"\x01\x02"))
+
+
+def test_machine_prove_at_2pow18_v1_shaped(be, nz, oracle):
+    """The shape of the reference's v1 machine: LOG_CONSTRAINT_DEGREE = 2 (reference components/mod.rs:12), a wide
+    interaction tree, small extra components of other sizes (machine.rs:82-91) — scaled to 2^18 rows so that the oracle finishes."""
+    comps = [(16, 27, 347, 128)] + [(8 + k, 2, 4 + k, 4) for k in range(6)]
+    kw = dict(log_constraint_degree=2)
+    words = be.prove_machine(comps, nz.default_config(**kw), seed=5)
+    _same(M.prove_machine(comps, O.default_cfg(**kw), seed=5, threads=THREADS), words)
+
+
+def _run_ranks(nz, world, fn):
+    from nexus_zkvm_amd.sharded import ThreadGroup
+    group = ThreadGroup(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            b = nz.HipBackend(0)
+            comm = nz.make_comm(rank, world, group.comm(rank, b))
+            results[rank] = fn(b, comm, rank)
+            b.close()
+        except Exception as e:   # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            try:
+                group.barrier.abort()
+            except Exception:
+                pass
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world,comps,kw", [
+    (2, [(9, 4, 20, 8)], dict(pow_bits=5)),
+    (4, [(10, 27, 40, 12), (6, 2, 5, 4)], dict(pow_bits=6)),
+    (2, [(9, 4, 18, 4)], dict(pow_bits=5, log_constraint_degree=2)),
+    (8, [(8, 3, 20, 24), (8, 2, 3, 0), (6, 2, 2, 8)], dict(pow_bits=6, hash_mode=1, fri_alpha_mode=1)),
+    (4, [(14, 5, 35, 16), (13, 3, 17, 8)], dict(pow_bits=7)),
+    (8, [(13, 27, 347, 64)], dict(pow_bits=8)),
+])
+def test_machine_row_sharded_equals_single_gpu(be, nz, world, comps, kw):
+    """ONE proof on 2 / 4 / 8 ranks (threads with one context each on this GPU): the logup interaction trace is computed on row
+    blocks, its last column finalised from an all-gather, the columns go back to column shards for the LDE — every rank returns the
+    single-GPU bytes (which test_machine_prove_bit_exact_vs_oracle ties to the oracle)."""
+    cfg = nz.default_config(**kw)
+    ref = be.prove_machine(comps, cfg, seed=31, ad=b"m")
+    res = _run_ranks(nz, world, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=31, ad=b"m", comm=comm, want_stats=True))
+    for r in range(world):
+        _same(ref, res[r][0])
+    assert res[0][1]["comm_bytes"] > 0
+
+
+def test_session_driven_by_several_ranks(be, nz, oracle):
+    """The generic session (nx_prover_*) as ONE proof on 2 and 4 ranks: every rank replays the same transcript calls, tree_begin hands
+    it only its columns, the proof equals the single-rank session's and the oracle session's (the logup-style AIR of air_examples)."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    log = 9
+    kw = dict(pow_bits=4)
+    cfg, ocfg = nz.default_config(**kw), O.default_cfg(**kw)
+    nat, fin = AE.logup_main_trace(log, 42)
+
+    def drive(session, uploader):
+        session.mix_u64(log)
+        session.commit([])                                    # no preprocessed columns
+        uploader(fin)
+        z, alpha = session.draw_felt(), session.draw_felt()
+        inter, shift = AE.logup_interaction_trace(log, nat, z, alpha)
+        session.mix_felts(np.zeros(4, np.uint32))
+        uploader(inter)
+        return session.prove([AE.logup_component(ap, log, z, alpha, shift)])
+
+    o = O.ProverSession(ocfg, log)
+    ref = drive(o, lambda cols: o.commit(cols))
+    s = be.prover_session(cfg, log)
+    single = drive(s, lambda cols: s.commit(cols))
+    s.close()
+    _same(ref, single)
+    for world in (2, 4):
+        def fn(b, comm, rank):
+            ss = b.prover_session(cfg, log)
+            ss.set_comm(comm)
+            out = drive(ss, lambda cols: ss.commit(cols))
+            ss.close()
+            return out
+        for w in _run_ranks(nz, world, fn):
+            _same(ref, w)

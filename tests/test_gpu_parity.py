@@ -575,14 +575,18 @@ def test_constraint_violation_is_a_proving_error(be, nz):
 
 @pytest.mark.parametrize("world,comps,kw", [
     (2, [(9, 20, 40, 24)], dict(pow_bits=6)),
-    (3, [(10, 27, 100, 64)], dict(pow_bits=8)),
-    (4, [(8, 3, 20, 0)], dict(pow_bits=5, log_constraint_degree=2)),       # fewer 16-column blocks than ranks; no interaction tree
+    (4, [(10, 27, 100, 64)], dict(pow_bits=8)),
+    (4, [(8, 3, 20, 0)], dict(pow_bits=5, log_constraint_degree=2)),       # constraint domain above the LDE: re-evaluation + a second all-to-all; no interaction tree
     (2, [(9, 18, 33, 17)], dict(pow_bits=6, hash_mode=1, fri_alpha_mode=1)),
-    (2, [(8, 3, 12, 5)], dict(pow_bits=5)),                                   # every tree fits one block: rank 0 holds all columns, rank 1 none
+    (8, [(8, 3, 5, 2)], dict(pow_bits=5)),                                    # fewer columns than ranks: some ranks transform nothing
+    (2, [(14, 4, 20, 8), (11, 2, 9, 4)], dict(pow_bits=7)),                   # FRI layers large enough to stay row-sharded; two column sizes
+    (4, [(13, 3, 18, 8), (13, 2, 7, 0), (9, 2, 3, 4)], dict(pow_bits=6, log_constraint_degree=2)),   # a run of two equal-size components shares one plan
+    (8, [(12, 27, 347, 64)], dict(pow_bits=10)),
 ])
 def test_sharded_prove_is_bit_identical_to_single_gpu(nz, oracle, world, comps, kw):
-    """SURVEY §8(e) / BASELINE config #4: nx_prove_synth_sharded with `world` ranks (one context per rank on this GPU, threads,
-    loopback transport) must return, on every rank, the proof nx_prove_synth returns on one GPU — which the oracle proves too."""
+    """SURVEY §8(e) / BASELINE config #4: ONE proof on `world` ranks (one context per rank on this GPU, threads, loopback transport):
+    column-parallel LDE, one all-to-all per tree into row blocks, local leaf hashing / constraints / quotients / FRI folds, W subtree
+    roots per tree.  Every rank must return the proof nx_prove_synth returns on one GPU — which the oracle proves too."""
     import threading
     from nexus_zkvm_amd.sharded import ThreadGroup
     cfg = nz.default_config(**kw)
@@ -610,7 +614,7 @@ def test_sharded_prove_is_bit_identical_to_single_gpu(nz, oracle, world, comps, 
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=120)
+        t.join(timeout=300)
     assert not errors, errors
     for r in range(world):
         assert results[r] is not None and np.array_equal(results[r], ref), (world, r)
