@@ -289,6 +289,11 @@ typedef struct nx_comm {
     /* device all-gather: d_recv = world x n_words, rank r's contribution at r * n_words */
     int (*allgather_dev)(void* user, const uint32_t* d_send, size_t n_words, uint32_t* d_recv);
 } nx_comm;
+/* Which columns of a tree a GPU transforms: groups = (column count, log size) per component in commit order; consecutive groups
+ * of one size form a run whose columns are cut into `world` contiguous balanced ranges; lo/hi[i] = this rank's [lo, hi) of group i.
+ * Host arithmetic only (no context, no GPU). */
+int nx_plan_local_columns(const uint32_t* group_n_cols, const uint32_t* group_log_sizes, uint32_t n_groups, int32_t rank,
+                          int32_t world, uint32_t* lo, uint32_t* hi);
 /* nx_prove_synth on the GPUs of `comm`. */
 int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg,
                            uint64_t seed, const uint8_t* ad, size_t ad_len, const nx_comm* comm, uint32_t** proof_words,

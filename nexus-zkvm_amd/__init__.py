@@ -79,11 +79,11 @@ def make_comm(rank, world, impl):
         C.memmove(h_buf, data, nbytes)
 
     def _alltoallv(_u, sp, soff, scnt, rp, roff, rcnt):
-        impl.alltoallv(sp, [soff[i] for i in range(world)], [scnt[i] for i in range(world)], rp, [roff[i] for i in range(world)], [rcnt[i] for i in range(world)])
+        impl.alltoallv(sp or 0, [soff[i] for i in range(world)], [scnt[i] for i in range(world)], rp or 0, [roff[i] for i in range(world)], [rcnt[i] for i in range(world)])
 
     c = NxComm(rank, world, None, _SEND_T(guard(lambda _u, dst, p, n: impl.send(dst, p, n))), _RECV_T(guard(lambda _u, src, p, n: impl.recv(src, p, n))),
                _ALLREDUCE_T(guard(lambda _u, p, n: impl.allreduce_m31(p, n))), _ALLGATHER_T(guard(_allgather)), _BROADCAST_T(guard(_broadcast)),
-               _ALLTOALLV_T(guard(_alltoallv)), _ALLGATHER_DEV_T(guard(lambda _u, sp, n, rp: impl.allgather_dev(sp, n, rp))))
+               _ALLTOALLV_T(guard(_alltoallv)), _ALLGATHER_DEV_T(guard(lambda _u, sp, n, rp: impl.allgather_dev(sp or 0, n, rp or 0))))
     c._impl = impl   # keep the callbacks' target alive
     return c
 

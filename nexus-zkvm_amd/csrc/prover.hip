@@ -1145,6 +1145,19 @@ int nx_merkle_decommit(nx_ctx* ctx, const nx_tree* tree, const uint32_t* const* 
     return NX_OK;
 }
 
+// The share of a tree's columns each GPU of a row-sharded prove transforms (plan_local_columns): consecutive groups of one log size
+// form a run, a run's columns are cut into `world` contiguous balanced ranges.  Pure host arithmetic (no context): a caller that
+// fills its own trace uses it to know which columns of which component are its own.
+int nx_plan_local_columns(const uint32_t* group_n_cols, const uint32_t* group_log_sizes, uint32_t n_groups, int32_t rank, int32_t world, uint32_t* lo, uint32_t* hi) {
+    if ((n_groups && (!group_n_cols || !group_log_sizes || !lo || !hi)) || world < 1 || rank < 0 || rank >= world) return set_err(nullptr, NX_ERR_ARG, "nx_plan_local_columns: bad argument");
+    std::vector<std::pair<uint32_t, uint32_t>> groups(n_groups), out;
+    for (uint32_t i = 0; i < n_groups; i++) groups[i] = {group_n_cols[i], group_log_sizes[i]};
+    nxhip::Dist d; d.rank = rank; d.world = world;
+    nxhip::plan_local_columns(groups, d, &out);
+    for (uint32_t i = 0; i < n_groups; i++) { lo[i] = out[i].first; hi[i] = out[i].second; }
+    return NX_OK;
+}
+
 // ---------------------------------------------------------------- nx_prover session (recorded AIRs) --
 int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_size, nx_prover** out) {
     NX_GUARD(ctx);

@@ -310,9 +310,12 @@ class TorchDistComm:
     nx_m31_narrow, since RCCL has no modular reduction (8 ranks x (p-1) < 2^34)."""
 
     def __init__(self, backend, device):
+        """device: the torch CUDA device of this rank's context — or None for HOST buffers (the gloo transport tests on CPU: the same
+        split / offset logic an 8-GPU RCCL run uses, over plain memory)."""
         import torch
         import torch.distributed as dist
         self.be, self.torch, self.dist, self.device = backend, torch, dist, device
+        self.host = device is None or getattr(device, "type", "") == "cpu"
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
 
     def _sync(self):
@@ -365,24 +368,41 @@ class TorchDistComm:
 
     # ---- the device collectives of the row-sharded prove: RCCL works directly on the library's buffers (zero-copy views)
     def _view(self, ptr, n):
+        if int(n) == 0:              # a rank without columns hands over a NULL buffer
+            return self.torch.empty(0, dtype=self.torch.int32) if self.host else self.torch.empty(0, dtype=self.torch.int32, device=self.device)
+        if self.host:                # host memory
+            import ctypes as C
+            return self.torch.frombuffer((C.c_int32 * max(int(n), 1)).from_address(int(ptr)), dtype=self.torch.int32)[:int(n)]
         return self.torch.as_tensor(_DevView(ptr, max(int(n), 1)), device=self.device)[:int(n)]
+
+    def _to_dev(self, t):
+        return t if self.host else t.to(self.device)
+
+    def _dev_sync(self):
+        if not self.host:
+            self.torch.cuda.synchronize(self.device)
 
     def alltoallv(self, send_ptr, soff, scnt, recv_ptr, roff, rcnt):
         W = self.world
         contiguous = all(soff[r + 1] == soff[r] + scnt[r] for r in range(W - 1)) and all(roff[r + 1] == roff[r] + rcnt[r] for r in range(W - 1))
         staged = self.dist.get_backend() != "nccl"       # gloo (tests): through host memory
-        if contiguous and sum(scnt) + sum(rcnt) > 0:
+        if contiguous:
             src = self._view(send_ptr + 4 * soff[0], sum(scnt))
             dst = self._view(recv_ptr + 4 * roff[0], sum(rcnt))
             if staged:
                 out = self.torch.empty(sum(rcnt), dtype=self.torch.int32)
-                self.dist.all_to_all_single(out, src.cpu(), list(rcnt), list(scnt))
-                dst.copy_(out.to(self.device))
+                self.dist.all_to_all_single(out, src.cpu().contiguous(), list(rcnt), list(scnt))
+                dst.copy_(self._to_dev(out))
             else:
                 self.dist.all_to_all_single(dst, src, list(rcnt), list(scnt))
         else:
             ops, keep = [], []
+            if scnt[self.rank]:      # the own share: a local copy (gloo cannot send to itself)
+                assert scnt[self.rank] == rcnt[self.rank]
+                self._view(recv_ptr + 4 * roff[self.rank], rcnt[self.rank]).copy_(self._view(send_ptr + 4 * soff[self.rank], scnt[self.rank]))
             for r in range(W):
+                if r == self.rank:
+                    continue
                 if scnt[r]:
                     t = self._view(send_ptr + 4 * soff[r], scnt[r]); t = t.cpu() if staged else t
                     keep.append(t); ops.append(self.dist.P2POp(self.dist.isend, t, r))
@@ -394,15 +414,15 @@ class TorchDistComm:
             if staged:
                 for k in keep:
                     if isinstance(k, tuple):
-                        k[0].copy_(k[1].to(self.device))
-        self.torch.cuda.synchronize(self.device)
+                        k[0].copy_(self._to_dev(k[1]))
+        self._dev_sync()
 
     def allgather_dev(self, send_ptr, n, recv_ptr):
         src, dst = self._view(send_ptr, n), self._view(recv_ptr, n * self.world)
         if self.dist.get_backend() != "nccl":
-            out = self.torch.empty(n * self.world, dtype=self.torch.int32)
-            self.dist.all_gather_into_tensor(out, src.cpu())
-            dst.copy_(out.to(self.device))
+            parts = [self.torch.empty(n, dtype=self.torch.int32) for _ in range(self.world)]
+            self.dist.all_gather(parts, src.cpu().contiguous())
+            dst.copy_(self._to_dev(self.torch.cat(parts)))
         else:
             self.dist.all_gather_into_tensor(dst, src)
-        self.torch.cuda.synchronize(self.device)
+        self._dev_sync()

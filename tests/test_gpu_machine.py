@@ -150,3 +150,39 @@ def test_session_driven_by_several_ranks(be, nz, oracle):
             return out
         for w in _run_ranks(nz, world, fn):
             _same(ref, w)
+
+
+def test_torch_transport_on_device_buffers_nccl_world1(be, nz):
+    """The RCCL transport of the row-sharded prove (nexus_zkvm_amd.sharded.TorchDistComm) on REAL device buffers of the library:
+    zero-copy torch views over nx_alloc memory, dist.all_to_all_single with split sizes and all_gather_into_tensor on the nccl (= RCCL)
+    backend.  RCCL refuses two ranks on one GPU, so this runs a one-rank group: it pins the interop (pointer views, dtypes, stream
+    hand-over) that an 8-GPU run relies on; the multi-rank split logic is covered over gloo (test_sharded_cpu.py) and by the
+    thread-rank proves above."""
+    import torch.distributed as dist
+    from nexus_zkvm_amd.sharded import TorchDistComm
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        comm = TorchDistComm(be, dev)
+        n = 1 << 12
+        a = be.columns_from_host(np.arange(n, dtype=np.uint32)[None, :])
+        b = be.columns(1, 12)
+        comm.alltoallv(a.ptr.value, [0], [n], b.ptr.value, [0], [n])
+        assert np.array_equal(b.to_cpu()[0], np.arange(n, dtype=np.uint32))
+        c = be.columns(1, 12)
+        comm.allgather_dev(a.ptr.value + 4 * 100, 1000, c.ptr.value)
+        assert np.array_equal(c.to_cpu()[0][:1000], np.arange(100, 1100, dtype=np.uint32))
+        comm.alltoallv(0, [0], [0], 0, [0], [0])                 # a rank without columns
+        # the view really is the library's memory: a torch write is seen by nx_download
+        comm._view(b.ptr.value, n)[:4] = torch.tensor([7, 8, 9, 10], dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        assert list(b.to_cpu()[0][:5]) == [7, 8, 9, 10, 4]
+        assert comm.allgather(b"abc") == [b"abc"]
+        # and one whole proof through the callbacks (world 1: the collectives are never needed, the plumbing is)
+        w = be.prove_machine([(8, 3, 9, 4)], nz.default_config(pow_bits=4), seed=3, comm=nz.make_comm(0, 1, comm))
+        assert np.array_equal(w, be.prove_machine([(8, 3, 9, 4)], nz.default_config(pow_bits=4), seed=3))
+    finally:
+        dist.destroy_process_group()

@@ -204,3 +204,91 @@ def test_torch_transport_host_buffers_over_gloo(tmp_path):
     world = 3
     mp.spawn(_host_comm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok_{r}").exists() for r in range(world))
+
+
+# ---------------- the row-sharded prove: column plan and the device collectives' split logic (host buffers over gloo) ----------
+
+def test_plan_local_columns_partitions_every_run():
+    """nx_plan_local_columns (host arithmetic of libnexus_hip.so, no GPU): consecutive groups of one size form a run; the ranks'
+    ranges partition every run contiguously and in rank order, balanced to within one column."""
+    import ctypes as C
+    import nexus_zkvm_amd as nz
+    L = nz.load_library()
+    groups = [(27, 12), (5, 12), (0, 12), (9, 10), (3, 12), (1, 7), (2, 7)]
+    n = np.array([g[0] for g in groups], np.uint32); lg = np.array([g[1] for g in groups], np.uint32)
+    for world in (1, 2, 4, 8):
+        owned = [[[] for _ in groups] for _ in range(world)]
+        for r in range(world):
+            lo, hi = np.zeros(len(groups), np.uint32), np.zeros(len(groups), np.uint32)
+            assert L.nx_plan_local_columns(n.ctypes.data_as(C.c_void_p), lg.ctypes.data_as(C.c_void_p), len(groups), r, world, lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p)) == 0
+            for g in range(len(groups)):
+                assert lo[g] <= hi[g] <= n[g]
+                owned[r][g] = list(range(lo[g], hi[g]))
+        for g in range(len(groups)):
+            assert sum((owned[r][g] for r in range(world)), []) == list(range(n[g])), (world, g)        # a partition, in rank order
+        for run in ([0, 1, 2], [3], [4], [5, 6]):
+            per_rank = [sum(len(owned[r][g]) for g in run) for r in range(world)]
+            assert max(per_rank) - min(per_rank) <= 1, (world, run, per_rank)
+    bad = np.zeros(1, np.uint32)
+    assert L.nx_plan_local_columns(n.ctypes.data_as(C.c_void_p), lg.ctypes.data_as(C.c_void_p), 1, 3, 2, bad.ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p)) != 0
+
+
+def _rowshard_worker(rank, world, port, result_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from nexus_zkvm_amd.sharded import TorchDistComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = TorchDistComm(None, None)                     # HOST buffers: the split / offset logic of the RCCL path, over plain memory
+        cut = lambda n, r: n * r // world
+        # (1) the transposition of TreeBuilder::commit_dist: column shards [lo, hi) x M rows -> rows [r Mb, (r+1) Mb) of ALL columns
+        n_run, M = 11, 64
+        mb = M // world
+        full = (np.arange(n_run * M, dtype=np.uint32).reshape(n_run, M) * 2654435761 % 1000003).astype(np.uint32)
+        lo, hi = cut(n_run, rank), cut(n_run, rank + 1)
+        n_loc = hi - lo
+        send = np.ascontiguousarray(np.stack([full[lo:hi, d * mb:(d + 1) * mb] for d in range(world)]).reshape(-1) if n_loc else np.zeros(0, np.uint32))   # transpose_blocks(pack)
+        recv = np.zeros(n_run * mb, np.uint32)
+        soff, scnt = [d * n_loc * mb for d in range(world)], [n_loc * mb] * world
+        roff, rcnt = [cut(n_run, s) * mb for s in range(world)], [(cut(n_run, s + 1) - cut(n_run, s)) * mb for s in range(world)]
+        comm.alltoallv(send.ctypes.data if n_loc else recv.ctypes.data, soff, scnt, recv.ctypes.data, roff, rcnt)
+        assert np.array_equal(recv.reshape(n_run, mb), full[:, rank * mb:(rank + 1) * mb])
+        # (2) back: row blocks of all columns -> column shards (the logup interaction trace before its LDE)
+        rows = np.ascontiguousarray(full[:, rank * mb:(rank + 1) * mb]).reshape(-1)
+        back = np.zeros(max(n_loc, 1) * M, np.uint32)
+        comm.alltoallv(rows.ctypes.data, [cut(n_run, d) * mb for d in range(world)], [(cut(n_run, d + 1) - cut(n_run, d)) * mb for d in range(world)],
+                       back.ctypes.data, [s * n_loc * mb for s in range(world)], [n_loc * mb] * world)
+        if n_loc:
+            got = back[:world * n_loc * mb].reshape(world, n_loc, mb).transpose(1, 0, 2).reshape(n_loc, M)             # transpose_blocks(unpack)
+            assert np.array_equal(got, full[lo:hi])
+        # (3) receive regions that are NOT contiguous in rank order (columns_on_eval_domain with interleaved owners): the point-to-point route
+        blocks = np.arange(world * 5, dtype=np.uint32) + 100 * rank
+        scat = np.zeros(world * 8, np.uint32)
+        comm.alltoallv(blocks.ctypes.data, [5 * d for d in range(world)], [5] * world, scat.ctypes.data, [8 * ((s + 1) % world) for s in range(world)], [5] * world)
+        for s_ in range(world):
+            assert np.array_equal(scat[8 * ((s_ + 1) % world):8 * ((s_ + 1) % world) + 5], np.arange(5 * rank, 5 * rank + 5, dtype=np.uint32) + 100 * s_)
+        # (4) all-gather of a row block into the whole column (masked columns, composition accumulator, FRI tail)
+        whole = np.zeros(M, np.uint32)
+        mine = np.ascontiguousarray(full[3, rank * mb:(rank + 1) * mb])
+        comm.allgather_dev(mine.ctypes.data, mb, whole.ctypes.data)
+        assert np.array_equal(whole, full[3])
+        open(os.path.join(result_dir, f"ok_{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_shard_collectives_over_gloo(tmp_path, world):
+    """The two device collectives of the row-sharded prove (nx_comm.alltoallv / allgather_dev as nexus_zkvm_amd.sharded.TorchDistComm
+    implements them for RCCL) with world_size 2 and 4 over gloo on host buffers, on the exact offset / count patterns the prover
+    produces: the column-shard -> row-block transposition with a column count that does not divide (11 columns), its inverse, a
+    receive layout that is not contiguous in rank order, and the row-block all-gather."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rowshard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok_{r}").exists() for r in range(world))
