@@ -251,6 +251,14 @@ int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps
                    nx_prove_stats* stats);
 void nx_free_host(void* p);
 
+/* The reference's proof bytes: `nexus_vm_prover::machine::Proof { stark_proof, claimed_sum, log_size }` (reference
+ * prover/src/machine.rs:93-98) in postcard, the serde format the SDK ships proofs in (reference sdk/Cargo.toml:22,
+ * sdk/src/stwo/seq.rs:60-64), from an NXP1 word stream plus the per-component claimed sums (4 words each) and log sizes.  Field
+ * order = Stwo's derive(Serialize) declarations [upstream-recollection — pinned only once tools/dump_reference.rs has run on a box
+ * with cargo].  Host arithmetic only (no context).  *bytes: free with nx_free_host. */
+int nx_proof_serialize_stwo(const uint32_t* proof_words, size_t n_words, const uint32_t* claimed_sums, const uint32_t* log_sizes,
+                            uint32_t n_components, uint8_t** bytes, size_t* n_bytes);
+
 /* The reference-shaped machine: as nx_prove_synth, but the interaction tree is a REAL logup trace — lookup elements (z, alpha) drawn
  * after the main commit (reference machine.rs:239-240), one fraction per logup column over main-trace columns
  * (LogupTraceGenerator, reference traits.rs:124-145, chips/range_check/range256.rs:271-288: nx_logup_col per column, then
