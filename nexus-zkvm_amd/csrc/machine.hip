@@ -216,46 +216,62 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc) 
     for (uint32_t k = 0; k < c.n_pre; k++) { g.cols.push_back({0u, (uint32_t)loc.pre0 + k}); g.masks.push_back({0}); }
     for (uint32_t k = 0; k < c.n_main; k++) { g.cols.push_back({1u, (uint32_t)loc.main0 + k}); g.masks.push_back(k < 2 ? std::vector<int>{0, 1} : std::vector<int>{0}); }
     for (uint32_t k = 0; k < c.n_inter; k++) { g.cols.push_back({2u, (uint32_t)loc.inter0 + k}); g.masks.push_back(k / 4 + 1 == L ? std::vector<int>{-1, 0} : std::vector<int>{0}); }
-    // registers: B 0..7; E quads from 8: SA, SB (rolling S_{j-1} / S_j), DEN, T, Z, ALPHA, SHIFT, NEGZ, PR (previous row)
-    enum { T0 = 0, T1 = 1, T2 = 2, T3 = 3, R0 = 4 /* R0..R2: rolling main values */, ESA = 8, ESB = 12, EDEN = 16, ET = 20, EZ = 24, EAL = 28, ESH = 32, ENZ = 36, EPR = 40, NREGS = 44 };
+    // Emission order: the column loads of every chunk of constraints come first, then the arithmetic — a run of independent loads
+    // is what both the interpreter (it issues a run together) and the compiler (all requests of a chunk in flight before the first
+    // use) turn into memory-level parallelism.  Registers: B 0..3 scratch, 4..13 a ring of main-column values (a chunk of 8 plus
+    // the two predecessors the degree-2 constraints read), 14..25 tuple / multiplicity values of a logup chunk; E quads after that.
+    enum { T0 = 0, T1 = 1, T2 = 2, T3 = 3, RING = 4, NRING = 10, TUP = 14, EBASE = 28,
+           EZ = EBASE, EAL = EBASE + 4, ESH = EBASE + 8, ENZ = EBASE + 12, EDEN = EBASE + 16, ET = EBASE + 20, EPR = EBASE + 24, ES = EBASE + 28 /* 5 quads: S_{j-1} and a chunk of 4 */, NREGS = EBASE + 48 };
     g.n_regs = NREGS;
     ProgEmit e;
     uint32_t nc = 0;
+    auto ring = [&](uint32_t k) { return (uint32_t)RING + k % NRING; };
     // (main0' - main0 - 1)(1 - is_last), (main1' - main1 - main0)(1 - is_last)
-    e.op(NX_C_LOAD, R0 + 0, MAIN + 0, 0); e.op(NX_C_LOAD, R0 + 1, MAIN + 1, 0);
-    e.op(NX_C_CONST, T2, 1); e.op(NX_C_LOAD, T3, PRE + 1, 0); e.op(NX_C_SUB, T3, T2, T3);
-    e.op(NX_C_LOAD, T0, MAIN + 0, 1); e.op(NX_C_SUB, T0, T0, R0 + 0); e.op(NX_C_SUB, T0, T0, T2); e.op(NX_C_MUL, T0, T0, T3); e.op(NX_C_CONSTRAINT_B, 0, T0); nc++;
-    e.op(NX_C_LOAD, T0, MAIN + 1, 1); e.op(NX_C_SUB, T0, T0, R0 + 1); e.op(NX_C_SUB, T0, T0, R0 + 0); e.op(NX_C_MUL, T0, T0, T3); e.op(NX_C_CONSTRAINT_B, 0, T0); nc++;
-    for (uint32_t k = 2; k < c.n_main; k++) {
-        const uint32_t rv = R0 + k % 3, rb = R0 + (k - 1) % 3, ra = R0 + (k - 2) % 3;
-        e.op(NX_C_LOAD, rv, MAIN + k, 0);
-        if (!synth_col_is_free(k)) {
-            e.op(NX_C_MUL, T0, rb, rb); e.op(NX_C_MUL, T1, ra, ra); e.op(NX_C_SUB, T2, rv, T0); e.op(NX_C_SUB, T2, T2, T1); e.op(NX_C_CONSTRAINT_B, 0, T2); nc++;
-        }
+    e.op(NX_C_LOAD, ring(0), MAIN + 0, 0); e.op(NX_C_LOAD, ring(1), MAIN + 1, 0);
+    e.op(NX_C_LOAD, T0, MAIN + 0, 1); e.op(NX_C_LOAD, T1, MAIN + 1, 1); e.op(NX_C_LOAD, T3, PRE + 1, 0);
+    e.op(NX_C_CONST, T2, 1); e.op(NX_C_SUB, T3, T2, T3);
+    e.op(NX_C_SUB, T0, T0, ring(0)); e.op(NX_C_SUB, T0, T0, T2); e.op(NX_C_MUL, T0, T0, T3); e.op(NX_C_CONSTRAINT_B, 0, T0); nc++;
+    e.op(NX_C_SUB, T1, T1, ring(1)); e.op(NX_C_SUB, T1, T1, ring(0)); e.op(NX_C_MUL, T1, T1, T3); e.op(NX_C_CONSTRAINT_B, 0, T1); nc++;
+    for (uint32_t k0 = 2; k0 < c.n_main; k0 += 8) {
+        const uint32_t k1 = std::min(c.n_main, k0 + 8);
+        for (uint32_t k = k0; k < k1; k++) e.op(NX_C_LOAD, ring(k), MAIN + k, 0);
+        for (uint32_t k = k0; k < k1; k++)
+            if (!synth_col_is_free(k)) {
+                e.op(NX_C_MUL, T0, ring(k - 1), ring(k - 1)); e.op(NX_C_MUL, T1, ring(k - 2), ring(k - 2)); e.op(NX_C_SUB, T2, ring(k), T0); e.op(NX_C_SUB, T2, T2, T1);
+                e.op(NX_C_CONSTRAINT_B, 0, T2); nc++;
+            }
     }
     if (L) {
         e.op(NX_C_CONSTE, EZ, 0); e.op(NX_C_CONSTE, EAL, 1); e.op(NX_C_CONSTE, ESH, 2); e.op(NX_C_CONSTE, ENZ, 3); e.op(NX_C_SUBE, ENZ, ENZ, EZ);   // -z
-        for (uint32_t j = 0; j < L; j++) {
-            uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m);
-            const uint32_t cur = (j & 1) ? ESB : ESA, prev = (j & 1) ? ESA : ESB;
-            e.op(NX_C_LOAD, T0, MAIN + a, 0);
-            if (j & 1) { e.op(NX_C_LOAD, T1, MAIN + b, 0); e.op(NX_C_MULEB, EDEN, EAL, T1); e.op(NX_C_ADDEB, EDEN, EDEN, T0); e.op(NX_C_ADDE, EDEN, EDEN, ENZ); }
-            else e.op(NX_C_ADDEB, EDEN, ENZ, T0);
-            e.op(NX_C_LOADE, cur, INT + 4 * j, 0);
-            if (j + 1 < L) {
-                if (j == 0) e.op(NX_C_MULE, ET, cur, EDEN);
-                else { e.op(NX_C_SUBE, ET, cur, prev); e.op(NX_C_MULE, ET, ET, EDEN); }
-            } else {
-                e.op(NX_C_LOADE, EPR, INT + 4 * j, (uint32_t)-1);
-                e.op(NX_C_SUBE, ET, cur, EPR);
-                if (j > 0) e.op(NX_C_SUBE, ET, ET, prev);
-                e.op(NX_C_ADDE, ET, ET, ESH);
-                e.op(NX_C_MULE, ET, ET, EDEN);
+        auto S = [&](uint32_t j) { return (uint32_t)ES + 4 * (j % 5); };       // S_j lives in slot j % 5: a chunk of 4 never overwrites S_{j0 - 1}
+        for (uint32_t j0 = 0; j0 < L; j0 += 4) {
+            const uint32_t j1 = std::min(L, j0 + 4);
+            for (uint32_t j = j0; j < j1; j++) {                               // the chunk's loads
+                uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m);
+                const uint32_t t = TUP + 3 * (j - j0);
+                e.op(NX_C_LOAD, t, MAIN + a, 0);
+                if (j & 1) e.op(NX_C_LOAD, t + 1, MAIN + b, 0);
+                if (j % 3 == 2) e.op(NX_C_LOAD, t + 2, MAIN + m, 0);
+                e.op(NX_C_LOADE, S(j), INT + 4 * j, 0);
+                if (j + 1 == L) e.op(NX_C_LOADE, EPR, INT + 4 * j, (uint32_t)-1);
             }
-            if (j % 3 == 2) e.op(NX_C_LOAD, T2, MAIN + m, 0);   // - num = + main[m]
-            else e.op(NX_C_CONST, T2, P - 1);                     // - num = - 1
-            e.op(NX_C_ADDEB, ET, ET, T2);
-            e.op(NX_C_CONSTRAINT_E, 0, ET); nc++;
+            for (uint32_t j = j0; j < j1; j++) {
+                const uint32_t t = TUP + 3 * (j - j0), cur = S(j), prev = S(j + 4);   // (j - 1) % 5 == (j + 4) % 5
+                if (j & 1) { e.op(NX_C_MULEB, EDEN, EAL, t + 1); e.op(NX_C_ADDEB, EDEN, EDEN, t); e.op(NX_C_ADDE, EDEN, EDEN, ENZ); }
+                else e.op(NX_C_ADDEB, EDEN, ENZ, t);
+                if (j + 1 < L) {
+                    if (j == 0) e.op(NX_C_MULE, ET, cur, EDEN);
+                    else { e.op(NX_C_SUBE, ET, cur, prev); e.op(NX_C_MULE, ET, ET, EDEN); }
+                } else {
+                    e.op(NX_C_SUBE, ET, cur, EPR);
+                    if (j > 0) e.op(NX_C_SUBE, ET, ET, prev);
+                    e.op(NX_C_ADDE, ET, ET, ESH);
+                    e.op(NX_C_MULE, ET, ET, EDEN);
+                }
+                if (j % 3 == 2) e.op(NX_C_ADDEB, ET, ET, t + 2);              // - num = + main[m]
+                else { e.op(NX_C_CONST, T2, P - 1); e.op(NX_C_ADDEB, ET, ET, T2); }   // - num = - 1
+                e.op(NX_C_CONSTRAINT_E, 0, ET); nc++;
+            }
         }
     }
     g.prog = std::move(e.p);
