@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--cpu-log-rows", type=int, default=20)   # a bounded sample of the same machine: ~10-20 s of host work on the GPU box
     ap.add_argument("--no-v1-shaped", action="store_true", help="skip the second, reference-v1-shaped workload")
     ap.add_argument("--v1-logup", type=int, default=250)      # ~250 logup columns ~ 1.0 k interaction base columns (SURVEY §8 preamble)
+    ap.add_argument("--lcd", type=int, default=1, help="log_constraint_degree of the main workload (the reference's v1 has 2, components/mod.rs:12)")
+    ap.add_argument("--extra-comps", type=int, default=0, help="small extra components of 2^8, 2^9, ... rows next to the main one (machine.rs:82-91)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: one independent proof per GPU (weak scaling) instead of ONE row-sharded proof")
     ap.add_argument("--legacy-synth", action="store_true", help="prove the round-1 machine (synthetic interaction fill, hand-written constraint kernel)")
     args = ap.parse_args()
@@ -88,8 +90,8 @@ def main():
     import nexus_zkvm_amd as nz
     be = nz.HipBackend(local_rank)
     n_inter = 4 * args.n_logup
-    comps = [(args.log_rows, args.n_pre, args.n_main, n_inter)]
-    cfg = nz.default_config(pow_bits=args.pow_bits, hash_mode=args.hash_mode)
+    comps = [(args.log_rows, args.n_pre, args.n_main, n_inter)] + [(8 + k, 2, 6 + k, 4) for k in range(args.extra_comps)]
+    cfg = nz.default_config(pow_bits=args.pow_bits, hash_mode=args.hash_mode, log_constraint_degree=args.lcd)
 
     def barrier():
         be.sync()
@@ -202,8 +204,8 @@ def main():
             import numpy as np
             O.build_oracle()
             cores = os.cpu_count() or 1
-            ccomps = [(args.cpu_log_rows, args.n_pre, args.n_main, n_inter)]
-            ocfg = O.default_cfg(pow_bits=args.pow_bits, hash_mode=args.hash_mode)
+            ccomps = [(args.cpu_log_rows, args.n_pre, args.n_main, n_inter)] + comps[1:]
+            ocfg = O.default_cfg(pow_bits=args.pow_bits, hash_mode=args.hash_mode, log_constraint_degree=args.lcd)
             t0 = time.perf_counter()
             if args.legacy_synth:
                 ref = O.prove_synth(ccomps, ocfg, seed=7, threads=cores)

@@ -13,11 +13,12 @@
 #include <string>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 
 struct nx_air_kernel {
     nx_ctx* ctx;
     hipModule_t module;
-    hipFunction_t fn;
+    std::vector<hipFunction_t> fns;      // one kernel per program segment (air_kernel, air_kernel_1, ...), launched back to back
     uint32_t n_cols, n_econsts, n_constraints;
 };
 
@@ -62,15 +63,33 @@ FI u32 row_offset(u32 r, int log_size, int e, int offset) {
 }
 )SRC";
 
-static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs) {
-    std::string s = AIR_PRELUDE;
-    s += "extern \"C\" __attribute__((global)) __attribute__((amdgpu_flat_work_group_size(256, 256))) void air_kernel(const u32* const* __restrict__ cols, const u32* __restrict__ econst, const u32* __restrict__ pw,\n"
+// Straight-line code has no loops, so its size grows with the AIR: the reference-shaped machine with 250 logup columns is > 1 MB of
+// instructions, far beyond the 64 KB instruction cache — every wave then streams its code from L2 and the kernel runs at a tenth of
+// the memory rate (measured: 173 ms for 92 GB of column reads).  The generator therefore cuts the program at constraint boundaries
+// into segments of bounded estimated code size; each segment becomes its own kernel holding exactly the instructions its
+// constraints depend on (backward slice over the register file, original order kept), and the segments accumulate into the same
+// rows one launch after the other.  A program that fits is one segment: the same source as ever.
+static uint32_t instr_cost(uint32_t op) {   // rough gfx950 instruction counts of the emitted statements
+    switch (op) {
+    case NX_C_LOAD: return 6; case NX_C_CONST: return 1; case NX_C_ADD: case NX_C_SUB: return 4; case NX_C_MUL: return 7; case NX_C_NEG: return 3;
+    case NX_C_CONSTE: return 4; case NX_C_ADDE: case NX_C_SUBE: return 16; case NX_C_MULE: return 160; case NX_C_MULEB: return 30; case NX_C_ADDEB: return 4;
+    case NX_C_LOADE: return 24; case NX_C_CONSTRAINT_B: return 14; case NX_C_CONSTRAINT_E: return 170; default: return 1;
+    }
+}
+static uint32_t segment_budget() {
+    static const uint32_t v = []() { const char* e = getenv("NX_AIR_SEGMENT"); int x = e ? atoi(e) : 6000; return (uint32_t)std::max(200, x); }();   // ~48 KB of code
+    return v;
+}
+
+static std::string generate_kernel(const nx_cinstr* prog, const std::vector<uint32_t>& keep, const std::vector<uint32_t>& cons_index, uint32_t n_regs, const std::string& name) {
+    std::string s;
+    s += "extern \"C\" __attribute__((global)) __attribute__((amdgpu_flat_work_group_size(256, 256))) void " + name + "(const u32* const* __restrict__ cols, const u32* __restrict__ econst, const u32* __restrict__ pw,\n"
          "    const u32* __restrict__ denom_inv, int log_size, int e, u32* a0, u32* a1, u32* a2, u32* a3, u32 row_begin, u32 row_end) {\n"
          "  const u32 r = row_begin + __builtin_amdgcn_workgroup_id_x() * 256 + __builtin_amdgcn_workitem_id_x();\n  if (r >= row_end) return;\n"
          "  u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;\n";
     // which row offsets occur
     std::vector<int> offs;
-    for (uint32_t i = 0; i < n_instr; i++)
+    for (uint32_t i : keep)
         if (prog[i].op == NX_C_LOAD || prog[i].op == NX_C_LOADE) { int o = (int)prog[i].b; if (std::find(offs.begin(), offs.end(), o) == offs.end()) offs.push_back(o); }
     auto off_name = [](int o) { return std::string("row_") + (o < 0 ? "m" : "p") + std::to_string(o < 0 ? -o : o); };
     for (int o : offs) s += "  const u32 " + off_name(o) + " = row_offset(r, log_size, e, " + std::to_string(o) + ");\n";
@@ -80,9 +99,9 @@ static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, 
     auto setE = [&](uint32_t d, const std::string& expr) {
         return "  { const Q t_ = " + expr + "; " + R(d) + " = t_.a; " + R(d + 1) + " = t_.b; " + R(d + 2) + " = t_.c; " + R(d + 3) + " = t_.d; }\n";
     };
-    uint32_t j = 0, pending = 0;
+    uint32_t pending = 0;
     const std::string fold = "  s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3);\n";
-    for (uint32_t i = 0; i < n_instr; i++) {
+    for (uint32_t i : keep) {
         const nx_cinstr& in = prog[i];
         switch (in.op) {
         case NX_C_LOAD: s += "  " + R(in.dst) + " = G(cols[" + std::to_string(in.a) + "])[" + off_name((int)in.b) + "];\n"; break;
@@ -104,17 +123,15 @@ static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, 
             break;
         }
         case NX_C_CONSTRAINT_B: {
-            std::string b = std::to_string(4 * j);
+            std::string b = std::to_string(4 * cons_index[i]);
             s += "  s0 = acc_mad(s0, pw[" + b + "], " + R(in.a) + "); s1 = acc_mad(s1, pw[" + b + " + 1], " + R(in.a) + "); s2 = acc_mad(s2, pw[" + b + " + 2], " + R(in.a) + "); s3 = acc_mad(s3, pw[" + b +
                  " + 3], " + R(in.a) + ");\n";
-            j++;
             if (++pending == 4) { s += fold; pending = 0; }
             break;
         }
         case NX_C_CONSTRAINT_E: {
-            std::string b = std::to_string(4 * j);
+            std::string b = std::to_string(4 * cons_index[i]);
             s += "  { const Q t_ = q_mul(Q{pw[" + b + "], pw[" + b + " + 1], pw[" + b + " + 2], pw[" + b + " + 3]}, " + E(in.a) + "); s0 += t_.a; s1 += t_.b; s2 += t_.c; s3 += t_.d; }\n";
-            j++;
             if (++pending == 4) { s += fold; pending = 0; }
             break;
         }
@@ -124,6 +141,64 @@ static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, 
     s += "  const u32 di = denom_inv[r >> log_size];\n"
          "  a0[r] = m_add(a0[r], m_mul(acc_final(s0), di)); a1[r] = m_add(a1[r], m_mul(acc_final(s1), di));\n"
          "  a2[r] = m_add(a2[r], m_mul(acc_final(s2), di)); a3[r] = m_add(a3[r], m_mul(acc_final(s3), di));\n}\n";
+    return s;
+}
+
+static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t* n_kernels = nullptr) {
+    // register-level dependencies: deps[i] = the instructions that last wrote the registers instruction i reads
+    std::vector<int> last(n_regs, -1);
+    std::vector<std::vector<uint32_t>> deps(n_instr);
+    std::vector<uint32_t> cons_index(n_instr, 0);
+    uint32_t n_c = 0;
+    auto use = [&](uint32_t i, uint32_t reg, uint32_t w) { for (uint32_t k = 0; k < w; k++) if (reg + k < n_regs && last[reg + k] >= 0) deps[i].push_back((uint32_t)last[reg + k]); };
+    auto def = [&](uint32_t i, uint32_t reg, uint32_t w) { for (uint32_t k = 0; k < w; k++) if (reg + k < n_regs) last[reg + k] = (int)i; };
+    for (uint32_t i = 0; i < n_instr; i++) {
+        const nx_cinstr& in = prog[i];
+        switch (in.op) {
+        case NX_C_LOAD: case NX_C_CONST: def(i, in.dst, 1); break;
+        case NX_C_ADD: case NX_C_SUB: case NX_C_MUL: use(i, in.a, 1); use(i, in.b, 1); def(i, in.dst, 1); break;
+        case NX_C_NEG: use(i, in.a, 1); def(i, in.dst, 1); break;
+        case NX_C_CONSTE: case NX_C_LOADE: def(i, in.dst, 4); break;
+        case NX_C_ADDE: case NX_C_SUBE: case NX_C_MULE: use(i, in.a, 4); use(i, in.b, 4); def(i, in.dst, 4); break;
+        case NX_C_MULEB: case NX_C_ADDEB: use(i, in.a, 4); use(i, in.b, 1); def(i, in.dst, 4); break;
+        case NX_C_CONSTRAINT_B: use(i, in.a, 1); cons_index[i] = n_c++; break;
+        case NX_C_CONSTRAINT_E: use(i, in.a, 4); cons_index[i] = n_c++; break;
+        default: break;
+        }
+    }
+    // segments: consecutive constraints whose slices fit the budget
+    std::string s = AIR_PRELUDE;
+    uint32_t n_seg = 0;
+    std::vector<char> in_seg(n_instr, 0);
+    std::vector<uint32_t> seg_cons;
+    uint32_t cost = 0;
+    auto add_slice = [&](uint32_t root) {        // marks the slice of `root`, returns the added cost
+        uint32_t added = 0;
+        std::vector<uint32_t> st{root};
+        while (!st.empty()) {
+            uint32_t i = st.back(); st.pop_back();
+            if (in_seg[i]) continue;
+            in_seg[i] = 1; added += instr_cost(prog[i].op);
+            for (uint32_t d : deps[i]) if (!in_seg[d]) st.push_back(d);
+        }
+        return added;
+    };
+    auto flush = [&]() {
+        std::vector<uint32_t> keep;
+        for (uint32_t i = 0; i < n_instr; i++) if (in_seg[i]) keep.push_back(i);
+        s += generate_kernel(prog, keep, cons_index, n_regs, n_seg == 0 ? std::string("air_kernel") : "air_kernel_" + std::to_string(n_seg));
+        n_seg++;
+        std::fill(in_seg.begin(), in_seg.end(), 0); cost = 0;
+    };
+    const uint32_t budget = segment_budget();
+    bool any = false;
+    for (uint32_t i = 0; i < n_instr; i++) {
+        if (prog[i].op != NX_C_CONSTRAINT_B && prog[i].op != NX_C_CONSTRAINT_E) continue;
+        if (any && cost >= budget) { flush(); any = false; }
+        cost += add_slice(i); any = true;
+    }
+    if (any || n_seg == 0) flush();
+    if (n_kernels) *n_kernels = n_seg;
     return s;
 }
 
@@ -180,7 +255,8 @@ int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint
     uint32_t n_c = 0;
     NX_TRY(validate_air_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, &n_c));
     if (n_c != n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: the program adds a different number of constraints than announced");
-    const std::string src = generate_air_source(program, n_instr, n_regs);
+    uint32_t n_kernels = 1;
+    const std::string src = generate_air_source(program, n_instr, n_regs, &n_kernels);
     if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
     if (!out) return NX_OK;
     if (!ctx) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: a context is needed to load the kernel");
@@ -201,7 +277,9 @@ int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint
     nx_air_kernel* k = new nx_air_kernel();
     k->ctx = ctx; k->n_cols = n_cols; k->n_econsts = n_econsts; k->n_constraints = n_constraints;
     hipError_t e = hipModuleLoadData(&k->module, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&k->fn, k->module, "air_kernel");
+    k->fns.resize(n_kernels);
+    for (uint32_t f = 0; f < n_kernels && e == hipSuccess; f++)
+        e = hipModuleGetFunction(&k->fns[f], k->module, f == 0 ? "air_kernel" : ("air_kernel_" + std::to_string(f)).c_str());
     if (e != hipSuccess) { delete k; return hip_fail(ctx, e, "hipModuleLoadData(air kernel)", __FILE__, __LINE__); }
     *out = k;
     return NX_OK;
@@ -245,8 +323,10 @@ int air_eval_rows(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_
     uint32_t* a0 = d_acc4[0]; uint32_t* a1 = d_acc4[1]; uint32_t* a2 = d_acc4[2]; uint32_t* a3 = d_acc4[3];
     uint32_t rb = row_begin, re = row_begin + n_rows;
     void* args[] = {&p_cols, &p_ec, &p_pw, &p_den, &ls, &le, &a0, &a1, &a2, &a3, &rb, &re};
-    hipError_t er = hipModuleLaunchKernel(k->fn, (n_rows + 255) / 256, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
-    if (er != hipSuccess) return hip_fail(ctx, er, "nx_air_eval", __FILE__, __LINE__);
+    for (hipFunction_t fn : k->fns) {       // the segments of a large program accumulate into the same rows, one launch after the other
+        hipError_t er = hipModuleLaunchKernel(fn, (n_rows + 255) / 256, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+        if (er != hipSuccess) return hip_fail(ctx, er, "nx_air_eval", __FILE__, __LINE__);
+    }
     return NX_OK;
 }
 }  // namespace nx

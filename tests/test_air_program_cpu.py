@@ -3,6 +3,8 @@ program semantics (oracle/constraints.h).  The oracle is pinned by the only prop
 trace that satisfies the AIR, sum_j alpha^j C_j / Z_trace evaluated on the constraint domain is a POLYNOMIAL of the degree the
 constraint degree allows (its upper coefficients vanish) — wrong masks, wrong row offsets or wrong vanishing denominators
 all break that."""
+import os
+
 import numpy as np
 import pytest
 
@@ -154,3 +156,33 @@ def test_air_jit_rejects_malformed_program():
     prog, n_cols = _small_program()
     with pytest.raises(nx.NexusHipError):
         nx.air_source(prog, n_cols - 1)          # a LOAD now indexes past the column table
+
+
+def test_air_jit_splits_large_programs_into_segments(tmp_path):
+    """Straight-line code larger than the instruction cache runs at a fraction of the memory rate, so nx_air_compile cuts a recorded
+    program at constraint boundaries into kernels of bounded code size, each holding the backward slice of its constraints.  With a
+    tiny budget (NX_AIR_SEGMENT, read once per process — hence the subprocess) the synthetic AIR becomes several kernels: every
+    constraint's alpha power appears exactly once over all kernels, and the text still cross-compiles for gfx950."""
+    import shutil, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import nexus_zkvm_amd as nx, nexus_zkvm_amd.air_program as ap
+        from test_air_program_cpu import synthetic_program
+        prog = synthetic_program(ap, 3, 40, 20)
+        open(sys.argv[1], "w").write(nx.air_source(prog, 63))
+        print(prog.n_constraints)
+    """ % (root, os.path.join(root, "tests")))
+    f = tmp_path / "seg.hip"
+    env = dict(os.environ, NX_AIR_SEGMENT="300")
+    out = subprocess.run([sys.executable, "-c", script, str(f)], check=True, capture_output=True, text=True, env=env, timeout=120)
+    n_constraints = int(out.stdout.strip().splitlines()[-1])
+    src = f.read_text()
+    n_kernels = src.count("void air_kernel")
+    assert n_kernels >= 3 and "air_kernel_1(" in src
+    import re
+    used = sorted(int(x) // 4 for x in re.findall(r"s0 = acc_mad\(s0, pw\[(\d+)\]", src))
+    assert used == list(range(n_constraints))           # every constraint exactly once, with its own alpha power
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-c", str(f), "-o", str(tmp_path / "seg.o")], check=True, timeout=300)
