@@ -421,6 +421,9 @@ typedef struct nx_logup_frac {
 } nx_logup_frac;
 int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, const nx_logup_frac* frac_b,
                  const uint32_t* const* d_prev4, uint32_t* const* d_out4);
+/* The n_cols logup columns of a component in ONE launch: column j = sum over i <= j of fraction i(row), i.e. what n_cols calls of
+ * nx_logup_col with d_prev4 = the previous column produce, reading every tuple column once.  d_out: 4 n_cols coordinate columns. */
+int nx_logup_cols(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, uint32_t n_cols, uint32_t* const* d_out);
 /* LogupTraceGenerator::finalize_last on the last column (in place): claimed_sum = sum over all rows; the column becomes
  * the inclusive prefix sum, in natural coset order, of (value - claimed_sum / 2^log_size). */
 int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_col4, uint32_t claimed_sum[4]);

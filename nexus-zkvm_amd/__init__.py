@@ -671,6 +671,23 @@ class HipBackend:
         self._chk(self.L.nx_logup_col(self.ctx, frac_a["tuple"].log_size, C.byref(fa), C.byref(fb) if fb is not None else None, self._ptr4(prev), out.col_ptrs()))
         return out
 
+    def logup_cols(self, fracs):
+        """All the logup columns of a component in one launch (nx_logup_cols): column j = sum of the first j + 1 fractions of the
+        row.  fracs: dicts as for logup_col.  Returns one 4-column DeviceColumns per fraction."""
+        keep, arr = [], (LogupFrac * len(fracs))()
+        for i, f in enumerate(fracs):
+            t = f["tuple"]
+            ptrs = t.col_ptrs(); ap = _u32(f["alphas"]).reshape(-1); z = _u32(f["z"]); sc = _u32(f.get("scale", (1, 0, 0, 0)))
+            keep.extend([ptrs, ap, z, sc])
+            m = f.get("mult")
+            arr[i] = LogupFrac(C.cast(ptrs, C.c_void_p), t.n_cols, ap.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                               m.ptr if m is not None else None, sc.ctypes.data_as(C.c_void_p))
+        log = fracs[0]["tuple"].log_size
+        outs = [DeviceColumns(self, 4, log) for _ in fracs]
+        ptrs = (C.c_void_p * (4 * len(fracs)))(*[o.ptr.value + k * (4 << log) for o in outs for k in range(4)])
+        self._chk(self.L.nx_logup_cols(self.ctx, log, arr, len(fracs), ptrs))
+        return outs
+
     def logup_finalize_last(self, col4):
         """LogupTraceGenerator::finalize_last in place; returns the claimed sum (4 words)."""
         cs = np.zeros(4, np.uint32)

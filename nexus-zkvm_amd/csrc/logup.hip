@@ -83,6 +83,33 @@ __global__ __launch_bounds__(256) void logup_col_kernel(LogupTupleFrac fa, Logup
     out.c[0][r] = v.a.a; out.c[1][r] = v.a.b; out.c[2][r] = v.b.a; out.c[3][r] = v.b.b;
 }
 
+
+// All the logup columns of a component in ONE launch (LogupTraceGenerator driven column after column): column j of a row is the
+// running sum of the row's first j + 1 fractions, so a lane walks the fractions of its row once — every tuple column is read once,
+// no previous column is re-read, 16 bytes are written per column.  Descriptors live in device memory (flat pointer / alpha-power
+// tables), so the tuple width is not limited by the kernel argument size (the reference's widest relation has 200 elements).
+struct LogupBatchFrac { u32 first_col, n_cols, first_ap, pad; const u32* mult; QM31 z, scale; };
+__global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* __restrict__ fr, u32 n_fracs, const u32* const* __restrict__ tuple_cols,
+                                                         const u32* __restrict__ ap /*4 words each*/, u32* const* __restrict__ out /*4 per fraction*/, u32 n) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    QM31 run = q_zero();
+    for (u32 j = 0; j < n_fracs; j++) {
+        const LogupBatchFrac f = fr[j];
+        u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (u32 k = 0; k < f.n_cols; k++) {
+            const u32 v = gld(tuple_cols[f.first_col + k] + r);
+            const u32* a = ap + 4 * (size_t)(f.first_ap + k);
+            s0 = acc_mad(s0, a[0], v); s1 = acc_mad(s1, a[1], v); s2 = acc_mad(s2, a[2], v); s3 = acc_mad(s3, a[3], v);
+            if ((k & 3) == 3) { s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3); }
+        }
+        const QM31 den = q_sub(qm(acc_final(s0), acc_final(s1), acc_final(s2), acc_final(s3)), f.z);
+        const QM31 num = f.mult ? q_mul_m(f.scale, gld(f.mult + r)) : f.scale;
+        run = q_add(run, q_mul(num, q_inv(den)));
+        gst(out[4 * j] + r, run.a.a); gst(out[4 * j + 1] + r, run.a.b); gst(out[4 * j + 2] + r, run.b.a); gst(out[4 * j + 3] + r, run.b.b);
+    }
+}
+
 // position (bit-reversed circle-domain order) of natural coset row c
 __device__ __forceinline__ u32 pos_of_coset_row(u32 c, int log) {
     const u32 N = 1u << log;
@@ -250,6 +277,54 @@ int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, co
     const u32 n = 1u << log_size;
     hipLaunchKernelGGL(logup_col_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fa, fb, frac_b != nullptr, prev, d_prev4 != nullptr, n, o);
     NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+
+// n_cols logup columns of one component in one launch: column j = sum over i <= j of fraction i (what n_cols calls of nx_logup_col
+// with d_prev4 = the previous column produce).  d_out: 4 n_cols coordinate columns.
+int nx_logup_cols(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, uint32_t n_cols, uint32_t* const* d_out) {
+    NX_GUARD(ctx);
+    if (!ctx || (n_cols && (!fracs || !d_out))) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: NULL argument");
+    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: log_size too large");
+    if (!n_cols) return NX_OK;
+    std::vector<LogupBatchFrac> h(n_cols);
+    std::vector<const u32*> cols; std::vector<u32> ap;
+    for (u32 j = 0; j < n_cols; j++) {
+        const nx_logup_frac& f = fracs[j];
+        if (!f.alpha_powers || !f.z || !f.scale || (f.n_tuple_cols && !f.d_tuple_cols)) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: incomplete fraction");
+        h[j].first_col = (u32)cols.size(); h[j].n_cols = f.n_tuple_cols; h[j].first_ap = (u32)(ap.size() / 4); h[j].pad = 0;
+        for (u32 k = 0; k < f.n_tuple_cols; k++) { if (!f.d_tuple_cols[k]) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: NULL tuple column"); cols.push_back(f.d_tuple_cols[k]); }
+        ap.insert(ap.end(), f.alpha_powers, f.alpha_powers + 4 * (size_t)f.n_tuple_cols);
+        h[j].mult = f.d_mult; h[j].z = q_load(f.z); h[j].scale = q_load(f.scale);
+        for (int q = 0; q < 4; q++) if (!d_out[4 * j + q]) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: NULL output column");
+    }
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t b_fr = h.size() * sizeof(LogupBatchFrac), b_cols = cols.size() * 8, b_ap = ap.size() * 4, b_out = (size_t)n_cols * 32;
+    const size_t o_cols = al(b_fr), o_ap = o_cols + al(b_cols), o_out = o_ap + al(b_ap), total = o_out + al(b_out) + 16;
+    std::vector<uint8_t> host(total, 0);
+    memcpy(host.data(), h.data(), b_fr);
+    if (b_cols) memcpy(host.data() + o_cols, cols.data(), b_cols);
+    if (b_ap) memcpy(host.data() + o_ap, ap.data(), b_ap);
+    memcpy(host.data() + o_out, d_out, b_out);
+    uint8_t* blob = nullptr;
+    NX_TRY(dev_alloc(ctx, total, (void**)&blob));      // owned (not the staging ring): hundreds of wide fractions exceed a ring slot's lifetime guarantees
+    hipError_t e = hipSuccess;
+    for (size_t off = 0; off < total && e == hipSuccess; off += (size_t)4 << 20) {
+        const size_t nb = std::min(total - off, (size_t)4 << 20);
+        void* st = nullptr;
+        int rc = stage(ctx, host.data() + off, nb, &st);
+        if (rc != NX_OK) { dev_free(ctx, blob); return rc; }
+        e = hipMemcpyAsync(blob + off, st, nb, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    const u32 n = 1u << log_size;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(logup_cols_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const LogupBatchFrac*)blob, n_cols, (const u32* const*)(blob + o_cols),
+                           (const u32*)(blob + o_ap), (u32* const*)(blob + o_out), n);
+        e = hipGetLastError();
+    }
+    dev_free(ctx, blob);   // stream-ordered: reused only by later work on this stream
+    if (e != hipSuccess) return hip_fail(ctx, e, "nx_logup_cols", __FILE__, __LINE__);
     return NX_OK;
 }
 

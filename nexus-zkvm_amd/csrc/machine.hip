@@ -308,16 +308,20 @@ void machine_kernels_release(nx_ctx* ctx) {   // nx_ctx_destroy: the modules bel
 static int logup_columns(nx_ctx* ctx, const nx_component_spec& c, uint32_t log_rows, const std::map<uint32_t, const uint32_t*>& mainv, const uint32_t z[4], const uint32_t alpha[4],
                          uint32_t* const* inter) {
     const uint32_t L = c.n_inter / 4;
-    const uint32_t one[4] = {1, 0, 0, 0}, minus_one[4] = {P - 1, 0, 0, 0};
+    static const uint32_t one[4] = {1, 0, 0, 0}, minus_one[4] = {P - 1, 0, 0, 0};
     uint32_t ap[8] = {1, 0, 0, 0, alpha[0], alpha[1], alpha[2], alpha[3]};     // LookupElements alpha powers [1, alpha]
+    static const bool per_column = []() { const char* e = getenv("NX_LOGUP_PER_COLUMN"); return e && atoi(e) != 0; }();   // A/B: one nx_logup_col launch per column
+    std::vector<nx_logup_frac> fr(L);
+    std::vector<const uint32_t*> tuples(2 * (size_t)L);
     for (uint32_t j = 0; j < L; j++) {
         uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m);
-        const uint32_t* tuple[2] = {mainv.at(a), (j & 1) ? mainv.at(b) : nullptr};
-        nx_logup_frac f;
-        f.d_tuple_cols = tuple; f.n_tuple_cols = (j & 1) ? 2 : 1; f.alpha_powers = ap; f.z = z;
+        tuples[2 * j] = mainv.at(a); tuples[2 * j + 1] = (j & 1) ? mainv.at(b) : nullptr;
+        nx_logup_frac& f = fr[j];
+        f.d_tuple_cols = &tuples[2 * j]; f.n_tuple_cols = (j & 1) ? 2 : 1; f.alpha_powers = ap; f.z = z;
         f.d_mult = j % 3 == 2 ? mainv.at(m) : nullptr; f.scale = j % 3 == 2 ? minus_one : one;
-        H_TRY(nx_logup_col(ctx, log_rows, &f, nullptr, j ? (const uint32_t* const*)(inter + 4 * (j - 1)) : nullptr, inter + 4 * j));
+        if (per_column) H_TRY(nx_logup_col(ctx, log_rows, &f, nullptr, j ? (const uint32_t* const*)(inter + 4 * (j - 1)) : nullptr, inter + 4 * j));
     }
+    if (!per_column) H_TRY(nx_logup_cols(ctx, log_rows, fr.data(), L, inter));
     return NX_OK;
 }
 static std::set<uint32_t> logup_main_columns(const nx_component_spec& c) {

@@ -984,6 +984,14 @@ def test_logup_pipeline_matches_oracle(be, oracle, log):
     f1 = be.logup_col(dict(fa, mult=d_mult0, scale=minus_one), dict(tuple=d_tuple, alphas=alphas, z=z, mult=d_mult1), prev=f0)
     assert np.array_equal(f1.to_cpu(), np.stack(ref1))
 
+    # batched form: every column of the component in one launch (a third fraction with a wide tuple on top)
+    wide = dict(tuple=d_tuple, alphas=alphas, z=z, mult=d_mult1, scale=minus_one)
+    b0, b1, b2 = be.logup_cols([fa, dict(fa, mult=d_mult0, scale=minus_one), wide])
+    assert np.array_equal(b0.to_cpu(), np.stack(ref0))
+    ref_b1 = oracle.logup_finalize_col(ref_den_a, scale_a=minus_one, mult_a=mult[0], prev=ref0)
+    assert np.array_equal(b1.to_cpu(), np.stack(ref_b1))
+    assert np.array_equal(b2.to_cpu(), np.stack(oracle.logup_finalize_col(ref_den_b, scale_a=minus_one, mult_a=mult[1], prev=ref_b1)))
+
     claimed = be.logup_finalize_last(col1)
     ref_last, ref_claimed = oracle.logup_finalize_last(ref1)
     assert np.array_equal(claimed, ref_claimed)
