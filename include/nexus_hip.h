@@ -267,6 +267,8 @@ int nx_proof_serialize_stwo(const uint32_t* proof_words, size_t n_words, const u
  * shim takes for the reference's own AIR.  n_inter = 4 x (logup columns of the component).  comm: NULL = one GPU; otherwise ONE
  * proof on the GPUs of the communicator (nx_comm below). */
 struct nx_comm;
+/* The HIP source nx_air_compile generates for the recorded AIR of one such component (host only; free with nx_free_host). */
+int nx_machine_air_source(const nx_component_spec* comp, char** h_source);
 int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed,
                      const uint8_t* ad, size_t ad_len, const struct nx_comm* comm, uint32_t** proof_words, size_t* n_words,
                      nx_prove_stats* stats);

@@ -510,6 +510,14 @@ int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t
     return hand_out(ctx, nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats), w, proof_words, n_words, "nx_prove_synth_sharded");
 }
 
+// The HIP source nx_air_compile generates for the recorded AIR of one nx_prove_machine component (host only, no GPU): for offline
+// inspection of the generated kernels (register use, code size) with hipcc.  *h_source: free with nx_free_host.
+int nx_machine_air_source(const nx_component_spec* comp, char** h_source) {
+    if (!comp || !h_source || comp->n_inter % 4 || comp->n_pre < 2 || comp->n_main < 2) return set_err(nullptr, NX_ERR_ARG, "nx_machine_air_source: bad argument");
+    nxhip::GComponent g = nxhip::machine_component(*comp, nxhip::Loc{0, 0, 0});
+    return nx_air_compile(nullptr, g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), (uint32_t)g.econsts.size() / 4, g.n_constraints, nullptr, h_source);
+}
+
 int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,
                      size_t ad_len, const nx_comm* comm, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats) {
     NX_GUARD(ctx);
