@@ -77,7 +77,7 @@ static uint32_t instr_cost(uint32_t op) {   // rough gfx950 instruction counts o
     }
 }
 static uint32_t segment_budget() {
-    static const uint32_t v = []() { const char* e = getenv("NX_AIR_SEGMENT"); int x = e ? atoi(e) : 20000; return (uint32_t)std::max(200, x); }();   // ~160 KB of code: 2-3x the instruction cache still streams well (measured), 20x does not
+    static const uint32_t v = []() { const char* e = getenv("NX_AIR_SEGMENT"); int x = e ? atoi(e) : 9000; return (uint32_t)std::max(200, x); }();   // ~70 KB of code per kernel; measured sweep 1500..60000 (profiles/r02_segment_sweep.txt): 4500-13000 is flat and best
     return v;
 }
 
