@@ -1,4 +1,4 @@
-"""BASELINE config #4: ONE proof of a 2^log-row trace with its columns sharded over the GPUs of a node.
+"""BASELINE config #4: ONE proof of a 2^log-row trace on the GPUs of a node (column-parallel LDE, all-to-all into row blocks — DESIGN.md §7).
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/sharded_prove.py --log-rows 24
 One process per GPU, RCCL over xGMI through torch.distributed (nexus_zkvm_amd.sharded.TorchDistComm -> nx_comm).  Rank 0 prints one
 JSON line; every rank's proof is compared with rank 0's (sha256), and with --check also with a single-GPU proof on rank 0.
@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--machine", action="store_true", help="nx_prove_machine (real logup interaction trace, recorded AIR) instead of nx_prove_synth")
+    ap.add_argument("--lcd", type=int, default=1)
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -38,12 +40,14 @@ def main():
     be = nz.HipBackend(dev_index)
     comm = nz.make_comm(rank, world, TorchDistComm(be, dev))
     comps = [(a.log, a.n_pre, a.n_main, a.n_inter)]
-    cfg = nz.default_config(pow_bits=a.pow_bits)
+    cfg = nz.default_config(pow_bits=a.pow_bits, log_constraint_degree=a.lcd)
+    prove_n = (lambda seed: be.prove_machine(comps, cfg, seed=seed, comm=comm)) if a.machine else (lambda seed: be.prove_sharded(comps, comm, cfg, seed=seed))
+    prove_1 = (lambda seed: be.prove_machine(comps, cfg, seed=seed)) if a.machine else (lambda seed: be.prove(comps, cfg, seed=seed))
     best, words = 1e9, None
     for rep in range(a.reps + 1):
         be.sync(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        words = be.prove_sharded(comps, comm, cfg, seed=4000 + rep)
+        words = prove_n(4000 + rep)
         be.sync(); dist.barrier(); torch.cuda.synchronize()
         if rep:
             best = min(best, time.perf_counter() - t0)
@@ -56,7 +60,7 @@ def main():
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     single_ok = None
     if a.check and rank == 0:
-        single = be.prove(comps, cfg, seed=4000 + a.reps)
+        single = prove_1(4000 + a.reps)
         single_ok = bool(np.array_equal(single, words))
     if rank == 0:
         print(json.dumps({"workload": "config #4: one proof, 2^%d rows, %d+%d+%d columns sharded over %d GPUs (%s)" % (a.log, a.n_pre, a.n_main, a.n_inter, world, a.backend),
