@@ -24,7 +24,6 @@ if rows:
         if a > ce: union += ce - cs; cs, ce = a, b
         else: ce = max(ce, b)
     union += ce - cs
-    n_fill = cur.execute("select count(*) from kernels where name like '%synth_fill%'").fetchone()[0]
-    proves = max(1, n_fill // 3)
+    proves = max(1, cur.execute("select count(*) from kernels where name like '%grind_kernel%'").fetchone()[0])   # one PoW grind per prove
     print("\n# LDE kernels (fft13_kernel passes + lde_mid_kernel): %d launches, sum of durations %.1f us, union of their intervals %.1f us (%d proves -> %.2f ms of LDE wall time per prove; "
           "bench.py roofline.kernel_ms measures this with HIP events)" % (len(rows), total / 1e3, union / 1e3, proves, union / 1e6 / proves), file=out)
