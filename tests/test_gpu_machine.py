@@ -115,6 +115,20 @@ def test_machine_row_sharded_equals_single_gpu(be, nz, world, comps, kw):
     assert res[0][1]["comm_bytes"] > 0
 
 
+def test_config5_keccak_shaped_machine(be, nz, oracle):
+    """BASELINE config #5 shape (two keccak round components of 16 and 8 rows per instance, byte-lane main columns, 4
+    logup columns per lane-level lookup, so the interaction tree is the widest one): real logup columns and the recorded AIR on the
+    device, word for word against the oracle machine; then the same bytes as ONE proof on 8 ranks."""
+    comps = [(12, 8, 160, 256), (11, 8, 96, 160), (6, 2, 5, 4)]
+    kw = dict(pow_bits=6)
+    cfg = nz.default_config(**kw)
+    words = be.prove_machine(comps, cfg, seed=0x5EED, ad=b"keccak-shaped")
+    _same(M.prove_machine(comps, O.default_cfg(**kw), seed=0x5EED, ad=b"keccak-shaped", threads=THREADS), words)
+    res = _run_ranks(nz, 8, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=0x5EED, ad=b"keccak-shaped", comm=comm))
+    for r in range(8):
+        _same(words, res[r])
+
+
 def test_session_driven_by_several_ranks(be, nz, oracle):
     """The generic session (nx_prover_*) as ONE proof on 2 and 4 ranks: every rank replays the same transcript calls, tree_begin hands
     it only its columns, the proof equals the single-rank session's and the oracle session's (the logup-style AIR of air_examples)."""

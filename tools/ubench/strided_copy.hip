@@ -12,10 +12,13 @@ typedef u32 __attribute__((ext_vector_type(4))) u32x4;
 typedef __attribute__((address_space(1))) const u32x4* gptr4c;
 typedef __attribute__((address_space(1))) u32x4* gptr4;
 
-template <int LOGR> __global__ __launch_bounds__(512) void tile_copy(const u32* __restrict__ src, u32* __restrict__ dst, int cols) {
+// XCD = 1: neighbouring tiles (the two 64-B halves of a 128-B line when R = 16) run on the same XCD, as lde_mid_kernel maps them
+template <int LOGR, int XCD> __global__ __launch_bounds__(512) void tile_copy(const u32* __restrict__ src, u32* __restrict__ dst, int cols) {
     constexpr u32 R = 1u << LOGR, ROWS = (1u << TILE) / R, STRIDE = (1u << LOGN) / ROWS;
     const u32 tiles = 1u << (LOGN - TILE);
-    const u32 t = blockIdx.x % tiles, c = blockIdx.x / tiles;
+    u32 t, c;
+    if (XCD) { const u32 x = blockIdx.x & 7, y = blockIdx.x >> 3; c = y % cols; t = x * (tiles >> 3) + y / cols; }
+    else { t = blockIdx.x % tiles; c = blockIdx.x / tiles; }
     const u32* s = src + ((size_t)c << LOGN) + (size_t)t * R;
     u32* d = dst + ((size_t)c << LOGN) + (size_t)t * R;
     u32x4 v[4];
@@ -31,13 +34,13 @@ template <int LOGR> __global__ __launch_bounds__(512) void tile_copy(const u32* 
     }
 }
 
-template <int LOGR> static double run(const u32* src, u32* dst, int cols, int reps) {
+template <int LOGR, int XCD> static double run(const u32* src, u32* dst, int cols, int reps) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const unsigned grid = (unsigned)cols << (LOGN - TILE);
-    hipLaunchKernelGGL(tile_copy<LOGR>, dim3(grid), dim3(512), 0, 0, src, dst, cols);
+    hipLaunchKernelGGL((tile_copy<LOGR, XCD>), dim3(grid), dim3(512), 0, 0, src, dst, cols);
     hipDeviceSynchronize();
     hipEventRecord(a, 0);
-    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(tile_copy<LOGR>, dim3(grid), dim3(512), 0, 0, src, dst, cols);
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((tile_copy<LOGR, XCD>), dim3(grid), dim3(512), 0, 0, src, dst, cols);
     hipEventRecord(b, 0); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     return 2.0 * 4.0 * cols * (double)(1u << LOGN) * reps / (ms * 1e-3) / 1e9;
@@ -51,8 +54,10 @@ int main() {
     printf("{\"unit\": \"GB/s read+write\", \"tile_words\": 8192, \"column_words\": %u", 1u << LOGN);
     for (int cols : {4, 64}) {       // 4 columns = 128 MiB of in + out (Infinity-Cache resident), 64 columns = 2 GiB (HBM)
         const int reps = cols == 4 ? 160 : 10;
-        printf(", \"cols_%d\": {\"run_64B\": %.0f, \"run_128B\": %.0f, \"run_256B\": %.0f, \"run_1KiB\": %.0f, \"run_32KiB\": %.0f}", cols,
-               run<4>(src, dst, cols, reps), run<5>(src, dst, cols, reps), run<6>(src, dst, cols, reps), run<8>(src, dst, cols, reps), run<13>(src, dst, cols, reps));
+        printf(", \"cols_%d\": {\"run_64B\": %.0f, \"run_128B\": %.0f, \"run_256B\": %.0f, \"run_1KiB\": %.0f, \"run_32KiB\": %.0f, "
+               "\"xcd_run_64B\": %.0f, \"xcd_run_128B\": %.0f, \"xcd_run_256B\": %.0f, \"xcd_run_32KiB\": %.0f}", cols,
+               run<4, 0>(src, dst, cols, reps), run<5, 0>(src, dst, cols, reps), run<6, 0>(src, dst, cols, reps), run<8, 0>(src, dst, cols, reps), run<13, 0>(src, dst, cols, reps),
+               run<4, 1>(src, dst, cols, reps), run<5, 1>(src, dst, cols, reps), run<6, 1>(src, dst, cols, reps), run<13, 1>(src, dst, cols, reps));
     }
     printf("}\n");
     return 0;
