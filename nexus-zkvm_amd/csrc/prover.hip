@@ -35,8 +35,10 @@ int Dist::allgather_dev(nx_ctx* ctx, const uint32_t* d_send, size_t words, uint3
     if (comm_bytes) *comm_bytes += words * 4 * (size_t)(world - 1);
     return NX_OK;
 }
-int Dist::alltoallv(nx_ctx* ctx, const uint32_t* d_send, const size_t* soff, const size_t* scnt, uint32_t* d_recv, const size_t* roff, const size_t* rcnt) const {
-    H_TRY(nx_sync(ctx));
+int Dist::alltoallv(nx_ctx* ctx, const uint32_t* d_send, const size_t* soff, const size_t* scnt, uint32_t* d_recv, const size_t* roff, const size_t* rcnt,
+                    hipEvent_t ready) const {
+    if (ready) NX_HIP(ctx, hipEventSynchronize(ready));
+    else H_TRY(nx_sync(ctx));
     CommClock clk(*this);
     C_TRY(comm->alltoallv(comm->user, d_send, soff, scnt, d_recv, roff, rcnt));
     if (comm_bytes) for (int r = 0; r < world; r++) if (r != rank) *comm_bytes += scnt[r] * 4;
@@ -248,6 +250,15 @@ int TreeBuilder::commit_single(Blake2sChannel& channel) {
     return NX_OK;
 }
 
+// Column chunks of a row-sharded commit (NX_DIST_CHUNKS overrides; the same on every GPU: it depends on the run, not on the rank).
+// Chunks pay only where the exchange is worth hiding: >= 4 columns per GPU and chunk, >= 2^27 words in the run.
+static uint32_t dist_chunks(uint32_t n_run, int world, uint32_t el) {
+    const uint32_t min_loc = n_run / (uint32_t)world;
+    if (const char* e = getenv("NX_DIST_CHUNKS")) return (uint32_t)std::max(1, std::min(atoi(e), (int)std::max<uint32_t>(1, min_loc)));
+    if (((uint64_t)n_run << el) < ((uint64_t)1 << 27)) return 1;
+    return std::max<uint32_t>(1, std::min<uint32_t>(4, min_loc / 4));
+}
+
 // One proof on W GPUs: every GPU extends its share of each run of equally sized columns (iFFT + FFT need whole columns), one
 // all-to-all per run turns the column shards into row blocks, the Merkle subtree over the block is local, the W subtree roots are
 // all-gathered and the top log2 W levels computed by everyone.  Coefficients stay with the GPU that transformed them (OODS sampling
@@ -298,29 +309,60 @@ int TreeBuilder::commit_dist(Blake2sChannel& channel) {
                     off += groups[g].n_cols;
                 }
             }
+            // The share is extended and exchanged in Q column chunks (the same Q on every GPU): chunk q+1's LDE is enqueued before the
+            // host blocks in chunk q's all-to-all, so the transforms run while the links carry the previous chunk.  The receive slab
+            // is chunk-major, rank-major inside a chunk: every exchange is contiguous on both sides.
+            const uint32_t Q = dist_chunks(n_run, D.world, el);
+            auto chunk_cols = [&](int r, uint32_t q) { const uint32_t nl = Dist::cut(n_run, r + 1, D.world) - Dist::cut(n_run, r, D.world); return Dist::cut(nl, (int)q + 1, (int)Q) - Dist::cut(nl, (int)q, (int)Q); };
+            std::vector<size_t> chunk_base(Q + 1, 0);        // in columns
+            for (uint32_t q = 0; q < Q; q++) { size_t n = 0; for (int r = 0; r < D.world; r++) n += chunk_cols(r, q); chunk_base[q + 1] = chunk_base[q] + n; }
             DevBuf rows; H_TRY(rows.alloc(ctx, (size_t)n_run * mb));
             {
-                DevBuf lde, send;
-                if (n_loc) {
-                    H_TRY(lde.alloc(ctx, (size_t)n_loc << el));
-                    auto out = col_ptrs(lde.p, n_loc, el);
-                    H_TRY(nx_lde_batch(ctx, cs.tw, in.data(), n_loc, log, blow, out.data()));                                   // K3 + K4, column-parallel
-                    H_TRY(send.alloc(ctx, (size_t)n_loc << el));
-                    H_TRY(transpose_blocks(ctx, lde.p, (uint64_t)1 << el, send.p, n_loc, (uint64_t)1 << el, (uint32_t)D.world, false));
+                struct Chunk { DevBuf send; hipEvent_t ev = nullptr; uint32_t n = 0; };
+                std::vector<Chunk> ch(Q);
+                struct EvGuard { std::vector<Chunk>& c; ~EvGuard() { for (auto& x : c) if (x.ev) (void)hipEventDestroy(x.ev); } } ev_guard{ch};
+                auto exchange = [&](uint32_t q) -> int {
+                    std::vector<size_t> soff(D.world), scnt(D.world), roff(D.world), rcnt(D.world);
+                    size_t at = chunk_base[q];
+                    for (int r = 0; r < D.world; r++) {
+                        soff[r] = (size_t)r * ch[q].n * mb; scnt[r] = (size_t)ch[q].n * mb;
+                        roff[r] = at * mb; rcnt[r] = (size_t)chunk_cols(r, q) * mb; at += chunk_cols(r, q);
+                    }
+                    H_TRY(D.alltoallv(ctx, ch[q].send.p, soff.data(), scnt.data(), rows.p, roff.data(), rcnt.data(), Q > 1 ? ch[q].ev : nullptr));   // the transposition
+                    ch[q].send.release();
+                    return NX_OK;
+                };
+                for (uint32_t q = 0; q < Q; q++) {
+                    const uint32_t c0 = Dist::cut(n_loc, (int)q, (int)Q), c1 = Dist::cut(n_loc, (int)q + 1, (int)Q);
+                    ch[q].n = c1 - c0;
+                    if (ch[q].n) {
+                        DevBuf lde; H_TRY(lde.alloc(ctx, (size_t)ch[q].n << el));
+                        auto out = col_ptrs(lde.p, ch[q].n, el);
+                        H_TRY(nx_lde_batch(ctx, cs.tw, in.data() + c0, ch[q].n, log, blow, out.data()));                            // K3 + K4, column-parallel
+                        H_TRY(ch[q].send.alloc(ctx, (size_t)ch[q].n << el));
+                        H_TRY(transpose_blocks(ctx, lde.p, (uint64_t)1 << el, ch[q].send.p, ch[q].n, (uint64_t)1 << el, (uint32_t)D.world, false));
+                    }
+                    if (Q > 1) { NX_HIP(ctx, hipEventCreateWithFlags(&ch[q].ev, hipEventDisableTiming)); NX_HIP(ctx, hipEventRecord(ch[q].ev, ctx->cur)); }
+                    if (q > 0) H_TRY(exchange(q - 1));
                 }
-                std::vector<size_t> soff(D.world), scnt(D.world), roff(D.world), rcnt(D.world);
-                for (int r = 0; r < D.world; r++) {
-                    soff[r] = (size_t)r * n_loc * mb; scnt[r] = (size_t)n_loc * mb;
-                    const uint32_t rlo = Dist::cut(n_run, r, D.world), rhi = Dist::cut(n_run, r + 1, D.world);
-                    roff[r] = (size_t)rlo * mb; rcnt[r] = (size_t)(rhi - rlo) * mb;
+                H_TRY(exchange(Q - 1));
+            }
+            // where column c of the run landed: its owner's chunk, then its place inside the owner's part of that chunk
+            std::vector<uint32_t*> blk_of(n_run);
+            for (int r = 0; r < D.world; r++) {
+                const uint32_t rlo = Dist::cut(n_run, r, D.world), nl = Dist::cut(n_run, r + 1, D.world) - rlo;
+                for (uint32_t q = 0; q < Q; q++) {
+                    size_t at = chunk_base[q];
+                    for (int r2 = 0; r2 < r; r2++) at += chunk_cols(r2, q);
+                    const uint32_t k0 = Dist::cut(nl, (int)q, (int)Q), k1 = Dist::cut(nl, (int)q + 1, (int)Q);
+                    for (uint32_t k = k0; k < k1; k++) blk_of[rlo + k] = rows.p + (at + (k - k0)) * mb;
                 }
-                H_TRY(D.alltoallv(ctx, send.p, soff.data(), scnt.data(), rows.p, roff.data(), rcnt.data()));                     // the transposition
             }
             for (uint32_t c = 0; c < n_run; c++) {
                 const bool local = c >= lo && c < hi;
                 int own = 0; while (!(c >= Dist::cut(n_run, own, D.world) && c < Dist::cut(n_run, own + 1, D.world))) own++;
                 t.polys.push_back({local ? in[c - lo] : nullptr, log, false}); t.owner.push_back(own);
-                uint32_t* blk = rows.p + (size_t)c * mb;
+                uint32_t* blk = blk_of[c];
                 t.evals.push_back({blk, el, true});
                 all_cols.push_back(blk); all_logs.push_back(el);
             }

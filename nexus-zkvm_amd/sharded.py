@@ -317,6 +317,9 @@ class TorchDistComm:
         self.be, self.torch, self.dist, self.device = backend, torch, dist, device
         self.host = device is None or getattr(device, "type", "") == "cpu"
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        # the device collectives run on a stream of their own and the host waits for THAT stream only: the library may have queued
+        # the next column chunk's transforms behind the buffer being exchanged (Dist::alltoallv waits for an event, not for its stream)
+        self.stream = None if self.host else torch.cuda.Stream(device=device)
 
     def _sync(self):
         self.be.sync()
@@ -379,10 +382,19 @@ class TorchDistComm:
         return t if self.host else t.to(self.device)
 
     def _dev_sync(self):
-        if not self.host:
-            self.torch.cuda.synchronize(self.device)
+        if self.stream is not None:
+            self.stream.synchronize()
+
+    def _comm_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def alltoallv(self, send_ptr, soff, scnt, recv_ptr, roff, rcnt):
+        with self._comm_stream():
+            self._alltoallv(send_ptr, soff, scnt, recv_ptr, roff, rcnt)
+            self._dev_sync()
+
+    def _alltoallv(self, send_ptr, soff, scnt, recv_ptr, roff, rcnt):
         W = self.world
         contiguous = all(soff[r + 1] == soff[r] + scnt[r] for r in range(W - 1)) and all(roff[r + 1] == roff[r] + rcnt[r] for r in range(W - 1))
         staged = self.dist.get_backend() != "nccl"       # gloo (tests): through host memory
@@ -418,11 +430,12 @@ class TorchDistComm:
         self._dev_sync()
 
     def allgather_dev(self, send_ptr, n, recv_ptr):
-        src, dst = self._view(send_ptr, n), self._view(recv_ptr, n * self.world)
-        if self.dist.get_backend() != "nccl":
-            parts = [self.torch.empty(n, dtype=self.torch.int32) for _ in range(self.world)]
-            self.dist.all_gather(parts, src.cpu().contiguous())
-            dst.copy_(self._to_dev(self.torch.cat(parts)))
-        else:
-            self.dist.all_gather_into_tensor(dst, src)
-        self._dev_sync()
+        with self._comm_stream():
+            src, dst = self._view(send_ptr, n), self._view(recv_ptr, n * self.world)
+            if self.dist.get_backend() != "nccl":
+                parts = [self.torch.empty(n, dtype=self.torch.int32) for _ in range(self.world)]
+                self.dist.all_gather(parts, src.cpu().contiguous())
+                dst.copy_(self._to_dev(self.torch.cat(parts)))
+            else:
+                self.dist.all_gather_into_tensor(dst, src)
+            self._dev_sync()

@@ -115,6 +115,19 @@ def test_machine_row_sharded_equals_single_gpu(be, nz, world, comps, kw):
     assert res[0][1]["comm_bytes"] > 0
 
 
+@pytest.mark.parametrize("world,chunks", [(2, 3), (4, 2), (8, 4)])
+def test_machine_row_sharded_with_chunked_exchange(be, nz, monkeypatch, world, chunks):
+    """The column chunks of the row-sharded commit (chunk q+1's LDE enqueued before chunk q's all-to-all; the receive slab is
+    chunk-major): forced on at a small size through NX_DIST_CHUNKS, the proof is still the single-GPU one on every rank."""
+    comps = [(11, 27, 96, 64), (9, 3, 40, 8)]
+    cfg = nz.default_config(pow_bits=6)
+    ref = be.prove_machine(comps, cfg, seed=99, ad=b"q")
+    monkeypatch.setenv("NX_DIST_CHUNKS", str(chunks))
+    res = _run_ranks(nz, world, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=99, ad=b"q", comm=comm))
+    for r in range(world):
+        _same(ref, res[r])
+
+
 def test_config5_keccak_shaped_machine(be, nz, oracle):
     """BASELINE config #5 shape (two keccak round components of 16 and 8 rows per instance, byte-lane main columns, 4
     logup columns per lane-level lookup, so the interaction tree is the widest one): real logup columns and the recorded AIR on the
