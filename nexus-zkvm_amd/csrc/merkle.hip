@@ -323,6 +323,45 @@ static int launch_merkle_top(nx_ctx* ctx, u32* buf, int top) {
 }
 
 
+// Levels in_log-1 .. in_log-d of a tree in ONE launch (no columns injected there): block b owns the 128 nodes [128 b, 128 b + 128) of
+// level in_log (written by the previous launch) and the subtrees above them — d <= 7 levels, one quad of lanes per node, the nodes
+// LDS-resident between levels.  Replaces d launches of 5-6 us each whose work is a few hundred thousand compressions in total.
+constexpr int SUBTREE_LEAVES = 128;
+template <int MODE>
+__global__ __launch_bounds__(2 * SUBTREE_LEAVES) void merkle_subtree_kernel(u32* __restrict__ base, int in_log, int d) {
+    __shared__ __attribute__((aligned(16))) u32 lv[(2 * SUBTREE_LEAVES - 1) * 8];   // level k of the block at node offset 256 - (256 >> k)
+    QuadLane L;
+    quad_lane_init(L);
+    const u32 tid = threadIdx.x, b = blockIdx.x;
+    {
+        const u32* src = base + (((size_t)1 << in_log) - 1 + (size_t)b * SUBTREE_LEAVES) * 8;
+        const uint4 v = gld4(src + 4 * tid);                                          // 128 nodes x 8 words = 256 lanes x 4 words
+        lv[4 * tid] = v.x; lv[4 * tid + 1] = v.y; lv[4 * tid + 2] = v.z; lv[4 * tid + 3] = v.w;
+    }
+    __syncthreads();
+    for (int k = 1; k <= d; k++) {
+        const u32 n = SUBTREE_LEAVES >> k, i = tid >> 2;
+        const u32* in_l = lv + (size_t)(2 * SUBTREE_LEAVES - ((2 * SUBTREE_LEAVES) >> (k - 1))) * 8;
+        u32* out_l = lv + (size_t)(2 * SUBTREE_LEAVES - ((2 * SUBTREE_LEAVES) >> k)) * 8;
+        u32* out_g = base + (((size_t)1 << (in_log - k)) - 1 + (size_t)b * n) * 8;
+        if (i < n) {                                                                  // whole quads are active or idle together
+            u32 lo, hi;
+            b2s_compress_quad<MODE>(L, in_l + (size_t)i * 16, MODE == 0 ? 64u : 0u, MODE == 0 ? 0xFFFFFFFFu : 0u, lo, hi);
+            out_l[(size_t)i * 8 + L.q] = lo; out_l[(size_t)i * 8 + 4 + L.q] = hi;
+            gst(out_g + (size_t)i * 8 + L.q, lo); gst(out_g + (size_t)i * 8 + 4 + L.q, hi);
+        }
+        __syncthreads();
+    }
+}
+
+static int launch_merkle_subtree(nx_ctx* ctx, u32* buf, int in_log, int d) {
+    const unsigned blocks = 1u << (in_log - 7);
+    if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_subtree_kernel<0>, dim3(blocks), dim3(2 * SUBTREE_LEAVES), 0, ctx->stream, buf, in_log, d);
+    else hipLaunchKernelGGL(merkle_subtree_kernel<1>, dim3(blocks), dim3(2 * SUBTREE_LEAVES), 0, ctx->stream, buf, in_log, d);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
 // ---------------------------------------------------------------- FRI tail: the last layers of FriProver::commit in ONE launch
 // Below ~2^12 points a FRI layer costs ~60 us of launches and host round trips (Merkle layers, root download, channel,
 // alpha upload, fold) for a few microseconds of work, and the layers are strictly sequential (alpha_{k+1} = H(root_k)).  This
@@ -537,10 +576,17 @@ static int build_inner_layers(nx_ctx* ctx, nx_tree* t, uint32_t max_log, const s
     const size_t n = sorted.size();
     int smallest_col_log = n ? (int)logs[n - 1] : (int)max_log;
     int top_fused = std::min(10, std::min((int)max_log - 1, smallest_col_log - 1));
+    // levels [top_fused + 1, SUBTREE_TOP] without injected columns: one launch (merkle_subtree_kernel) instead of one per level
+    static const int SUBTREE_TOP = []() { const char* e = getenv("NX_MERKLE_SUBTREE"); return e ? atoi(e) : 17; }();   // 0 = off; thread-safe
     for (int log = (int)max_log - 1; log >= 0; log--) {
         if (log == top_fused && log >= 1) {
             NX_TRY(launch_merkle_top(ctx, buf, log));
             break;
+        }
+        if (top_fused >= 1 && log <= SUBTREE_TOP && log - top_fused >= 2 && log - top_fused <= 7 && smallest_col_log > log) {
+            NX_TRY(launch_merkle_subtree(ctx, buf, log + 1, log - top_fused));       // levels log .. top_fused + 1
+            log = top_fused + 1;
+            continue;
         }
         size_t c0 = ci;
         while (ci < n && logs[ci] == (uint32_t)log) ci++;
