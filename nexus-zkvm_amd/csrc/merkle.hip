@@ -59,6 +59,28 @@ __device__ __forceinline__ void b2s_compress(u32 h[8], const u32 m[16], u32 t0, 
     h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
 }
 
+// 16 consecutive columns of one 64-byte message block at row i: the column addresses first (one uniform branch, wide scalar loads of
+// the pointer table), then 16 global loads issued back to back; columns past n_cols read as zero (the padded last block)
+__device__ __forceinline__ void load_block16(const ColSet& cols, u32 n_cols, u32 c0, u64 i, u32* dst) {
+    const u32* p[16];
+    if (c0 + 16 <= n_cols) {
+        if (cols.table) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) p[k] = cols.table[c0 + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) p[k] = cols.base + (uint64_t)(c0 + k) * cols.stride;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[k] = gld(p[k] + i);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) p[k] = cols.col(min(c0 + k, n_cols - 1));
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? gld(p[k] + i) : 0u;
+    }
+}
+
 // One Merkle layer: node i = H(prev[2i] ‖ prev[2i+1] ‖ col_0[i] ‖ col_1[i] ‖ ...).
 //   MODE 0: standard Blake2s-256 (byte counter, final-block flag, IV ^ parameter block)
 //   MODE 1: zero-state raw compression chaining, t = f = 0, zero-padded 64-byte blocks
@@ -95,27 +117,7 @@ __global__ __launch_bounds__(256) void merkle_layer_kernel(ColSet cols, u32 n_co
     // stream the columns 16 at a time, double-buffered: the 16 loads of chunk k+1 are in flight while the
     // ~1000 VALU ops of chunk k's compression run
     u32 nx_[16];
-    auto load_chunk = [&](u32 c0, u32* dst) {
-        // the 16 column addresses first (one uniform branch, wide scalar loads of the pointer table), then 16 global loads
-        // issued back to back
-        const u32* p[16];
-        if (c0 + 16 <= n_cols) {
-            if (cols.table) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) p[k] = cols.table[c0 + k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) p[k] = cols.base + (uint64_t)(c0 + k) * cols.stride;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = gld(p[k] + i);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) p[k] = cols.col(min(c0 + k, n_cols - 1));
-#pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? gld(p[k] + i) : 0u;
-        }
-    };
+    auto load_chunk = [&](u32 c0, u32* dst) { load_block16(cols, n_cols, c0, i, dst); };
     if (n_cols) load_chunk(0, nx_);
     for (u32 c0 = 0; c0 < n_cols; c0 += 16) {
 #pragma unroll
@@ -157,27 +159,7 @@ __global__ __launch_bounds__(256) void merkle_leaf_chain_kernel(ColSet cols, u32
     const u32 total_bytes = 4u * total_cols;
     u32 t = 4u * col_offset;   // bytes hashed by the previous shards
     u32 m[16], nx_[16];
-    auto load_chunk = [&](u32 c0, u32* dst) {
-        // the 16 column addresses first (one uniform branch, wide scalar loads of the pointer table), then 16 global loads
-        // issued back to back
-        const u32* p[16];
-        if (c0 + 16 <= n_cols) {
-            if (cols.table) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) p[k] = cols.table[c0 + k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) p[k] = cols.base + (uint64_t)(c0 + k) * cols.stride;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = gld(p[k] + i);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) p[k] = cols.col(min(c0 + k, n_cols - 1));
-#pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? gld(p[k] + i) : 0u;
-        }
-    };
+    auto load_chunk = [&](u32 c0, u32* dst) { load_block16(cols, n_cols, c0, i, dst); };
     if (n_cols) load_chunk(0, nx_);
     for (u32 c0 = 0; c0 < n_cols; c0 += 16) {
 #pragma unroll
