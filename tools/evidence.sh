@@ -4,6 +4,8 @@
 OUT=${1:-gpurun_out/evidence.jsonl}
 mkdir -p "$(dirname "$OUT")"; : > "$OUT"
 run() { echo "{\"tool\": \"$1\", \"args\": \"${*:2}\", \"result\": $(timeout 400 python tools/$1 "${@:2}" 2>/dev/null | tail -1 || echo null)}" >> "$OUT"; }
+run fft_tune.py 20 347 5             # BASELINE config #2: 347 columns x 2^20, LDE (K3+K4) and Merkle commit (K5), GB/s against both ceilings
+run fft_tune.py 22 347 3             # the same at the headline height
 run cp_bench.py 22                 # recorded constraints: interpreter vs hiprtc JIT, 438 columns x 2^23 rows
 run session_bench.py 22            # headline prove through the recorded-AIR session vs nx_prove_synth (same bytes)
 run logup_bench.py 22              # logup kernels

@@ -28,4 +28,4 @@ for r in range(reps):
     bm = min(bm, dt)
 malg = ncols * 4 * (2 << log) + 128 * (2 << log)
 print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("NX_")}, "log": log, "ncols": ncols, "lde_ms": best * 1e3,
-                  "lde_alg_GBs": alg / best / 1e9, "merkle_ms": bm * 1e3, "merkle_alg_GBs": malg / bm / 1e9}))
+                  "lde_alg_GBs": alg / best / 1e9, "lde_frac_of_8TBs": alg / best / 8e12, "lde_frac_of_measured_copy_6.29TBs": alg / best / 6.29e12, "merkle_ms": bm * 1e3, "merkle_alg_GBs": malg / bm / 1e9}))
