@@ -293,7 +293,9 @@ typedef struct nx_comm {
     int (*allgather)(void* user, const void* h_send, size_t bytes, void* h_recv);         /* host: recv = world x bytes               */
     int (*broadcast)(void* user, void* h_buf, size_t bytes, int32_t root);                /* host (unused by the row-sharded prove)   */
     /* device all-to-all: words [send_off[r], send_off[r] + send_cnt[r]) of d_send go to rank r; what rank r sent lands at
-     * [recv_off[r], recv_off[r] + recv_cnt[r]) of d_recv (arrays of `world` entries; the own share is copied too) */
+     * [recv_off[r], recv_off[r] + recv_cnt[r]) of d_recv (arrays of `world` entries; the own share is copied too).  d_send is complete
+     * on entry, d_recv must be complete on return; OTHER work of the library may still be queued on the context's stream (the next
+     * column chunk's transforms), so run the collective on a stream of the transport's own and wait for that stream only */
     int (*alltoallv)(void* user, const uint32_t* d_send, const size_t* send_off, const size_t* send_cnt, uint32_t* d_recv,
                      const size_t* recv_off, const size_t* recv_cnt);
     /* device all-gather: d_recv = world x n_words, rank r's contribution at r * n_words */
