@@ -68,6 +68,22 @@ def test_machine_prove_at_2pow18_v1_shaped(be, nz, oracle):
     _same(M.prove_machine(comps, O.default_cfg(**kw), seed=5, threads=THREADS), words)
 
 
+def test_machine_whole_proof_byte_equal_at_2pow20(be, nz, oracle):
+    """What bench.py proves (27 + 347 columns, 16 real logup columns = 64 interaction columns, recorded AIR) at 2^20 rows — the size of the
+    bench's cpu_baseline sample: every proof word equals the oracle machine's."""
+    comps = [(20, 27, 347, 64)]
+    words = be.prove_machine(comps, nz.default_config(), seed=7)
+    _same(M.prove_machine(comps, O.default_cfg(), seed=7, threads=THREADS), words)
+
+
+@pytest.mark.skipif(os.environ.get("NX_RUN_SLOW", "0") != "1", reason="slow: the oracle proves the 2^22-row machine on the host (minutes, tens of GB of RAM); NX_RUN_SLOW=1")
+def test_machine_whole_proof_byte_equal_at_2pow22_headline(be, nz, oracle):
+    """The bench's headline statement itself (BASELINE config #3 with the real logup interaction trace), every word."""
+    comps = [(22, 27, 347, 64)]
+    words = be.prove_machine(comps, nz.default_config(), seed=2001)
+    _same(M.prove_machine(comps, O.default_cfg(), seed=2001, threads=THREADS), words)
+
+
 def _run_ranks(nz, world, fn):
     from nexus_zkvm_amd.sharded import ThreadGroup
     group = ThreadGroup(world)
