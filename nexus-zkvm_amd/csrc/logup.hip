@@ -14,6 +14,7 @@
 #include "internal.h"
 #include <algorithm>
 #include <string.h>
+#include <stdlib.h>
 
 namespace nx {
 
@@ -210,6 +211,87 @@ __global__ __launch_bounds__(256) void logup_scan_fix_kernel(const Sec4* __restr
     col.c[0][p] = v.a.a; col.c[1][p] = v.a.b; col.c[2][p] = v.b.a; col.c[3][p] = v.b.b;
 }
 
+// ---- the same scan with coalesced accesses (log_size >= 13) --------------------------------------------------------------------
+// Coset rows 2k and 2k+1 sit at positions 2m and N-1-2m with m = bitrev_{n-1}(k): the even row in the lower "E" word, the odd row in
+// the mirrored "O" word.  S(2k) = X[k] + E[k], S(2k+1) = X[k] + E[k] + O[k] with X the exclusive scan of E + O over k — a scan over an
+// array stored in bit-reversed order.  A block takes 2^T neighbouring values of the low part of m (runs of 2^(T+1) words: E's at the
+// even words, the mirror block's O's between them) times all 2^H values of the top part: that is 2^T k-segments of 2^H consecutive
+// pairs, transposed through LDS.  Levels: segment-local scan (this kernel), the segment totals (logup_scan_sums_kernel, as before),
+// the fix-up with the same tiling.  One (column, coordinate) per blockIdx.y: a QM31 sum and a multiple of the shift are coordinate-wise.
+constexpr int SC_H = 7, SC_T = 5, SC_MIN_LOG = SC_H + SC_T + 1;
+struct ScanTile { u32 m, s, kl; };   // pair index in memory order; its segment (k >> H) and place in it
+__device__ __forceinline__ ScanTile scan_tile_index(u32 mh, u32 ml_hi, u32 t, int n1) {
+    const int L = n1 - SC_H;
+    ScanTile x;
+    x.m = (mh << L) | (ml_hi << SC_T) | t;
+    x.s = (bitrev(t, SC_T) << (L - SC_T)) | (L > SC_T ? bitrev(ml_hi, L - SC_T) : 0u);
+    x.kl = bitrev(mh, SC_H);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void logup_scan_tile_kernel(const Sec4* __restrict__ cols, int log, u32* __restrict__ all_sums /*[column][segment][4]*/) {
+    constexpr u32 SEGS = 1u << SC_T, LEN = 1u << SC_H, PITCH = LEN + 1;
+    __shared__ u32 E[SEGS * PITCH], O[SEGS * PITCH];
+    const int n1 = log - 1;
+    const u32 N = 1u << log, n_seg = 1u << (n1 - SC_H);
+    const u32 q = blockIdx.y & 3;
+    u32* __restrict__ col = cols[blockIdx.y >> 2].c[q];
+    u32* __restrict__ sums = all_sums + (size_t)(blockIdx.y >> 2) * n_seg * 4;
+    const u32 t = threadIdx.x & (SEGS - 1), mh0 = threadIdx.x >> SC_T;      // 8 values of mh per sweep
+    for (u32 mh = mh0; mh < LEN; mh += 256 >> SC_T) {
+        const ScanTile x = scan_tile_index(mh, blockIdx.x, t, n1);
+        E[t * PITCH + x.kl] = gld(col + 2 * (size_t)x.m);
+        O[t * PITCH + x.kl] = gld(col + (N - 1 - 2 * (size_t)x.m));
+    }
+    __syncthreads();
+    {   // 8 lanes per segment, 16 consecutive pairs per lane
+        const u32 seg = threadIdx.x >> 3, j = threadIdx.x & 7, base = seg * PITCH + j * (LEN / 8);
+        u32 run = 0;
+#pragma unroll
+        for (u32 i = 0; i < LEN / 8; i++) run = m_add(run, m_add(E[base + i], O[base + i]));
+        u32 incl = run;                                                     // inclusive scan of the 8 lane totals of the segment
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) { const u32 up = __shfl_up(incl, d, 8); if ((int)j >= d) incl = m_add(incl, up); }
+        u32 x = m_sub(incl, run);                                           // exclusive offset of this lane inside its segment
+#pragma unroll
+        for (u32 i = 0; i < LEN / 8; i++) {
+            const u32 e = E[base + i], o = O[base + i];
+            const u32 se = m_add(x, e), so = m_add(se, o);
+            E[base + i] = se; O[base + i] = so; x = so;
+        }
+        if (j == 7) {
+            const u32 s = (bitrev(seg, SC_T) << (n1 - SC_H - SC_T)) | ((n1 - SC_H) > SC_T ? bitrev(blockIdx.x, n1 - SC_H - SC_T) : 0u);
+            sums[4 * (size_t)s + q] = incl;
+        }
+    }
+    __syncthreads();
+    for (u32 mh = mh0; mh < LEN; mh += 256 >> SC_T) {
+        const ScanTile x = scan_tile_index(mh, blockIdx.x, t, n1);
+        gst(col + 2 * (size_t)x.m, E[t * PITCH + x.kl]);
+        gst(col + (N - 1 - 2 * (size_t)x.m), O[t * PITCH + x.kl]);
+    }
+}
+
+// fix-up with the same tiling: value += offset[segment] - (coset row + 1) * shift
+__global__ __launch_bounds__(256) void logup_scan_tile_fix_kernel(const Sec4* __restrict__ cols, int log, const u32* __restrict__ all_offsets /*exclusive, [column][segment][4]*/,
+                                                                  const u32* __restrict__ meta) {
+    const int n1 = log - 1;
+    const u32 N = 1u << log, n_seg = 1u << (n1 - SC_H);
+    const u32 q = blockIdx.y & 3;
+    u32* __restrict__ col = cols[blockIdx.y >> 2].c[q];
+    const u32* __restrict__ offs = all_offsets + (size_t)(blockIdx.y >> 2) * n_seg * 4;
+    const u32 shift = meta[8 * (blockIdx.y >> 2) + 4 + q];
+    const u32 t = threadIdx.x & ((1u << SC_T) - 1);
+    const u32 sweeps = (1u << SC_H) / (256 >> SC_T);                         // blockIdx.x = ml_hi * sweeps + sweep
+    const u32 ml_hi = blockIdx.x / sweeps, mh = (blockIdx.x % sweeps) * (256 >> SC_T) + (threadIdx.x >> SC_T);
+    const ScanTile x = scan_tile_index(mh, ml_hi, t, n1);
+    const u32 off = offs[4 * (size_t)x.s + q];
+    const u64 c = 2 * (((u64)x.s << SC_H) | x.kl);                           // the even coset row of the pair
+    u32* pe = col + 2 * (size_t)x.m; u32* po = col + (N - 1 - 2 * (size_t)x.m);
+    gst(pe, m_sub(m_add(gld(pe), off), m_mul(shift, m_reduce64(c + 1))));
+    gst(po, m_sub(m_add(gld(po), off), m_mul(shift, m_reduce64(c + 2))));
+}
+
 }  // namespace nx
 
 using namespace nx;
@@ -336,7 +418,10 @@ int nx_logup_finalize_last_batch(nx_ctx* ctx, uint32_t log_size, uint32_t* const
     if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: log_size too large");
     if (n_cols == 0) return NX_OK;
     if (n_cols > 65535) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: at most 65535 columns per call");
-    const u32 n = 1u << log_size, n_blocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    // coalesced tiles from 2^13 rows (NX_LOGUP_SCAN_TILED=0: the per-row gather kernels at every size, kept for A/B and small columns)
+    static const bool tiled_on = []() { const char* e = getenv("NX_LOGUP_SCAN_TILED"); return !e || atoi(e) != 0; }();
+    const bool tiled = tiled_on && log_size >= (uint32_t)SC_MIN_LOG && n_cols * 4 <= 65535;
+    const u32 n = 1u << log_size, n_blocks = tiled ? 1u << (log_size - 1 - SC_H) : (n + SCAN_BLOCK - 1) / SCAN_BLOCK;   // tiled: one total per 128-pair segment
     std::vector<Sec4> h(n_cols);
     for (u32 k = 0; k < n_cols; k++) for (int q = 0; q < 4; q++) { if (!d_cols4[4 * k + q]) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: NULL column"); h[k].c[q] = d_cols4[4 * k + q]; }
     uint8_t* blob = nullptr;
@@ -344,7 +429,13 @@ int nx_logup_finalize_last_batch(nx_ctx* ctx, uint32_t log_size, uint32_t* const
     NX_TRY(dev_alloc(ctx, b_tab + b_sums + b_meta, (void**)&blob));
     const Sec4* d_tab = (const Sec4*)blob; u32* d_sums = (u32*)(blob + b_tab); u32* d_meta = (u32*)(blob + b_tab + b_sums);
     hipError_t e = hipMemcpyAsync(blob, h.data(), (size_t)n_cols * sizeof(Sec4), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
+    if (e == hipSuccess && tiled) {
+        const u32 tiles = 1u << (log_size - 1 - SC_H - SC_T), sweeps = (1u << SC_H) / (256 >> SC_T);
+        hipLaunchKernelGGL(logup_scan_tile_kernel, dim3(tiles, n_cols * 4), dim3(256), 0, ctx->stream, d_tab, (int)log_size, d_sums);
+        hipLaunchKernelGGL(logup_scan_sums_kernel, dim3(n_cols), dim3(SCAN_THREADS), 0, ctx->stream, d_sums, n_blocks, (int)log_size, d_meta);
+        hipLaunchKernelGGL(logup_scan_tile_fix_kernel, dim3(tiles * sweeps, n_cols * 4), dim3(256), 0, ctx->stream, d_tab, (int)log_size, (const u32*)d_sums, (const u32*)d_meta);
+        e = hipGetLastError();
+    } else if (e == hipSuccess) {
         hipLaunchKernelGGL(logup_scan_local_kernel, dim3(n_blocks, n_cols), dim3(SCAN_THREADS), 0, ctx->stream, d_tab, (int)log_size, d_sums);
         hipLaunchKernelGGL(logup_scan_sums_kernel, dim3(n_cols), dim3(SCAN_THREADS), 0, ctx->stream, d_sums, n_blocks, (int)log_size, d_meta);
         hipLaunchKernelGGL(logup_scan_fix_kernel, dim3((n + 255) / 256, n_cols), dim3(256), 0, ctx->stream, d_tab, (int)log_size, (const u32*)d_sums, n_blocks, (const u32*)d_meta);
