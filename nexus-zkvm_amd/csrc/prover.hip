@@ -511,9 +511,12 @@ class FriProver {
     }
 
     // The per-layer host channel.  Row-sharded: the first-layer columns and the line layers are row blocks — trees are subtree + W
-    // roots, folds are local (pairs are adjacent) — until a layer has fewer than 2^FRI_DIST_MIN_LOCAL rows per GPU: then the layer
-    // and the remaining circle columns are all-gathered and the tail runs replicated on every GPU.
+    // roots, folds are local (pairs are adjacent) — while that pays: a sharded layer costs a host all-gather of the W subtree roots
+    // (a collective plus two host round trips, ~0.2 ms) and saves (1 - 1/W) of the layer's hashing, which is 0.14 ms for 2^21 rows on
+    // the whole chip.  Below 2^NX_FRI_DIST_MIN_LOG rows (default 21; the tests set 0), or 2^FRI_DIST_MIN_LOCAL rows per GPU, the
+    // layer and the remaining circle columns are all-gathered and the tail runs replicated on every GPU.
     static constexpr uint32_t FRI_DIST_MIN_LOCAL = 10;
+    static uint32_t fri_dist_min_log() { const char* e = getenv("NX_FRI_DIST_MIN_LOG"); return e ? (uint32_t)std::max(0, atoi(e)) : 21u; }
     int commit_host_channel(Blake2sChannel& channel, std::vector<SecureColumn>&& cols) {
         columns = std::move(cols);
         if (columns.empty()) return set_err(ctx, NX_ERR_ARG, "fri: no columns");
@@ -523,6 +526,7 @@ class FriProver {
         const QM31 first_alpha = folding_alpha;
         uint32_t layer_log = columns[0].log - 1;
         bool sharded = D.on();
+        const uint32_t min_log = fri_dist_min_log();
         SecureColumn layer;
         if (sharded) H_TRY(layer.alloc_rows(ctx, layer_log, D.block(layer_log), true)); else H_TRY(layer.alloc(ctx, layer_log));
         H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
@@ -530,7 +534,7 @@ class FriProver {
         size_t ci = 0; uint32_t n_doublings = 0;
         std::vector<SecureColumn> gathered;   // whole copies of the circle columns folded in after the switch to the replicated tail
         while (layer_log > last_log) {
-            if (sharded && layer_log < (uint32_t)D.log_w + FRI_DIST_MIN_LOCAL) {
+            if (sharded && (layer_log < (uint32_t)D.log_w + FRI_DIST_MIN_LOCAL || layer_log < min_log)) {
                 SecureColumn whole; H_TRY(gather_secure(ctx, D, layer, &whole));
                 layer = std::move(whole);
                 gathered.resize(columns.size());

@@ -18,6 +18,13 @@ P = O.P
 THREADS = max(4, os.cpu_count() or 4)
 
 
+@pytest.fixture(autouse=True)
+def _small_sharded_fri_layers(monkeypatch):
+    """Row-sharded proves keep a FRI layer sharded only from 2^21 rows up (NX_FRI_DIST_MIN_LOG): the tests lower the limit so that the
+    sharded layer trees and folds run at test sizes too."""
+    monkeypatch.setenv("NX_FRI_DIST_MIN_LOG", "0")
+
+
 @pytest.fixture(scope="module")
 def be():
     import nexus_zkvm_amd as nz
@@ -140,6 +147,19 @@ def test_machine_row_sharded_with_chunked_exchange(be, nz, monkeypatch, world, c
     ref = be.prove_machine(comps, cfg, seed=99, ad=b"q")
     monkeypatch.setenv("NX_DIST_CHUNKS", str(chunks))
     res = _run_ranks(nz, world, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=99, ad=b"q", comm=comm))
+    for r in range(world):
+        _same(ref, res[r])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_machine_row_sharded_default_fri_switch(be, nz, monkeypatch, world):
+    """The product's own limit (a FRI layer stays sharded from 2^21 rows up, then the layer is all-gathered and the tail runs replicated):
+    a 2^20-row statement has one sharded line layer (2^21) before the switch; same bytes as on one GPU."""
+    monkeypatch.delenv("NX_FRI_DIST_MIN_LOG", raising=False)
+    comps = [(20, 8, 40, 16), (12, 2, 9, 4)]
+    cfg = nz.default_config(pow_bits=6)
+    ref = be.prove_machine(comps, cfg, seed=77, ad=b"f")
+    res = _run_ranks(nz, world, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=77, ad=b"f", comm=comm))
     for r in range(world):
         _same(ref, res[r])
 

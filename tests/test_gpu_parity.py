@@ -22,6 +22,13 @@ P = O.P
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.fixture(autouse=True)
+def _small_sharded_fri_layers(monkeypatch):
+    """Row-sharded proves keep a FRI layer sharded only from 2^21 rows up (NX_FRI_DIST_MIN_LOG): the tests lower the limit so that the
+    sharded layer trees and folds run at test sizes too."""
+    monkeypatch.setenv("NX_FRI_DIST_MIN_LOG", "0")
+
+
 @pytest.fixture(scope="module")
 def be():
     import nexus_zkvm_amd as nz
