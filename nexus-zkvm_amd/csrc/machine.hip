@@ -429,7 +429,8 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
                     // everyone (the claimed sum enters the transcript); the other columns go back to column shards by one all-to-all
                     DevBuf last; H_TRY(last.alloc(ctx, (size_t)4 << log));
                     uint32_t* lp[4];
-                    for (int q = 0; q < 4; q++) { lp[q] = last.p + ((size_t)q << log); H_TRY(D.allgather_dev(ctx, ip[4 * (L - 1) + q], (size_t)nb, lp[q])); }
+                    for (int q = 0; q < 4; q++) lp[q] = last.p + ((size_t)q << log);
+                    H_TRY(D.allgather_cols(ctx, {ip[4 * (L - 1)], ip[4 * (L - 1) + 1], ip[4 * (L - 1) + 2], ip[4 * (L - 1) + 3]}, (size_t)nb, last.p, (uint64_t)1 << log));
                     H_TRY(nx_logup_finalize_last(ctx, log, lp, cs4));
                     const uint32_t n_loc = hi - lo;
                     DevBuf recv; H_TRY(recv.alloc(ctx, (size_t)std::max<uint32_t>(n_loc, 1) << log));

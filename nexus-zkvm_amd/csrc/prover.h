@@ -52,6 +52,9 @@ struct Dist {
     static uint32_t cut(uint32_t n, int r, int world) { return (uint32_t)(((uint64_t)n * (uint64_t)r) / (uint64_t)world); }
     int allgather_host(nx_ctx* ctx, const void* send, size_t bytes, void* recv) const;
     int allgather_dev(nx_ctx* ctx, const uint32_t* d_send, size_t words, uint32_t* d_recv) const;
+    // several row blocks (rb words each) -> their whole columns (whole_base + k * whole_stride, world * rb words each) with ONE collective:
+    // the blocks travel as one buffer, the [rank][column][rb] result is unpacked by transpose_blocks
+    int allgather_cols(nx_ctx* ctx, const std::vector<const uint32_t*>& blk, size_t rb, uint32_t* whole_base, uint64_t whole_stride) const;
     // ready: an event recorded on the context's stream after the send buffer was written — the host then waits for that event only,
     // so work enqueued behind it (the next column chunk's LDE) keeps the GPU busy during the exchange; null = drain the stream.
     int alltoallv(nx_ctx* ctx, const uint32_t* d_send, const size_t* soff, const size_t* scnt, uint32_t* d_recv, const size_t* roff, const size_t* rcnt,

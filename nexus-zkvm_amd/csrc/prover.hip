@@ -35,6 +35,24 @@ int Dist::allgather_dev(nx_ctx* ctx, const uint32_t* d_send, size_t words, uint3
     if (comm_bytes) *comm_bytes += words * 4 * (size_t)(world - 1);
     return NX_OK;
 }
+int Dist::allgather_cols(nx_ctx* ctx, const std::vector<const uint32_t*>& blk, size_t rb, uint32_t* whole_base, uint64_t whole_stride) const {
+    const size_t n = blk.size();
+    if (n == 0) return NX_OK;
+    if (n == 1) return allgather_dev(ctx, blk[0], rb, whole_base);
+    bool contiguous = true;
+    for (size_t k = 1; k < n; k++) contiguous = contiguous && blk[k] == blk[0] + k * rb;
+    DevBuf send, tmp;
+    const uint32_t* src = blk[0];
+    if (!contiguous) {
+        H_TRY(send.alloc(ctx, n * rb));
+        for (size_t k = 0; k < n; k++) H_TRY(nx_copy(ctx, send.p + k * rb, blk[k], rb));
+        src = send.p;
+    }
+    H_TRY(tmp.alloc(ctx, (size_t)world * n * rb));
+    H_TRY(allgather_dev(ctx, src, n * rb, tmp.p));
+    return transpose_blocks(ctx, whole_base, whole_stride, tmp.p, (uint32_t)n, (uint64_t)world * rb, (uint32_t)world, true);
+}
+
 int Dist::alltoallv(nx_ctx* ctx, const uint32_t* d_send, const size_t* soff, const size_t* scnt, uint32_t* d_recv, const size_t* roff, const size_t* rcnt,
                     hipEvent_t ready) const {
     if (ready) NX_HIP(ctx, hipEventSynchronize(ready));
@@ -403,8 +421,7 @@ static std::vector<size_t> queries_fold(const std::vector<size_t>& q, uint32_t n
 // all-gather a row-sharded secure column into a whole one (the FRI tail, the composition accumulator)
 static int gather_secure(nx_ctx* ctx, const Dist& D, const SecureColumn& blk, SecureColumn* whole) {
     H_TRY(whole->alloc(ctx, blk.log));
-    for (int k = 0; k < 4; k++) H_TRY(D.allgather_dev(ctx, blk.c[k], (size_t)blk.rows, whole->c[k]));
-    return NX_OK;
+    return D.allgather_cols(ctx, {blk.c[0], blk.c[1], blk.c[2], blk.c[3]}, (size_t)blk.rows, whole->c[0], (uint64_t)1 << blk.log);
 }
 
 class FriProver {
@@ -793,13 +810,15 @@ int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pa
         for (size_t k = 0; k < n; k++) blk[k] = rows.p + roff[own[k]] + (size_t)pos[k] * mb;
         out->keep.push_back(std::move(rows));
     }
-    for (size_t k = 0; k < n; k++) {
-        if (k < masked.size() && masked[k]) {       // neighbour rows live in other blocks: the whole column
-            DevBuf whole; H_TRY(whole.alloc(ctx, (size_t)1 << e));
-            H_TRY(D.allgather_dev(ctx, blk[k], (size_t)mb, whole.p));
-            out->ptrs[k] = whole.p;
+    {   // columns read at a non-zero mask offset: neighbour rows live in other blocks, so the whole columns — one all-gather for all of them
+        std::vector<const uint32_t*> mblk; std::vector<size_t> mk;
+        for (size_t k = 0; k < n; k++) { if (k < masked.size() && masked[k]) { mblk.push_back(blk[k]); mk.push_back(k); } else out->ptrs[k] = bias_rows(blk[k], rb); }
+        if (!mblk.empty()) {
+            DevBuf whole; H_TRY(whole.alloc(ctx, mblk.size() << e));
+            H_TRY(D.allgather_cols(ctx, mblk, (size_t)mb, whole.p, (uint64_t)1 << e));
+            for (size_t i = 0; i < mk.size(); i++) out->ptrs[mk[i]] = whole.p + (i << e);
             out->keep.push_back(std::move(whole));
-        } else out->ptrs[k] = bias_rows(blk[k], rb);
+        }
     }
     return NX_OK;
 }
