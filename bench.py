@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--extra-comps", type=int, default=0, help="small extra components of 2^8, 2^9, ... rows next to the main one (machine.rs:82-91)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: one independent proof per GPU (weak scaling) instead of ONE row-sharded proof")
     ap.add_argument("--legacy-synth", action="store_true", help="prove the round-1 machine (synthetic interaction fill, hand-written constraint kernel)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank on GPU 0 (RCCL refuses that; use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -79,13 +81,18 @@ def main():
         print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libnexus_hip has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import nexus_zkvm_amd as nz
     be = nz.HipBackend(local_rank)
