@@ -241,6 +241,25 @@ def test_session_driven_by_several_ranks(be, nz, oracle):
             _same(ref, w)
 
 
+def test_bench_two_processes_one_proof(tmp_path):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank) — over gloo with both ranks on this
+    box's GPU, since RCCL refuses two ranks on one device: ONE row-sharded proof per step, one JSON line from rank 0."""
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ); env.pop("NX_FRI_DIST_MIN_LOG", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-rows", "14", "--backend", "gloo", "--same-device"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 1 and out["value"] > 0
+    assert out["xgmi"]["bytes_sent_per_gpu_per_proof"] > 0 and "cpu_baseline" not in out
+
+
 def test_torch_transport_on_device_buffers_nccl_world1(be, nz):
     """The RCCL transport of the row-sharded prove (nexus_zkvm_amd.sharded.TorchDistComm) on REAL device buffers of the library:
     zero-copy torch views over nx_alloc memory, dist.all_to_all_single with split sizes and all_gather_into_tensor on the nccl (= RCCL)
