@@ -201,7 +201,7 @@ using namespace nx;
 
 extern "C" {
 
-const char* nx_version(void) { return "nexus_hip 0.1 (gfx950)"; }
+const char* nx_version(void) { return "nexus_hip 0.2 (gfx950)"; }
 
 const char* nx_last_error(const nx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
