@@ -178,6 +178,7 @@ struct TreePipe {
     uint32_t max_log = 0, total_leaf_cols = 0, absorbed = 0;
     std::vector<const uint32_t*> pending;   // columns handed in but not yet hashed (kept until a 16-column block is complete)
     bool any_launch = false;
+    bool side_stream = false;              // hash on ctx->hash_stream behind the next column group's LDE (NX_PIPE_COLS); else in stream order
 };
 int tree_pipe_begin(nx_ctx* ctx, uint32_t max_log, uint32_t total_leaf_cols, TreePipe* tp);
 int tree_pipe_absorb(nx_ctx* ctx, TreePipe* tp, const uint32_t* const* d_cols, uint32_t n_cols, bool flush);

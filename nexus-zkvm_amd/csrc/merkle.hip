@@ -601,10 +601,14 @@ int tree_pipe_absorb(nx_ctx* ctx, TreePipe* tp, const uint32_t* const* d_cols, u
     size_t take = (flush || is_end) && is_end ? tp->pending.size() : (tp->pending.size() / 16) * 16;
     if (take == 0) return NX_OK;
     ColSet cs; NX_TRY(make_colset(ctx, tp->pending.data(), (uint32_t)take, &cs));   // pointer table staged on the main stream
-    NX_HIP(ctx, hipEventRecord(ctx->hash_ev, ctx->stream));
-    NX_HIP(ctx, hipStreamWaitEvent(ctx->hash_stream, ctx->hash_ev, 0));
+    hipStream_t hs = ctx->stream;
+    if (tp->side_stream) {
+        NX_HIP(ctx, hipEventRecord(ctx->hash_ev, ctx->stream));
+        NX_HIP(ctx, hipStreamWaitEvent(ctx->hash_stream, ctx->hash_ev, 0));
+        hs = ctx->hash_stream;
+    }
     u32* leaves = tp->tree->layers[tp->max_log];
-    NX_TRY(leaf_chain_launch(ctx, ctx->hash_stream, cs, (u32)take, tp->absorbed, tp->total_leaf_cols, tp->absorbed ? leaves : nullptr, leaves, 0,
+    NX_TRY(leaf_chain_launch(ctx, hs, cs, (u32)take, tp->absorbed, tp->total_leaf_cols, tp->absorbed ? leaves : nullptr, leaves, 0,
                              (u64)1 << tp->max_log));
     tp->absorbed += (uint32_t)take;
     tp->pending.erase(tp->pending.begin(), tp->pending.begin() + take);
@@ -615,7 +619,7 @@ int tree_pipe_absorb(nx_ctx* ctx, TreePipe* tp, const uint32_t* const* d_cols, u
 int tree_pipe_finish(nx_ctx* ctx, TreePipe* tp, const uint32_t* const* d_small_cols, const uint32_t* small_logs, uint32_t n_small, nx_tree** out) {
     int rc = tree_pipe_absorb(ctx, tp, nullptr, 0, true);
     if (rc == NX_OK && tp->absorbed != tp->total_leaf_cols) rc = set_err(ctx, NX_ERR_ARG, "tree_pipe_finish: fewer leaf columns than announced");
-    if (rc == NX_OK) {
+    if (rc == NX_OK && tp->side_stream) {
         hipError_t e = hipEventRecord(ctx->hash_ev, ctx->hash_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->hash_ev, 0);
         if (e != hipSuccess) rc = hip_fail(ctx, e, "tree_pipe_finish", __FILE__, __LINE__);

@@ -222,7 +222,7 @@ int TreeBuilder::commit_single(Blake2sChannel& channel) {
     for (auto& g : groups) if (g.lo != 0 || g.hi != g.n_cols) return set_err(ctx, NX_ERR_ARG, "TreeBuilder: a column shard was handed to a single-GPU commitment scheme");
     TreePipe tp;
     struct PipeGuard { nx_ctx* c; TreePipe* p; ~PipeGuard() { if (p->tree) { (void)nx_sync(c); nx_tree_destroy(p->tree); p->tree = nullptr; } } } guard{ctx, &tp};
-    if (total_leaf_cols) H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp));
+    if (total_leaf_cols) { H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp)); tp.side_stream = pipe_group_cols() < (1u << 29); }
     std::vector<const uint32_t*> small_cols; std::vector<uint32_t> small_logs;
     const uint32_t G = pipe_group_cols();
     // consecutive groups of one size (the components of a prover2-style statement) are extended by ONE batch call: a tree of 55 small
