@@ -421,6 +421,16 @@ class HipBackend:
     def set_hash_mode(self, mode):
         self._chk(self.L.nx_ctx_set_hash_mode(self.ctx, mode))
 
+    def set_option(self, name, value):
+        """Per-context policy / tuning (nx_ctx_set_option): "fft.pipe", "fft.pipe_grid", "fft.batch_cols", "fft.streams",
+        "fri.dist_min_log", "dist.chunks", "air.segment", ...  The NX_* environment variables only seed a new context's defaults."""
+        self._chk(self.L.nx_ctx_set_option(self.ctx, name.encode(), C.c_int64(int(value))))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        self._chk(self.L.nx_ctx_get_option(self.ctx, name.encode(), C.byref(v)))
+        return v.value
+
     # ---- Column ops ----
     def clone_columns(self, cols):
         """Column::clone on device (nx_copy)."""

@@ -76,9 +76,12 @@ static uint32_t instr_cost(uint32_t op) {   // rough gfx950 instruction counts o
     case NX_C_LOADE: return 24; case NX_C_CONSTRAINT_B: return 14; case NX_C_CONSTRAINT_E: return 170; default: return 1;
     }
 }
-static uint32_t segment_budget() {
-    static const uint32_t v = []() { const char* e = getenv("NX_AIR_SEGMENT"); int x = e ? atoi(e) : 9000; return (uint32_t)std::max(200, x); }();   // ~70 KB of code per kernel; measured sweep 1500..60000 (profiles/r02_segment_sweep.txt): 4500-13000 is flat and best
-    return v;
+// estimated-instruction budget of one generated kernel: ~70 KB of code per kernel at the default 9000; measured sweep 1500..60000
+// (profiles/r02_segment_sweep.txt): 4500-13000 is flat and best.  Per context ("air.segment").
+static uint32_t segment_budget(const nx_ctx* ctx) {
+    if (ctx) return (uint32_t)ctx->opt.air_segment;
+    const char* e = getenv("NX_AIR_SEGMENT");   // source-only generation without a context (CPU suite): the process default
+    return (uint32_t)std::max(200, e ? atoi(e) : 9000);
 }
 
 static std::string generate_kernel(const nx_cinstr* prog, const std::vector<uint32_t>& keep, const std::vector<uint32_t>& cons_index, uint32_t n_regs, const std::string& name) {
@@ -144,7 +147,7 @@ static std::string generate_kernel(const nx_cinstr* prog, const std::vector<uint
     return s;
 }
 
-static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t* n_kernels = nullptr) {
+static std::string generate_air_source(const nx_ctx* ctx, const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t* n_kernels = nullptr) {
     // register-level dependencies: deps[i] = the instructions that last wrote the registers instruction i reads
     std::vector<int> last(n_regs, -1);
     std::vector<std::vector<uint32_t>> deps(n_instr);
@@ -190,7 +193,7 @@ static std::string generate_air_source(const nx_cinstr* prog, uint32_t n_instr, 
         n_seg++;
         std::fill(in_seg.begin(), in_seg.end(), 0); cost = 0;
     };
-    const uint32_t budget = segment_budget();
+    const uint32_t budget = segment_budget(ctx);
     bool any = false;
     for (uint32_t i = 0; i < n_instr; i++) {
         if (prog[i].op != NX_C_CONSTRAINT_B && prog[i].op != NX_C_CONSTRAINT_E) continue;
@@ -256,7 +259,7 @@ int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint
     NX_TRY(validate_air_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, &n_c));
     if (n_c != n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: the program adds a different number of constraints than announced");
     uint32_t n_kernels = 1;
-    const std::string src = generate_air_source(program, n_instr, n_regs, &n_kernels);
+    const std::string src = generate_air_source(ctx, program, n_instr, n_regs, &n_kernels);
     if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
     if (!out) return NX_OK;
     if (!ctx) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: a context is needed to load the kernel");

@@ -205,6 +205,48 @@ const char* nx_version(void) { return "nexus_hip 0.2 (gfx950)"; }
 
 const char* nx_last_error(const nx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+static nx_options options_from_env() {
+    nx_options o;
+    o.fft_pipe = env_int("NX_FFT_PIPE", 1) != 0;
+    o.fft_pipe_blocks_per_cu = clampi(env_int("NX_FFT_PGRID", 2), 1, 2);
+    o.fft_pipe_grid = 0;
+    o.fft_batch_cols = std::max(1, env_int("NX_FFT_BATCH", 2));
+    o.fft_streams = clampi(env_int("NX_FFT_STREAMS", 2), 1, 4);
+    o.fri_dist_min_log = std::max(0, env_int("NX_FRI_DIST_MIN_LOG", 21));
+    o.dist_chunks = std::max(0, env_int("NX_DIST_CHUNKS", 0));
+    o.air_segment = std::max(200, env_int("NX_AIR_SEGMENT", 9000));
+    return o;
+}
+struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
+static const OptEntry k_options[] = {
+    {"fft.pipe", &nx_options::fft_pipe, 0, 1},
+    {"fft.pipe_blocks_per_cu", &nx_options::fft_pipe_blocks_per_cu, 1, 2},
+    {"fft.pipe_grid", &nx_options::fft_pipe_grid, 0, 1 << 20},
+    {"fft.batch_cols", &nx_options::fft_batch_cols, 1, 256},
+    {"fft.streams", &nx_options::fft_streams, 1, 4},
+    {"fri.dist_min_log", &nx_options::fri_dist_min_log, 0, 31},
+    {"dist.chunks", &nx_options::dist_chunks, 0, 64},
+    {"air.segment", &nx_options::air_segment, 200, 1 << 30},
+};
+int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return set_err(ctx, NX_ERR_ARG, "nx_ctx_set_option: NULL argument");
+    for (const OptEntry& e : k_options)
+        if (!strcmp(e.name, name)) {
+            if (value < e.lo || value > e.hi) return set_err(ctx, NX_ERR_ARG, std::string("nx_ctx_set_option: value out of range for ") + name);
+            ctx->opt.*(e.field) = (int)value;
+            return NX_OK;
+        }
+    return set_err(ctx, NX_ERR_ARG, std::string("nx_ctx_set_option: unknown option ") + name);
+}
+int nx_ctx_get_option(const nx_ctx* ctx, const char* name, int64_t* value) {
+    if (!ctx || !name || !value) return set_err(const_cast<nx_ctx*>(ctx), NX_ERR_ARG, "nx_ctx_get_option: NULL argument");
+    for (const OptEntry& e : k_options)
+        if (!strcmp(e.name, name)) { *value = ctx->opt.*(e.field); return NX_OK; }
+    return set_err(const_cast<nx_ctx*>(ctx), NX_ERR_ARG, std::string("nx_ctx_get_option: unknown option ") + name);
+}
+
 int nx_ctx_create(int device, nx_ctx** out) {
     if (!out) return set_err(nullptr, NX_ERR_ARG, "nx_ctx_create: out is NULL");
     int count = 0;
@@ -218,6 +260,7 @@ int nx_ctx_create(int device, nx_ctx** out) {
         return set_err(nullptr, NX_ERR_NO_DEVICE, std::string("nx_ctx_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     NX_HIP(nullptr, hipSetDevice(device));
     nx_ctx* c = new nx_ctx();
+    c->opt = options_from_env();
     c->device = device; c->hash_mode = NX_HASH_BLAKE2S; c->timing = false; c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->scratch_size = 16u << 20; c->scratch_off = 0; c->d_scratch = nullptr; c->h_scratch = nullptr; c->cached_bytes = 0;
     for (int i = 0; i < 4; i++) { c->kind_ms[i] = 0; c->kind_bytes[i] = 0; }

@@ -246,8 +246,8 @@ __global__ void fft_tiny_kernel(ColSet src, ColSet dst, u32 n_cols, int n, int l
 }
 
 // ---- planning ----
-struct FftTune { int smax, bmax, threads, batch_cols, legacy, streams; };
-static FftTune g_tune = {13, 5, 256, 2, 0, 2};   // 2 streams x 2 columns in flight: the working set of a batch (48 MiB per column at 2^22) stays in the 256 MiB Infinity Cache between its four passes
+struct FftTune { int smax, bmax, threads, legacy; };   // columns per launch and streams are per-context options (nx_ctx_set_option)
+static FftTune g_tune = {13, 5, 256, 0};   // 2 streams x 2 columns in flight: the working set of a batch (48 MiB per column at 2^22) stays in the 256 MiB Infinity Cache between its four passes
 static std::once_flag g_tune_once;
 // Read once per process, under std::call_once: contexts on several host threads (one per GPU, tools/concurrent_proves.py, ThreadGroup)
 // plan their first transform concurrently and must all see the fully clamped values.
@@ -257,13 +257,10 @@ static void tune_init() {
         if (const char* e = getenv("NX_FFT_SMAX")) t.smax = atoi(e);
         if (const char* e = getenv("NX_FFT_B")) t.bmax = atoi(e);
         if (const char* e = getenv("NX_FFT_THREADS")) t.threads = atoi(e);
-        if (const char* e = getenv("NX_FFT_BATCH")) t.batch_cols = atoi(e);
         if (const char* e = getenv("NX_FFT_LEGACY")) t.legacy = atoi(e);
-        if (const char* e = getenv("NX_FFT_STREAMS")) t.streams = std::max(1, std::min(4, atoi(e)));
         t.smax = std::max(6, std::min(t.smax, 15));
         t.bmax = std::max(2, std::min(t.bmax, 6));
         if (t.threads != 128 && t.threads != 256 && t.threads != 512 && t.threads != 1024) t.threads = 256;
-        t.batch_cols = std::max(1, t.batch_cols);
         g_tune = t;
     });
 }
@@ -384,17 +381,17 @@ static int evaluate_cols(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n
 // Columns per launch: g_tune.batch_cols (2) is sized for 2^22-row columns — four of them in flight fill the Infinity Cache.  Smaller
 // columns get proportionally more per launch (the same bytes in flight): at 2^18 rows a 2-column launch is ~10 us of work behind
 // ~5 us of launch latency, and a 438-column tree needs 657 of them.
-static u32 batch_for(uint32_t log_size) {
+static u32 batch_for(const nx_ctx* ctx, uint32_t log_size) {
     const int shift = log_size < 22 ? (int)(22 - log_size) : 0;
-    return (u32)std::min<uint64_t>((uint64_t)g_tune.batch_cols << std::min(shift, 8), 256);
+    return (u32)std::min<uint64_t>((uint64_t)ctx->opt.fft_batch_cols << std::min(shift, 8), 256);
 }
 
 int fft_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, uint32_t log_size) {
     NX_TRY(check_tw(ctx, tw, (int)log_size));
     tune_init();
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * 8ull << log_size);
-    const u32 bc = batch_for(log_size);
-    const int ns = n_cols > bc ? g_tune.streams : 1;
+    const u32 bc = batch_for(ctx, log_size);
+    const int ns = n_cols > bc ? ctx->opt.fft_streams : 1;
     NX_TRY(streams_fork(ctx, ns));
     int rc = NX_OK;
     for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += bc, bi++) {
@@ -411,8 +408,8 @@ int fft_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_co
     NX_TRY(check_tw(ctx, tw, n));
     tune_init();
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * ((4ull << log_size) + (4ull << n)));
-    const u32 bc = batch_for(log_size);
-    const int ns = n_cols > bc ? g_tune.streams : 1;
+    const u32 bc = batch_for(ctx, log_size);
+    const int ns = n_cols > bc ? ctx->opt.fft_streams : 1;
     NX_TRY(streams_fork(ctx, ns));
     int rc = NX_OK;
     for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += bc, bi++) {
@@ -431,13 +428,17 @@ int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, ui
     tune_init();
     // algorithmic bytes: read N evals, write N coeffs, write M = 2^n LDE words
     KTimer t(ctx, NX_T_LDE, (uint64_t)n_cols * ((8ull << log_size) + (4ull << n)));
-    const u32 bc = batch_for(log_size);
-    const int ns = n_cols > bc ? g_tune.streams : 1;
+    const u32 bc = batch_for(ctx, log_size);
+    const int ns = n_cols > bc ? ctx->opt.fft_streams : 1;
     NX_TRY(streams_fork(ctx, ns));
     int rc = NX_OK;
     for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += bc, bi++) {
         u32 nb = std::min<u32>(bc, n_cols - c0);
         streams_pick(ctx, (int)bi, ns);
+        if (log_expand == 1 && !g_tune.legacy && ctx->opt.fft_pipe && fft_pipe_supports((int)log_size)) {
+            rc = fft_pipe_lde(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, sub_colset(out, c0));   // persistent, LDS-DMA pipelined (fft_pipe.hip)
+            continue;
+        }
         if (log_expand == 1 && log_size >= 14 && !g_tune.legacy && fft13_lde_fused_enabled()) {
             rc = fft13_lde(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, sub_colset(out, c0));   // middle passes fused (fft13.hip)
             continue;

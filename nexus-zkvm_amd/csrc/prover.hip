@@ -268,11 +268,11 @@ int TreeBuilder::commit_single(Blake2sChannel& channel) {
     return NX_OK;
 }
 
-// Column chunks of a row-sharded commit (NX_DIST_CHUNKS overrides; the same on every GPU: it depends on the run, not on the rank).
+// Column chunks of a row-sharded commit (option "dist.chunks" overrides; the same on every GPU: it depends on the run, not on the rank).
 // Chunks pay only where the exchange is worth hiding: >= 4 columns per GPU and chunk, >= 2^27 words in the run.
-static uint32_t dist_chunks(uint32_t n_run, int world, uint32_t el) {
+static uint32_t dist_chunks(const nx_ctx* ctx, uint32_t n_run, int world, uint32_t el) {
     const uint32_t min_loc = n_run / (uint32_t)world;
-    if (const char* e = getenv("NX_DIST_CHUNKS")) return (uint32_t)std::max(1, std::min(atoi(e), (int)std::max<uint32_t>(1, min_loc)));
+    if (ctx->opt.dist_chunks > 0) return (uint32_t)std::max(1, std::min(ctx->opt.dist_chunks, (int)std::max<uint32_t>(1, min_loc)));
     if (((uint64_t)n_run << el) < ((uint64_t)1 << 27)) return 1;
     return std::max<uint32_t>(1, std::min<uint32_t>(4, min_loc / 4));
 }
@@ -330,7 +330,7 @@ int TreeBuilder::commit_dist(Blake2sChannel& channel) {
             // The share is extended and exchanged in Q column chunks (the same Q on every GPU): chunk q+1's LDE is enqueued before the
             // host blocks in chunk q's all-to-all, so the transforms run while the links carry the previous chunk.  The receive slab
             // is chunk-major, rank-major inside a chunk: every exchange is contiguous on both sides.
-            const uint32_t Q = dist_chunks(n_run, D.world, el);
+            const uint32_t Q = dist_chunks(ctx, n_run, D.world, el);
             auto chunk_cols = [&](int r, uint32_t q) { const uint32_t nl = Dist::cut(n_run, r + 1, D.world) - Dist::cut(n_run, r, D.world); return Dist::cut(nl, (int)q + 1, (int)Q) - Dist::cut(nl, (int)q, (int)Q); };
             std::vector<size_t> chunk_base(Q + 1, 0);        // in columns
             for (uint32_t q = 0; q < Q; q++) { size_t n = 0; for (int r = 0; r < D.world; r++) n += chunk_cols(r, q); chunk_base[q + 1] = chunk_base[q] + n; }
@@ -530,10 +530,9 @@ class FriProver {
     // The per-layer host channel.  Row-sharded: the first-layer columns and the line layers are row blocks — trees are subtree + W
     // roots, folds are local (pairs are adjacent) — while that pays: a sharded layer costs a host all-gather of the W subtree roots
     // (a collective plus two host round trips, ~0.2 ms) and saves (1 - 1/W) of the layer's hashing, which is 0.14 ms for 2^21 rows on
-    // the whole chip.  Below 2^NX_FRI_DIST_MIN_LOG rows (default 21; the tests set 0), or 2^FRI_DIST_MIN_LOCAL rows per GPU, the
+    // the whole chip.  Below 2^"fri.dist_min_log" rows (context option, default 21; the tests set 0), or 2^FRI_DIST_MIN_LOCAL rows per GPU, the
     // layer and the remaining circle columns are all-gathered and the tail runs replicated on every GPU.
     static constexpr uint32_t FRI_DIST_MIN_LOCAL = 10;
-    static uint32_t fri_dist_min_log() { const char* e = getenv("NX_FRI_DIST_MIN_LOG"); return e ? (uint32_t)std::max(0, atoi(e)) : 21u; }
     int commit_host_channel(Blake2sChannel& channel, std::vector<SecureColumn>&& cols) {
         columns = std::move(cols);
         if (columns.empty()) return set_err(ctx, NX_ERR_ARG, "fri: no columns");
@@ -543,7 +542,7 @@ class FriProver {
         const QM31 first_alpha = folding_alpha;
         uint32_t layer_log = columns[0].log - 1;
         bool sharded = D.on();
-        const uint32_t min_log = fri_dist_min_log();
+        const uint32_t min_log = (uint32_t)ctx->opt.fri_dist_min_log;
         SecureColumn layer;
         if (sharded) H_TRY(layer.alloc_rows(ctx, layer_log, D.block(layer_log), true)); else H_TRY(layer.alloc(ctx, layer_log));
         H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));

@@ -1,0 +1,177 @@
+// CPU replay of the pipelined Circle-FFT kernels (nexus-zkvm_amd/csrc/fft_pipe.hip) — TEST INFRASTRUCTURE.
+//
+// The kernels' lane-level code (tile swizzle, row ownership, twiddle indexing, butterfly rounds, fused stores) lives in
+// csrc/fft_pipe.cuh as __host__ __device__ functions.  This file drives exactly those functions lane by lane, phase by phase
+// (a phase = the code between two block barriers), with plain arrays standing in for LDS and the LDS-DMA, and checks the result of
+// a whole LDE (iFFT in place + FFT onto twice the points) against the oracle's interpolate / evaluate (oracle/poly.h).
+// What it cannot check — barrier placement, DMA / store completion counts — is covered by the GPU parity tests.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../nexus-zkvm_amd/csrc/fft_pipe.cuh"
+#include "../oracle/poly.h"
+
+using nx::u32;
+namespace pp = nx::pipe;
+
+namespace {
+
+struct Tables { u32 tw_log; std::vector<u32> tw2, itw2; };
+
+// LDS-DMA of one tile: slot s <- the 4-word group swz(s) of the tile; goff maps a tile row to its global word offset
+template <class Goff>
+void dma_tile(u32* lds, const u32* src, Goff goff) {
+    for (u32 s = 0; s < pp::T_GROUPS; s++) {
+        const u32 g = pp::swz(s);
+        for (int j = 0; j < 4; j++) lds[4 * s + j] = src[goff(4 * g) + j];
+    }
+}
+
+// LDS-DMA of a twiddle slab: layers L0..L1 of the 2^n-point transform's doubled table, the tile's slices one after the other
+void dma_slab(u32* slab, const std::vector<u32>& tbl2, u32 tw_log, int n, u32 tile, int L0, int L1) {
+    for (int l = L0; l <= L1; l++) {
+        const u32 cnt = 1u << (12 - l);
+        for (u32 i = 0; i < cnt; i++) slab[pp::slab_off(L0, l) + i] = tbl2[pp::lvl_off(tw_log, n, l) + tile * cnt + i];
+    }
+}
+
+void p1_tile(const Tables& T, int n, u32 tile, u32* col) {
+    alignas(16) static u32 X[pp::T_ROWS], SA[pp::slab_words(1, 3)], SB[pp::slab_words(4, 7)];
+    u32* base = col + ((size_t)tile << pp::T_S);
+    dma_tile(X, base, [](u32 t) { return t; });
+    dma_slab(SA, T.itw2, T.tw_log, n, tile, 1, 3);
+    dma_slab(SB, T.itw2, T.tw_log, n, tile, 4, 7);
+    u32 tw[16];
+    for (u32 tid = 0; tid < pp::NT; tid++) { pp::slab_tw_fetch<0, 4, true>(SA, tid, tw); pp::round16_low<true, true>(X, tid, tw); }
+    for (u32 tid = 0; tid < pp::NT; tid++) { pp::slab_tw_fetch<4, 4, false>(SB, tid, tw); pp::round16<4, 4, true>(X, tid, tw); }
+    for (u32 tid = 0; tid < pp::NT; tid++) { pp::first_tw_fetch<8, 4, false>(T.itw2.data(), T.tw_log, n, tile, tid & ~255u, tw); pp::round16<8, 4, true>(X, tid, tw); }
+    const u32 te2 = T.itw2[pp::lvl_off(T.tw_log, n, 12) + tile];
+    for (u32 tid = 0; tid < pp::NT; tid++) pp::ifirst_store(X, tid, base, te2);
+}
+
+void p3_tile(const Tables& T, int n /* log size of the forward transform */, u32 tile, u32* col) {
+    alignas(16) static u32 X[pp::T_ROWS], SB[pp::slab_words(5, 8)], SA[pp::slab_words(2, 4)], S1[pp::slab_words(1, 1)];
+    u32* base = col + ((size_t)tile << pp::T_S);
+    dma_tile(X, base, [](u32 t) { return t; });
+    dma_slab(SB, T.tw2, T.tw_log, n, tile, 5, 8);
+    dma_slab(SA, T.tw2, T.tw_log, n, tile, 2, 4);
+    dma_slab(S1, T.tw2, T.tw_log, n, tile, 1, 1);
+    u32 tw[16];
+    for (u32 tid = 0; tid < pp::NT; tid++) { pp::first_tw_fetch<9, 4, false>(T.tw2.data(), T.tw_log, n, tile, 0, tw); pp::round16<9, 4, false>(X, tid, tw); }
+    for (u32 tid = 0; tid < pp::NT; tid++) { pp::slab_tw_fetch<5, 4, false>(SB, tid, tw); pp::round16<5, 4, false>(X, tid, tw); }
+    for (u32 tid = 0; tid < pp::NT; tid++) { pp::slab_tw_fetch<2, 3, false>(SA, tid, tw); pp::round16<2, 3, false>(X, tid, tw); }
+    for (u32 tid = 0; tid < pp::NT; tid++) {
+        uint4 x[4]; u32 tws[8];
+        pp::ffirst_store_load(X, S1, tid, x, tws);
+        pp::ffirst_store_finish(x, tws, tid, base, tile);
+    }
+}
+
+template <int K, bool INV>
+void mid_rounds(u32* Z, const u32* dir_tw) {
+    using P = pp::MidPlan<K>;
+    u32 tw[16];
+    auto rem = [&]() {
+        if constexpr (P::REM > 0)
+            for (u32 tid = 0; tid < pp::NT; tid++) { pp::mid_tw_fetch<P::B, P::REM>(dir_tw, P::B, tid, tw); pp::round16<P::B, P::REM, INV>(Z, tid, tw); }
+    };
+    auto full = [&]() {
+        if constexpr (P::NFULL > 0)
+            for (u32 tid = 0; tid < pp::NT; tid++) { pp::mid_tw_fetch<P::BPF, 4>(dir_tw, P::B, tid, tw); pp::round16<P::BPF, 4, INV>(Z, tid, tw); }
+    };
+    if (INV) { rem(); full(); } else { full(); rem(); }
+}
+
+template <int K>
+void p2_all(const Tables& T, int n, u32* col, u32* out) {
+    using P = pp::MidPlan<K>;
+    constexpr int B = P::B;
+    // the block's LDS twiddle tables: inverse, forward replica 0, forward replica 1
+    const u32 W = pp::mid_tw_words(B);
+    std::vector<u32> ltw(3 * (size_t)W + 8, 0);
+    for (int b = B; b < 11; b++)
+        for (u32 i = 0; i < (1u << (12 - b)); i++) {
+            ltw[0 * W + pp::mid_tw_off(B, b) + i] = T.itw2[pp::lvl_off(T.tw_log, n, b + K) + i];
+            for (u32 r = 0; r < 2; r++) ltw[(1 + r) * W + pp::mid_tw_off(B, b) + i] = T.tw2[pp::lvl_off(T.tw_log, n + 1, b + K) + (r << (12 - b)) + i];
+        }
+    pp::MidConsts k;
+    for (int j = 0; j < 2; j++) k.i11[j] = T.itw2[pp::lvl_off(T.tw_log, n, 11 + K) + j];
+    k.i12 = T.itw2[pp::lvl_off(T.tw_log, n, 12 + K)];
+    for (int r = 0; r < 2; r++) {
+        k.f12[r] = T.tw2[pp::lvl_off(T.tw_log, n + 1, 12 + K) + r];
+        for (int j = 0; j < 2; j++) k.f11[2 * r + j] = T.tw2[pp::lvl_off(T.tw_log, n + 1, 11 + K) + 2 * r + j];
+    }
+    k.scale = orc::m31_inv(1u << n);
+    alignas(16) static u32 X[pp::T_ROWS], Y[pp::T_ROWS];
+    for (u32 tile = 0; tile < (1u << K); tile++) {
+        u32* ct = col + ((size_t)tile << B);
+        dma_tile(X, ct, [](u32 t) { return pp::mid_goff(t, B); });
+        mid_rounds<K, true>(X, ltw.data());
+        for (u32 tid = 0; tid < pp::NT; tid++) pp::mid_handover(X, Y, tid, k, ct, B);
+        for (int r = 0; r < 2; r++) {
+            u32* Z = r ? Y : X;
+            mid_rounds<K, false>(Z, ltw.data() + (1 + r) * (size_t)W);
+            for (u32 tid = 0; tid < pp::NT; tid++) pp::mid_store(Z, tid, out + ((size_t)r << n) + ((size_t)tile << B), B);
+        }
+    }
+}
+
+}  // namespace
+
+// Returns 0 when the replayed LDE of `ncols` seeded random columns of 2^n rows equals the oracle's, else a code: 1 coefficients,
+// 2 evaluations, -1 unsupported n.  mode 0: LDE (P1, P2, P3); mode 1: only P1 + P3 as the first / last pass of a plain
+// interpolate / evaluate is not separable here, so it is the same path.
+extern "C" int fftpipe_emul_lde(int n, int ncols, uint64_t seed) {
+    if (n < 17 || n > 22) return -1;
+    orc::Twiddles OT = orc::precompute_twiddles(n);   // half coset of the 2^(n+1)-point domain
+    Tables T; T.tw_log = (u32)n; T.tw2.resize(OT.tw.size()); T.itw2.resize(OT.tw.size());
+    for (size_t i = 0; i < OT.tw.size(); i++) { T.tw2[i] = OT.tw[i] << 1; T.itw2[i] = OT.itw[i] << 1; }
+    const size_t N = (size_t)1 << n;
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + 12345;
+    for (int c = 0; c < ncols; c++) {
+        std::vector<u32> col(N), ref(N), out(2 * N), lde(2 * N);
+        for (size_t i = 0; i < N; i++) { st = st * 6364136223846793005ull + 1442695040888963407ull; col[i] = (u32)((st >> 33) % nx::P); }
+        if (c == 0) { col[0] = nx::P - 1; col[1] = 0; col[N - 1] = nx::P - 1; }
+        ref = col;
+        orc::interpolate(ref.data(), n, OT);
+        orc::evaluate(ref.data(), n, lde.data(), n + 1, OT);
+        for (u32 t = 0; t < (1u << (n - 13)); t++) p1_tile(T, n, t, col.data());
+        switch (n - 13) {
+        case 4: p2_all<4>(T, n, col.data(), out.data()); break;
+        case 5: p2_all<5>(T, n, col.data(), out.data()); break;
+        case 6: p2_all<6>(T, n, col.data(), out.data()); break;
+        case 7: p2_all<7>(T, n, col.data(), out.data()); break;
+        case 8: p2_all<8>(T, n, col.data(), out.data()); break;
+        case 9: p2_all<9>(T, n, col.data(), out.data()); break;
+        }
+        for (u32 t = 0; t < (1u << (n + 1 - 13)); t++) p3_tile(T, n + 1, t, out.data());
+        if (memcmp(col.data(), ref.data(), N * 4)) return 1;
+        if (memcmp(out.data(), lde.data(), 2 * N * 4)) return 2;
+    }
+    return 0;
+}
+
+// the whole inverse / forward transform of 2^n points through P1 + a generic pass is not replayed here: P1 and P3 are checked
+// through the LDE above (P1 is the first pass of the iFFT, P3 the last pass of the FFT).
+extern "C" int fftpipe_emul_item_bijection(uint32_t tiles, uint32_t n_cols) {
+    std::vector<uint8_t> seen((size_t)tiles * n_cols, 0);
+    for (u32 i = 0; i < tiles * n_cols; i++) {
+        const pp::Item it = pp::decode_item(i, tiles, n_cols);
+        if (it.tile >= tiles || it.col >= n_cols) return 1;
+        uint8_t& s = seen[(size_t)it.tile * n_cols + it.col];
+        if (s) return 2;
+        s = 1;
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    int lo = argc > 1 ? atoi(argv[1]) : 17, hi = argc > 2 ? atoi(argv[2]) : 19;
+    for (int n = lo; n <= hi; n++) {
+        const int rc = fftpipe_emul_lde(n, 1, 7 + n);
+        printf("n=%d rc=%d\n", n, rc);
+        if (rc) return 1;
+    }
+    return 0;
+}

@@ -74,7 +74,7 @@ def test_interpolate_evaluate_match_oracle(be, oracle, log):
         lde.free()
 
 
-@pytest.mark.parametrize("log", [13, 14, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("log", [13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_fused_lde_matches_oracle_at_every_pass_shape(be, oracle, log):
     """nx_lde_batch with blow-up 2 takes the fused-middle route from 2^14 rows up (lde_mid_kernel with 1..7 layers here, 8 and 9 in
     the large-transform test, the 3-pass plan at 2^23): coefficients and every LDE value against the oracle, an odd column count so
@@ -90,6 +90,51 @@ def test_fused_lde_matches_oracle_at_every_pass_shape(be, oracle, log):
     got = lde.to_cpu()
     for c in range(n_cols):
         assert np.array_equal(got[c], otw.evaluate(coeffs[c], log + 1)), (log, c)
+
+
+@pytest.mark.parametrize("log,grid,n_cols", [(17, 8, 5), (17, 24, 3), (18, 16, 4), (20, 64, 3), (22, 256, 2)])
+def test_pipelined_lde_item_loop_matches_oracle(nz, oracle, log, grid, n_cols):
+    """The pipelined kernels (fft_pipe.hip) with FEW persistent blocks ("fft.pipe_grid"), so that every block walks many work items
+    through its two LDS buffers: prefetch by LDS-DMA, twiddle slabs re-filled per item, stores draining behind — coefficients and
+    every LDE value against the oracle.  A second context with the option off (fft13.hip) must give the same words."""
+    vals = rand_cols(4200 + log + grid, n_cols, log)
+    otw = oracle.Twiddles(log + 1)
+    coeffs = np.stack([otw.interpolate(v) for v in vals])
+    ref = np.stack([otw.evaluate(c, log + 1) for c in coeffs])
+    outs = []
+    for pipe in (1, 0):
+        b = nz.HipBackend(0)
+        try:
+            b.set_option("fft.pipe", pipe)
+            if pipe:
+                b.set_option("fft.pipe_grid", grid)
+                b.set_option("fft.batch_cols", 256)      # the whole column set in one launch: items = tiles * n_cols >> grid
+                assert b.get_option("fft.pipe_grid") == grid
+            tw = b.precompute_twiddles(log)
+            cols = b.columns_from_host(vals)
+            lde = b.lde(tw, cols, 1)
+            assert np.array_equal(cols.to_cpu(), coeffs), (log, pipe)
+            got = lde.to_cpu()
+            assert np.array_equal(got, ref), (log, pipe)
+            outs.append(got)
+            lde.free(); cols.free()
+        finally:
+            b.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_context_options_are_per_context_and_validated(nz):
+    a, b = nz.HipBackend(0), nz.HipBackend(0)
+    try:
+        a.set_option("fft.streams", 1); b.set_option("fft.streams", 3)
+        a.set_option("dist.chunks", 2)
+        assert a.get_option("fft.streams") == 1 and b.get_option("fft.streams") == 3
+        assert a.get_option("dist.chunks") == 2 and b.get_option("dist.chunks") == 0
+        for name, v in (("fft.streams", 9), ("fft.pipe", 2), ("no.such.option", 1), ("air.segment", 1)):
+            with pytest.raises(nz.NexusHipError):
+                a.set_option(name, v)
+    finally:
+        a.close(); b.close()
 
 
 @pytest.mark.parametrize("log", [21, 22, 23])

@@ -1,5 +1,6 @@
-"""Micro-benchmark of the fused LDE (iFFT + FFT) and Merkle commit for tuning; prints one JSON line.
-Env knobs (read once per process by fft.hip): NX_FFT_SMAX, NX_FFT_B, NX_FFT_THREADS, NX_FFT_BATCH."""
+"""Micro-benchmark of the fused LDE (iFFT + FFT) and Merkle commit for tuning; prints one JSON line per option set.
+usage: fft_tune.py LOG NCOLS REPS [name=value,name=value ...]   each further argument is one set of nx_ctx_set_option settings
+(e.g. fft.pipe=0  fft.pipe=1,fft.batch_cols=4,fft.streams=1); without any, the context's defaults."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,23 +10,33 @@ import nexus_zkvm_amd as nz
 log = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 ncols = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+sets = sys.argv[4:] or [""]
 be = nz.HipBackend(0)
 tw = be.precompute_twiddles(log)
 cols = be.synth_fill_tree([(log, 2, ncols, 0)], 1, seed=3)[0]
 out = be.columns(ncols, log + 1)
 be.sync()
-best = 1e9
-for r in range(reps + 1):
-    be.sync(); t0 = time.perf_counter()
-    be._chk(be.L.nx_lde_batch(be.ctx, tw.h, cols.col_ptrs(), ncols, log, 1, out.col_ptrs()))
-    be.sync(); dt = time.perf_counter() - t0
-    if r: best = min(best, dt)
-alg = ncols * 16 * (1 << log)
-bm = 1e9
-for r in range(reps):
-    be.sync(); t0 = time.perf_counter()
-    t = be.merkle_commit([out]); be.sync(); dt = time.perf_counter() - t0
-    bm = min(bm, dt)
-malg = ncols * 4 * (2 << log) + 128 * (2 << log)
-print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("NX_")}, "log": log, "ncols": ncols, "lde_ms": best * 1e3,
-                  "lde_alg_GBs": alg / best / 1e9, "lde_frac_of_8TBs": alg / best / 8e12, "lde_frac_of_measured_copy_6.29TBs": alg / best / 6.29e12, "merkle_ms": bm * 1e3, "merkle_alg_GBs": malg / bm / 1e9}))
+defaults = {k: be.get_option(k) for k in ("fft.pipe", "fft.pipe_blocks_per_cu", "fft.pipe_grid", "fft.batch_cols", "fft.streams")}
+for st in sets:
+    for k, v in defaults.items():
+        be.set_option(k, v)
+    opts = dict(kv.split("=") for kv in st.split(",") if kv)
+    for k, v in opts.items():
+        be.set_option(k, int(v))
+    best = 1e9
+    for r in range(reps + 1):
+        be.sync(); t0 = time.perf_counter()
+        be._chk(be.L.nx_lde_batch(be.ctx, tw.h, cols.col_ptrs(), ncols, log, 1, out.col_ptrs()))
+        be.sync(); dt = time.perf_counter() - t0
+        if r: best = min(best, dt)
+    alg = ncols * 16 * (1 << log)
+    print(json.dumps({"opts": st, "log": log, "ncols": ncols, "lde_ms": round(best * 1e3, 3), "lde_alg_GBs": round(alg / best / 1e9, 1),
+                      "frac_of_8TBs": round(alg / best / 8e12, 4)}), flush=True)
+if os.environ.get("FFT_TUNE_MERKLE", "1") != "0":
+    bm = 1e9
+    for r in range(reps):
+        be.sync(); t0 = time.perf_counter()
+        t = be.merkle_commit([out]); be.sync(); dt = time.perf_counter() - t0
+        bm = min(bm, dt)
+    malg = ncols * 4 * (2 << log) + 128 * (2 << log)
+    print(json.dumps({"log": log, "ncols": ncols, "merkle_ms": round(bm * 1e3, 3), "merkle_alg_GBs": round(malg / bm / 1e9, 1)}))
