@@ -209,7 +209,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 static nx_options options_from_env() {
     nx_options o;
-    o.fft_pipe = env_int("NX_FFT_PIPE", 1) != 0;
+    o.fft_pipe = env_int("NX_FFT_PIPE", 0) != 0;   // opt-in: measured 7-9 % slower than fft13.hip at 2^22 rows (profiles/r03_fft_pipe_*)
     o.fft_pipe_blocks_per_cu = clampi(env_int("NX_FFT_PGRID", 2), 1, 2);
     o.fft_pipe_grid = 0;
     o.fft_batch_cols = std::max(1, env_int("NX_FFT_BATCH", 2));

@@ -47,9 +47,24 @@ NX_HD void bfly2(u32& x0, u32& x1, u32 t2, bool neg) {
 // R butterfly layers over the 16 rows a lane holds (rows differ in tile bits [bp, bp+4); layers act on the low R of them, the
 // upper 4-R bits only select independent sub-blocks).  CIRCLE: layer 0 is the circle layer, its twiddles are derived from the
 // first line layer's (x, y) pairs as [y, -y, -x, x] (Stwo circle.rs / oracle poly.h circle_twiddle).
+// NX_PIPE_ABL (tools/fftpipe/build_abl.sh, never the product build): 1 = no butterfly arithmetic (one XOR per row keeps the LDS round
+// trips and the twiddle reads alive), 2 = no global traffic (fft_pipe.hip: no DMA, no stores).  Ablation timing only.
+#ifndef NX_PIPE_ABL
+#define NX_PIPE_ABL 0
+#endif
 template <int R, bool INV, bool CIRCLE>
 NX_HD void butterflies16(u32* v, const u32* tw) {
     static_assert(!CIRCLE || R >= 2, "circle rounds need the (x, y) pair of the first line layer");
+#if NX_PIPE_ABL & 1
+    u32 x = 0;
+#pragma unroll
+    for (int q = CIRCLE ? 1 : 0; q < R; q++)
+#pragma unroll
+        for (int h = 0; h < (8 >> q); h++) x ^= tw[(16 - (16 >> q)) + h];
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] ^= x;
+    return;
+#endif
 #pragma unroll
     for (int qq = 0; qq < R; qq++) {
         const int q = INV ? qq : R - 1 - qq;
@@ -129,7 +144,11 @@ NX_HD u32* ldsp(u32* const* p) { return *(u32* NX_PIPE_AS4 const*)p; }
 NX_HD uint4 ldg4(const u32* p) { const pv4 v = *(NX_PIPE_AS1 const pv4*)p; return make_uint4(v.x, v.y, v.z, v.w); }
 NX_HD uint2 ldg2(const u32* p) { const pv2 v = *(NX_PIPE_AS1 const pv2*)p; return make_uint2(v.x, v.y); }
 NX_HD u32 ldg1(const u32* p) { return *(NX_PIPE_AS1 const u32*)p; }
+#if NX_PIPE_ABL & 2
+NX_HD void stg4(u32* p, uint4 v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p)); }
+#else
 NX_HD void stg4(u32* p, uint4 v) { pv4 w = {v.x, v.y, v.z, v.w}; *(NX_PIPE_AS1 pv4*)p = w; }
+#endif
 #else
 NX_HD uint4 ldg4(const u32* p) { return make_uint4(p[0], p[1], p[2], p[3]); }
 NX_HD uint2 ldg2(const u32* p) { return make_uint2(p[0], p[1]); }
@@ -235,6 +254,10 @@ NX_HD void first_forward_low2(u32* x, u32 a, u32 b, u32 gp) {
     bfly2<false>(x[2], x[3], tc, !odd);
 }
 
+// The wave that ran a tile's last wave-local rounds also stores it: wave w owns rows [1024 w, 1024 w + 1024) = groups [256 w, 256 w + 256);
+// pass `it` of a store covers 64 consecutive groups (1 KiB of the tile) per wave.
+NX_HD u32 wave_group(u32 tid, int it) { return ((tid >> 6) << 8) + ((u32)it << 6) + (tid & 63u); }
+
 NX_HD u32 comp4(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // Inverse FIRST pass, store: tile bit 12 (one twiddle for the whole tile, te2 = 2 * twiddle) fused.  No 1/N here: a transform of
@@ -258,7 +281,7 @@ NX_HD void ifirst_store(const u32* X, u32 tid, u32* dst_tile, u32 te2) {
 NX_HD void ffirst_store_load(const u32* X, const u32* slab1, u32 tid, uint4* x, u32* tws) {
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-        const u32 g = tid + (u32)NT * it;
+        const u32 g = wave_group(tid, it);
         x[it] = *reinterpret_cast<const uint4*>(X + 4 * swz(g));
         ld_words<2, MEM_LDS>(slab1 + (g & ~1u), tws + 2 * it);
     }
@@ -266,7 +289,7 @@ NX_HD void ffirst_store_load(const u32* X, const u32* slab1, u32 tid, uint4* x, 
 NX_HD void ffirst_store_finish(const uint4* xin, const u32* tws, u32 tid, u32* dst_tile, u32 tile) {
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-        const u32 g = tid + (u32)NT * it;
+        const u32 g = wave_group(tid, it);
         u32 x[4] = {xin[it].x, xin[it].y, xin[it].z, xin[it].w};
         first_forward_low2(x, tws[2 * it], tws[2 * it + 1], tile * T_GROUPS + g);
         stg4(dst_tile + 4 * g, make_uint4(x[0], x[1], x[2], x[3]));
@@ -309,7 +332,7 @@ NX_HD void mid_handover(u32* X, u32* Y, u32 tid, const MidConsts& k, u32* coef_t
 NX_HD void mid_store(const u32* Z, u32 tid, u32* out_tile, int B) {
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-        const u32 g = tid + (u32)NT * it;
+        const u32 g = wave_group(tid, it);
         stg4(out_tile + mid_goff(4 * g, B), *reinterpret_cast<const uint4*>(Z + 4 * swz(g)));
     }
 }

@@ -18,6 +18,14 @@
 //    global stores, so "everything for tile k+1 has landed" is exactly `s_waitcnt vmcnt(4)` at the top of iteration k+1;
 //  * block barriers are bare s_barrier + lgkmcnt(0): __syncthreads() would drain vmcnt (the DMA writes LDS) and with it the prefetch.
 // The lane-level code is shared with the CPU replay (tests/fftpipe_emul.cpp); results are bit-identical to fft13.hip.
+//
+// STATUS (round 3, measured on MI355X: profiles/r03_fft_pipe_*): correct at every size, LDS bank conflicts 0 (SQ_LDS_BANK_CONFLICT),
+// the prefetch hides the loads — and the LDE is still 7-9 % SLOWER than fft13.hip at 2^22 rows (64 columns: 3.33 ms vs 2.93-3.2).
+// Ablations of the same build: no global traffic 2.72 ms, no butterfly arithmetic 2.36 ms, neither (LDS round trips + barriers +
+// addressing only) 1.5 ms: the LDS instruction stream (8.5 k wave-instructions per column and CU, ~4 cycles each) and the VALU work
+// (~35 us per column and CU at the measured instruction rates) do not overlap with only 4 waves per SIMD — which is what the two
+// 80-KB blocks per CU allow — and the iteration's four store instructions block their waves while they are issued.  The schedule
+// therefore stays OPT-IN (context option "fft.pipe", environment default NX_FFT_PIPE=1); DESIGN.md §6 item 17 has the numbers.
 #include "internal.h"
 #include "fft_pipe.cuh"
 #include <atomic>
@@ -30,12 +38,20 @@ using namespace pipe;
 #define NX_LDS_AS __attribute__((address_space(3)))
 
 __device__ __forceinline__ void blk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Between two rounds that touch only the wave's own rows (a wave of 64 lanes x 16 rows owns rows [1024 w, 1024 w + 1024) in every round
+// at tile bits < 10): the wave's LDS writes have landed, no other wave is involved.  Waves of a block then drift apart, so their LDS
+// and VALU phases overlap instead of hitting each pipe together.
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // One LDS-DMA instruction: every active lane fetches the 16 bytes at base + byte_off; lane l's land at LDS byte address lds_addr + 16 l.
 // Inline asm on purpose: hipcc treats the builtin as "may write any LDS" and puts s_waitcnt vmcnt(0) in front of the next ds_read —
 // i.e. it waits for the prefetch just issued.  M0 (the LDS base) is compiler-reserved: saved and restored inside the statement; the
 // leading s_nop covers a base SGPR fresh from v_readfirstlane (guide §5.7).  Completion is counted by hand (wait_prefetch below).
 __device__ __forceinline__ void dma16(const u32* base, u32 byte_off, u32 lds_addr) {
+#if NX_PIPE_ABL & 2
+    asm volatile("" ::"v"(byte_off), "s"(base), "s"(lds_addr));
+    return;
+#endif
     u32 keep;
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(byte_off), "s"(base), "s"(lds_addr) : "memory");
@@ -66,10 +82,19 @@ __device__ __forceinline__ void dma_slab(u32* slab, const u32* tbl2, u32 tw_log,
     }
 }
 // "every DMA this wave issued before its last 4 (store) instructions has landed" / "everything has landed"
+#if NX_PIPE_ABL & 2
+__device__ __forceinline__ void wait_prefetch() { asm volatile("" ::: "memory"); }
+#else
 __device__ __forceinline__ void wait_prefetch() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+#endif
 __device__ __forceinline__ void wait_all_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // keeps the LDS addresses of a round from being hoisted out of the item loop and held in registers for the whole kernel
 __device__ __forceinline__ u32 opaque(u32 v) { asm volatile("" : "+v"(v)); return v; }
+#ifdef NX_PIPE_HOIST   // A/B: let the FIRST passes keep their LDS addresses in registers across items (93 / 112 VGPRs)
+__device__ __forceinline__ u32 opaque1(u32 v) { return v; }
+#else
+__device__ __forceinline__ u32 opaque1(u32 v) { return opaque(v); }
+#endif
 __device__ __forceinline__ u32* col_ptr(const ColSet& c, u32 col) { return c.table ? ldsp(c.table + col) : c.base + (uint64_t)col * c.stride; }
 
 struct PipeFirst {
@@ -121,16 +146,15 @@ __global__ __launch_bounds__(NT, 4) void pipe_ifirst_kernel(PipeFirst a) {
             dma_tile(plds + (cur ^ 1u) * T_ROWS, nbase, tid, wv, ident);
         }
         u32 tw[16];
-        { const u32 t = opaque(tid); slab_tw_fetch<0, 4, true>(SA, t, tw); round16_low<true, true>(X, t, tw); }
+        { const u32 t = opaque1(tid); slab_tw_fetch<0, 4, true>(SA, t, tw); round16_low<true, true>(X, t, tw); }
+        wave_sync();             // bits [0, 8) stay inside the wave's 1024 rows
+        { const u32 t = opaque1(tid); slab_tw_fetch<4, 4, false>(SB, t, tw); round16<4, 4, true>(X, t, tw); }
         blk_barrier();
-        if (has_next) dma_slab<1, 3>(SA, a.tw2, a.tw_log, a.n, nit.tile, lane, wv);
-        { const u32 t = opaque(tid); slab_tw_fetch<4, 4, false>(SB, t, tw); round16<4, 4, true>(X, t, tw); }
-        blk_barrier();
-        if (has_next) dma_slab<4, 7>(SB, a.tw2, a.tw_log, a.n, nit.tile, lane, wv);
-        round16<8, 4, true>(X, opaque(tid), twC);
+        if (has_next) { dma_slab<1, 3>(SA, a.tw2, a.tw_log, a.n, nit.tile, lane, wv); dma_slab<4, 7>(SB, a.tw2, a.tw_log, a.n, nit.tile, lane, wv); }
+        round16<8, 4, true>(X, opaque1(tid), twC);
         blk_barrier();
         if (has_next) first_tw_fetch<8, 4, false, MEM_SCALAR>(a.tw2, a.tw_log, a.n, nit.tile, utid, twC);
-        ifirst_store(X, opaque(tid), base, te2);     // the iteration's 4 global stores
+        ifirst_store(X, opaque1(tid), base, te2);     // the iteration's 4 global stores
         if (!has_next) break;
         te2 = lds1(a.tw2 + lvl_off(a.tw_log, a.n, 12) + nit.tile);
         item = nxt; it = nit; base = nbase; cur ^= 1u;
@@ -176,21 +200,23 @@ __global__ __launch_bounds__(NT, 4) void pipe_ffirst_kernel(PipeFirst a) {
             nbase = col_ptr(a.cols, nit.col) + ((size_t)nit.tile << T_S);
             dma_tile(plds + (cur ^ 1u) * T_ROWS, nbase, tid, wv, ident);
         }
-        round16<9, 4, false>(X, opaque(tid), twC);
+        round16<9, 4, false>(X, opaque1(tid), twC);
         blk_barrier();
         if (has_next) first_tw_fetch<9, 4, false, MEM_SCALAR>(a.tw2, a.tw_log, a.n, nit.tile, 0, twC);
         u32 tw[16];
-        { const u32 t = opaque(tid); slab_tw_fetch<5, 4, false>(SB, t, tw); round16<5, 4, false>(X, t, tw); }
-        blk_barrier();
-        if (has_next) dma_slab<5, 8>(SB, a.tw2, a.tw_log, a.n, nit.tile, lane, wv);
-        { const u32 t = opaque(tid); slab_tw_fetch<2, 3, false>(SA, t, tw); round16<2, 3, false>(X, t, tw); }
-        blk_barrier();
-        if (has_next) dma_slab<2, 4>(SA, a.tw2, a.tw_log, a.n, nit.tile, lane, wv);
+        { const u32 t = opaque1(tid); slab_tw_fetch<5, 4, false>(SB, t, tw); round16<5, 4, false>(X, t, tw); }
+        wave_sync();             // bits [0, 9) stay inside the wave's 1024 rows: no block barrier until the slabs are re-filled
+        { const u32 t = opaque1(tid); slab_tw_fetch<2, 3, false>(SA, t, tw); round16<2, 3, false>(X, t, tw); }
+        wave_sync();
         uint4 x[4];
         u32 tws[8];
-        ffirst_store_load(X, S1, opaque(tid), x, tws);
-        blk_barrier();           // every lane has its layer-1 pairs: the slab may be re-filled
-        if (has_next) dma_slab<1, 1>(S1, a.tw2, a.tw_log, a.n, nit.tile, lane, wv);
+        ffirst_store_load(X, S1, opaque1(tid), x, tws);
+        blk_barrier();           // every wave is done with the three slabs: they may be re-filled
+        if (has_next) {
+            dma_slab<5, 8>(SB, a.tw2, a.tw_log, a.n, nit.tile, lane, wv);
+            dma_slab<2, 4>(SA, a.tw2, a.tw_log, a.n, nit.tile, lane, wv);
+            dma_slab<1, 1>(S1, a.tw2, a.tw_log, a.n, nit.tile, lane, wv);
+        }
         ffirst_store_finish(x, tws, tid, base, it.tile);     // the iteration's 4 global stores
         if (!has_next) break;
         item = nxt; it = nit; base = nbase; cur ^= 1u;
@@ -207,17 +233,23 @@ struct PipeMid {
 };
 
 // the rounds of tile bits [B, 11) on buffer Z, a block barrier after each; twiddles from the block's LDS tables of one direction
+// `last_is_wave_local`: the caller follows the forward rounds with a wave-local step (the tile store), so the barrier after the last
+// round may be the wave's own when that round stayed inside the wave's rows.
 template <int K, bool INV>
 __device__ __forceinline__ void mid_rounds(u32* Z, const u32* dir_tw, u32 tid) {
     using P = MidPlan<K>;
+    constexpr bool REM_LOCAL = P::B + 4 <= 10;     // the remainder round's 16 rows per lane span tile bits [B, B + 4): inside 1024 rows?
     u32 tw[16];
-    auto rem = [&]() {
-        if constexpr (P::REM > 0) { const u32 t = opaque(tid); mid_tw_fetch<P::B, P::REM>(dir_tw, P::B, t, tw); round16<P::B, P::REM, INV>(Z, t, tw); blk_barrier(); }
+    auto rem = [&](bool barrier) {
+        if constexpr (P::REM > 0) {
+            const u32 t = opaque(tid); mid_tw_fetch<P::B, P::REM>(dir_tw, P::B, t, tw); round16<P::B, P::REM, INV>(Z, t, tw);
+            if (barrier) blk_barrier(); else wave_sync();
+        }
     };
     auto full = [&]() {
         if constexpr (P::NFULL > 0) { const u32 t = opaque(tid); mid_tw_fetch<P::BPF, 4>(dir_tw, P::B, t, tw); round16<P::BPF, 4, INV>(Z, t, tw); blk_barrier(); }
     };
-    if constexpr (INV) { rem(); full(); } else { full(); rem(); }
+    if constexpr (INV) { rem(true); full(); } else { full(); rem(!REM_LOCAL); }
 }
 
 // LDS (words): X [0, 8192), Y [8192, 16384), then the twiddle tables of the inverse direction and of the two forward replicas
