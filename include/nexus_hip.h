@@ -227,12 +227,18 @@ int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t*
  * carries the synthetic wide-Fibonacci-style machine of SURVEY.md §8(d): */
 typedef struct nx_component_spec {
     uint32_t log_size, n_pre, n_main, n_inter;
+    /* The component's log constraint-degree bound: its constraints are evaluated on CanonicCoset(log_size + bound) and the composition
+     * polynomial has log size max over components of (log_size + bound) — per component as in the reference (v1: the main component
+     * +2, prover/src/components/mod.rs:12,44-45, every extension +1, prover/src/extensions/multiplicity.rs:108-110; prover2: 1, the
+     * shifts 2, prover2/machine/src/framework/traits/builtin.rs:23, composition size = the maximum, prove.rs:44-48).
+     * 0 = nx_pcs_config.log_constraint_degree; otherwise 1 <= bound <= that field (the twiddle tree is sized by the config's). */
+    uint32_t log_constraint_degree_bound;
 } nx_component_spec;
 
 typedef struct nx_pcs_config {
     uint32_t pow_bits, log_blowup, n_queries, log_last_layer_degree_bound; /* PcsConfig / FriConfig */
     uint32_t hash_mode, fri_alpha_mode;                                    /* switchable rules       */
-    uint32_t log_constraint_degree;                                        /* 1 or 2 (components/mod.rs:12) */
+    uint32_t log_constraint_degree;   /* 1 or 2 (components/mod.rs:12): the default AND the largest per-component bound (twiddle sizing, machine.rs:184-194) */
 } nx_pcs_config;
 
 typedef struct nx_prove_stats { /* milliseconds, device-synchronised stage boundaries */
@@ -403,6 +409,7 @@ typedef struct {
     const uint32_t* col_tree; const uint32_t* col_index; uint32_t n_cols;
     const uint32_t* mask_count; const int32_t* mask_offsets;
     const nx_air_kernel* kernel;
+    uint32_t log_constraint_degree_bound;   /* this component's bound (see nx_component_spec): 0 = the session config's log_constraint_degree */
 } nx_air_component;
 /* stwo::prover::prove.  NX_ERR_PROTOCOL = ProvingError::ConstraintsNotSatisfied.  *proof_words: free with nx_free_host. */
 int nx_prover_prove(nx_prover* prover, const nx_air_component* components, uint32_t n_components, uint32_t** proof_words,

@@ -28,7 +28,8 @@ class NexusHipError(RuntimeError):
 
 
 class ComponentSpec(C.Structure):
-    _fields_ = [("log_size", C.c_uint32), ("n_pre", C.c_uint32), ("n_main", C.c_uint32), ("n_inter", C.c_uint32)]
+    _fields_ = [("log_size", C.c_uint32), ("n_pre", C.c_uint32), ("n_main", C.c_uint32), ("n_inter", C.c_uint32),
+                ("log_constraint_degree_bound", C.c_uint32)]   # 0 = the config's log_constraint_degree
 
 
 class PcsConfig(C.Structure):
@@ -141,7 +142,7 @@ class AirKernel:
 class AirComponentC(C.Structure):
     _fields_ = [("log_size", C.c_uint32), ("program", C.c_void_p), ("n_instr", C.c_uint32), ("n_regs", C.c_uint32), ("econsts", C.c_void_p),
                 ("n_econsts", C.c_uint32), ("n_constraints", C.c_uint32), ("col_tree", C.c_void_p), ("col_index", C.c_void_p), ("n_cols", C.c_uint32),
-                ("mask_count", C.c_void_p), ("mask_offsets", C.c_void_p), ("kernel", C.c_void_p)]
+                ("mask_count", C.c_void_p), ("mask_offsets", C.c_void_p), ("kernel", C.c_void_p), ("log_constraint_degree_bound", C.c_uint32)]
 
 
 class ProverSession:
@@ -219,6 +220,7 @@ class ProverSession:
             a.col_tree, a.col_index, a.n_cols = ct.ctypes.data if len(ct) else None, ci.ctypes.data if len(ci) else None, len(c.cols)
             a.mask_count, a.mask_offsets = mc.ctypes.data if len(mc) else None, mo.ctypes.data if len(mo) else None
             a.kernel = kernels[i].h if kernels else None
+            a.log_constraint_degree_bound = getattr(c, "log_constraint_degree_bound", 0)
         words, n = C.POINTER(C.c_uint32)(), C.c_size_t(0)
         stats = ProveStats()
         self.be._chk(self.be.L.nx_prover_prove(self.h, arr, len(components), C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
@@ -734,12 +736,12 @@ class HipBackend:
     # ---- synthetic machine ----
     @staticmethod
     def _comps(comps):
-        return (ComponentSpec * len(comps))(*[ComponentSpec(*c) for c in comps])
+        return (ComponentSpec * len(comps))(*[ComponentSpec(*[int(x) for x in c]) for c in comps])   # 4- or 5-tuples (bound defaults to 0)
 
     def synth_fill_tree(self, comps, tree, seed, inter_seed=0):
         sets = []
         ptrs = []
-        for (ls, a, b, c) in comps:
+        for (ls, a, b, c) in [tuple(x)[:4] for x in comps]:
             n = [a, b, c][tree]
             s = DeviceColumns(self, n, ls)
             sets.append(s)

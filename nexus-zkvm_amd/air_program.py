@@ -60,8 +60,10 @@ class Component:
     each column is sampled at.  cols[k] = (tree, column index in that tree) for the program's column k; a column the program
     never loads is still sampled at offset 0 (every committed column must be claimed by a component)."""
 
-    def __init__(self, log_size, program, cols, masks=None):
+    def __init__(self, log_size, program, cols, masks=None, log_constraint_degree_bound=0):
         self.log_size, self.program, self.cols = int(log_size), program, [(int(t), int(i)) for t, i in cols]
+        # the component's own bound (the reference's is per component: components/mod.rs:12, extensions/multiplicity.rs:108-110); 0 = the session config's
+        self.log_constraint_degree_bound = int(log_constraint_degree_bound)
         self.masks = [list(masks[k]) if masks is not None else list(program.masks.get(k, (0,))) for k in range(len(self.cols))]
 
 

@@ -49,7 +49,6 @@ struct SynthAir : AirProver {
     // ComponentProvers::compute_composition_polynomial for the synthetic machine
     int compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) override {
         nx_ctx* ctx = cs.ctx;
-        const uint32_t lcd = cs.cfg.log_constraint_degree;
         size_t total = 0;
         for (uint32_t i = 0; i < n_comps; i++) total += synth_n_constraints(comps[i]);
         std::vector<QM31> powers(total);
@@ -62,7 +61,7 @@ struct SynthAir : AirProver {
             std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> den_cache;
             for (uint32_t ci = 0; ci < n_comps; ci++) {
                 const nx_component_spec& c = comps[ci];
-                const uint32_t e = c.log_size + lcd;
+                const uint32_t e = c.log_size + comp_log_cd(c.log_constraint_degree_bound, cs.cfg);
                 const size_t nc = synth_n_constraints(c);
                 off_pw[ci] = params.size();
                 params.resize(params.size() + 4 * nc);   // this component takes the LAST nc remaining powers, reversed
@@ -80,7 +79,7 @@ struct SynthAir : AirProver {
         H_TRY(upload_owned(ctx, params.data(), params.size(), &d_params));
         for (uint32_t ci = 0; ci < n_comps; ci++) {
             const nx_component_spec& c = comps[ci];
-            const uint32_t e = c.log_size + lcd;
+            const uint32_t e = c.log_size + comp_log_cd(c.log_constraint_degree_bound, cs.cfg);
             std::vector<std::pair<uint32_t, uint32_t>> cc;
             for (uint32_t k = 0; k < c.n_pre; k++) cc.push_back({0u, (uint32_t)locs[ci].pre0 + k});
             for (uint32_t k = 0; k < c.n_main; k++) cc.push_back({1u, (uint32_t)locs[ci].main0 + k});
@@ -117,8 +116,11 @@ struct SynthAir : AirProver {
 static int check_components(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg) {
     if (n_comps == 0) return set_err(ctx, NX_ERR_ARG, "prove: no components");
     if (ucfg->log_blowup < 1 || ucfg->log_constraint_degree < 1 || ucfg->log_constraint_degree > 2) return set_err(ctx, NX_ERR_ARG, "prove: log_blowup >= 1 and log_constraint_degree in {1,2} required");
-    for (uint32_t i = 0; i < n_comps; i++)
+    for (uint32_t i = 0; i < n_comps; i++) {
         if (comps[i].n_pre < 2 || comps[i].n_main < 2 || comps[i].log_size < 1 || comps[i].log_size > 28) return set_err(ctx, NX_ERR_ARG, "synthetic component needs n_pre >= 2, n_main >= 2, 1 <= log_size <= 28");
+        if (!comp_log_cd_ok(comps[i].log_constraint_degree_bound, ucfg->log_constraint_degree))
+            return set_err(ctx, NX_ERR_ARG, "prove: a component's log_constraint_degree_bound exceeds the config's log_constraint_degree (the twiddle tree is sized by it)");
+    }
     return NX_OK;
 }
 
@@ -468,6 +470,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     GenericAir air; air.ctx = ctx;
     for (uint32_t i = 0; i < n_comps; i++) {
         GComponent g = machine_component(comps[i], locs[i]);
+        g.log_cd = comps[i].log_constraint_degree_bound;
         const QM31 shift = q_mul_m(claimed[i], m_inv((1u << comps[i].log_size) % P));
         memcpy(&g.econsts[0], z, 16); memcpy(&g.econsts[4], alpha, 16); q_store(&g.econsts[8], shift);
         H_TRY(cached_kernel(ctx, g, &g.kernel));

@@ -67,6 +67,12 @@ int dist_init(nx_ctx* ctx, const nx_comm* comm, Dist* out);   // validates the c
 struct ColumnRef { uint32_t* ptr; uint32_t log; bool block; };
 
 struct PcsConfig { uint32_t pow_bits, log_blowup, n_queries, log_last_layer_degree_bound, fri_alpha_mode, log_constraint_degree; };
+// A component's log constraint-degree bound (nx_component_spec / nx_air_component .log_constraint_degree_bound): 0 = the config's.
+// The reference's bound is per component — v1 main +2 (prover/src/components/mod.rs:12,44-45), extensions +1
+// (prover/src/extensions/multiplicity.rs:108-110), prover2 1 / shifts 2 (framework/traits/builtin.rs:23) — and the composition
+// polynomial takes the maximum (prover2/machine/src/prove.rs:44-48).
+inline uint32_t comp_log_cd(uint32_t bound, const PcsConfig& cfg) { return bound ? bound : cfg.log_constraint_degree; }
+inline bool comp_log_cd_ok(uint32_t bound, uint32_t cfg_lcd) { return bound <= cfg_lcd; }   // 0 (default) or 1 .. the config's (twiddle sizing)
 struct MerkleDecommitment { std::vector<Blake2sHash> hash_witness; std::vector<uint32_t> column_witness; };
 
 // A committed Merkle tree: whole on this GPU (log_w == 0), or row-sharded — the subtree over this GPU's row block plus host copies of
@@ -223,6 +229,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
 // ---------------------------------------------------------------- recorded AIRs (the nx_prover session, machine.hip) ---
 struct GComponent {
     uint32_t log_size = 0, n_regs = 0, n_constraints = 0;
+    uint32_t log_cd = 0;                                  // log constraint-degree bound of this component; 0 = cfg.log_constraint_degree
     std::vector<nx_cinstr> prog;
     std::vector<uint32_t> econsts;
     std::vector<std::pair<uint32_t, uint32_t>> cols;     // component column -> (tree, column in tree)

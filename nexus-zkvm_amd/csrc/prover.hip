@@ -1049,7 +1049,6 @@ int GenericAir::check(const CommitmentSchemeProver& cs) {
 }
 
 int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) {
-    const uint32_t lcd = cs.cfg.log_constraint_degree;
     size_t total = 0;
     for (auto& c : comps) total += c.n_constraints;
     std::vector<QM31> powers(total);
@@ -1057,7 +1056,7 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
     std::map<uint32_t, SecureColumn> sub;
     size_t remaining = total;
     for (auto& c : comps) {
-        const uint32_t e = c.log_size + lcd;
+        const uint32_t e = c.log_size + comp_log_cd(c.log_cd, cs.cfg);      // per component; finalize_accumulation lifts to the largest
         const size_t nc = c.n_constraints;
         std::vector<uint32_t> pw(4 * nc);          // the LAST nc remaining powers, reversed (accumulator.columns())
         for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[remaining - 1 - j]);
@@ -1331,7 +1330,9 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
         if (!u.program || (u.n_cols && (!u.col_tree || !u.col_index || !u.mask_count)) || (u.n_econsts && !u.econsts)) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: NULL pointer in a component");
         if (!u.mask_offsets) for (uint32_t k = 0; k < u.n_cols; k++) if (u.mask_count[k]) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: mask_offsets is NULL but a column has a nonzero mask_count");
         nxhip::GComponent g;
-        g.log_size = u.log_size; g.n_regs = u.n_regs; g.n_constraints = u.n_constraints; g.kernel = u.kernel;
+        if (!nxhip::comp_log_cd_ok(u.log_constraint_degree_bound, p->cfg.log_constraint_degree))
+            return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: a component's log_constraint_degree_bound exceeds the session config's log_constraint_degree (the twiddle tree is sized by it)");
+        g.log_size = u.log_size; g.n_regs = u.n_regs; g.n_constraints = u.n_constraints; g.kernel = u.kernel; g.log_cd = u.log_constraint_degree_bound;
         g.prog.assign(u.program, u.program + u.n_instr);
         if (u.n_econsts) g.econsts.assign(u.econsts, u.econsts + 4 * (size_t)u.n_econsts);
         size_t m = 0;

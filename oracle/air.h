@@ -19,7 +19,11 @@ namespace orc {
 
 static const int AIR_GROUP = 16;  // every 16 columns two are "free" (unconstrained witness input)
 
-struct ComponentSpec { int log_size, n_pre, n_main, n_inter; };
+// log_cd: the component's log constraint-degree bound (its constraints are evaluated on CanonicCoset(log_size + log_cd)); 0 = the
+// configuration's log_constraint_degree.  Per component as in the reference: v1's main component +2 (prover/src/components/mod.rs:12,
+// 44-45), every extension +1 (prover/src/extensions/multiplicity.rs:108-110); prover2: 1, the shifts 2 (framework/traits/builtin.rs:23).
+struct ComponentSpec { int log_size, n_pre, n_main, n_inter, log_cd; };
+template <class Cfg> static inline int comp_log_cd(const ComponentSpec& c, const Cfg& cfg) { return c.log_cd > 0 ? c.log_cd : cfg.log_constraint_degree; }
 
 static inline bool col_is_free(int k) { return (k % AIR_GROUP) < 2; }
 static inline int n_constraints(const ComponentSpec& c) {

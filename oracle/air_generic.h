@@ -17,6 +17,7 @@ namespace orc {
 
 struct GComponent {
     int log_size = 0;
+    int log_cd = 0;                                 // log constraint-degree bound of this component; 0 = cfg.log_constraint_degree
     std::vector<CInstr> prog; u32 n_regs = 0;
     std::vector<u32> econsts;                       // 4 words per secure constant (lookup elements, claimed sums, ...)
     size_t n_constraints = 0;
@@ -26,7 +27,7 @@ struct GComponent {
 struct GAir { std::vector<GComponent> comps; };
 
 // flat u32 encoding used over the C boundary (tests/oracle_lib.py builds it):
-//   n_comps, then per component: log_size, n_instr, n_regs, n_econsts, n_constraints, n_cols, n_mask_total,
+//   n_comps, then per component: log_size, n_instr, n_regs, n_econsts, n_constraints, n_cols, n_mask_total, log_cd,
 //   instrs[4*n_instr], econsts[4*n_econsts], col_tree[n_cols], col_index[n_cols], mask_count[n_cols], mask_offsets[n_mask_total] (int32)
 static inline bool gair_decode(const u32* w, size_t n, GAir& air) {
     size_t i = 0;
@@ -34,8 +35,8 @@ static inline bool gair_decode(const u32* w, size_t n, GAir& air) {
     const u32* h = take(1); if (!h) return false;
     u32 nc = h[0];
     for (u32 c = 0; c < nc; c++) {
-        h = take(7); if (!h) return false;
-        GComponent g; g.log_size = (int)h[0]; g.n_regs = h[2]; g.n_constraints = h[4];
+        h = take(8); if (!h) return false;
+        GComponent g; g.log_size = (int)h[0]; g.n_regs = h[2]; g.n_constraints = h[4]; g.log_cd = (int)h[7];
         u32 n_instr = h[1], n_ec = h[3], n_cols = h[5], n_mask = h[6];
         const u32* p = take(4 * (size_t)n_instr); if (!p) return false;
         for (u32 k = 0; k < n_instr; k++) g.prog.push_back({p[4 * k], p[4 * k + 1], p[4 * k + 2], p[4 * k + 3]});
@@ -62,6 +63,7 @@ static inline std::string gair_check(const GAir& air, const std::vector<std::vec
     for (int t = 0; t < 3; t++) claimed[t].assign(tree_logs[t].size(), 0);
     for (auto& c : air.comps) {
         if (c.cols.size() != c.masks.size()) return "cols / masks length mismatch";
+        if (c.log_cd < 0 || c.log_cd > 2) return "component log constraint-degree bound outside {0 (default), 1, 2}";
         for (size_t k = 0; k < c.cols.size(); k++) {
             int t = c.cols[k].first, i = c.cols[k].second;
             if (t < 0 || t > 2 || i < 0 || (size_t)i >= tree_logs[t].size()) return "component column outside the committed trees";
@@ -107,7 +109,7 @@ static inline std::vector<std::vector<std::vector<int>>> g_mask_offsets(const GA
 static inline AirHooks g_hooks(const GAir& air, const PcsConfig& cfg, const std::vector<std::vector<int>>& tree_logs) {
     AirHooks h;
     h.composition_log = 0;
-    for (auto& c : air.comps) h.composition_log = std::max(h.composition_log, c.log_size + cfg.log_constraint_degree);
+    for (auto& c : air.comps) h.composition_log = std::max(h.composition_log, c.log_size + (c.log_cd > 0 ? c.log_cd : cfg.log_constraint_degree));
     std::vector<size_t> n_cols = {tree_logs[0].size(), tree_logs[1].size(), tree_logs[2].size()};
     auto offs = std::make_shared<std::vector<std::vector<std::vector<int>>>>(g_mask_offsets(air, n_cols));
     auto logs = std::make_shared<std::vector<std::vector<int>>>(tree_logs);
@@ -154,7 +156,7 @@ static inline AirHooks g_hooks(const GAir& air, const PcsConfig& cfg, const std:
         std::map<int, SecureCols> sub;
         size_t remaining = total;
         for (auto& c : air.comps) {
-            const int e = c.log_size + cfg.log_constraint_degree;
+            const int e = c.log_size + (c.log_cd > 0 ? c.log_cd : cfg.log_constraint_degree);
             const size_t nc = c.n_constraints;
             std::vector<u32> pw(4 * nc);          // the LAST nc remaining powers, reversed (accumulator.columns())
             for (size_t j = 0; j < nc; j++) qm31_store(&pw[4 * j], powers[remaining - 1 - j]);

@@ -27,7 +27,7 @@ static PcsConfig cfg_from(const int* c) {
 }
 static AirSpec air_from(const int* comps, int n) {
     AirSpec a;
-    for (int i = 0; i < n; i++) a.comps.push_back({comps[4 * i], comps[4 * i + 1], comps[4 * i + 2], comps[4 * i + 3]});
+    for (int i = 0; i < n; i++) a.comps.push_back({comps[5 * i], comps[5 * i + 1], comps[5 * i + 2], comps[5 * i + 3], comps[5 * i + 4]});   // (log_size, n_pre, n_main, n_inter, log_cd)
     return a;
 }
 
@@ -142,7 +142,7 @@ void orc_fold_circle_into_line(uint32_t** dst4, const uint32_t** src4, int src_l
 }
 
 // ---- synthetic AIR ----
-int orc_n_constraints(const int* comp) { ComponentSpec c = {comp[0], comp[1], comp[2], comp[3]}; return n_constraints(c); }
+int orc_n_constraints(const int* comp) { ComponentSpec c = {comp[0], comp[1], comp[2], comp[3], 0}; return n_constraints(c); }
 // Finalized (bit-reversed circle-domain order) columns of one tree; out[i] must hold 2^log_i words.
 void orc_synth_tree_columns(const int* comps, int ncomp, int tree, uint64_t seed, uint64_t inter_seed, int n_threads, uint32_t** out) {
     AirSpec air = air_from(comps, ncomp);
@@ -152,7 +152,7 @@ void orc_synth_tree_columns(const int* comps, int ncomp, int tree, uint64_t seed
 }
 // Natural-order rows (row-major: n_pre+n_main+n_inter values per row) for one component.
 void orc_synth_rows(const int* comp, uint32_t ci, uint64_t seed, uint64_t inter_seed, uint32_t row0, uint32_t nrows, uint32_t* out) {
-    ComponentSpec c = {comp[0], comp[1], comp[2], comp[3]};
+    ComponentSpec c = {comp[0], comp[1], comp[2], comp[3], 0};
     size_t w = c.n_pre + c.n_main + c.n_inter;
     for (uint32_t r = 0; r < nrows; r++) synth_fill_row(c, ci, seed, inter_seed, row0 + r, out + r * w, out + r * w + c.n_pre, out + r * w + c.n_pre + c.n_main);
 }

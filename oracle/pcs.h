@@ -530,7 +530,7 @@ struct AirHooks {
 };
 
 static inline int composition_log(const AirSpec& air, const PcsConfig& cfg) {
-    int m = 0; for (auto& c : air.comps) m = std::max(m, c.log_size + cfg.log_constraint_degree); return m;
+    int m = 0; for (auto& c : air.comps) m = std::max(m, c.log_size + comp_log_cd(c, cfg)); return m;   // max over components (prover2/machine/src/prove.rs:44-48)
 }
 
 // ComponentProvers::compute_composition_polynomial: 4 coordinate polynomials (coefficients) of log
@@ -544,7 +544,7 @@ static inline std::vector<std::vector<u32>> compute_composition(const AirSpec& a
     size_t remaining = total;
     for (size_t ci = 0; ci < air.comps.size(); ci++) {
         const ComponentSpec& c = air.comps[ci];
-        int e = c.log_size + cfg.log_constraint_degree;
+        int e = c.log_size + comp_log_cd(c, cfg);
         size_t nc = n_constraints(c);
         // accumulator.columns(): this component takes the LAST nc remaining powers, then reverses them
         std::vector<QM31> pw(powers.begin() + (remaining - nc), powers.begin() + remaining);

@@ -6,7 +6,7 @@ emitter of machine.hip), the trace and the logup interaction trace come from the
 transcript follows reference prover/src/machine.rs:197-290 through the oracle's prover session (oracle/air_generic.h).  The
 proof must equal nx_prove_machine's word for word.
 
-Component (log_size, n_pre, n_main, 4 L).  Fraction j of a row: den_j = main[a_j] - z (j even) or main[a_j] + alpha main[b_j] - z
+Component (log_size, n_pre, n_main, 4 L[, log constraint-degree bound — 0 / absent = the config's]).  Fraction j of a row: den_j = main[a_j] - z (j even) or main[a_j] + alpha main[b_j] - z
 (j odd); num_j = 1, or -main[m_j] when j % 3 == 2; a_j = (3 + 7 j) % n_main, b_j = (5 + 11 j) % n_main, m_j = (2 + 13 j) % n_main.
 """
 import os
@@ -24,7 +24,7 @@ def logup_cols(j, n_main):
 
 def machine_component(ap, comp, loc, z, alpha, shift):
     """The component's AIR through the recording evaluator: what `add_constraints` of a FrameworkEval would declare."""
-    log, n_pre, n_main, n_inter = comp
+    log, n_pre, n_main, n_inter = comp[:4]
     L = n_inter // 4
     pre0, main0, inter0 = loc
     pb = ap.ProgramBuilder()
@@ -61,13 +61,13 @@ def machine_component(ap, comp, loc, z, alpha, shift):
     prog = pb.build()
     # mask lists exactly as the machine declares them (columns the program happens not to load are still sampled at offset 0)
     masks = [[0]] * n_pre + [[0, 1], [0, 1]] + [[0]] * (n_main - 2) + [([-1, 0] if k // 4 + 1 == L else [0]) for k in range(n_inter)]
-    return ap.Component(log, prog, cols, masks)
+    return ap.Component(log, prog, cols, masks, log_constraint_degree_bound=comp[4] if len(comp) > 4 else 0)
 
 
 def interaction_trace(comp, main_cols, z, alpha):
     """LogupTraceGenerator as the reference drives it (one fraction per column, finalize_col, finalize_last) on the oracle.
     main_cols: the component's finalized main-trace columns.  Returns (4 L coordinate columns, claimed sum)."""
-    log, n_pre, n_main, n_inter = comp
+    log, n_pre, n_main, n_inter = comp[:4]
     L = n_inter // 4
     if L == 0:
         return [], np.zeros(4, np.uint32)

@@ -99,8 +99,8 @@ def default_cfg(pow_bits=10, log_blowup=1, n_queries=3, log_last=0, hash_mode=HA
 
 
 def comps_array(comps):
-    """comps: list of (log_size, n_pre, n_main, n_inter)."""
-    return np.array(comps, dtype=np.int32).reshape(-1, 4).copy()
+    """comps: list of (log_size, n_pre, n_main, n_inter[, log_constraint_degree_bound]) — the bound defaults to 0 = the config's."""
+    return np.array([tuple(c) + (0,) * (5 - len(c)) for c in comps], dtype=np.int32).reshape(-1, 5).copy()
 
 
 class Twiddles:
@@ -173,7 +173,7 @@ def lde_commit(cols, log_blowup=1, mode=HASH_STD, threads=4, root_log=None):
 def synth_tree_columns(comps, tree, seed, inter_seed=0, threads=4):
     comps = comps_array(comps)
     outs = []
-    for (ls, a, b, c) in comps:
+    for (ls, a, b, c, _) in comps:
         n = [a, b, c][tree]
         outs += [np.zeros(1 << ls, np.uint32) for _ in range(n)]
     lib().orc_synth_tree_columns(ptr(comps), len(comps), tree, seed, inter_seed, threads, ptr_array(outs))
@@ -345,7 +345,7 @@ def encode_component(c):
     ins = np.asarray(pr.instrs, dtype=np.uint32).reshape(-1)
     ec = np.asarray(pr.econsts, dtype=np.uint32).reshape(-1)
     offs = [o for m in c.masks for o in m]
-    head = [c.log_size, len(ins) // 4, pr.n_regs, len(ec) // 4, pr.n_constraints, len(c.cols), len(offs)]
+    head = [c.log_size, len(ins) // 4, pr.n_regs, len(ec) // 4, pr.n_constraints, len(c.cols), len(offs), getattr(c, "log_constraint_degree_bound", 0)]
     parts = [np.array(head, np.uint32), ins, ec, np.array([t for t, _ in c.cols], np.uint32), np.array([i for _, i in c.cols], np.uint32),
              np.array([len(m) for m in c.masks], np.uint32), np.array(offs, np.int32).view(np.uint32)]
     return np.concatenate(parts)

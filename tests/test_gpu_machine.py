@@ -53,6 +53,10 @@ MACHINE_CASES = [
     ([(8, 3, 20, 24), (8, 2, 3, 0), (5, 2, 2, 8)], dict(pow_bits=6, hash_mode=1, fri_alpha_mode=1)),   # a component without logup columns
     ([(12, 27, 347, 64)], dict(pow_bits=10)),                                                    # the bench's machine, small
     ([(14, 5, 35, 16), (13, 3, 17, 8), (7, 2, 6, 4)], dict(pow_bits=7, log_constraint_degree=2)),
+    # per-component constraint-degree bounds: big +1 components with one small +2 component (the composition tree is the smaller one) ...
+    ([(13, 5, 35, 16, 1), (10, 3, 17, 8, 2), (7, 2, 6, 4, 1)], dict(pow_bits=7, log_constraint_degree=2)),
+    # ... and the v1 shape: the main component +2 (components/mod.rs:12), the extensions +1 (extensions/multiplicity.rs:108-110)
+    ([(12, 27, 90, 32, 2)] + [(6 + k, 2, 4 + k, 4, 1) for k in range(4)], dict(pow_bits=6, log_constraint_degree=2)),
 ]
 
 
@@ -69,7 +73,7 @@ def test_machine_prove_bit_exact_vs_oracle(be, nz, oracle, comps, kw):
 def test_machine_prove_at_2pow18_v1_shaped(be, nz, oracle):
     """The shape of the reference's v1 machine: LOG_CONSTRAINT_DEGREE = 2 (reference components/mod.rs:12), a wide
     interaction tree, small extra components of other sizes (machine.rs:82-91) — scaled to 2^18 rows so that the oracle finishes."""
-    comps = [(16, 27, 347, 128)] + [(8 + k, 2, 4 + k, 4) for k in range(6)]
+    comps = [(16, 27, 347, 128, 2)] + [(8 + k, 2, 4 + k, 4, 1) for k in range(6)]     # main +2, extensions +1 (extensions/multiplicity.rs:108-110)
     kw = dict(log_constraint_degree=2)
     words = be.prove_machine(comps, nz.default_config(**kw), seed=5)
     _same(M.prove_machine(comps, O.default_cfg(**kw), seed=5, threads=THREADS), words)
@@ -125,6 +129,7 @@ def _run_ranks(nz, world, fn):
     (8, [(8, 3, 20, 24), (8, 2, 3, 0), (6, 2, 2, 8)], dict(pow_bits=6, hash_mode=1, fri_alpha_mode=1)),
     (4, [(14, 5, 35, 16), (13, 3, 17, 8)], dict(pow_bits=7)),
     (8, [(13, 27, 347, 64)], dict(pow_bits=8)),
+    (4, [(12, 5, 35, 16, 1), (9, 3, 17, 8, 2), (7, 2, 6, 4, 1)], dict(pow_bits=6, log_constraint_degree=2)),    # per-component bounds
 ])
 def test_machine_row_sharded_equals_single_gpu(be, nz, world, comps, kw):
     """ONE proof on 2 / 4 / 8 ranks (threads with one context each on this GPU): the logup interaction trace is computed on row

@@ -324,6 +324,10 @@ PROVE_CASES = [
     ([(13, 4, 33, 0), (11, 3, 17, 16), (4, 2, 2, 0)], dict(pow_bits=7, log_constraint_degree=2)),
     ([(15, 8, 61, 20), (14, 3, 17, 16)], dict(pow_bits=9)),                       # every transform through the multi-pass wide kernel (13 + 2/3 layers)
     ([(16, 5, 35, 0)], dict(pow_bits=8, log_constraint_degree=2)),                # constraint domain 2^18: replicas x4 in the LDE top pass
+    # per-component constraint-degree bounds (reference: v1 main +2, extensions +1; prover2 1 / shifts 2): the composition polynomial
+    # takes the largest log_size + bound — here 2^(12+1), not the 2^(12+2) a global bound of 2 gives
+    ([(12, 4, 33, 8, 1), (9, 3, 17, 16, 2), (5, 2, 2, 0, 1)], dict(pow_bits=7, log_constraint_degree=2)),
+    ([(11, 5, 21, 4, 2), (11, 2, 6, 0, 1), (8, 2, 3, 4)], dict(pow_bits=6, log_constraint_degree=2)),   # main +2, extensions +1 / defaulted
 ]
 
 
@@ -623,6 +627,8 @@ def test_constraint_violation_is_a_proving_error(be, nz):
     only pin the error code path of the argument check."""
     with pytest.raises(nz.NexusHipError):
         be.prove([(6, 2, 4, 0)], nz.default_config(log_constraint_degree=0))
+    with pytest.raises(nz.NexusHipError, match="log_constraint_degree_bound exceeds"):
+        be.prove([(6, 2, 4, 0, 2)], nz.default_config(log_constraint_degree=1))
 
 
 @pytest.mark.parametrize("world,comps,kw", [
@@ -634,6 +640,7 @@ def test_constraint_violation_is_a_proving_error(be, nz):
     (2, [(14, 4, 20, 8), (11, 2, 9, 4)], dict(pow_bits=7)),                   # FRI layers large enough to stay row-sharded; two column sizes
     (4, [(13, 3, 18, 8), (13, 2, 7, 0), (9, 2, 3, 4)], dict(pow_bits=6, log_constraint_degree=2)),   # a run of two equal-size components shares one plan
     (8, [(12, 27, 347, 64)], dict(pow_bits=10)),
+    (4, [(12, 4, 33, 8, 1), (9, 3, 17, 16, 2), (6, 2, 2, 0, 1)], dict(pow_bits=6, log_constraint_degree=2)),   # per-component bounds: only the small component is re-evaluated
 ])
 def test_sharded_prove_is_bit_identical_to_single_gpu(nz, oracle, world, comps, kw):
     """SURVEY §8(e) / BASELINE config #4: ONE proof on `world` ranks (one context per rank on this GPU, threads, loopback transport):
@@ -848,14 +855,16 @@ def test_session_proves_the_recorded_synthetic_machine_identically(be, nz, oracl
     s.close()
 
 
-@pytest.mark.parametrize("logs,lcd", [((5, 7), 1), ((6,), 2), ((7, 5, 6), 1), ((11, 9), 1)])
-def test_session_logup_air_matches_the_oracle_session(be, nz, oracle, logs, lcd):
+@pytest.mark.parametrize("logs,lcd,bounds", [((5, 7), 1, None), ((6,), 2, None), ((7, 5, 6), 1, None), ((11, 9), 1, None),
+                                             ((12, 8, 10), 2, (1, 2, 1)),    # per-component bounds: big +1 components, one small +2 component
+                                             ((9, 9), 2, (2, 1))])
+def test_session_logup_air_matches_the_oracle_session(be, nz, oracle, logs, lcd, bounds):
     """A multi-component AIR with a secure logup column at offsets [-1, 0] and lookup elements drawn from the session's
     channel: same draws, same roots, same proof bytes as the CPU oracle's session, and the oracle's verifier accepts."""
     from test_prover_session_cpu import build_mixed_air
     ocfg = oracle.default_cfg(pow_bits=2, log_constraint_degree=lcd, log_blowup=lcd)
     cfg = _hip_cfg(nz, ocfg)
-    drive, tree_logs = build_mixed_air(logs, lcd=lcd)
+    drive, tree_logs = build_mixed_air(logs, lcd=lcd, bounds=bounds)
     so = oracle.ProverSession(ocfg, max(logs))
     oroots = []
     ocomps = drive(so, lambda cols: oroots.append(so.commit(cols)))
@@ -915,6 +924,8 @@ def test_session_refuses_invalid_traces_and_misuse(be, nz, oracle):
         s.prove([ap.Component(c0.log_size, c0.program, c0.cols, [[0]] * len(c0.cols))])
     with pytest.raises(nz.NexusHipError, match="already committed"):
         s.tree_begin([5])
+    with pytest.raises(nz.NexusHipError, match="log_constraint_degree_bound exceeds"):   # the twiddle tree is sized by the config's bound (1 here)
+        s.prove([ap.Component(c0.log_size, c0.program, c0.cols, c0.masks, log_constraint_degree_bound=2)])
     assert len(s.prove(comps)) > 0                       # the session is still usable after the refused calls
     s = be.prover_session(cfg, 5)
     s.commit([np.zeros(32, np.uint32)])

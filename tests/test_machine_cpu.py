@@ -33,6 +33,9 @@ def _verify(comps, cfg, words, ad=b""):
     ([(6, 3, 9, 8)], dict(pow_bits=4)),
     ([(7, 2, 20, 12), (5, 2, 4, 4), (4, 2, 3, 0)], dict(pow_bits=3, log_constraint_degree=2)),
     ([(5, 2, 5, 4)], dict(pow_bits=2, hash_mode=1)),
+    # per-component constraint-degree bounds (the reference's are per component): big +1 components, one small +2 component
+    ([(7, 2, 20, 12, 1), (5, 2, 4, 4, 2), (4, 2, 3, 0, 1)], dict(pow_bits=3, log_constraint_degree=2)),
+    ([(6, 2, 9, 8, 2), (6, 2, 4, 4, 1), (3, 2, 3, 0)], dict(pow_bits=3, log_constraint_degree=2)),     # the v1 shape: main +2, extensions +1, one defaulted
 ])
 def test_oracle_machine_proves_and_verifies(oracle, comps, kw):
     import nexus_zkvm_amd.air_program as ap
@@ -86,3 +89,24 @@ def test_logup_constraints_catch_a_wrong_interaction_trace(oracle):
             s.prove([comp])
     finally:
         M.logup_cols = real
+
+
+def test_per_component_degree_bound_sets_the_composition_size(oracle):
+    """The composition polynomial's log size is the maximum over components of log_size + bound (reference
+    prover2/machine/src/prove.rs:44-48; v1: main +2, extensions +1 — prover/src/components/mod.rs:12, extensions/multiplicity.rs:108-110):
+    with big +1 components and one small +2 component the composition tree is HALF the size a global bound of 2 gives — other roots,
+    fewer decommitment hashes, a shorter proof — and a bound above the configuration's is refused."""
+    big = [(7, 2, 20, 12), (5, 2, 4, 4), (4, 2, 3, 0)]
+    cfg2 = O.default_cfg(pow_bits=3, log_constraint_degree=2)
+    per = [big[0] + (1,), big[1] + (2,), big[2] + (1,)]
+    w_global = M.prove_machine(big, cfg2, seed=4, ad=b"d", threads=4)
+    w_per = M.prove_machine(per, cfg2, seed=4, ad=b"d", threads=4)
+    w_default = M.prove_machine([c + (0,) for c in big], cfg2, seed=4, ad=b"d", threads=4)
+    assert np.array_equal(w_global, w_default)                       # 0 = the configuration's bound
+    assert len(w_per) < len(w_global)                                # composition tree 2^(8+1) instead of 2^(9+1) leaves
+    assert np.array_equal(w_per[6:30], w_global[6:30])               # the three trace roots do not depend on the bound ...
+    assert not np.array_equal(w_per[30:38], w_global[30:38])         # ... the composition root does
+    # the synthetic machine of nx_prove_synth takes the same field
+    sy_g = O.prove_synth([c for c in big], cfg2, seed=9)
+    sy_p = O.prove_synth(per, cfg2, seed=9)
+    assert len(sy_p) < len(sy_g) and O.verify_synth(per, cfg2, sy_p) is None and O.verify_synth(big, cfg2, sy_p) is not None

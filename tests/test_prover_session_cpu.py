@@ -77,8 +77,9 @@ def _roots_from_proof(words):
     return [w[n_hdr + 1 + 8 * t: n_hdr + 9 + 8 * t].copy() for t in range(4)]
 
 
-def build_mixed_air(logs=(5, 7), seed=3, lcd=1):
-    """Two logup components of different sizes + the committed columns.  Returns (drive(session) -> components, tree_logs)."""
+def build_mixed_air(logs=(5, 7), seed=3, lcd=1, bounds=None):
+    """Two logup components of different sizes + the committed columns.  Returns (drive(session) -> components, tree_logs).
+    bounds: per-component log constraint-degree bounds (0 / None = the configuration's)."""
     ap = _ap()
 
     def drive(sess, commit, tamper=None):
@@ -94,20 +95,23 @@ def build_mixed_air(logs=(5, 7), seed=3, lcd=1):
             cols4, shift = X.logup_interaction_trace(l, mains[i][0], z, alpha)
             inter += cols4
             comps.append(X.logup_component(ap, l, z, alpha, shift, main0=3 * i, inter0=4 * i))
+            comps[-1].log_constraint_degree_bound = bounds[i] if bounds else 0
             sess.mix_felts(shift)
         commit(inter)
         # the preprocessed column is claimed (sampled at 0) by a constraint-free reader: attach it to component 0
         c0 = comps[0]
-        comps[0] = ap.Component(c0.log_size, c0.program, c0.cols + [(0, 0)], c0.masks + [[0]])
+        comps[0] = ap.Component(c0.log_size, c0.program, c0.cols + [(0, 0)], c0.masks + [[0]], c0.log_constraint_degree_bound)
         return comps
     tree_logs = [[logs[0]], [l for l in logs for _ in range(3)], [l for l in logs for _ in range(4)]]
     return drive, tree_logs
 
 
-@pytest.mark.parametrize("logs,lcd", [((5, 7), 1), ((6,), 2), ((7, 5, 6), 1)])
-def test_logup_air_round_trip_and_rejections(logs, lcd):
+@pytest.mark.parametrize("logs,lcd,bounds", [((5, 7), 1, None), ((6,), 2, None), ((7, 5, 6), 1, None),
+                                             ((7, 5, 6), 2, (1, 2, 1)),      # per-component bounds: composition 2^8, not 2^9
+                                             ((6, 6), 2, (2, 1))])
+def test_logup_air_round_trip_and_rejections(logs, lcd, bounds):
     cfg = O.default_cfg(pow_bits=2, log_constraint_degree=lcd, log_blowup=lcd)
-    drive, tree_logs = build_mixed_air(logs, lcd=lcd)
+    drive, tree_logs = build_mixed_air(logs, lcd=lcd, bounds=bounds)
     s = O.ProverSession(cfg, max(logs))
     roots = []
     comps = drive(s, lambda cols: roots.append(s.commit(cols)))
@@ -132,7 +136,9 @@ def test_logup_air_round_trip_and_rejections(logs, lcd):
     # a verifier that assumes other lookup elements evaluates other constraints: OODS mismatch
     ap = _ap()
     other = [X.logup_component(ap, l, (1, 2, 3, 4), alpha, np.asarray(c.program.econsts, np.uint32)[2], 3 * i, 4 * i) for i, (l, c) in enumerate(zip(logs, comps))]
-    other[0] = ap.Component(other[0].log_size, other[0].program, other[0].cols + [(0, 0)], other[0].masks + [[0]])
+    for o, c in zip(other, comps):
+        o.log_constraint_degree_bound = c.log_constraint_degree_bound
+    other[0] = ap.Component(other[0].log_size, other[0].program, other[0].cols + [(0, 0)], other[0].masks + [[0]], other[0].log_constraint_degree_bound)
     assert "Oods" in verifier(other, words)[0]
 
 
