@@ -7,10 +7,13 @@ main tree commits (Circle-FFT LDE + Blake2s Merkle) -> lookup elements -> REAL l
 decommit -> proof bytes on the host; everything resident in HBM (the trace is generated on device).
 `value` = 2^log_n_rows * steps / seconds (max over ranks).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 22] [--no-cpu-baseline] [--no-v1-shaped] [--replicas]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 22] [--no-cpu-baseline] [--no-v1-shaped] [--one-proof]
 For N > 1 it is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
-RCCL): by default the N GPUs prove ONE trace together (row-sharded prove, "scaling": "strong" — DESIGN.md §7); --replicas runs
-one independent proof per GPU instead (batch throughput, "weak").
+RCCL).  Default for N > 1: one independent proof of the 2^22-row trace per GPU (batch throughput, "scaling": "weak").
+--one-proof: the N GPUs prove ONE trace together (row-sharded prove, "strong" — DESIGN.md §7); that path is byte-exact on thread
+ranks and over gloo but has never run on more than one physical GPU (this pool has one per box), so it is opt-in until it has: the
+first warm-up step then also checks, on real hardware, that every rank's bytes equal rank 0's single-GPU proof
+("one_proof_equals_single_gpu").
 """
 import argparse
 import json
@@ -67,9 +70,12 @@ def main():
     ap.add_argument("--v1-logup", type=int, default=250)      # ~250 logup columns ~ 1.0 k interaction base columns (SURVEY §8 preamble)
     ap.add_argument("--lcd", type=int, default=1, help="log_constraint_degree of the main workload (the reference's v1 has 2, components/mod.rs:12)")
     ap.add_argument("--extra-comps", type=int, default=0, help="small extra components of 2^8, 2^9, ... rows next to the main one (machine.rs:82-91)")
-    ap.add_argument("--replicas", action="store_true", help="N > 1: one independent proof per GPU (weak scaling) instead of ONE row-sharded proof")
+    ap.add_argument("--replicas", action="store_true", help="(the default for N > 1) one independent proof per GPU, weak scaling")
+    ap.add_argument("--one-proof", action="store_true", help="N > 1: ONE row-sharded proof on all GPUs (strong scaling) instead of one independent proof per GPU")
     ap.add_argument("--legacy-synth", action="store_true", help="prove the round-1 machine (synthetic interaction fill, hand-written constraint kernel)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--transport", default=None, choices=["rccl-native", "torch"],
+                    help="--one-proof: who carries the collectives — the library's own RCCL transport (csrc/comm_rccl.hip, the default with --backend nccl) or the torch.distributed callbacks")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank on GPU 0 (RCCL refuses that; use with --backend gloo)")
     args = ap.parse_args()
 
@@ -107,13 +113,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sharded = world > 1 and not args.replicas
+    sharded = world > 1 and args.one_proof and not args.replicas
     comm = None
     if sharded:
         if world & (world - 1):
             raise SystemExit("one row-sharded proof needs a power-of-two number of GPUs (use --replicas otherwise)")
-        from nexus_zkvm_amd.sharded import TorchDistComm
-        comm = nz.make_comm(rank, world, TorchDistComm(be, torch.device("cuda", local_rank)))
+        transport = args.transport or ("rccl-native" if args.backend == "nccl" else "torch")
+        if transport == "rccl-native":
+            # the 128-byte RCCL unique id travels over the process group torch.distributed.run set up; the proof's collectives do not
+            box = [nz.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = be.rccl_comm(box[0], rank, world)
+        else:
+            from nexus_zkvm_amd.sharded import TorchDistComm
+            comm = nz.make_comm(rank, world, TorchDistComm(be, torch.device("cuda", local_rank)))
 
     def prove(cs, cf, seed, want_stats=False):
         sd = seed if sharded else seed + rank * 97            # one proof together, or one independent proof per rank
@@ -136,6 +149,18 @@ def main():
             el = float(t.item())
         return el
 
+    one_proof_equal = None
+    if sharded:
+        # first contact with real multi-GPU hardware: every rank's proof of one small statement must equal the single-GPU proof
+        import numpy as np
+        chk = [(min(args.log_rows, 16), args.n_pre, args.n_main, n_inter)]
+        mine = be.prove_machine(chk, cfg, seed=77, comm=comm)
+        solo = be.prove_machine(chk, cfg, seed=77)
+        ok = torch.tensor([1 if (len(mine) == len(solo) and np.array_equal(mine, solo)) else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        one_proof_equal = bool(int(ok.item()))
+        if not one_proof_equal:
+            raise SystemExit("bench.py --one-proof: a rank's row-sharded proof differs from the single-GPU proof")
     elapsed = timed(comps, cfg, args.steps, args.warmup)
     # one extra instrumented step (outside the timed region) for the per-stage split and the FFT roofline
     words, stats = prove(comps, cfg, 4242, want_stats=True)
@@ -204,7 +229,8 @@ def main():
                        "achieved_GBs": stats["merkle_algorithmic_bytes"] / (stats["merkle_kernel_ms"] * 1e-3) / 1e9 if stats["merkle_kernel_ms"] > 0 else 0.0},
         }
         if sharded:
-            out["xgmi"] = {"bytes_sent_per_gpu_per_proof": int(stats["comm_bytes"]), "ms_in_collectives_per_proof": round(stats["comm_ms"], 3),
+            out["one_proof_equals_single_gpu"] = one_proof_equal
+            out["xgmi"] = {"transport": transport, "bytes_sent_per_gpu_per_proof": int(stats["comm_bytes"]), "ms_in_collectives_per_proof": round(stats["comm_ms"], 3),
                            "collectives": "one all-to-all per trace tree (LDE columns -> row blocks), all-gather of W subtree roots per tree, of the columns read at a non-zero mask offset, of the composition accumulator and of the FRI tail; sampled / queried values (KBs)"}
         if v1 is not None:
             out["config_v1_shaped"] = v1

@@ -315,6 +315,14 @@ typedef struct nx_comm {
     /* device all-gather: d_recv = world x n_words, rank r's contribution at r * n_words */
     int (*allgather_dev)(void* user, const uint32_t* d_send, size_t n_words, uint32_t* d_recv);
 } nx_comm;
+/* The native transport: RCCL over xGMI (csrc/comm_rccl.hip; librccl is opened at run time, NX_ERR_HIP when it is not there).  Rank 0
+ * calls nx_rccl_unique_id and ships the 128 bytes to the other ranks through any side channel (environment, file, socket — the
+ * bootstrap every NCCL program has); every rank then creates its communicator on its own context and hands `*out` to the prove
+ * entries / nx_prover_set_comm.  Collectives run on a stream of the transport's own (see alltoallv above).  One process or thread
+ * per GPU; RCCL itself refuses two ranks on one device. */
+int nx_rccl_unique_id(uint8_t id[128]);
+int nx_comm_rccl_create(nx_ctx* ctx, const uint8_t unique_id[128], int32_t rank, int32_t world, nx_comm** out);
+void nx_comm_rccl_destroy(nx_comm* comm);
 /* Which columns of a tree a GPU transforms: groups = (column count, log size) per component in commit order; consecutive groups
  * of one size form a run whose columns are cut into `world` contiguous balanced ranges; lo/hi[i] = this rank's [lo, hi) of group i.
  * Host arithmetic only (no context, no GPU). */

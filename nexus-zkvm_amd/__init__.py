@@ -89,6 +89,16 @@ def make_comm(rank, world, impl):
     return c
 
 
+def rccl_unique_id():
+    """ncclGetUniqueId through the library's native RCCL transport (rank 0 calls it and ships the 128 bytes to the other ranks)."""
+    L = load_library()
+    buf = (C.c_uint8 * 128)()
+    rc = L.nx_rccl_unique_id(buf)
+    if rc != 0:
+        raise NexusHipError(f"nx_rccl_unique_id failed ({rc}): {L.nx_last_error(None).decode()}")
+    return bytes(buf)
+
+
 def air_source(program, n_cols):
     """The HIP source nx_air_compile generates for a recorded program (needs no GPU and no context)."""
     L = load_library()
@@ -422,6 +432,19 @@ class HipBackend:
 
     def set_hash_mode(self, mode):
         self._chk(self.L.nx_ctx_set_hash_mode(self.ctx, mode))
+
+    def rccl_comm(self, unique_id, rank, world):
+        """The native RCCL transport (csrc/comm_rccl.hip) as an NxComm for prove_machine(comm=...) / ProverSession.set_comm: no Python in
+        the data path.  Free with free_rccl_comm."""
+        p = C.c_void_p()
+        idb = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self.L.nx_comm_rccl_create(self.ctx, idb, int(rank), int(world), C.byref(p)))
+        comm = NxComm.from_address(p.value)
+        comm._native = p
+        return comm
+
+    def free_rccl_comm(self, comm):
+        self.L.nx_comm_rccl_destroy(comm._native)
 
     def set_option(self, name, value):
         """Per-context policy / tuning (nx_ctx_set_option): "fft.pipe", "fft.pipe_grid", "fft.batch_cols", "fft.streams",

@@ -1,0 +1,243 @@
+// Native RCCL transport for ONE proof on the GPUs of a node (include/nexus_hip.h: nx_comm; BASELINE.json north_star: "RCCL
+// all-gather over xGMI").  The reference has no collective to mirror (distributed communication backend: none): the
+// contract implemented here is the library's own nx_comm (prover.h Dist).  A host written in Rust / C++ gets its transport from
+// this file instead of from Python: one process (or thread) per GPU,
+//     rank 0: nx_rccl_unique_id(id) -> ship the 128 bytes to the other ranks (any side channel: env, file, socket)
+//     all   : nx_comm_rccl_create(ctx, id, rank, world, &comm); nx_prove_machine(..., comm, ...); nx_comm_rccl_destroy(comm)
+//
+// librccl is opened at run time (dlopen) — libnexus_hip.so itself stays loadable on hosts without RCCL, and a process that already
+// carries an RCCL (PyTorch bundles one) keeps using that one.  Only the rccl.h TYPES are compiled in.
+//
+// Streams: every collective runs on the transport's own stream; the library guarantees that a send buffer is complete when a
+// callback is entered (Dist::alltoallv waits for the pack event, the other paths drain the context's stream) and expects the receive
+// buffer to be complete on return, so a callback ends with a synchronisation of THAT stream only — kernels the library has already
+// queued on the context's streams (the next column chunk's LDE) keep running while the links carry this chunk.
+//   * alltoallv      = ncclGroupStart { ncclSend / ncclRecv per peer } ncclGroupEnd; the own share is a device-to-device copy
+//   * allgather_dev  = ncclAllGather on the library's buffers (zero copy)
+//   * allgather      = host bytes through a pinned staging pair + ncclAllGather (KB-sized: roots, sampled values, decommitted words)
+//   * allreduce_m31 / send / recv / broadcast: the column-sharded building blocks of round 1 (widen to u64, ncclSum, narrow)
+#include "internal.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <string.h>
+
+namespace nx {
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+// process-wide, opened once; "" on success, else why RCCL is unavailable
+static std::string rccl_open(RcclApi** out) {
+    static RcclApi api;
+    static std::string err = []() -> std::string {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // an RCCL the process already carries (e.g. PyTorch's)
+            if (api.lib) break;
+        }
+        for (size_t i = 0; !api.lib && i < sizeof names / sizeof names[0]; i++) api.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) return std::string("librccl.so not found (") + (dlerror() ? dlerror() : "dlopen failed") + ")";
+#define NX_SYM(field, sym) do { *(void**)(&api.field) = dlsym(api.lib, sym); if (!api.field) return std::string("librccl: missing symbol ") + sym; } while (0)
+        NX_SYM(GetUniqueId, "ncclGetUniqueId"); NX_SYM(CommInitRank, "ncclCommInitRank"); NX_SYM(CommDestroy, "ncclCommDestroy");
+        NX_SYM(AllGather, "ncclAllGather"); NX_SYM(AllReduce, "ncclAllReduce"); NX_SYM(Broadcast, "ncclBroadcast");
+        NX_SYM(Send, "ncclSend"); NX_SYM(Recv, "ncclRecv"); NX_SYM(GroupStart, "ncclGroupStart"); NX_SYM(GroupEnd, "ncclGroupEnd");
+        NX_SYM(GetErrorString, "ncclGetErrorString");
+#undef NX_SYM
+        return "";
+    }();
+    *out = &api;
+    return err;
+}
+
+struct RcclComm {
+    nx_comm iface;            // FIRST member: nx_comm* <-> RcclComm*
+    nx_ctx* ctx = nullptr;
+    RcclApi* api = nullptr;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int rank = 0, world = 1;
+    uint8_t* h_pin = nullptr;     // pinned staging of the host all-gather: [send | world x recv]
+    uint8_t* d_stage = nullptr;   // its device twin
+    size_t stage_bytes = 0;
+    std::string err;
+};
+
+#define R_HIP(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (c)->err = std::string(#call) + ": " + hipGetErrorString(e__); (void)set_err((c)->ctx, NX_ERR_HIP, "rccl transport: " + (c)->err); return 1; } } while (0)
+#define R_NCCL(c, call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { (c)->err = std::string(#call) + ": " + (c)->api->GetErrorString(r__); (void)set_err((c)->ctx, NX_ERR_HIP, "rccl transport: " + (c)->err); return 1; } } while (0)
+
+static int ensure_stage(RcclComm* c, size_t bytes_per_rank) {
+    const size_t need = bytes_per_rank * (size_t)(c->world + 1);
+    if (need <= c->stage_bytes) return 0;
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    c->h_pin = nullptr; c->d_stage = nullptr; c->stage_bytes = 0;
+    const size_t cap = std::max<size_t>(need, 1u << 16);
+    R_HIP(c, hipHostMalloc((void**)&c->h_pin, cap, hipHostMallocDefault));
+    R_HIP(c, hipMalloc((void**)&c->d_stage, cap));
+    c->stage_bytes = cap;
+    return 0;
+}
+
+static int cb_allgather(void* user, const void* h_send, size_t bytes, void* h_recv) {
+    RcclComm* c = (RcclComm*)user;
+    DeviceGuard g(c->ctx);
+    if (bytes == 0) return 0;
+    const size_t b = (bytes + 15) & ~(size_t)15;
+    if (ensure_stage(c, b)) return 1;
+    memcpy(c->h_pin, h_send, bytes);
+    R_HIP(c, hipMemcpyAsync(c->d_stage, c->h_pin, b, hipMemcpyHostToDevice, c->stream));
+    R_NCCL(c, c->api->AllGather(c->d_stage, c->d_stage + b, b, ncclUint8, c->comm, c->stream));
+    R_HIP(c, hipMemcpyAsync(c->h_pin + b, c->d_stage + b, b * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    R_HIP(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < c->world; r++) memcpy((uint8_t*)h_recv + (size_t)r * bytes, c->h_pin + b + (size_t)r * b, bytes);
+    return 0;
+}
+
+static int cb_broadcast(void* user, void* h_buf, size_t bytes, int32_t root) {
+    RcclComm* c = (RcclComm*)user;
+    DeviceGuard g(c->ctx);
+    if (bytes == 0) return 0;
+    if (ensure_stage(c, bytes)) return 1;
+    if (c->rank == root) memcpy(c->h_pin, h_buf, bytes);
+    R_HIP(c, hipMemcpyAsync(c->d_stage, c->h_pin, bytes, hipMemcpyHostToDevice, c->stream));
+    R_NCCL(c, c->api->Broadcast(c->d_stage, c->d_stage, bytes, ncclUint8, root, c->comm, c->stream));
+    R_HIP(c, hipMemcpyAsync(c->h_pin, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    R_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(h_buf, c->h_pin, bytes);
+    return 0;
+}
+
+static int cb_allgather_dev(void* user, const uint32_t* d_send, size_t n_words, uint32_t* d_recv) {
+    RcclComm* c = (RcclComm*)user;
+    DeviceGuard g(c->ctx);
+    if (n_words == 0) return 0;
+    R_NCCL(c, c->api->AllGather(d_send, d_recv, n_words, ncclUint32, c->comm, c->stream));
+    R_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int cb_alltoallv(void* user, const uint32_t* d_send, const size_t* soff, const size_t* scnt, uint32_t* d_recv, const size_t* roff, const size_t* rcnt) {
+    RcclComm* c = (RcclComm*)user;
+    DeviceGuard g(c->ctx);
+    if (scnt[c->rank]) {
+        if (scnt[c->rank] != rcnt[c->rank]) { (void)set_err(c->ctx, NX_ERR_ARG, "rccl transport: own share of an all-to-all has different send / receive counts"); return 1; }
+        R_HIP(c, hipMemcpyAsync(d_recv + roff[c->rank], d_send + soff[c->rank], scnt[c->rank] * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    R_NCCL(c, c->api->GroupStart());
+    for (int r = 0; r < c->world; r++) {
+        if (r == c->rank) continue;
+        if (scnt[r]) R_NCCL(c, c->api->Send(d_send + soff[r], scnt[r], ncclUint32, r, c->comm, c->stream));
+        if (rcnt[r]) R_NCCL(c, c->api->Recv(d_recv + roff[r], rcnt[r], ncclUint32, r, c->comm, c->stream));
+    }
+    R_NCCL(c, c->api->GroupEnd());
+    R_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int cb_send(void* user, int32_t dst, const uint32_t* d_buf, size_t n_words) {
+    RcclComm* c = (RcclComm*)user;
+    DeviceGuard g(c->ctx);
+    R_HIP(c, hipStreamSynchronize(c->ctx->stream));
+    R_NCCL(c, c->api->Send(d_buf, n_words, ncclUint32, dst, c->comm, c->stream));
+    R_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int cb_recv(void* user, int32_t src, uint32_t* d_buf, size_t n_words) {
+    RcclComm* c = (RcclComm*)user;
+    DeviceGuard g(c->ctx);
+    R_HIP(c, hipStreamSynchronize(c->ctx->stream));
+    R_NCCL(c, c->api->Recv(d_buf, n_words, ncclUint32, src, c->comm, c->stream));
+    R_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+// RCCL has no modular reduction: widen to u64 (world x (p - 1) < 2^34), ncclSum, narrow back (nx_m31_widen / nx_m31_narrow)
+static int cb_allreduce_m31(void* user, uint32_t* d_buf, size_t n_words) {
+    RcclComm* c = (RcclComm*)user;
+    DeviceGuard g(c->ctx);
+    uint64_t* wide = nullptr;
+    R_HIP(c, hipMalloc((void**)&wide, n_words * 8));
+    int rc = nx_m31_widen(c->ctx, wide, d_buf, n_words);
+    if (rc == NX_OK) rc = nx_sync(c->ctx);
+    if (rc == NX_OK) {
+        ncclResult_t r = c->api->AllReduce(wide, wide, n_words, ncclUint64, ncclSum, c->comm, c->stream);
+        if (r != ncclSuccess) { (void)set_err(c->ctx, NX_ERR_HIP, std::string("rccl transport: ncclAllReduce: ") + c->api->GetErrorString(r)); rc = NX_ERR_HIP; }
+    }
+    if (rc == NX_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = NX_ERR_HIP;
+    if (rc == NX_OK) rc = nx_m31_narrow(c->ctx, d_buf, wide, n_words);
+    if (rc == NX_OK) rc = nx_sync(c->ctx);
+    (void)hipFree(wide);
+    return rc == NX_OK ? 0 : 1;
+}
+
+}  // namespace
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+int nx_rccl_unique_id(uint8_t id[128]) {
+    if (!id) return set_err(nullptr, NX_ERR_ARG, "nx_rccl_unique_id: NULL argument");
+    RcclApi* api = nullptr;
+    const std::string e = rccl_open(&api);
+    if (!e.empty()) return set_err(nullptr, NX_ERR_HIP, "nx_rccl_unique_id: " + e);
+    ncclUniqueId u;
+    ncclResult_t r = api->GetUniqueId(&u);
+    if (r != ncclSuccess) return set_err(nullptr, NX_ERR_HIP, std::string("ncclGetUniqueId: ") + api->GetErrorString(r));
+    static_assert(sizeof u == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id, &u, 128);
+    return NX_OK;
+}
+
+int nx_comm_rccl_create(nx_ctx* ctx, const uint8_t unique_id[128], int32_t rank, int32_t world, nx_comm** out) {
+    NX_GUARD(ctx);
+    if (!ctx || !unique_id || !out) return set_err(ctx, NX_ERR_ARG, "nx_comm_rccl_create: NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return set_err(ctx, NX_ERR_ARG, "nx_comm_rccl_create: 0 <= rank < world required");
+    RcclApi* api = nullptr;
+    const std::string e = rccl_open(&api);
+    if (!e.empty()) return set_err(ctx, NX_ERR_HIP, "nx_comm_rccl_create: " + e);
+    RcclComm* c = new RcclComm();
+    c->ctx = ctx; c->api = api; c->rank = rank; c->world = world;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_err(ctx, NX_ERR_HIP, "nx_comm_rccl_create: hipStreamCreate failed"); }
+    ncclUniqueId u; memcpy(&u, unique_id, 128);
+    ncclResult_t r = api->CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        const std::string msg = std::string("ncclCommInitRank: ") + api->GetErrorString(r);
+        (void)hipStreamDestroy(c->stream); delete c;
+        return set_err(ctx, NX_ERR_HIP, "nx_comm_rccl_create: " + msg);
+    }
+    memset(&c->iface, 0, sizeof c->iface);
+    c->iface.rank = rank; c->iface.world = world; c->iface.user = c;
+    c->iface.send = cb_send; c->iface.recv = cb_recv; c->iface.allreduce_m31 = cb_allreduce_m31;
+    c->iface.allgather = cb_allgather; c->iface.broadcast = cb_broadcast;
+    c->iface.alltoallv = cb_alltoallv; c->iface.allgather_dev = cb_allgather_dev;
+    *out = &c->iface;
+    return NX_OK;
+}
+
+void nx_comm_rccl_destroy(nx_comm* comm) {
+    if (!comm) return;
+    RcclComm* c = (RcclComm*)comm->user;
+    DeviceGuard g(c->ctx);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)c->api->CommDestroy(c->comm);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+}  // extern "C"

@@ -255,7 +255,7 @@ def test_bench_two_processes_one_proof(tmp_path):
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     env = dict(os.environ); env.pop("NX_FRI_DIST_MIN_LOG", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-rows", "14", "--backend", "gloo", "--same-device"],
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--one-proof", "--steps", "1", "--warmup", "1", "--log-rows", "14", "--backend", "gloo", "--same-device"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -263,6 +263,14 @@ def test_bench_two_processes_one_proof(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 1 and out["value"] > 0
     assert out["xgmi"]["bytes_sent_per_gpu_per_proof"] > 0 and "cpu_baseline" not in out
+    assert out["one_proof_equals_single_gpu"] is True      # the first-contact check every --one-proof run makes
+    # the default for N > 1: one independent proof per GPU
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port + 1 if port < 65000 else port - 1),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-rows", "14", "--backend", "gloo", "--same-device"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "xgmi" not in out and "independent proof" in out["config"]["parallelism"]
 
 
 def test_torch_transport_on_device_buffers_nccl_world1(be, nz):
@@ -299,3 +307,37 @@ def test_torch_transport_on_device_buffers_nccl_world1(be, nz):
         assert np.array_equal(w, be.prove_machine([(8, 3, 9, 4)], nz.default_config(pow_bits=4), seed=3))
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_transport_world1(be, nz):
+    """The library's own RCCL transport (csrc/comm_rccl.hip: ncclSend / ncclRecv all-to-all, ncclAllGather on device buffers, host
+    all-gather through a pinned pair, u64-widened all-reduce) on a one-rank communicator — RCCL refuses two ranks on one GPU and the pool
+    has one GPU per box, so what can be pinned here is the plumbing: librccl found at run time, communicator creation, every callback
+    of nx_comm on real device buffers, and a whole nx_prove_machine handed the native communicator.  The multi-rank split / offset
+    logic is the library's (Dist), covered by the thread-rank and gloo tests."""
+    import ctypes as C
+    comm = be.rccl_comm(nz.rccl_unique_id(), 0, 1)
+    try:
+        assert comm.rank == 0 and comm.world == 1
+        n = 1 << 12
+        a = be.columns_from_host(np.arange(n, dtype=np.uint32)[None, :])
+        b = be.columns(1, 12)
+        be.sync()
+        assert comm.allgather_dev(comm.user, a.ptr, n, b.ptr) == 0
+        assert np.array_equal(b.to_cpu(), a.to_cpu())
+        off, cnt = (C.c_size_t * 1)(5), (C.c_size_t * 1)(100)
+        roff = (C.c_size_t * 1)(17)
+        be._chk(be.L.nx_memset_zero(be.ctx, b.ptr, C.c_size_t(n))); be.sync()
+        assert comm.alltoallv(comm.user, a.ptr, off, cnt, b.ptr, roff, cnt) == 0
+        got = b.to_cpu()[0]
+        assert np.array_equal(got[17:117], np.arange(5, 105, dtype=np.uint32)) and not got[:17].any() and not got[117:].any()
+        src = (C.c_uint8 * 37)(*range(37)); dst = (C.c_uint8 * 37)()
+        assert comm.allgather(comm.user, src, 37, dst) == 0 and bytes(dst) == bytes(src)
+        assert comm.broadcast(comm.user, src, 37, 0) == 0
+        assert comm.allreduce_m31(comm.user, a.ptr, n) == 0
+        assert np.array_equal(a.to_cpu()[0], np.arange(n, dtype=np.uint32))
+        comps = [(10, 4, 24, 8), (7, 2, 5, 4)]
+        cfg = nz.default_config(pow_bits=6)
+        _same(be.prove_machine(comps, cfg, seed=3, ad=b"n"), be.prove_machine(comps, cfg, seed=3, ad=b"n", comm=comm))
+    finally:
+        be.free_rccl_comm(comm)
