@@ -199,6 +199,33 @@ int transpose_blocks(nx_ctx* ctx, uint32_t* full, uint64_t col_stride, uint32_t*
 
 using namespace nx;
 
+// Column::clone of many equally long columns in ONE launch (a wide AIR keeps ~10^3 main columns per component for its logup
+// fractions: one nx_copy each was ~2.5 us of launch per 16..64 KB of work).  words % 4 == 0, 16-byte aligned columns.
+__global__ __launch_bounds__(256) void copy_cols_kernel(nx::ColSet dst, nx::ColSet src, size_t n4) {
+    const uint4* __restrict__ s = (const uint4*)src.col(blockIdx.y);
+    uint4* __restrict__ d = (uint4*)dst.col(blockIdx.y);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+namespace nx {
+int copy_columns(nx_ctx* ctx, uint32_t* const* h_dst, const uint32_t* const* h_src, uint32_t n_cols, size_t n_words) {
+    if (n_cols == 0 || n_words == 0) return NX_OK;
+    bool vec = (n_words & 3) == 0;
+    for (uint32_t k = 0; k < n_cols && vec; k++) vec = !(((uintptr_t)h_dst[k] | (uintptr_t)h_src[k]) & 15);
+    if (!vec || n_cols < 4) { for (uint32_t k = 0; k < n_cols; k++) NX_TRY(nx_copy(ctx, h_dst[k], h_src[k], n_words)); return NX_OK; }
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += 65535) {
+        const uint32_t nb = std::min<uint32_t>(65535, n_cols - c0);
+        ColSet d, s;
+        NX_TRY(make_colset(ctx, h_dst + c0, nb, &d));
+        NX_TRY(make_colset(ctx, (uint32_t* const*)(h_src + c0), nb, &s));
+        const size_t n4 = n_words / 4;
+        const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>((n4 + 255) / 256, std::max<size_t>(1, (size_t)ctx->n_cus * 16 / nb)));
+        hipLaunchKernelGGL(copy_cols_kernel, dim3(bx, nb), dim3(256), 0, ctx->stream, d, s, n4);
+        NX_LAUNCH_CHECK(ctx);
+    }
+    return NX_OK;
+}
+}  // namespace nx
+
 extern "C" {
 
 const char* nx_version(void) { return "nexus_hip 0.2 (gfx950)"; }

@@ -153,6 +153,8 @@ int dev_alloc(nx_ctx* ctx, size_t bytes, void** out);
 void dev_free(nx_ctx* ctx, void* p);
 void dev_cache_release(nx_ctx* ctx);
 
+// n_cols columns of n_words words each, dst[k] <- src[k], one launch (ctx.hip)
+int copy_columns(nx_ctx* ctx, uint32_t* const* h_dst, const uint32_t* const* h_src, uint32_t n_cols, size_t n_words);
 int transpose_blocks(nx_ctx* ctx, uint32_t* full, uint64_t col_stride, uint32_t* blocks, uint32_t n_cols, uint64_t rows, uint32_t world, bool unpack);
 
 // Event-pair span on ctx->stream, recorded only when ctx->timing is on; resolved by timing_flush.

@@ -388,12 +388,14 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
                 const uint64_t nb = D.on() ? D.block(log) : ((uint64_t)1 << log);
                 H_TRY(kept[i].alloc(ctx, need.size() * (size_t)nb));
                 size_t q = 0;
+                std::vector<uint32_t*> cd; std::vector<const uint32_t*> csrc;
                 for (uint32_t k : need) {
                     uint32_t* dst = kept[i].p + q * (size_t)nb;
-                    if (!D.on()) H_TRY(nx_copy(ctx, dst, slab.p + ((size_t)k << log), (size_t)nb));            // Column::clone (R4)
+                    if (!D.on()) { cd.push_back(dst); csrc.push_back(slab.p + ((size_t)k << log)); }              // Column::clone (R4), batched below
                     else { uint32_t* one[1] = {dst}; H_TRY(synth_fill_range(ctx, c, i, 1, seed, 0, k, 1, one, (uint32_t)D.begin(log), (uint32_t)nb)); }
                     kept_ptr[i][k] = dst; q++;
                 }
+                H_TRY(copy_columns(ctx, cd.data(), csrc.data(), (uint32_t)cd.size(), (size_t)nb));
             }
             tb.extend_evals_local(std::move(slab), c.n_main, log, lo, hi);
         }

@@ -183,6 +183,20 @@ def test_config5_keccak_shaped_machine(be, nz, oracle):
         _same(words, res[r])
 
 
+def test_config5_keccak_shaped_at_full_width(be, nz, oracle):
+    """Config #5 with the column counts SURVEY §8(d) gives (two round components of ~10^3 main + ~2 x 10^3 interaction columns = 500
+    logup columns each, the XOR / NOT-AND / rotate tables, every bound +1 — tools/keccak_shaped.py) at 1/16 of the height (2^14 / 2^13
+    rows): every proof word against the oracle machine.  The full-height run is timed by the tool (profiles/r03_keccak_shaped.json)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("keccak_shaped", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "keccak_shaped.py"))
+    ks = importlib.util.module_from_spec(spec); spec.loader.exec_module(ks)
+    comps = ks.keccak_shaped_components(shift=4)
+    assert [c[0] for c in comps] == [14, 13, 8, 8, 7] and comps[0][2] == 1000 and comps[0][3] == 2000
+    kw = dict(pow_bits=6)
+    words = be.prove_machine(comps, nz.default_config(**kw), seed=0xCEC, ad=b"k5")
+    _same(M.prove_machine(comps, O.default_cfg(**kw), seed=0xCEC, ad=b"k5", threads=THREADS), words)
+
+
 def _prover2_shaped(shift):
     """tools/many_components.py's statement (reference prover2/machine/src/lib.rs:9-65: ~55 components of different sizes, few columns
     each) with every size reduced by `shift` bits so that the CPU checker finishes in seconds"""

@@ -155,3 +155,37 @@ def test_whole_proof_byte_equal_at_2pow22_headline(be, nz, oracle):
     words = be.prove(comps, nz.default_config(), seed=2001)
     ref = oracle.prove_synth(comps, O.default_cfg(), seed=2001, threads=THREADS)
     _assert_same_proof(ref, words)
+
+
+def test_config4_trace_2pow24_lde_matches_oracle(be, oracle):
+    """BASELINE config #4's trace size on ONE GPU: nx_lde_batch of 2^24-row columns onto 2^25 points — the three-pass transform plan
+    (13 + 6 + 5 layers, the fused middle launch at its smallest layer count): coefficients and every LDE value of two columns
+    against the oracle (values at both ends of the field in the first rows)."""
+    log = 24
+    vals = np.random.default_rng(2400).integers(0, P, (2, 1 << log), dtype=np.uint32)
+    vals[0, :4] = [P - 1, 0, P - 1, 1]
+    tw = be.precompute_twiddles(log)
+    otw = oracle.Twiddles(log + 1)
+    cols = be.columns_from_host(vals)
+    lde = be.lde(tw, cols, 1)
+    coeffs = np.stack([otw.interpolate(v) for v in vals])
+    assert np.array_equal(cols.to_cpu(), coeffs)
+    got = lde.to_cpu()
+    assert got.max() < P
+    for c in range(2):
+        assert np.array_equal(got[c], otw.evaluate(coeffs[c], log + 1)), c
+    lde.free(); cols.free()
+
+
+def test_config4_trace_2pow24_prove_is_accepted_and_tamper_rejected(be, nz, oracle):
+    """A 2^24-row statement (27 + 347 + 64 columns: BASELINE config #4's trace, proved on one GPU — 288 GB of HBM hold its 110 GB of
+    coefficients and LDE): the oracle's verifier (whose cost does not grow with the trace) accepts the proof, rejects a flipped word
+    and a different transcript.  Size-independent property check; byte parity with the oracle prover stops at 2^22 (NX_RUN_SLOW)."""
+    comps = [(24, 27, 347, 64)]
+    cfg, ocfg = nz.default_config(pow_bits=8), O.default_cfg(pow_bits=8)
+    w = be.prove(comps, cfg, seed=24, ad=b"cfg4")
+    assert oracle.verify_synth(comps, ocfg, w, ad=b"cfg4") is None
+    for pos in (len(w) // 3, len(w) - 7):
+        bad = w.copy(); bad[pos] ^= 1
+        assert oracle.verify_synth(comps, ocfg, bad, ad=b"cfg4") is not None
+    assert oracle.verify_synth(comps, ocfg, w, ad=b"other") is not None

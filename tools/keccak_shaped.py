@@ -1,0 +1,58 @@
+"""BASELINE config #5 at the size SURVEY.md §8(d) states — the keccak-precompile guest's AIR shape — proved on ONE GPU through
+nx_prove_machine (real logup interaction trace on the device, recorded AIR, hiprtc):
+  * two keccak round components: 2^14 permutation instances x 16 resp. 8 rounds per row block -> log sizes 18 and 17
+    (reference prover/src/extensions/keccak/mod.rs:15-24); a lane is 8 byte columns (round/constants.rs:45) -> ~10^3 main columns;
+    4 logup columns per lane-level lookup (round/interaction_trace.rs:51-70,113-114,158-159) x ~130 lookups per round
+    (round/mod.rs:11-51) -> ~0.5 k logup columns = ~2 k interaction base columns per round component;
+  * the XOR and NOT-AND tables at log 12 (keccak/bitwise_table/mod.rs:108), the rotate table at log 11 (keccak/bit_rotate/mod.rs:57);
+  * every extension's constraint-degree bound is +1 (keccak/round/eval.rs:28-30).
+usage: keccak_shaped.py [--shift S] [--steps K] [--check]     --shift: every log size reduced by S bits (--check: against the oracle)
+Prints one JSON line: ms per prove, stage split, LDE / Merkle kernel time."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def keccak_shaped_components(shift=0, n_main=1000, n_logup=500):
+    return [(18 - shift, 8, n_main, 4 * n_logup, 1), (17 - shift, 8, n_main, 4 * n_logup, 1),
+            (12 - shift, 2, 6, 8, 1), (12 - shift, 2, 6, 8, 1), (11 - shift, 2, 5, 8, 1)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shift", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--n-main", type=int, default=1000)
+    ap.add_argument("--n-logup", type=int, default=500)
+    ap.add_argument("--check", action="store_true", help="compare the proof with the CPU oracle's, word for word (use with --shift >= 4)")
+    a = ap.parse_args()
+    import numpy as np
+    import nexus_zkvm_amd as nz
+    comps = keccak_shaped_components(a.shift, a.n_main, a.n_logup)
+    be = nz.HipBackend(0)
+    cfg = nz.default_config(pow_bits=10)
+    t0 = time.perf_counter(); be.prove_machine(comps, cfg, seed=5); be.sync(); first = time.perf_counter() - t0   # includes the hiprtc compile
+    be.sync(); t0 = time.perf_counter()
+    for s in range(a.steps):
+        words = be.prove_machine(comps, cfg, seed=100 + s)
+    be.sync(); el = (time.perf_counter() - t0) / a.steps
+    words, st = be.prove_machine(comps, cfg, seed=5, want_stats=True)
+    n_cells = sum((c[1] + c[2] + c[3]) << c[0] for c in comps)
+    out = {"workload": "keccak-shaped (BASELINE config #5): round components 2^%d / 2^%d rows x (8 + %d + %d columns), tables 2^%d, 2^%d, 2^%d; per-component degree bound 1"
+           % (comps[0][0], comps[1][0], a.n_main, 4 * a.n_logup, comps[2][0], comps[3][0], comps[4][0]),
+           "n_columns": sum(c[1] + c[2] + c[3] for c in comps), "trace_cells": n_cells, "ms_per_prove": round(1e3 * el, 3),
+           "first_prove_ms_with_jit": round(1e3 * first, 1), "cells_per_s": n_cells / el, "proof_words": int(len(words)),
+           "stages_ms": {k: round(st[k], 3) for k in ("trace_gen", "commit", "interaction", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")},
+           "lde_kernel_ms": round(st["lde_kernel_ms"], 3), "merkle_kernel_ms": round(st["merkle_kernel_ms"], 3)}
+    if a.check:
+        import oracle_lib as O, machine_ref
+        ref = machine_ref.prove_machine(comps, O.default_cfg(pow_bits=10), seed=5, threads=os.cpu_count() or 4)
+        out["proof_equals_oracle"] = bool(len(ref) == len(words) and np.array_equal(ref, words))
+    print(json.dumps(out))
+    be.close()
+    if a.check and not out["proof_equals_oracle"]:
+        raise SystemExit(1)
+
+
+if __name__ == "__main__":
+    main()
