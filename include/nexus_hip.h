@@ -265,7 +265,9 @@ int nx_prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps
                    nx_prove_stats* stats);
 void nx_free_host(void* p);
 
-/* The reference's proof bytes: `nexus_vm_prover::machine::Proof { stark_proof, claimed_sum, log_size }` (reference
+/* EXPERIMENTAL until a real postcard dump of the reference has been replayed (tools/dump_reference.rs -> tools/replay_reference_dump.py):
+ * the field order below is a recollection of Stwo @ 0790eba's derive(Serialize) declarations; a wrong order yields unparseable bytes.
+ * The reference's proof bytes: `nexus_vm_prover::machine::Proof { stark_proof, claimed_sum, log_size }` (reference
  * prover/src/machine.rs:93-98) in postcard, the serde format the SDK ships proofs in (reference sdk/Cargo.toml:22,
  * sdk/src/stwo/seq.rs:60-64), from an NXP1 word stream plus the per-component claimed sums (4 words each) and log sizes.  Field
  * order = Stwo's derive(Serialize) declarations [upstream-recollection — pinned only once tools/dump_reference.rs has run on a box
@@ -419,7 +421,8 @@ typedef struct {
     const nx_air_kernel* kernel;
     uint32_t log_constraint_degree_bound;   /* this component's bound (see nx_component_spec): 0 = the session config's log_constraint_degree */
 } nx_air_component;
-/* stwo::prover::prove.  NX_ERR_PROTOCOL = ProvingError::ConstraintsNotSatisfied.  *proof_words: free with nx_free_host. */
+/* stwo::prover::prove.  NX_ERR_PROTOCOL = ProvingError::ConstraintsNotSatisfied.  *proof_words: free with nx_free_host.  The session's
+ * trees and channel are as before the call when it returns (success or failure): proving again gives the same bytes. */
 int nx_prover_prove(nx_prover* prover, const nx_air_component* components, uint32_t n_components, uint32_t** proof_words,
                     size_t* n_words, nx_prove_stats* stats);
 

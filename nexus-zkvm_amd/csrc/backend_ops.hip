@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void batch_inverse_qm31_kernel(Sec4C s, Sec4 d
 }
 
 // FriOps::decompose: lambda = (sum over the first half - sum over the second half) / N of a bit-reversed circle evaluation,
-// g = f - lambda on the first half, f + lambda on the second.  Two launches: block partial sums (signed by the half), then the
-// subtraction with lambda recomputed per block from the (<= 1024) partials.
+// g = f - lambda on the first half, f + lambda on the second.  Three launches: block partial sums (signed by the half), then the
+// one block's reduction of the partials to lambda, then the subtraction.
 constexpr int DEC_THREADS = 256, DEC_ITEMS = 16;
 __global__ __launch_bounds__(DEC_THREADS) void decompose_sum_kernel(Sec4C s, u32 n, u32* __restrict__ partial /*[blocks][4]*/) {
     __shared__ u32 red[4][DEC_THREADS / 64];
@@ -56,15 +56,27 @@ __global__ __launch_bounds__(DEC_THREADS) void decompose_sum_kernel(Sec4C s, u32
         partial[4 * blockIdx.x + threadIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(256) void decompose_apply_kernel(Sec4C s, Sec4 g, u32 n, u32 n_inv, const u32* __restrict__ partial, u32 n_partial,
-                                                              u32* __restrict__ lambda_out) {
-    __shared__ u32 lam[4];
-    if (threadIdx.x < 4) {
-        u32 t = 0;
-        for (u32 b = 0; b < n_partial; b++) t = m_add(t, partial[4 * b + threadIdx.x]);
-        lam[threadIdx.x] = m_mul(t, n_inv);
-        if (blockIdx.x == 0) lambda_out[threadIdx.x] = lam[threadIdx.x];
+// lambda = (sum of the block partials) / N, reduced ONCE by one block (the partial count grows with the column: 2^30 rows = 2^18 blocks)
+__global__ __launch_bounds__(256) void decompose_lambda_kernel(const u32* __restrict__ partial, u32 n_partial, u32 n_inv, u32* __restrict__ lambda_out) {
+    __shared__ u32 red[4][256];
+    u32 acc[4] = {0, 0, 0, 0};
+    for (u32 b = threadIdx.x; b < n_partial; b += 256)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = m_add(acc[q], partial[4 * b + q]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) red[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+#pragma unroll
+            for (int q = 0; q < 4; q++) red[q][threadIdx.x] = m_add(red[q][threadIdx.x], red[q][threadIdx.x + off]);
+        __syncthreads();
     }
+    if (threadIdx.x < 4) lambda_out[threadIdx.x] = m_mul(red[threadIdx.x][0], n_inv);
+}
+__global__ __launch_bounds__(256) void decompose_apply_kernel(Sec4C s, Sec4 g, u32 n, const u32* __restrict__ lambda) {
+    __shared__ u32 lam[4];
+    if (threadIdx.x < 4) lam[threadIdx.x] = lambda[threadIdx.x];
     __syncthreads();
     const u32 half = n >> 1;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -147,7 +159,8 @@ int nx_fri_decompose(nx_ctx* ctx, const uint32_t* const* d_src4, uint32_t log_si
     NX_TRY(dev_alloc(ctx, ((size_t)n_blocks * 4 + 4) * 4, (void**)&d_part));
     u32* d_lambda = d_part + (size_t)n_blocks * 4;
     hipLaunchKernelGGL(decompose_sum_kernel, dim3(n_blocks), dim3(DEC_THREADS), 0, ctx->stream, s, n, d_part);
-    hipLaunchKernelGGL(decompose_apply_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, s, g, n, m_inv(n % P), (const u32*)d_part, n_blocks, d_lambda);
+    hipLaunchKernelGGL(decompose_lambda_kernel, dim3(1), dim3(256), 0, ctx->stream, (const u32*)d_part, n_blocks, m_inv(n % P), d_lambda);
+    hipLaunchKernelGGL(decompose_apply_kernel, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, s, g, n, (const u32*)d_lambda);
     hipError_t e = hipGetLastError();
     int rc = e == hipSuccess ? nx_download(ctx, lambda, d_lambda, 4) : hip_fail(ctx, e, "nx_fri_decompose", __FILE__, __LINE__);
     dev_free(ctx, d_part);

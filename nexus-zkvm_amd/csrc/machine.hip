@@ -289,14 +289,18 @@ static int cached_kernel(nx_ctx* ctx, const GComponent& g, const nx_air_kernel**
     std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
     key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs);
     KernelCache& kc = kernel_cache();
-    std::lock_guard<std::mutex> lk(kc.mu);
-    auto it = kc.map.find({ctx, key});
-    if (it == kc.map.end()) {
-        nx_air_kernel* k = nullptr;
-        H_TRY(nx_air_compile(ctx, g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), (uint32_t)g.econsts.size() / 4, g.n_constraints, &k, nullptr));
-        it = kc.map.insert({{ctx, key}, k}).first;
+    {
+        std::lock_guard<std::mutex> lk(kc.mu);
+        auto it = kc.map.find({ctx, key});
+        if (it != kc.map.end()) { *out = it->second; return NX_OK; }
     }
-    *out = it->second;
+    // compile OUTSIDE the lock: entries are per context and a context is driven by one thread, so nobody else can insert this key;
+    // holding the process-wide mutex across hiprtc would serialise the GPUs of a thread-rank group and let one stuck compile stall all
+    nx_air_kernel* k = nullptr;
+    H_TRY(nx_air_compile(ctx, g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), (uint32_t)g.econsts.size() / 4, g.n_constraints, &k, nullptr));
+    std::lock_guard<std::mutex> lk(kc.mu);
+    kc.map.insert({{ctx, key}, k});
+    *out = k;
     return NX_OK;
 }
 void machine_kernels_release(nx_ctx* ctx) {   // nx_ctx_destroy: the modules belong to the context's device
@@ -358,6 +362,25 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     if (comm) { H_TRY(dist_init(ctx, comm, &cs.dist)); cs.dist.comm_ms = &st->comm_ms; cs.dist.comm_bytes = &st->comm_bytes; }
     const Dist& D = cs.dist;
     for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
+    {
+        // Everything that can fail on ONE rank only before the exchanges start — the hiprtc compilation of the components' kernels
+        // (the text does not depend on the proof: lookup elements and claimed sums are run-time constants) — happens here, followed
+        // by a vote: a rank that failed must not leave its peers blocked in the first all-to-all.
+        int rc_local = NX_OK;
+        for (uint32_t i = 0; i < n_comps && rc_local == NX_OK; i++) {
+            GComponent g = machine_component(comps[i], locs[i]);
+            const nx_air_kernel* k = nullptr;
+            rc_local = cached_kernel(ctx, g, &k);
+        }
+        if (D.on()) {
+            std::vector<int32_t> all((size_t)D.world, 0);
+            const int32_t mine = rc_local;
+            H_TRY(D.allgather_host(ctx, &mine, sizeof mine, all.data()));
+            for (int r = 0; r < D.world; r++)
+                if (all[r] != NX_OK) return rc_local != NX_OK ? rc_local : set_err(ctx, NX_ERR_HIP, "nx_prove_machine: rank " + std::to_string(r) + " failed to prepare its kernels (code " + std::to_string(all[r]) + "); no rank proceeds");
+        }
+        H_TRY(rc_local);
+    }
     lap(&st->commit);
 
     { TreeBuilder tb = cs.tree_builder(); H_TRY(fill_and_extend(cs, tb, comps, n_comps, 0, seed, 0)); lap(&st->trace_gen); H_TRY(tb.commit(channel)); lap(&st->commit); }   // :208-228

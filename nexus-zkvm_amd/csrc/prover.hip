@@ -617,7 +617,9 @@ class FriProver {
         size_t bound = (size_t)1 << cfg.log_last_layer_degree_bound;
         for (size_t i = bound; i < n; i++) if (!q_is_zero(v[i])) return set_err(ctx, NX_ERR_PROTOCOL, "fri: invalid degree in the last layer");
         v.resize(bound);
-        channel.mix_felts(v);
+        // Stwo mixes `LinePoly::from_ordered_coefficients(coeffs)`, whose storage is the BIT-REVERSED coefficient vector
+        // [upstream-recollection; ADVICE r2]: the transcript sees that order (identical for bounds 0 and 1), the proof keeps the ordered one
+        { std::vector<QM31> m(bound); for (size_t i = 0; i < bound; i++) m[i] = v[bitrev((u32)i, (int)cfg.log_last_layer_degree_bound)]; channel.mix_felts(m); }
         last_layer_poly = v;
         return NX_OK;
     }
@@ -1355,7 +1357,13 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     double t_start = 0;
     if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = nxhip::now_ms(); }
     std::vector<uint32_t> w;
+    // prove_core appends the composition tree and advances the channel: both are put back afterwards, on success and on failure,
+    // so the session can prove the same committed statement again (other components / a retry after NX_ERR_PROTOCOL)
+    const size_t n_trees = p->cs->trees.size();
+    const nxhip::Blake2sChannel saved_channel = p->channel;
     int rc = nxhip::prove_core(ctx, *p->cs, p->channel, p->cfg, p->tw, air, &w, st, lap);
+    while (p->cs->trees.size() > n_trees) p->cs->trees.pop_back();
+    p->channel = saved_channel;
     if (timed) nxhip::finish_stats(ctx, st, t_start);
     ctx->timing = false;
     p->cs->dist.comm_ms = nullptr; p->cs->dist.comm_bytes = nullptr;

@@ -395,7 +395,8 @@ static inline FriProverState fri_commit(Channel& ch, const PcsConfig& cfg, std::
     size_t bound = (size_t)1 << cfg.log_last_layer_degree_bound;
     for (size_t i = bound; i < coeffs.size(); i++) if (!qm31_is_zero(coeffs[i])) throw std::string("fri: invalid degree");
     coeffs.resize(bound);
-    ch.mix_felts(coeffs.data(), coeffs.size());
+    // channel.mix_felts(&last_layer_poly): LinePoly stores its coefficients bit-reversed [upstream-recollection] — that is what is mixed
+    { std::vector<QM31> m(bound); for (size_t i = 0; i < bound; i++) m[i] = coeffs[bit_reverse_index((u32)i, (int)cfg.log_last_layer_degree_bound)]; ch.mix_felts(m.data(), m.size()); }
     st.last_layer_poly = coeffs;
     return st;
 }
@@ -802,7 +803,12 @@ static inline std::string verify_core(Channel& ch, const PcsConfig& cfg, const P
         if (proof.inner_layers.size() != expected_layers) return "InvalidNumFriLayers";
         for (auto& l : proof.inner_layers) { ch.mix_root(l.commitment); inner_alphas.push_back(ch.draw_secure_felt()); }
         if (proof.last_layer_poly.size() > ((size_t)1 << cfg.log_last_layer_degree_bound)) return "LastLayerDegreeInvalid";
-        ch.mix_felts(proof.last_layer_poly.data(), proof.last_layer_poly.size());
+        {   // the prover mixed the bit-reversed storage order of the (full-length) coefficient vector
+            const size_t bound = (size_t)1 << cfg.log_last_layer_degree_bound;
+            if (proof.last_layer_poly.size() != bound) return "LastLayerDegreeInvalid";
+            std::vector<QM31> m(bound); for (size_t i = 0; i < bound; i++) m[i] = proof.last_layer_poly[bit_reverse_index((u32)i, (int)cfg.log_last_layer_degree_bound)];
+            ch.mix_felts(m.data(), m.size());
+        }
     }
     if (!ch.verify_pow_nonce(cfg.pow_bits, proof.proof_of_work)) return "ProofOfWork";
     ch.mix_u64(proof.proof_of_work);

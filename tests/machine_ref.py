@@ -1,8 +1,9 @@
 """The reference-shaped synthetic machine of nx_prove_machine (nexus-zkvm_amd/csrc/machine.hip), restated on the CPU oracle.
 
-TEST INFRASTRUCTURE (checker / cpu_baseline only).  An independent statement of the same machine: the AIR is recorded with the
-Python ProgramBuilder (nexus_zkvm_amd.air_program — a different recorder, register allocation and instruction order than the C++
-emitter of machine.hip), the trace and the logup interaction trace come from the oracle (oracle/air.h, oracle/logup.h), the
+TEST INFRASTRUCTURE (checker / cpu_baseline only).  An independent statement of the same machine: the AIR is emitted by the
+checker's own tests/ref_emitter.py (one instruction per operation into fresh registers — nothing of the product is imported: not
+its recorder nexus_zkvm_amd.air_program, not the C++ emitter of machine.hip; only the ABI's opcode numbers are common ground),
+the trace and the logup interaction trace come from the oracle (oracle/air.h, oracle/logup.h), the
 transcript follows reference prover/src/machine.rs:197-290 through the oracle's prover session (oracle/air_generic.h).  The
 proof must equal nx_prove_machine's word for word.
 
@@ -27,7 +28,7 @@ def machine_component(ap, comp, loc, z, alpha, shift):
     log, n_pre, n_main, n_inter = comp[:4]
     L = n_inter // 4
     pre0, main0, inter0 = loc
-    pb = ap.ProgramBuilder()
+    pb = ap.Emitter()
     PRE, MAIN, INT = 0, n_pre, n_pre + n_main
     m0, m0n = pb.next_trace_mask(MAIN + 0, (0, 1))
     m1, m1n = pb.next_trace_mask(MAIN + 1, (0, 1))
@@ -88,7 +89,7 @@ def interaction_trace(comp, main_cols, z, alpha):
 
 def prove_machine(comps, cfg, seed=1, ad=b"", threads=None):
     """nexus_vm_prover::prove for the machine, on the CPU oracle: returns the NXP1 proof words."""
-    import nexus_zkvm_amd.air_program as ap
+    import ref_emitter as ap            # the checker's own emitter: the product's recorder is not imported
     threads = threads or max(4, os.cpu_count() or 4)
     O.lib().orc_logup_set_threads(threads)
     comps = [tuple(int(x) for x in c) for c in comps]

@@ -926,7 +926,8 @@ def test_session_refuses_invalid_traces_and_misuse(be, nz, oracle):
         s.tree_begin([5])
     with pytest.raises(nz.NexusHipError, match="log_constraint_degree_bound exceeds"):   # the twiddle tree is sized by the config's bound (1 here)
         s.prove([ap.Component(c0.log_size, c0.program, c0.cols, c0.masks, log_constraint_degree_bound=2)])
-    assert len(s.prove(comps)) > 0                       # the session is still usable after the refused calls
+    first = s.prove(comps)                               # the session is still usable after the refused calls ...
+    assert len(first) > 0 and np.array_equal(s.prove(comps), first)   # ... and after a proof: the composition tree and the channel are put back
     s = be.prover_session(cfg, 5)
     s.commit([np.zeros(32, np.uint32)])
     with pytest.raises(nz.NexusHipError, match="three trace trees"):

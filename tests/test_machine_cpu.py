@@ -13,7 +13,7 @@ P = O.P
 
 def _verify(comps, cfg, words, ad=b""):
     """core::verifier::verify with the transcript prefix of reference machine.rs:299-485 for the machine."""
-    import nexus_zkvm_amd.air_program as ap
+    import ref_emitter as ap
     hdr = 6
     roots = [words[hdr + 8 * t: hdr + 8 * (t + 1)] for t in range(3)]
     v = O.VerifierSession(cfg)
@@ -38,7 +38,7 @@ def _verify(comps, cfg, words, ad=b""):
     ([(6, 2, 9, 8, 2), (6, 2, 4, 4, 1), (3, 2, 3, 0)], dict(pow_bits=3, log_constraint_degree=2)),     # the v1 shape: main +2, extensions +1, one defaulted
 ])
 def test_oracle_machine_proves_and_verifies(oracle, comps, kw):
-    import nexus_zkvm_amd.air_program as ap
+    import ref_emitter as ap
     cfg = O.default_cfg(**kw)
     ad = b"\x05"
     words = M.prove_machine(comps, cfg, seed=11, ad=ad, threads=4)
@@ -69,7 +69,7 @@ def test_oracle_machine_proves_and_verifies(oracle, comps, kw):
 
 def test_logup_constraints_catch_a_wrong_interaction_trace(oracle):
     """A fraction with the wrong sign breaks the recorded logup constraints: the oracle prover's OODS check refuses."""
-    import nexus_zkvm_amd.air_program as ap
+    import ref_emitter as ap
     comps = [(5, 2, 6, 8)]
     cfg = O.default_cfg(pow_bits=2)
     real = M.logup_cols

@@ -6,7 +6,12 @@ rules does (Merkle node rule NX_HASH_BLAKE2S / NX_HASH_BLAKE2S_RAW0, FRI alpha m
 uses; nothing but the JSON crosses.
 
     python tools/replay_reference_dump.py reference_dump.json [--gpu]
+    python tools/replay_reference_dump.py --self-test          (no dump needed: see below)
 Exit code 0 when every known answer matches under ONE consistent choice of switches (printed), 1 otherwise.
+
+--self-test feeds the tool a dump SYNTHESISED FROM THE ORACLE (the "kat" section, once per Merkle node rule) and requires that every
+check passes and that the tool names the rule the dump was made with — so the day a real dump arrives, a FAIL line means the
+oracle disagrees with Stwo, not that this script is broken (tests/test_replay_tool_cpu.py runs it).
 """
 import argparse
 import json
@@ -36,20 +41,70 @@ def col(seed, c, log):
     return v.astype(np.uint32)
 
 
+def synth_dump(hash_mode):
+    """The "kat" section of tools/dump_reference.rs, produced by the oracle instead of Stwo (self-test input)."""
+    import ctypes as C
+    import oracle_lib as O
+    L = O.lib()
+    tw, itw = O.Twiddles(5).arrays()
+    otw = O.Twiddles(7)
+    co = otw.interpolate(col(0xC0FFEE, 0, 6))
+    chp = C.c_void_p(L.orc_channel_new()); L.orc_channel_mix_u64(chp, 99)
+    pt = np.zeros(8, np.uint32); L.orc_get_random_point(chp, O.ptr(pt)); L.orc_channel_free(chp)
+    cols = [col(1, c, 6) for c in range(18)] + [col(1, 99, 4)]
+    root = O.merkle_commit(cols, hash_mode).tobytes()
+    ch = C.c_void_p(L.orc_channel_new())
+    dig = np.zeros(8, np.uint32)
+    steps = []
+    L.orc_channel_mix_u64(ch, 0x0123456789ABCDEF); L.orc_channel_digest(ch, O.ptr(dig)); steps.append({"digest": dig.tobytes().hex()})
+    f = np.zeros(4, np.uint32); L.orc_channel_draw_secure_felt(ch, O.ptr(f)); steps.append({"draw_felt": [int(x) for x in f]})
+    fs = np.zeros((3, 4), np.uint32); L.orc_channel_draw_secure_felts(ch, C.c_size_t(3), O.ptr(fs)); steps.append({"draw_felts(3)": fs.tolist()})
+    L.orc_channel_mix_felts(ch, O.ptr(np.concatenate([f, fs[0]])), C.c_size_t(2)); L.orc_channel_digest(ch, O.ptr(dig)); steps.append({"digest": dig.tobytes().hex()})
+    L.orc_channel_mix_root(ch, O.ptr(np.frombuffer(root, np.uint32).copy())); L.orc_channel_digest(ch, O.ptr(dig)); steps.append({"digest": dig.tobytes().hex()})
+    w8 = np.zeros(8, np.uint32); L.orc_channel_draw_u32s(ch, O.ptr(w8)); steps.append({"draw_random_bytes": w8.tobytes().hex()})
+    L.orc_channel_free(ch)
+    return {"kat": {"twiddles_log5": {"twiddles": [int(x) for x in tw], "itwiddles": [int(x) for x in itw]},
+                    "lde_log6": {"coeffs": [int(x) for x in co], "lde": [int(x) for x in otw.evaluate(co, 7)]},
+                    "eval_at_point": {"point": [[int(x) for x in pt[:4]], [int(x) for x in pt[4:]]], "value": [int(x) for x in O.eval_at_point(co, pt)]},
+                    "merkle": {"root": root.hex()}, "channel": steps},
+            "prove": []}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("dump")
+    ap.add_argument("dump", nargs="?")
     ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--self-test", action="store_true")
     args = ap.parse_args()
-    d = json.load(open(args.dump))
-    k = d["kat"]
     import oracle_lib as O
     O.build_oracle()
-    L = O.lib()
     be = None
     if args.gpu:
         import nexus_zkvm_amd as nz
         be = nz.HipBackend(0)
+    if args.self_test:
+        rc = 0
+        for mode in (0, 1):
+            print("== self-test: dump synthesised from the oracle with hash_mode %d" % mode)
+            found = []
+            rc |= replay(synth_dump(mode), be, found)
+            if found != [[mode]]:
+                print("FAIL the tool reported hash modes %s for a dump made with %d" % (found, mode)); rc = 1
+        d = synth_dump(0); d["kat"]["lde_log6"]["coeffs"][3] ^= 1
+        print("== self-test: a corrupted known answer must be reported")
+        if replay(d, be, []) == 0:
+            print("FAIL a corrupted dump was accepted"); rc = 1
+        print("SELF-TEST OK" if rc == 0 else "SELF-TEST FAILED")
+        return rc
+    if not args.dump:
+        ap.error("a dump file (or --self-test) is required")
+    return replay(json.load(open(args.dump)), be, [])
+
+
+def replay(d, be, found_modes):
+    k = d["kat"]
+    import oracle_lib as O
+    L = O.lib()
     ok, notes = True, []
 
     def check(name, good, extra=""):
@@ -78,6 +133,7 @@ def main():
     cols = [col(1, c, 6) for c in range(18)] + [col(1, 99, 4)]
     want = bytes.fromhex(k["merkle"]["root"])
     modes = [m for m in (0, 1) if O.merkle_commit(cols, m).tobytes() == want]
+    found_modes.append(modes)
     check("merkle root (oracle)", bool(modes), "hash_mode=%s" % (modes or "NONE of {0: standard Blake2s, 1: raw zero-state compression}"))
     if modes and be:
         be.set_hash_mode(modes[0])
