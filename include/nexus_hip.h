@@ -421,8 +421,9 @@ typedef struct {
     const nx_air_kernel* kernel;
     uint32_t log_constraint_degree_bound;   /* this component's bound (see nx_component_spec): 0 = the session config's log_constraint_degree */
 } nx_air_component;
-/* stwo::prover::prove.  NX_ERR_PROTOCOL = ProvingError::ConstraintsNotSatisfied.  *proof_words: free with nx_free_host.  The session's
- * trees and channel are as before the call when it returns (success or failure): proving again gives the same bytes. */
+/* stwo::prover::prove.  NX_ERR_PROTOCOL = ProvingError::ConstraintsNotSatisfied.  *proof_words: free with nx_free_host.  After a proof
+ * nx_prover_channel_digest is the transcript's final state; another nx_prover_prove starts again from the state the first one found
+ * (and a failed call restores it at once), so proving the committed statement again — or retrying — gives the same bytes. */
 int nx_prover_prove(nx_prover* prover, const nx_air_component* components, uint32_t n_components, uint32_t** proof_words,
                     size_t* n_words, nx_prove_stats* stats);
 

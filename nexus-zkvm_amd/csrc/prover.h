@@ -258,4 +258,5 @@ struct nx_prover {
     nx_comm comm_copy; bool has_comm = false;
     struct Run { nxhip::DevBuf slab; uint32_t n_cols, log, lo, hi; };
     std::vector<Run> pending; bool open = false;
+    bool proved = false; size_t pre_trees = 0; nxhip::Blake2sChannel pre_channel;   // the state nx_prover_prove found (restored by the next call)
 };

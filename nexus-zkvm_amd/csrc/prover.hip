@@ -1346,6 +1346,7 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
         }
         air.comps.push_back(std::move(g));
     }
+    if (p->proved) { while (p->cs->trees.size() > p->pre_trees) p->cs->trees.pop_back(); p->channel = p->pre_channel; }   // a second prove of the session
     NX_TRY(air.check(*p->cs));
     const bool timed = stats != nullptr;
     nx_prove_stats local;
@@ -1357,13 +1358,12 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     double t_start = 0;
     if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = nxhip::now_ms(); }
     std::vector<uint32_t> w;
-    // prove_core appends the composition tree and advances the channel: both are put back afterwards, on success and on failure,
-    // so the session can prove the same committed statement again (other components / a retry after NX_ERR_PROTOCOL)
-    const size_t n_trees = p->cs->trees.size();
-    const nxhip::Blake2sChannel saved_channel = p->channel;
+    // prove_core appends the composition tree and advances the channel (nx_prover_channel_digest afterwards is the transcript's final
+    // state, as after stwo::prover::prove).  A later call starts again from the state the FIRST call found, and a failed call puts
+    // that state back at once: the session can prove the same committed statement again (a retry after NX_ERR_PROTOCOL, other components)
+    if (!p->proved) { p->pre_trees = p->cs->trees.size(); p->pre_channel = p->channel; p->proved = true; }
     int rc = nxhip::prove_core(ctx, *p->cs, p->channel, p->cfg, p->tw, air, &w, st, lap);
-    while (p->cs->trees.size() > n_trees) p->cs->trees.pop_back();
-    p->channel = saved_channel;
+    if (rc != NX_OK) { while (p->cs->trees.size() > p->pre_trees) p->cs->trees.pop_back(); p->channel = p->pre_channel; p->proved = false; }
     if (timed) nxhip::finish_stats(ctx, st, t_start);
     ctx->timing = false;
     p->cs->dist.comm_ms = nullptr; p->cs->dist.comm_bytes = nullptr;
