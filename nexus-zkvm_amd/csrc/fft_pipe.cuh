@@ -219,6 +219,16 @@ template <int K> struct MidPlan {
     static_assert(K >= 4 && K <= 9 && NFULL <= 1, "middle launch: 4 <= K <= 9");
 };
 
+// the same twiddle registers straight from the doubled global table (tile kernels: the middle pass's tables are a few KB shared by
+// every tile — L1 / L2 hits): layers BP+Q+K of the 2^n_dir-point transform, replica r's half
+template <int BP, int R, int Q = 0>
+NX_HD void mid_tw_fetch_global(const u32* tbl2, u32 tw_log, int n_dir, int K, u32 r, u32 tid, u32* tw) {
+    if constexpr (Q < R) {
+        ld_words<(8 >> Q), MEM_GLOBAL>(tbl2 + lvl_off(tw_log, n_dir, BP + Q + K) + (r << (12 - BP - Q)) + mid_tw_index<BP>(tid, Q), tw + (16 - (16 >> Q)));
+        mid_tw_fetch_global<BP, R, Q + 1>(tbl2, tw_log, n_dir, K, r, tid, tw);
+    }
+}
+
 // ---- fused edges -----------------------------------------------------------------------------------------------------------------------
 struct MidConsts {          // doubled twiddles of the two top tile bits (11, 12), tile independent
     u32 i11[2], i12;        // inverse: bit 11 entries 0/1, bit 12

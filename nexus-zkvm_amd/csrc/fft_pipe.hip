@@ -318,6 +318,134 @@ __global__ __launch_bounds__(NT, 4) void pipe_mid_kernel(PipeMid m) {
     }
 }
 
+// ======================================================================================================================================
+// Tile kernels: the SAME lane-level rounds (conflict-free swizzled tile, b128 low round, radix-4 hand-over, wave-local syncs) under
+// fft13.hip's schedule — one work item per block, loads staged through registers, twiddles from the global tables — so that 3-4
+// blocks per CU (one 32-KB tile each, <= 64-80 VGPRs) overlap each other's phases instead of one block pipelining its own.
+// ======================================================================================================================================
+#ifndef NX_TILE_WAVES     // waves per SIMD the FIRST tile kernels are compiled for: 8 = 4 blocks per CU (<= 64 VGPRs), 6 = 3 blocks (<= 80)
+#define NX_TILE_WAVES 6
+#endif
+
+// this wave's 1024 rows of the tile, coalesced (64 lanes x 16 B = 1 KiB per load), into their swizzled slots
+__device__ __forceinline__ void tile_stage_load(const u32* base, u32 tid, uint4* x) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = ldg4(base + 4 * wave_group(tid, i));
+}
+__device__ __forceinline__ void tile_stage_write(u32* X, u32 tid, const uint4* x) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(X + 4 * swz(wave_group(tid, i))) = x[i];
+}
+
+__global__ __launch_bounds__(NT, NX_TILE_WAVES) void tile_ifirst_kernel(PipeFirst a) {
+    extern __shared__ __attribute__((aligned(16))) u32 plds[];
+    u32* X = plds;
+    const u32 tid = threadIdx.x;
+    const u32 utid = __builtin_amdgcn_readfirstlane(tid & ~255u);
+    const Item it = decode_item(blockIdx.x, a.tiles, a.n_cols);
+    u32* base = col_ptr(a.cols, it.col) + ((size_t)it.tile << T_S);
+    uint4 x[4];
+    tile_stage_load(base, tid, x);
+    u32 twA[16], twB[16], twC[16];
+    first_tw_fetch<0, 4, true>(a.tw2, a.tw_log, a.n, it.tile, tid, twA);
+    first_tw_fetch<4, 4, false>(a.tw2, a.tw_log, a.n, it.tile, tid, twB);
+    const u32 te2 = lds1(a.tw2 + lvl_off(a.tw_log, a.n, 12) + it.tile);
+    tile_stage_write(X, tid, x);
+    wave_sync();                 // a wave stages, and then transforms, its own 1024 rows: bits [0, 8) need no block barrier
+    round16_low<true, true>(X, tid, twA);
+    wave_sync();
+    round16<4, 4, true>(X, tid, twB);
+    first_tw_fetch<8, 4, false, MEM_SCALAR>(a.tw2, a.tw_log, a.n, it.tile, utid, twC);
+    blk_barrier();
+    round16<8, 4, true>(X, tid, twC);
+    blk_barrier();
+    ifirst_store(X, tid, base, te2);
+}
+
+__global__ __launch_bounds__(NT, NX_TILE_WAVES) void tile_ffirst_kernel(PipeFirst a) {
+    extern __shared__ __attribute__((aligned(16))) u32 plds[];
+    u32* X = plds;
+    const u32 tid = threadIdx.x;
+    const Item it = decode_item(blockIdx.x, a.tiles, a.n_cols);
+    u32* base = col_ptr(a.cols, it.col) + ((size_t)it.tile << T_S);
+    uint4 x[4];
+    tile_stage_load(base, tid, x);
+    u32 twC[16], twB[16], twA[16];
+    first_tw_fetch<9, 4, false, MEM_SCALAR>(a.tw2, a.tw_log, a.n, it.tile, 0, twC);
+    first_tw_fetch<5, 4, false>(a.tw2, a.tw_log, a.n, it.tile, tid, twB);
+    tile_stage_write(X, tid, x);
+    blk_barrier();
+    round16<9, 4, false>(X, tid, twC);
+    first_tw_fetch<2, 3, false>(a.tw2, a.tw_log, a.n, it.tile, tid, twA);
+    blk_barrier();
+    round16<5, 4, false>(X, tid, twB);
+    wave_sync();                 // bits [0, 9): the wave's own rows
+    // the layer-1 pairs of the fused store come from the global table (the slab of the pipelined kernel is its LDS copy)
+    u32 tws[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) ld_words<2, MEM_GLOBAL>(a.tw2 + lvl_off(a.tw_log, a.n, 1) + ((it.tile * T_GROUPS + wave_group(tid, i)) & ~1u), tws + 2 * i);
+    round16<2, 3, false>(X, tid, twA);
+    wave_sync();
+    uint4 y[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) y[i] = *reinterpret_cast<const uint4*>(X + 4 * swz(wave_group(tid, i)));
+    ffirst_store_finish(y, tws, tid, base, it.tile);
+}
+
+template <int K, bool INV>
+__device__ __forceinline__ void tile_mid_rounds(u32* Z, const u32* tbl2, u32 tw_log, int n_dir, u32 r, u32 tid) {
+    using P = MidPlan<K>;
+    constexpr bool REM_LOCAL = P::B + 4 <= 10;
+    u32 twr[16], twf[16];
+    if constexpr (P::REM > 0) mid_tw_fetch_global<P::B, P::REM>(tbl2, tw_log, n_dir, K, r, tid, twr);
+    if constexpr (P::NFULL > 0) mid_tw_fetch_global<P::BPF, 4>(tbl2, tw_log, n_dir, K, r, tid, twf);
+    if constexpr (INV) {
+        if constexpr (P::REM > 0) { round16<P::B, P::REM, true>(Z, tid, twr); blk_barrier(); }
+        if constexpr (P::NFULL > 0) { round16<P::BPF, 4, true>(Z, tid, twf); blk_barrier(); }
+    } else {
+        if constexpr (P::NFULL > 0) { round16<P::BPF, 4, false>(Z, tid, twf); blk_barrier(); }
+        if constexpr (P::REM > 0) { round16<P::B, P::REM, false>(Z, tid, twr); if (REM_LOCAL) wave_sync(); else blk_barrier(); }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(NT, 4) void tile_mid_kernel(PipeMid m) {
+    using P = MidPlan<K>;
+    constexpr int B = P::B;
+    extern __shared__ __attribute__((aligned(16))) u32 plds[];
+    u32* X = plds;
+    u32* Y = plds + T_ROWS;
+    const u32 tid = threadIdx.x;
+    const Item it = decode_item(blockIdx.x, 1u << K, m.n_cols);
+    u32* ct = col_ptr(m.cols, it.col) + ((size_t)it.tile << B);
+    u32* oc = col_ptr(m.out, it.col) + ((size_t)it.tile << B);
+    uint4 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = ldg4(ct + mid_goff(4 * ((u32)i * NT + tid), B));
+    MidConsts k;
+    k.i11[0] = lds1(m.itw2 + lvl_off(m.tw_log, m.n, 11 + K)); k.i11[1] = lds1(m.itw2 + lvl_off(m.tw_log, m.n, 11 + K) + 1);
+    k.i12 = lds1(m.itw2 + lvl_off(m.tw_log, m.n, 12 + K));
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        k.f12[r] = lds1(m.tw2 + lvl_off(m.tw_log, m.n + 1, 12 + K) + r);
+        k.f11[2 * r] = lds1(m.tw2 + lvl_off(m.tw_log, m.n + 1, 11 + K) + 2 * r);
+        k.f11[2 * r + 1] = lds1(m.tw2 + lvl_off(m.tw_log, m.n + 1, 11 + K) + 2 * r + 1);
+    }
+    k.scale = m.scale;
+#pragma unroll
+    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(X + 4 * swz((u32)i * NT + tid)) = x[i];
+    blk_barrier();
+    tile_mid_rounds<K, true>(X, m.itw2, m.tw_log, m.n, 0, tid);
+    mid_handover(X, Y, tid, k, ct, B);
+    blk_barrier();
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        u32* Z = r ? Y : X;
+        tile_mid_rounds<K, false>(Z, m.tw2, m.tw_log, m.n + 1, (u32)r, tid);
+        mid_store(Z, tid, oc + ((size_t)r << m.n), B);
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
 bool fft_pipe_supports(int n) { return n >= 17 && n <= 22; }
 
@@ -358,6 +486,38 @@ static int launch_pipe_mid_t(nx_ctx* ctx, const PipeMid& m) {
     hipLaunchKernelGGL(pipe_mid_kernel<K>, dim3(pipe_grid(ctx, m.n_items)), dim3(NT), lds_bytes, ctx->cur, m);
     NX_LAUNCH_CHECK(ctx);
     return NX_OK;
+}
+
+template <class KernelT, class ArgT>
+static int launch_tile(nx_ctx* ctx, KernelT kernel, std::atomic<uint64_t>& set, const ArgT& a, u32 n_items, size_t lds_bytes) {
+    NX_TRY(pipe_set_lds(ctx, kernel, set));
+    hipLaunchKernelGGL(kernel, dim3(n_items), dim3(NT), lds_bytes, ctx->cur, a);
+    NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+template <int K>
+static int launch_tile_mid_t(nx_ctx* ctx, const PipeMid& m) {
+    static std::atomic<uint64_t> set{0};
+    return launch_tile(ctx, tile_mid_kernel<K>, set, m, m.n_items, 2 * (size_t)T_ROWS * 4);
+}
+// The LDE under the tile schedule (one item per block): iFFT FIRST, fused middle, FFT FIRST — three launches, 17 <= n <= 22.
+int fft_tile_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_cols, int n, ColSet out) {
+    if (!fft_pipe_supports(n)) return set_err(ctx, NX_ERR_ARG, "fft_tile_lde: 17 <= log_size <= 22");
+    static std::atomic<uint64_t> set_i{0}, set_f{0};
+    PipeFirst a; a.cols = cols; a.tw2 = tw->d_itw2; a.tw_log = tw->log_half; a.n = n; a.n_cols = n_cols; a.tiles = 1u << (n - T_S); a.n_items = a.tiles * n_cols;
+    NX_TRY(launch_tile(ctx, tile_ifirst_kernel, set_i, a, a.n_items, (size_t)T_ROWS * 4));
+    PipeMid m; m.cols = cols; m.out = out; m.itw2 = tw->d_itw2; m.tw2 = tw->d_tw2; m.tw_log = tw->log_half; m.n = n; m.n_cols = n_cols;
+    m.n_items = n_cols << (n - T_S); m.scale = m_inv(1u << n);
+    switch (n - T_S) {
+    case 4: NX_TRY(launch_tile_mid_t<4>(ctx, m)); break;
+    case 5: NX_TRY(launch_tile_mid_t<5>(ctx, m)); break;
+    case 6: NX_TRY(launch_tile_mid_t<6>(ctx, m)); break;
+    case 7: NX_TRY(launch_tile_mid_t<7>(ctx, m)); break;
+    case 8: NX_TRY(launch_tile_mid_t<8>(ctx, m)); break;
+    default: NX_TRY(launch_tile_mid_t<9>(ctx, m)); break;
+    }
+    PipeFirst f; f.cols = out; f.tw2 = tw->d_tw2; f.tw_log = tw->log_half; f.n = n + 1; f.n_cols = n_cols; f.tiles = 1u << (n + 1 - T_S); f.n_items = f.tiles * n_cols;
+    return launch_tile(ctx, tile_ffirst_kernel, set_f, f, f.n_items, (size_t)T_ROWS * 4);
 }
 
 // inverse FIRST pass of a 2^n-point iFFT (n >= 17), in place (never the last pass: no 1/N)

@@ -68,17 +68,31 @@ void p3_tile(const Tables& T, int n /* log size of the forward transform */, u32
     }
 }
 
+// dir: 0 inverse (2^n table), 1 / 2 forward replica 0 / 1 (2^(n+1) table).  Twiddles are fetched BOTH ways — from the block's LDS copy
+// (pipelined kernels) and straight from the global table (tile kernels) — and must agree.
+struct GlobalTw { const u32* tbl2; u32 tw_log; int n_dir, K; u32 r; };
+static int g_tw_mismatch = 0;
 template <int K, bool INV>
-void mid_rounds(u32* Z, const u32* dir_tw) {
+void mid_rounds(u32* Z, const u32* dir_tw, const GlobalTw& G) {
     using P = pp::MidPlan<K>;
-    u32 tw[16];
+    u32 tw[16], tg[16];
     auto rem = [&]() {
         if constexpr (P::REM > 0)
-            for (u32 tid = 0; tid < pp::NT; tid++) { pp::mid_tw_fetch<P::B, P::REM>(dir_tw, P::B, tid, tw); pp::round16<P::B, P::REM, INV>(Z, tid, tw); }
+            for (u32 tid = 0; tid < pp::NT; tid++) {
+                pp::mid_tw_fetch<P::B, P::REM>(dir_tw, P::B, tid, tw);
+                pp::mid_tw_fetch_global<P::B, P::REM>(G.tbl2, G.tw_log, G.n_dir, G.K, G.r, tid, tg);
+                for (int q = 0; q < P::REM; q++) for (int h = 0; h < (8 >> q); h++) g_tw_mismatch |= tw[16 - (16 >> q) + h] != tg[16 - (16 >> q) + h];
+                pp::round16<P::B, P::REM, INV>(Z, tid, tw);
+            }
     };
     auto full = [&]() {
         if constexpr (P::NFULL > 0)
-            for (u32 tid = 0; tid < pp::NT; tid++) { pp::mid_tw_fetch<P::BPF, 4>(dir_tw, P::B, tid, tw); pp::round16<P::BPF, 4, INV>(Z, tid, tw); }
+            for (u32 tid = 0; tid < pp::NT; tid++) {
+                pp::mid_tw_fetch<P::BPF, 4>(dir_tw, P::B, tid, tw);
+                pp::mid_tw_fetch_global<P::BPF, 4>(G.tbl2, G.tw_log, G.n_dir, G.K, G.r, tid, tg);
+                for (int q = 0; q < 4; q++) for (int h = 0; h < (8 >> q); h++) g_tw_mismatch |= tw[16 - (16 >> q) + h] != tg[16 - (16 >> q) + h];
+                pp::round16<P::BPF, 4, INV>(Z, tid, tw);
+            }
     };
     if (INV) { rem(); full(); } else { full(); rem(); }
 }
@@ -107,11 +121,11 @@ void p2_all(const Tables& T, int n, u32* col, u32* out) {
     for (u32 tile = 0; tile < (1u << K); tile++) {
         u32* ct = col + ((size_t)tile << B);
         dma_tile(X, ct, [](u32 t) { return pp::mid_goff(t, B); });
-        mid_rounds<K, true>(X, ltw.data());
+        mid_rounds<K, true>(X, ltw.data(), GlobalTw{T.itw2.data(), T.tw_log, n, K, 0});
         for (u32 tid = 0; tid < pp::NT; tid++) pp::mid_handover(X, Y, tid, k, ct, B);
         for (int r = 0; r < 2; r++) {
             u32* Z = r ? Y : X;
-            mid_rounds<K, false>(Z, ltw.data() + (1 + r) * (size_t)W);
+            mid_rounds<K, false>(Z, ltw.data() + (1 + r) * (size_t)W, GlobalTw{T.tw2.data(), T.tw_log, n + 1, K, (u32)r});
             for (u32 tid = 0; tid < pp::NT; tid++) pp::mid_store(Z, tid, out + ((size_t)r << n) + ((size_t)tile << B), B);
         }
     }
@@ -146,6 +160,7 @@ extern "C" int fftpipe_emul_lde(int n, int ncols, uint64_t seed) {
         case 9: p2_all<9>(T, n, col.data(), out.data()); break;
         }
         for (u32 t = 0; t < (1u << (n + 1 - 13)); t++) p3_tile(T, n + 1, t, out.data());
+        if (g_tw_mismatch) return 3;
         if (memcmp(col.data(), ref.data(), N * 4)) return 1;
         if (memcmp(out.data(), lde.data(), 2 * N * 4)) return 2;
     }

@@ -102,11 +102,12 @@ def test_pipelined_lde_item_loop_matches_oracle(nz, oracle, log, grid, n_cols):
     coeffs = np.stack([otw.interpolate(v) for v in vals])
     ref = np.stack([otw.evaluate(c, log + 1) for c in coeffs])
     outs = []
-    for pipe in (1, 0):
+    for pipe in ("pipe", "tile", "fft13"):
         b = nz.HipBackend(0)
         try:
-            b.set_option("fft.pipe", pipe)
-            if pipe:
+            b.set_option("fft.pipe", int(pipe == "pipe"))
+            b.set_option("fft.tile", int(pipe == "tile"))      # the same rounds, one item per block (tile kernels)
+            if pipe == "pipe":
                 b.set_option("fft.pipe_grid", grid)
                 b.set_option("fft.batch_cols", 256)      # the whole column set in one launch: items = tiles * n_cols >> grid
                 assert b.get_option("fft.pipe_grid") == grid
@@ -120,7 +121,7 @@ def test_pipelined_lde_item_loop_matches_oracle(nz, oracle, log, grid, n_cols):
             lde.free(); cols.free()
         finally:
             b.close()
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 def test_context_options_are_per_context_and_validated(nz):

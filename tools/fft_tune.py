@@ -15,8 +15,28 @@ be = nz.HipBackend(0)
 tw = be.precompute_twiddles(log)
 cols = be.synth_fill_tree([(log, 2, ncols, 0)], 1, seed=3)[0]
 out = be.columns(ncols, log + 1)
+import ctypes as _C
+if os.environ.get("FFT_TUNE_ZEROS") == "1":      # DVFS probe: all-zero data toggles far fewer bits (MI355X_MICROARCH.md: the chip clocks to its power budget)
+    be._chk(be.L.nx_memset_zero(be.ctx, cols.ptr, _C.c_size_t(ncols << log)))
 be.sync()
-defaults = {k: be.get_option(k) for k in ("fft.pipe", "fft.pipe_blocks_per_cu", "fft.pipe_grid", "fft.batch_cols", "fft.streams")}
+defaults = {k: be.get_option(k) for k in ("fft.pipe", "fft.tile", "fft.pipe_blocks_per_cu", "fft.pipe_grid", "fft.batch_cols", "fft.streams")}
+rounds = int(os.environ.get("FFT_TUNE_ROUNDS", "1"))     # > 1: the option sets are cycled A/B/C/A/B/C ... and min / median are reported per set
+samples = {st: [] for st in sets}
+for st in (sets * rounds if rounds > 1 else []):
+    for k, v in defaults.items():
+        be.set_option(k, v)
+    for k, v in dict(kv.split("=") for kv in st.split(",") if kv).items():
+        be.set_option(k, int(v))
+    for r in range(reps):
+        be.sync(); t0 = time.perf_counter()
+        be._chk(be.L.nx_lde_batch(be.ctx, tw.h, cols.col_ptrs(), ncols, log, 1, out.col_ptrs()))
+        be.sync(); samples[st].append(time.perf_counter() - t0)
+if rounds > 1:
+    for st in sets:
+        v = sorted(samples[st][1:])
+        print(json.dumps({"opts": st, "log": log, "ncols": ncols, "rounds": rounds, "min_ms": round(v[0] * 1e3, 3), "median_ms": round(v[len(v) // 2] * 1e3, 3),
+                          "median_frac_of_8TBs": round(ncols * 16 * (1 << log) / v[len(v) // 2] / 8e12, 4)}), flush=True)
+    sets = []
 for st in sets:
     for k, v in defaults.items():
         be.set_option(k, v)
@@ -30,7 +50,9 @@ for st in sets:
         be.sync(); dt = time.perf_counter() - t0
         if r: best = min(best, dt)
     alg = ncols * 16 * (1 << log)
-    print(json.dumps({"opts": st, "log": log, "ncols": ncols, "lde_ms": round(best * 1e3, 3), "lde_alg_GBs": round(alg / best / 1e9, 1),
+    if os.environ.get("FFT_TUNE_ZEROS") == "1":
+        be._chk(be.L.nx_memset_zero(be.ctx, cols.ptr, _C.c_size_t(ncols << log)))   # the LDE overwrote the columns with coefficients (zero stays zero)
+    print(json.dumps({"opts": st, "zeros": os.environ.get("FFT_TUNE_ZEROS") == "1", "log": log, "ncols": ncols, "lde_ms": round(best * 1e3, 3), "lde_alg_GBs": round(alg / best / 1e9, 1),
                       "frac_of_8TBs": round(alg / best / 8e12, 4)}), flush=True)
 if os.environ.get("FFT_TUNE_MERKLE", "1") != "0":
     bm = 1e9
