@@ -60,7 +60,8 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
  * context does is decided by its own options, so two contexts of one process may differ.  Names: "fft.pipe" (0/1: pipelined LDE
  * kernels of fft_pipe.hip, default 0), "fft.pipe_blocks_per_cu" (1..2), "fft.pipe_grid" (0 = automatic, else persistent blocks per launch), "fft.batch_cols",
  * "fft.streams" (1..4), "fri.dist_min_log" and "dist.chunks" (row-sharded prove: every GPU of a proof must use the same values),
- * "air.segment" (instruction budget of one generated AIR kernel).  Unknown names and out-of-range values are NX_ERR_ARG.
+ * "air.segment" (instruction budget of one generated AIR kernel), "air.degree_split" (1: degree-aware composition, see
+ * nx_air_constraint_degrees).  Unknown names and out-of-range values are NX_ERR_ARG.
  * None of them changes a result: proofs, roots and transforms are bit-identical under every setting. */
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value);
 int nx_ctx_get_option(const nx_ctx* ctx, const char* name, int64_t* value);
@@ -379,6 +380,22 @@ int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* kernel, const uint32_t* const*
                 const uint32_t* alpha_powers, const uint32_t* denom_inv, uint32_t log_size, uint32_t log_eval,
                 uint32_t* const* d_acc4);
 void nx_air_kernel_destroy(nx_air_kernel* kernel);
+/* Degree-aware evaluation.  FrameworkEval::max_constraint_log_degree_bound (reference prover/src/components/mod.rs:44-45: +2 for v1's
+ * main component) is the bound of the component's HIGHEST-degree constraint: Stwo evaluates every constraint, and therefore
+ * re-extends every column, on the domain of log_size + bound.  A constraint of degree d over columns of 2^n rows has its quotient in
+ * the FFT space of 2^(n+e) points iff d <= 2^e + 1, so the constraints of degree <= 3 (v1: all the logup constraints of
+ * finalize_logup, components/mod.rs:53, i.e. all 1000 interaction columns; most chip constraints) can be evaluated on the
+ * 2^(n+1)-point domain — with blowup 2 the committed evaluations, no re-extension — and lifted like a smaller component
+ * (DomainEvaluationAccumulator::finalize); the composition polynomial, and the proof, are the same bits.
+ * nx_air_constraint_degrees: an upper bound of every constraint's degree (host only; ctx may be NULL).
+ * nx_air_compile_subset: nx_air_compile for the constraints with select[j] != 0 (NULL = all) — same alpha-power and column
+ * indices as the whole program, so kernels of disjoint subsets add up to the whole; columns no selected constraint loads may be
+ * NULL in nx_air_eval's d_cols.  The prover does this by itself (context option "air.degree_split", default 1). */
+int nx_air_constraint_degrees(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols,
+                              uint32_t n_econsts, uint32_t n_constraints, uint32_t* degrees /* n_constraints */);
+int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols,
+                          uint32_t n_econsts, uint32_t n_constraints, const uint8_t* select /* n_constraints, or NULL */,
+                          nx_air_kernel** out, char** h_source_out);
 
 /* ------------------------------------------- the prover session: stwo::prover::prove over recorded AIRs
  * What `nexus_vm_prover::prove` does around Stwo (reference prover/src/machine.rs:184-296; prover2/machine/src/prove.rs) with

@@ -99,13 +99,24 @@ def rccl_unique_id():
     return bytes(buf)
 
 
-def air_source(program, n_cols):
-    """The HIP source nx_air_compile generates for a recorded program (needs no GPU and no context)."""
+def _select_arg(select, n_c):
+    if select is None:
+        return None, None
+    sel = np.ascontiguousarray(np.asarray(select, dtype=np.uint8).reshape(-1))
+    assert len(sel) == n_c, "one flag per constraint"
+    return sel, sel.ctypes.data_as(C.c_void_p)
+
+
+def air_source(program, n_cols, select=None):
+    """The HIP source nx_air_compile(_subset) generates for a recorded program (needs no GPU and no context).
+    select: one flag per constraint (None = all)."""
     L = load_library()
     ins = _u32(program.instrs).reshape(-1)
     n_c = int(sum(1 for op in ins[0::4] if op in (13, 14)))
     src = C.c_void_p()
-    rc = L.nx_air_compile(None, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, n_cols, len(_u32(program.econsts).reshape(-1)) // 4, n_c, None, C.byref(src))
+    sel, sel_p = _select_arg(select, n_c)
+    rc = L.nx_air_compile_subset(None, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, n_cols, len(_u32(program.econsts).reshape(-1)) // 4, n_c, sel_p,
+                                 None, C.byref(src))
     if rc != 0:
         raise NexusHipError(f"nx_air_compile failed ({rc}): {L.nx_last_error(None).decode()}")
     try:
@@ -114,16 +125,31 @@ def air_source(program, n_cols):
         L.nx_free_host(src)
 
 
-class AirKernel:
-    """A recorded AIR compiled by hiprtc (nx_air_compile); eval() matches HipBackend.eval_constraint_program."""
+def air_constraint_degrees(program, n_cols):
+    """nx_air_constraint_degrees: an upper bound of every constraint's degree in the trace columns (host only)."""
+    L = load_library()
+    ins = _u32(program.instrs).reshape(-1)
+    n_c = int(sum(1 for op in ins[0::4] if op in (13, 14)))
+    out = np.zeros(max(1, n_c), np.uint32)
+    rc = L.nx_air_constraint_degrees(None, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, n_cols, len(_u32(program.econsts).reshape(-1)) // 4, n_c,
+                                     out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise NexusHipError(f"nx_air_constraint_degrees failed ({rc}): {L.nx_last_error(None).decode()}")
+    return out[:n_c]
 
-    def __init__(self, be, program, n_cols):
+
+class AirKernel:
+    """A recorded AIR compiled by hiprtc (nx_air_compile / nx_air_compile_subset); eval() matches HipBackend.eval_constraint_program.
+    select: one flag per constraint — the kernel evaluates only those (columns they do not read may be passed as None to eval)."""
+
+    def __init__(self, be, program, n_cols, select=None):
         self.be, self.program, self.n_cols = be, program, n_cols
         ins = _u32(program.instrs).reshape(-1)
         self.n_constraints = int(sum(1 for op in ins[0::4] if op in (13, 14)))
         self.h = C.c_void_p()
-        be._chk(be.L.nx_air_compile(be.ctx, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, n_cols, len(_u32(program.econsts).reshape(-1)) // 4,
-                                    self.n_constraints, C.byref(self.h), None))
+        sel, sel_p = _select_arg(select, self.n_constraints)
+        be._chk(be.L.nx_air_compile_subset(be.ctx, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, n_cols, len(_u32(program.econsts).reshape(-1)) // 4,
+                                           self.n_constraints, sel_p, C.byref(self.h), None))
 
     def eval(self, column_ptrs, alpha_powers, denom_inv, log_size, log_eval, acc4, econsts=None):
         assert len(column_ptrs) == self.n_cols
@@ -661,9 +687,9 @@ class HipBackend:
     def prover_session(self, cfg, max_log_size):
         return ProverSession(self, cfg, max_log_size)
 
-    def compile_air(self, program, n_cols):
-        """nx_air_compile: the recorded program as a run-time-compiled gfx950 kernel (same semantics as the interpreter)."""
-        return AirKernel(self, program, n_cols)
+    def compile_air(self, program, n_cols, select=None):
+        """nx_air_compile(_subset): the recorded program as a run-time-compiled gfx950 kernel (same semantics as the interpreter)."""
+        return AirKernel(self, program, n_cols, select)
 
     # ---- logup interaction trace (SURVEY §8(f) rank 2) ----
     @staticmethod

@@ -1,5 +1,6 @@
 // Synthetic machine: shared host/device declarations (see air.hip).
 #pragma once
+#include <vector>
 #include "internal.h"
 
 namespace nx {
@@ -31,5 +32,8 @@ int validate_air_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr
 int air_eval_rows(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_cols, const uint32_t* econsts, const uint32_t* alpha_powers, const uint32_t* denom_inv,
                   uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4, uint32_t row_begin, uint32_t n_rows);
 void air_kernel_shape(const nx_air_kernel* k, uint32_t* n_cols, uint32_t* n_econsts, uint32_t* n_constraints);
+// degree-aware composition (air_jit.hip): an upper bound of every constraint's degree; the columns a subset of the constraints reads
+void air_constraint_degrees(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, std::vector<uint32_t>* out);
+void air_subset_columns(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, const uint8_t* select, std::vector<char>* used);
 
 }  // namespace nx

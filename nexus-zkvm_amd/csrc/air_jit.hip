@@ -147,12 +147,14 @@ static std::string generate_kernel(const nx_cinstr* prog, const std::vector<uint
     return s;
 }
 
-static std::string generate_air_source(const nx_ctx* ctx, const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t* n_kernels = nullptr) {
-    // register-level dependencies: deps[i] = the instructions that last wrote the registers instruction i reads
+// register-level dependencies of a straight-line program: deps[i] = the instructions that last wrote the registers instruction i
+// reads; cons_index[i] = the ordinal of constraint instruction i (its alpha power)
+struct ProgDeps { std::vector<std::vector<uint32_t>> deps; std::vector<uint32_t> cons_index; uint32_t n_constraints = 0; };
+static ProgDeps program_deps(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs) {
+    ProgDeps pd;
     std::vector<int> last(n_regs, -1);
-    std::vector<std::vector<uint32_t>> deps(n_instr);
-    std::vector<uint32_t> cons_index(n_instr, 0);
-    uint32_t n_c = 0;
+    pd.deps.resize(n_instr); pd.cons_index.assign(n_instr, 0);
+    auto& deps = pd.deps; auto& cons_index = pd.cons_index; uint32_t& n_c = pd.n_constraints;
     auto use = [&](uint32_t i, uint32_t reg, uint32_t w) { for (uint32_t k = 0; k < w; k++) if (reg + k < n_regs && last[reg + k] >= 0) deps[i].push_back((uint32_t)last[reg + k]); };
     auto def = [&](uint32_t i, uint32_t reg, uint32_t w) { for (uint32_t k = 0; k < w; k++) if (reg + k < n_regs) last[reg + k] = (int)i; };
     for (uint32_t i = 0; i < n_instr; i++) {
@@ -169,6 +171,15 @@ static std::string generate_air_source(const nx_ctx* ctx, const nx_cinstr* prog,
         default: break;
         }
     }
+    return pd;
+}
+
+// `select` (one flag per constraint, NULL = all): the kernels evaluate only the selected constraints — same alpha-power indices, same
+// column indices as the whole program, so a component's constraints can be evaluated in parts on different domains (the
+// degree-aware composition of prover.hip) and the parts add up to the whole.
+static std::string generate_air_source(const nx_ctx* ctx, const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t* n_kernels = nullptr, const uint8_t* select = nullptr) {
+    const ProgDeps pd = program_deps(prog, n_instr, n_regs);
+    const auto& deps = pd.deps; const auto& cons_index = pd.cons_index;
     // segments: consecutive constraints whose slices fit the budget
     std::string s = AIR_PRELUDE;
     uint32_t n_seg = 0;
@@ -197,6 +208,7 @@ static std::string generate_air_source(const nx_ctx* ctx, const nx_cinstr* prog,
     bool any = false;
     for (uint32_t i = 0; i < n_instr; i++) {
         if (prog[i].op != NX_C_CONSTRAINT_B && prog[i].op != NX_C_CONSTRAINT_E) continue;
+        if (select && !select[cons_index[i]]) continue;
         if (any && cost >= budget) { flush(); any = false; }
         cost += add_slice(i); any = true;
     }
@@ -208,6 +220,54 @@ static std::string generate_air_source(const nx_ctx* ctx, const nx_cinstr* prog,
 }  // namespace nx
 
 namespace nx {
+
+// Upper bound of every constraint's degree in the trace columns (a validated program): a column load is 1, a constant 0, a sum the
+// larger, a product the sum.  The rule behind FrameworkEval::max_constraint_log_degree_bound (reference
+// prover/src/components/mod.rs:44-45): a constraint of degree d over columns of 2^n rows has a quotient in the FFT space of
+// 2^(n+e) points iff d <= 2^e + 1.
+void air_constraint_degrees(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, std::vector<uint32_t>* out) {
+    std::vector<uint32_t> d(n_regs + 4, 0);
+    out->clear();
+    auto dE = [&](uint32_t r) { return std::max(std::max(d[r], d[r + 1]), std::max(d[r + 2], d[r + 3])); };
+    auto setE = [&](uint32_t r, uint32_t v) { d[r] = d[r + 1] = d[r + 2] = d[r + 3] = v; };
+    for (uint32_t i = 0; i < n_instr; i++) {
+        const nx_cinstr& in = prog[i];
+        switch (in.op) {
+        case NX_C_LOAD: d[in.dst] = 1; break;
+        case NX_C_CONST: d[in.dst] = 0; break;
+        case NX_C_ADD: case NX_C_SUB: d[in.dst] = std::max(d[in.a], d[in.b]); break;
+        case NX_C_MUL: d[in.dst] = d[in.a] + d[in.b]; break;
+        case NX_C_NEG: d[in.dst] = d[in.a]; break;
+        case NX_C_CONSTE: setE(in.dst, 0); break;
+        case NX_C_LOADE: setE(in.dst, 1); break;
+        case NX_C_ADDE: case NX_C_SUBE: setE(in.dst, std::max(dE(in.a), dE(in.b))); break;
+        case NX_C_MULE: setE(in.dst, dE(in.a) + dE(in.b)); break;
+        case NX_C_MULEB: setE(in.dst, dE(in.a) + d[in.b]); break;
+        case NX_C_ADDEB: setE(in.dst, std::max(dE(in.a), d[in.b])); break;
+        case NX_C_CONSTRAINT_B: out->push_back(d[in.a]); break;
+        case NX_C_CONSTRAINT_E: out->push_back(dE(in.a)); break;
+        default: break;
+        }
+    }
+}
+
+// The component columns the selected constraints read (the backward slices of generate_air_source).
+void air_subset_columns(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, const uint8_t* select, std::vector<char>* used) {
+    const ProgDeps pd = program_deps(prog, n_instr, n_regs);
+    used->assign(n_cols, 0);
+    std::vector<char> seen(n_instr, 0);
+    std::vector<uint32_t> st;
+    for (uint32_t i = 0; i < n_instr; i++)
+        if ((prog[i].op == NX_C_CONSTRAINT_B || prog[i].op == NX_C_CONSTRAINT_E) && (!select || select[pd.cons_index[i]])) st.push_back(i);
+    while (!st.empty()) {
+        const uint32_t i = st.back(); st.pop_back();
+        if (seen[i]) continue;
+        seen[i] = 1;
+        if (prog[i].op == NX_C_LOAD && prog[i].a < n_cols) (*used)[prog[i].a] = 1;
+        if (prog[i].op == NX_C_LOADE) for (uint32_t k = 0; k < 4; k++) if (prog[i].a + k < n_cols) (*used)[prog[i].a + k] = 1;
+        for (uint32_t d : pd.deps[i]) if (!seen[d]) st.push_back(d);
+    }
+}
 
 // Shared by nx_air_compile, nx_eval_constraint_program's callers and the prover session (GenericAir::check): every register index
 // (dst, a, b and the +3 of the secure-field ops), column index and secure-constant index of a recorded program is inside the
@@ -253,13 +313,31 @@ extern "C" {
 // h_source_out (optional): receives a malloc'd copy of the generated source (free with nx_free_host) — also usable without a GPU.
 int nx_air_compile(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints,
                    nx_air_kernel** out, char** h_source_out) {
+    return nx_air_compile_subset(ctx, program, n_instr, n_regs, n_cols, n_econsts, n_constraints, nullptr, out, h_source_out);
+}
+
+int nx_air_constraint_degrees(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints,
+                              uint32_t* degrees) {
+    NX_GUARD(ctx);
+    if (!program || !degrees) return set_err(ctx, NX_ERR_ARG, "nx_air_constraint_degrees: NULL argument");
+    uint32_t n_c = 0;
+    NX_TRY(validate_air_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, &n_c));
+    if (n_c != n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_air_constraint_degrees: the program adds a different number of constraints than announced");
+    std::vector<uint32_t> d;
+    air_constraint_degrees(program, n_instr, n_regs, &d);
+    std::copy(d.begin(), d.end(), degrees);
+    return NX_OK;
+}
+
+int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints,
+                          const uint8_t* select, nx_air_kernel** out, char** h_source_out) {
     NX_GUARD(ctx);
     if (!program || (!out && !h_source_out)) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: NULL argument");
     uint32_t n_c = 0;
     NX_TRY(validate_air_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, &n_c));
     if (n_c != n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: the program adds a different number of constraints than announced");
     uint32_t n_kernels = 1;
-    const std::string src = generate_air_source(ctx, program, n_instr, n_regs, &n_kernels);
+    const std::string src = generate_air_source(ctx, program, n_instr, n_regs, &n_kernels, select);
     if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
     if (!out) return NX_OK;
     if (!ctx) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: a context is needed to load the kernel");

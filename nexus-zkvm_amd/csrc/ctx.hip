@@ -245,6 +245,7 @@ static nx_options options_from_env() {
     o.fri_dist_min_log = std::max(0, env_int("NX_FRI_DIST_MIN_LOG", 21));
     o.dist_chunks = std::max(0, env_int("NX_DIST_CHUNKS", 0));
     o.air_segment = std::max(200, env_int("NX_AIR_SEGMENT", 9000));
+    o.air_degree_split = env_int("NX_AIR_DEGREE_SPLIT", 1) != 0;
     return o;
 }
 struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
@@ -258,6 +259,7 @@ static const OptEntry k_options[] = {
     {"fri.dist_min_log", &nx_options::fri_dist_min_log, 0, 31},
     {"dist.chunks", &nx_options::dist_chunks, 0, 64},
     {"air.segment", &nx_options::air_segment, 200, 1 << 30},
+    {"air.degree_split", &nx_options::air_degree_split, 0, 1},
 };
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return set_err(ctx, NX_ERR_ARG, "nx_ctx_set_option: NULL argument");

@@ -21,6 +21,7 @@ struct nx_options {
     int fri_dist_min_log;         // "fri.dist_min_log": row-sharded prove, FRI layers below this many rows run replicated
     int dist_chunks;              // "dist.chunks": 0 = automatic; else column chunks of a row-sharded commit's exchange
     int air_segment;              // "air.segment": estimated-instruction budget of one generated AIR kernel
+    int air_degree_split;         // "air.degree_split": constraints of degree <= 3 of a component with a bound > 1 are evaluated on the log_size + 1 domain
 };
 
 struct nx_ctx {

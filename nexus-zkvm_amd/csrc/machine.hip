@@ -211,9 +211,14 @@ struct ProgEmit {
 };
 
 // econsts of a component: [z, alpha, claimed / N, 0]
-static GComponent machine_component(const nx_component_spec& c, const Loc& loc) {
+// A component whose constraint-degree bound is 2 HAS constraints that need it (degree 4 or 5; v1's shift chips, reference
+// prover/src/chips/instructions/i/sra.rs:267-307): every degree-2 main-trace constraint of such a component is multiplied by the two
+// columns it squares — degree 4, satisfied by the same trace — so that all its main columns are needed on the 4x domain.  The logup
+// constraints keep degree 2, as the reference's one-fraction-per-column finalize_logup (components/mod.rs:53) makes them.
+static GComponent machine_component(const nx_component_spec& c, const Loc& loc, const PcsConfig& cfg) {
     GComponent g;
     g.log_size = c.log_size;
+    const bool quartic = comp_log_cd(c.log_constraint_degree_bound, cfg) >= 2;
     const uint32_t L = c.n_inter / 4, PRE = 0, MAIN = c.n_pre, INT = c.n_pre + c.n_main;
     for (uint32_t k = 0; k < c.n_pre; k++) { g.cols.push_back({0u, (uint32_t)loc.pre0 + k}); g.masks.push_back({0}); }
     for (uint32_t k = 0; k < c.n_main; k++) { g.cols.push_back({1u, (uint32_t)loc.main0 + k}); g.masks.push_back(k < 2 ? std::vector<int>{0, 1} : std::vector<int>{0}); }
@@ -240,6 +245,7 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc) 
         for (uint32_t k = k0; k < k1; k++)
             if (!synth_col_is_free(k)) {
                 e.op(NX_C_MUL, T0, ring(k - 1), ring(k - 1)); e.op(NX_C_MUL, T1, ring(k - 2), ring(k - 2)); e.op(NX_C_SUB, T2, ring(k), T0); e.op(NX_C_SUB, T2, T2, T1);
+                if (quartic) { e.op(NX_C_MUL, T2, T2, ring(k - 1)); e.op(NX_C_MUL, T2, T2, ring(k - 2)); }
                 e.op(NX_C_CONSTRAINT_B, 0, T2); nc++;
             }
     }
@@ -280,33 +286,6 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc) 
     g.n_constraints = nc;
     g.econsts.assign(16, 0);
     return g;
-}
-
-// compiled kernels are cached per context and per program text: one compilation serves every proof of an AIR
-struct KernelCache { std::mutex mu; std::map<std::pair<nx_ctx*, std::string>, nx_air_kernel*> map; };
-static KernelCache& kernel_cache() { static KernelCache c; return c; }
-static int cached_kernel(nx_ctx* ctx, const GComponent& g, const nx_air_kernel** out) {
-    std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
-    key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs);
-    KernelCache& kc = kernel_cache();
-    {
-        std::lock_guard<std::mutex> lk(kc.mu);
-        auto it = kc.map.find({ctx, key});
-        if (it != kc.map.end()) { *out = it->second; return NX_OK; }
-    }
-    // compile OUTSIDE the lock: entries are per context and a context is driven by one thread, so nobody else can insert this key;
-    // holding the process-wide mutex across hiprtc would serialise the GPUs of a thread-rank group and let one stuck compile stall all
-    nx_air_kernel* k = nullptr;
-    H_TRY(nx_air_compile(ctx, g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), (uint32_t)g.econsts.size() / 4, g.n_constraints, &k, nullptr));
-    std::lock_guard<std::mutex> lk(kc.mu);
-    kc.map.insert({{ctx, key}, k});
-    *out = k;
-    return NX_OK;
-}
-void machine_kernels_release(nx_ctx* ctx) {   // nx_ctx_destroy: the modules belong to the context's device
-    KernelCache& kc = kernel_cache();
-    std::lock_guard<std::mutex> lk(kc.mu);
-    for (auto it = kc.map.begin(); it != kc.map.end();) { if (it->first.first == ctx) { nx_air_kernel_destroy(it->second); it = kc.map.erase(it); } else ++it; }
 }
 
 // The logup interaction trace of one component from the main-trace columns `mainv` (evaluations, bit-reversed circle-domain order;
@@ -368,9 +347,9 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         // by a vote: a rank that failed must not leave its peers blocked in the first all-to-all.
         int rc_local = NX_OK;
         for (uint32_t i = 0; i < n_comps && rc_local == NX_OK; i++) {
-            GComponent g = machine_component(comps[i], locs[i]);
-            const nx_air_kernel* k = nullptr;
-            rc_local = cached_kernel(ctx, g, &k);
+            GComponent g = machine_component(comps[i], locs[i], cfg);
+            g.log_cd = comps[i].log_constraint_degree_bound;
+            rc_local = prepare_component_kernels(ctx, cfg, g);
         }
         if (D.on()) {
             std::vector<int32_t> all((size_t)D.world, 0);
@@ -494,11 +473,11 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     // machine.rs:265-285: the components (recorded programs; lookup elements and claimed-sum shifts are run-time constants)
     GenericAir air; air.ctx = ctx;
     for (uint32_t i = 0; i < n_comps; i++) {
-        GComponent g = machine_component(comps[i], locs[i]);
+        GComponent g = machine_component(comps[i], locs[i], cfg);
         g.log_cd = comps[i].log_constraint_degree_bound;
         const QM31 shift = q_mul_m(claimed[i], m_inv((1u << comps[i].log_size) % P));
         memcpy(&g.econsts[0], z, 16); memcpy(&g.econsts[4], alpha, 16); q_store(&g.econsts[8], shift);
-        H_TRY(cached_kernel(ctx, g, &g.kernel));
+        H_TRY(prepare_component_kernels(ctx, cfg, g));
         air.comps.push_back(std::move(g));
     }
     H_TRY(air.check(cs));
@@ -543,7 +522,8 @@ int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t
 // inspection of the generated kernels (register use, code size) with hipcc.  *h_source: free with nx_free_host.
 int nx_machine_air_source(const nx_component_spec* comp, char** h_source) {
     if (!comp || !h_source || comp->n_inter % 4 || comp->n_pre < 2 || comp->n_main < 2) return set_err(nullptr, NX_ERR_ARG, "nx_machine_air_source: bad argument");
-    nxhip::GComponent g = nxhip::machine_component(*comp, nxhip::Loc{0, 0, 0});
+    nxhip::PcsConfig one = {0, 1, 1, 0, 0, 1};      // a bound of 0 means "the config's": taken as 1 here (no config in this entry)
+    nxhip::GComponent g = nxhip::machine_component(*comp, nxhip::Loc{0, 0, 0}, one);
     return nx_air_compile(nullptr, g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), (uint32_t)g.econsts.size() / 4, g.n_constraints, nullptr, h_source);
 }
 

@@ -207,7 +207,7 @@ struct AirProver {
 // (`masked`) are all-gathered whole.
 struct EvalDomainCols { std::vector<const uint32_t*> ptrs; std::vector<DevBuf> keep; };
 int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pair<uint32_t, uint32_t>>& comp_cols, uint32_t log_size, uint32_t e,
-                           const std::vector<char>& masked, EvalDomainCols* out);
+                           const std::vector<char>& masked, EvalDomainCols* out, const std::vector<char>* used = nullptr);
 // per evaluation-domain size, this GPU's rows of the accumulation (whole on one GPU)
 int composition_accumulator(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, uint32_t e, SecureColumn** out);
 // DomainEvaluationAccumulator::finalize (row-sharded: all-gather of the accumulators first): 4 coefficient columns, replicated
@@ -235,7 +235,16 @@ struct GComponent {
     std::vector<std::pair<uint32_t, uint32_t>> cols;     // component column -> (tree, column in tree)
     std::vector<std::vector<int>> masks;                 // component column -> row offsets sampled
     const nx_air_kernel* kernel = nullptr; nx_air_kernel* owned = nullptr;
+    // degree-aware composition (prepare_component_kernels): the constraints of degree <= 3 ("low": evaluated on log_size + 1) and the
+    // others ("high": on log_size + bound), the columns each part reads, their kernels (context-cached)
+    struct Part { bool any = false; std::vector<uint8_t> select; std::vector<char> used; const nx_air_kernel* kernel = nullptr; };
+    bool split = false, prepared = false; Part low, high;
 };
+// compiled kernels are cached per context and per (program, selection): one compilation serves every proof of an AIR
+int cached_air_kernel(nx_ctx* ctx, const GComponent& g, const uint8_t* select, const nx_air_kernel** out);
+// everything compute_composition will launch for this component, compiled now (a row-sharded prove votes on the result before its
+// first exchange): the whole program, or its low / high parts when the component's bound exceeds 1 and "air.degree_split" is on
+int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g);
 struct GenericAir : AirProver {
     nx_ctx* ctx; std::vector<GComponent> comps;
     std::vector<std::vector<std::vector<int>>> offs;     // tree -> column -> union of sampled offsets (first-appearance order)

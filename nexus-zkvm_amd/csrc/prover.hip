@@ -3,6 +3,8 @@
 // recorded AIRs — see prover.h for the objects and for how one proof is spread over the GPUs of a node.
 #include "prover.h"
 #include <chrono>
+#include <mutex>
+#include <string>
 #include <numeric>
 #include <tuple>
 
@@ -760,21 +762,26 @@ std::vector<uint32_t> vanishing_denominators(uint32_t log_size, uint32_t e) {
     return den;
 }
 
+// `used` (optional): the component columns the kernel will read; the others get a NULL pointer and cost nothing (no re-evaluation, no
+// exchange) — the high-degree part of a degree-split component reads a fraction of the columns.
 int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pair<uint32_t, uint32_t>>& comp_cols, uint32_t log_size, uint32_t e,
-                           const std::vector<char>& masked, EvalDomainCols* out) {
+                           const std::vector<char>& masked, EvalDomainCols* out, const std::vector<char>* used) {
     nx_ctx* ctx = cs.ctx;
     const Dist& D = cs.dist;
     const size_t n = comp_cols.size();
     out->ptrs.assign(n, nullptr);
+    std::vector<size_t> sel;                                                          // the columns to provide
+    for (size_t k = 0; k < n; k++) if (!used || (k < used->size() && (*used)[k])) sel.push_back(k);
+    const size_t ns = sel.size();
     const bool committed = e == log_size + cs.cfg.log_blowup;
     if (!D.on()) {
-        if (committed) { for (size_t k = 0; k < n; k++) out->ptrs[k] = cs.trees[comp_cols[k].first].evals[comp_cols[k].second].ptr; return NX_OK; }
-        DevBuf ext; H_TRY(ext.alloc(ctx, std::max<size_t>(n, 1) << e));                 // "need_to_extend": re-evaluate the polynomials on the constraint domain
-        std::vector<const uint32_t*> src(n);
-        for (size_t k = 0; k < n; k++) src[k] = cs.trees[comp_cols[k].first].polys[comp_cols[k].second].ptr;
-        auto dst = col_ptrs(ext.p, (uint32_t)n, e);
-        if (n) H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), (uint32_t)n, log_size, e - log_size, dst.data()));
-        for (size_t k = 0; k < n; k++) out->ptrs[k] = dst[k];
+        if (committed) { for (size_t k : sel) out->ptrs[k] = cs.trees[comp_cols[k].first].evals[comp_cols[k].second].ptr; return NX_OK; }
+        DevBuf ext; H_TRY(ext.alloc(ctx, std::max<size_t>(ns, 1) << e));               // "need_to_extend": re-evaluate the polynomials on the constraint domain
+        std::vector<const uint32_t*> src(ns);
+        for (size_t i = 0; i < ns; i++) src[i] = cs.trees[comp_cols[sel[i]].first].polys[comp_cols[sel[i]].second].ptr;
+        auto dst = col_ptrs(ext.p, (uint32_t)ns, e);
+        if (ns) H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), (uint32_t)ns, log_size, e - log_size, dst.data()));
+        for (size_t i = 0; i < ns; i++) out->ptrs[sel[i]] = dst[i];
         out->keep.push_back(std::move(ext));
         return NX_OK;
     }
@@ -782,23 +789,23 @@ int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pa
     const uint64_t mb = D.block(e), rb = D.begin(e);
     std::vector<uint32_t*> blk(n, nullptr);
     if (committed) {
-        for (size_t k = 0; k < n; k++) blk[k] = cs.trees[comp_cols[k].first].evals[comp_cols[k].second].ptr;
+        for (size_t k : sel) blk[k] = cs.trees[comp_cols[k].first].evals[comp_cols[k].second].ptr;
     } else {
         // every GPU re-evaluates the polynomials it holds; one all-to-all hands out the rows.  Receive layout: by source GPU, the
         // source's columns in the component's column order.
-        std::vector<int> own(n); std::vector<uint32_t> pos(n); std::vector<uint32_t> cnt(D.world, 0);
-        for (size_t k = 0; k < n; k++) {
+        std::vector<int> own(n, -1); std::vector<uint32_t> pos(n, 0); std::vector<uint32_t> cnt(D.world, 0);
+        for (size_t k : sel) {
             own[k] = cs.trees[comp_cols[k].first].owner[comp_cols[k].second];
             if (own[k] < 0) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: a trace column is not column-sharded");
             pos[k] = cnt[own[k]]++;
         }
         const uint32_t n_loc = cnt[D.rank];
         DevBuf ext, send, rows;
-        H_TRY(rows.alloc(ctx, std::max<size_t>(n, 1) * mb));
+        H_TRY(rows.alloc(ctx, std::max<size_t>(ns, 1) * mb));
         if (n_loc) {
             H_TRY(ext.alloc(ctx, (size_t)n_loc << e));
             std::vector<const uint32_t*> src;
-            for (size_t k = 0; k < n; k++) if (own[k] == D.rank) src.push_back(cs.trees[comp_cols[k].first].polys[comp_cols[k].second].ptr);
+            for (size_t k : sel) if (own[k] == D.rank) src.push_back(cs.trees[comp_cols[k].first].polys[comp_cols[k].second].ptr);
             auto dst = col_ptrs(ext.p, n_loc, e);
             H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), n_loc, log_size, e - log_size, dst.data()));
             H_TRY(send.alloc(ctx, (size_t)n_loc << e));
@@ -808,12 +815,12 @@ int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pa
         size_t acc = 0;
         for (int r = 0; r < D.world; r++) { soff[r] = (size_t)r * n_loc * mb; scnt[r] = (size_t)n_loc * mb; roff[r] = acc; rcnt[r] = (size_t)cnt[r] * mb; acc += rcnt[r]; }
         H_TRY(D.alltoallv(ctx, send.p, soff.data(), scnt.data(), rows.p, roff.data(), rcnt.data()));
-        for (size_t k = 0; k < n; k++) blk[k] = rows.p + roff[own[k]] + (size_t)pos[k] * mb;
+        for (size_t k : sel) blk[k] = rows.p + roff[own[k]] + (size_t)pos[k] * mb;
         out->keep.push_back(std::move(rows));
     }
     {   // columns read at a non-zero mask offset: neighbour rows live in other blocks, so the whole columns — one all-gather for all of them
         std::vector<const uint32_t*> mblk; std::vector<size_t> mk;
-        for (size_t k = 0; k < n; k++) { if (k < masked.size() && masked[k]) { mblk.push_back(blk[k]); mk.push_back(k); } else out->ptrs[k] = bias_rows(blk[k], rb); }
+        for (size_t k : sel) { if (k < masked.size() && masked[k]) { mblk.push_back(blk[k]); mk.push_back(k); } else out->ptrs[k] = bias_rows(blk[k], rb); }
         if (!mblk.empty()) {
             DevBuf whole; H_TRY(whole.alloc(ctx, mblk.size() << e));
             H_TRY(D.allgather_cols(ctx, mblk, (size_t)mb, whole.p, (uint64_t)1 << e));
@@ -1050,6 +1057,82 @@ int GenericAir::check(const CommitmentSchemeProver& cs) {
     return NX_OK;
 }
 
+static void release_split_cache(nx_ctx* ctx);
+struct KernelCache { std::mutex mu; std::map<std::pair<nx_ctx*, std::string>, nx_air_kernel*> map; };
+static KernelCache& kernel_cache() { static KernelCache c; return c; }
+int cached_air_kernel(nx_ctx* ctx, const GComponent& g, const uint8_t* select, const nx_air_kernel** out) {
+    std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
+    key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs) + "|" + std::to_string(g.econsts.size() / 4);
+    if (select) { key += "|"; key.append((const char*)select, g.n_constraints); }
+    KernelCache& kc = kernel_cache();
+    {
+        std::lock_guard<std::mutex> lk(kc.mu);
+        auto it = kc.map.find({ctx, key});
+        if (it != kc.map.end()) { *out = it->second; return NX_OK; }
+    }
+    // compile OUTSIDE the lock: entries are per context and a context is driven by one thread, so nobody else can insert this key;
+    // holding the process-wide mutex across hiprtc would serialise the GPUs of a thread-rank group and let one stuck compile stall all
+    nx_air_kernel* k = nullptr;
+    H_TRY(nx_air_compile_subset(ctx, g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), (uint32_t)g.econsts.size() / 4, g.n_constraints, select, &k, nullptr));
+    std::lock_guard<std::mutex> lk(kc.mu);
+    kc.map.insert({{ctx, key}, k});
+    *out = k;
+    return NX_OK;
+}
+void machine_kernels_release(nx_ctx* ctx) {   // nx_ctx_destroy: the modules belong to the context's device
+    KernelCache& kc = kernel_cache();
+    std::lock_guard<std::mutex> lk(kc.mu);
+    for (auto it = kc.map.begin(); it != kc.map.end();) { if (it->first.first == ctx) { nx_air_kernel_destroy(it->second); it = kc.map.erase(it); } else ++it; }
+    release_split_cache(ctx);
+}
+
+// A constraint of degree d <= 3 over columns of 2^n rows has its quotient in the FFT space of the 2^(n+1)-point domain (d <= 2^e + 1
+// with e = 1): those constraints are evaluated there — on the committed evaluations when the blowup is 2 — and only the columns the
+// remaining constraints read are re-extended to log_size + bound.  finalize_accumulation lifts the small accumulator exactly like a
+// smaller component's, so the composition polynomial is the same, coefficient for coefficient.
+struct SplitCache { std::mutex mu; std::map<std::pair<nx_ctx*, std::string>, std::pair<GComponent::Part, GComponent::Part>> map; };
+static SplitCache& split_cache() { static SplitCache c; return c; }
+static void release_split_cache(nx_ctx* ctx) {
+    SplitCache& sc = split_cache();
+    std::lock_guard<std::mutex> lk(sc.mu);
+    for (auto it = sc.map.begin(); it != sc.map.end();) { if (it->first.first == ctx) it = sc.map.erase(it); else ++it; }
+}
+int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g) {
+    if (g.prepared) return NX_OK;
+    g.split = ctx->opt.air_degree_split && comp_log_cd(g.log_cd, cfg) > 1 && g.n_constraints > 0;
+    if (g.split) {
+        // the analysis and the two kernels depend on the program only: once per context and AIR
+        std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
+        key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs) + "|" + std::to_string(g.econsts.size() / 4);
+        SplitCache& sc = split_cache();
+        bool hit = false;
+        {
+            std::lock_guard<std::mutex> lk(sc.mu);
+            auto it = sc.map.find({ctx, key});
+            if (it != sc.map.end()) { g.low = it->second.first; g.high = it->second.second; hit = true; }
+        }
+        if (!hit) {
+            std::vector<uint32_t> deg;
+            air_constraint_degrees(g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, &deg);
+            if (deg.size() != g.n_constraints) return set_err(ctx, NX_ERR_ARG, "recorded AIR: constraint count mismatch");
+            g.low = GComponent::Part(); g.high = GComponent::Part();
+            g.low.select.assign(g.n_constraints, 0); g.high.select.assign(g.n_constraints, 0);
+            for (uint32_t j = 0; j < g.n_constraints; j++) { if (deg[j] <= 3) { g.low.select[j] = 1; g.low.any = true; } else { g.high.select[j] = 1; g.high.any = true; } }
+            for (GComponent::Part* part : {&g.low, &g.high}) {
+                if (!part->any || !g.low.any) continue;
+                air_subset_columns(g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), part->select.data(), &part->used);
+                H_TRY(cached_air_kernel(ctx, g, part->select.data(), &part->kernel));
+            }
+            std::lock_guard<std::mutex> lk(sc.mu);
+            sc.map.insert({{ctx, key}, {g.low, g.high}});
+        }
+        if (!g.low.any) g.split = false;              // nothing to move: the component is evaluated whole
+    }
+    if (!g.split && !g.kernel) H_TRY(cached_air_kernel(ctx, g, nullptr, &g.kernel));
+    g.prepared = true;
+    return NX_OK;
+}
+
 int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) {
     size_t total = 0;
     for (auto& c : comps) total += c.n_constraints;
@@ -1063,20 +1146,29 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
         std::vector<uint32_t> pw(4 * nc);          // the LAST nc remaining powers, reversed (accumulator.columns())
         for (size_t j = 0; j < nc; j++) q_store(&pw[4 * j], powers[remaining - 1 - j]);
         remaining -= nc;
-        const std::vector<uint32_t> den = vanishing_denominators(c.log_size, e);
         std::vector<char> masked(c.cols.size(), 0);
         for (size_t k = 0; k < c.cols.size(); k++) for (int o : c.masks[k]) if (o != 0) masked[k] = 1;
-        EvalDomainCols cols;
-        H_TRY(columns_on_eval_domain(cs, c.cols, c.log_size, e, masked, &cols));
-        SecureColumn* acc = nullptr;
-        H_TRY(composition_accumulator(cs, sub, e, &acc));
-        if (!c.kernel) {
-            H_TRY(nx_air_compile(ctx, c.prog.data(), (uint32_t)c.prog.size(), c.n_regs, (uint32_t)c.cols.size(), (uint32_t)c.econsts.size() / 4, c.n_constraints, &c.owned, nullptr));
-            c.kernel = c.owned;
+        H_TRY(prepare_component_kernels(ctx, cs.cfg, c));
+        // one pass per part: (domain, kernel, columns read); an unsplit component is one part on its own domain
+        struct Pass { uint32_t e; const nx_air_kernel* k; const std::vector<char>* used; };
+        std::vector<Pass> passes;
+        if (c.split) {
+            SecureColumn* whole = nullptr;
+            H_TRY(composition_accumulator(cs, sub, e, &whole));             // the composition keeps the size the bound declares, whatever the parts need
+            if (c.low.any) passes.push_back({c.log_size + 1, c.low.kernel, &c.low.used});
+            if (c.high.any) passes.push_back({e, c.high.kernel, &c.high.used});
+        } else passes.push_back({e, c.kernel, nullptr});
+        for (const Pass& ps : passes) {
+            const std::vector<uint32_t> den = vanishing_denominators(c.log_size, ps.e);
+            EvalDomainCols cols;
+            H_TRY(columns_on_eval_domain(cs, c.cols, c.log_size, ps.e, masked, &cols, ps.used));
+            SecureColumn* acc = nullptr;
+            H_TRY(composition_accumulator(cs, sub, ps.e, &acc));
+            const uint64_t rb = cs.dist.on() ? cs.dist.begin(ps.e) : 0;
+            uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = bias_rows(acc->c[k], rb);
+            H_TRY(air_eval_rows(ctx, ps.k, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), c.log_size, ps.e, a4, (uint32_t)rb, (uint32_t)acc->rows));
+            // `cols` (the re-evaluated columns) is released here: stream-ordered frees, the kernel above was enqueued first
         }
-        const uint64_t rb = cs.dist.on() ? cs.dist.begin(e) : 0;
-        uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = bias_rows(acc->c[k], rb);
-        H_TRY(air_eval_rows(ctx, c.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), c.log_size, e, a4, (uint32_t)rb, (uint32_t)acc->rows));
     }
     return finalize_accumulation(cs, sub, out_polys, out_log);
 }

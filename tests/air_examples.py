@@ -72,15 +72,23 @@ def logup_interaction_trace(log, nat_main, z, alpha):
     return [O.finalize_column(S[:, k].copy()) for k in range(4)], shift
 
 
-def logup_component(ap, log, z, alpha, shift, main0=0, inter0=0):
+def logup_component(ap, log, z, alpha, shift, main0=0, inter0=0, high_degree=False):
+    """high_degree: the same relation also as a degree-3 and a degree-4 constraint, interleaved with the others (what a component with a
+    constraint-degree bound of 2 is for): a degree-aware prover evaluates the parts on different domains, the alpha powers stay put."""
     pb = ap.ProgramBuilder()
     (a,) = pb.next_trace_mask(0)
     (b,) = pb.next_trace_mask(1)
     (c,) = pb.next_trace_mask(2)
     s_prev, s_cur = pb.next_secure_mask(3, (-1, 0))
+    if high_degree:
+        pb.add_constraint((c - a * b - 3) * a * b)
     pb.add_constraint(c - a * b - 3)
+    if high_degree:
+        pb.add_constraint((c - a * b - 3) * c)
     ze, al, sh = pb.econst(z), pb.econst(alpha), pb.econst(shift)
     den = ze - a - al * b
     pb.add_constraint((s_cur - s_prev + sh) * den - 1)
+    if high_degree:
+        pb.add_constraint(((s_cur - s_prev + sh) * den - 1) * a * c)
     cols = [(1, main0), (1, main0 + 1), (1, main0 + 2)] + [(2, inter0 + k) for k in range(4)]
     return ap.Component(log, pb.build(), cols)

@@ -23,9 +23,13 @@ def logup_cols(j, n_main):
     return (3 + 7 * j) % n_main, (5 + 11 * j) % n_main, (2 + 13 * j) % n_main
 
 
-def machine_component(ap, comp, loc, z, alpha, shift):
-    """The component's AIR through the recording evaluator: what `add_constraints` of a FrameworkEval would declare."""
+def machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd=1):
+    """The component's AIR through the recording evaluator: what `add_constraints` of a FrameworkEval would declare.
+    A component whose degree bound (its own, or the config's `cfg_lcd` when 0 / absent) is 2 has degree-4 constraints: each degree-2
+    main-trace constraint times the two columns it squares (the logup constraints stay degree 2, like finalize_logup's)."""
     log, n_pre, n_main, n_inter = comp[:4]
+    bound = comp[4] if len(comp) > 4 and comp[4] else cfg_lcd
+    quartic = bound >= 2
     L = n_inter // 4
     pre0, main0, inter0 = loc
     pb = ap.Emitter()
@@ -39,7 +43,8 @@ def machine_component(ap, comp, loc, z, alpha, shift):
     main = [m0, m1] + [pb.next_trace_mask(MAIN + k)[0] for k in range(2, n_main)]
     for k in range(2, n_main):
         if k % 16 >= 2:
-            pb.add_constraint(main[k] - main[k - 1] * main[k - 1] - main[k - 2] * main[k - 2])
+            c2 = main[k] - main[k - 1] * main[k - 1] - main[k - 2] * main[k - 2]
+            pb.add_constraint(c2 * main[k - 1] * main[k - 2] if quartic else c2)
     if L:
         ze, al, sh = pb.econst(z), pb.econst(alpha), pb.econst(shift)
         prev = None
@@ -114,5 +119,5 @@ def prove_machine(comps, cfg, seed=1, ad=b"", threads=None):
     locs, a, b, d = [], 0, 0, 0
     for c in comps:
         locs.append((a, b, d)); a += c[1]; b += c[2]; d += c[3]
-    components = [machine_component(ap, c, l, z, alpha, sh) for c, l, sh in zip(comps, locs, shifts)]
+    components = [machine_component(ap, c, l, z, alpha, sh, int(cfg[6])) for c, l, sh in zip(comps, locs, shifts)]
     return s.prove(components)                                # :286-290

@@ -186,3 +186,55 @@ def test_air_jit_splits_large_programs_into_segments(tmp_path):
     assert used == list(range(n_constraints))           # every constraint exactly once, with its own alpha power
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-c", str(f), "-o", str(tmp_path / "seg.o")], check=True, timeout=300)
+
+
+def _mixed_degree_program():
+    """Constraints of degree 1, 2, 3, 4, 5 and secure-field ones of degree 2 and 4 over 8 base columns + one secure column."""
+    import nexus_zkvm_amd.air_program as ap
+    pb = ap.ProgramBuilder()
+    c = [pb.next_trace_mask(k)[0] for k in range(8)]
+    (s,) = pb.next_secure_mask(8)
+    z = pb.econst((5, 6, 7, 8))
+    pb.add_constraint(c[0] - c[1] - 3)                            # 1
+    pb.add_constraint(c[2] - c[0] * c[1])                         # 2
+    pb.add_constraint(c[3] * (c[2] - c[0] * c[1]))                # 3
+    pb.add_constraint(c[4] * c[5] * (c[2] - c[0] * c[1]))         # 4
+    pb.add_constraint(c[6] * c[4] * c[5] * (c[2] - c[0] * c[1]))  # 5
+    pb.add_constraint(s * (z + c[7]) - 1)                         # 2, secure
+    pb.add_constraint((s * (z + c[7]) - 1) * c[6] * c[6])         # 4, secure
+    return pb.build(), 12
+
+
+def test_constraint_degrees_of_a_recorded_program():
+    """nx_air_constraint_degrees: loads 1, constants 0, sums the larger, products the sum — through register reuse and the
+    secure-field instructions.  The rule behind max_constraint_log_degree_bound: degree d needs a bound e with d <= 2^e + 1."""
+    import nexus_zkvm_amd as nx
+    prog, n_cols = _mixed_degree_program()
+    assert list(nx.air_constraint_degrees(prog, n_cols)) == [1, 2, 3, 4, 5, 2, 4]
+    sm, n = _small_program()
+    assert set(nx.air_constraint_degrees(sm, n)) <= {1, 2}        # the synthetic machine: transition + degree-2 constraints
+
+
+def test_subset_kernels_partition_the_constraints(tmp_path):
+    """nx_air_compile_subset: the kernels of the degree <= 3 constraints and of the rest use the whole program's alpha-power and column
+    indices, every constraint lands in exactly one of them, each holds only its own slice (the high part never loads column 3, which
+    only the cubic constraint reads), and both cross-compile for gfx950."""
+    import re, shutil, subprocess
+    import nexus_zkvm_amd as nx
+    prog, n_cols = _mixed_degree_program()
+    deg = nx.air_constraint_degrees(prog, n_cols)
+    low, high = (deg <= 3).astype(np.uint8), (deg > 3).astype(np.uint8)
+    src_low, src_high = nx.air_source(prog, n_cols, low), nx.air_source(prog, n_cols, high)
+
+    def powers(src):
+        return sorted([int(x) // 4 for x in re.findall(r"s0 = acc_mad\(s0, pw\[(\d+)\]", src)] + [int(x) // 4 for x in re.findall(r"q_mul\(Q\{pw\[(\d+)\]", src)])
+    assert powers(src_low) == [0, 1, 2, 5] and powers(src_high) == [3, 4, 6]
+    assert powers(nx.air_source(prog, n_cols)) == list(range(7))
+    assert "cols[3]" in src_low and "cols[3]" not in src_high and "cols[6]" in src_high and "cols[6]" not in src_low
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    for name, src in (("low", src_low), ("high", src_high)):
+        f = tmp_path / f"{name}.hip"
+        f.write_text(src)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-c", str(f), "-o", str(tmp_path / f"{name}.o")], check=True, timeout=300)
+    with pytest.raises(AssertionError):
+        nx.air_source(prog, n_cols, low[:3])

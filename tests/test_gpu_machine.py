@@ -70,6 +70,19 @@ def test_machine_prove_bit_exact_vs_oracle(be, nz, oracle, comps, kw):
     _same(ref, be.prove_machine(comps, nz.default_config(**kw), seed=0xBEEF, ad=b"\x01\x02"))
 
 
+def test_machine_degree_split_off_gives_the_same_bytes(nz, oracle):
+    """The machine's +2 components carry degree-4 main-trace constraints and degree-2 logup constraints: with "air.degree_split" the
+    logup constraints run on the committed evaluations and only the main columns are re-extended 4x; without it everything runs on the
+    4x domain like Stwo.  Same proof (== the oracle's, test above), sharded or not."""
+    comps, kw = MACHINE_CASES[-1]
+    ref = M.prove_machine(comps, O.default_cfg(**kw), seed=3, ad=b"z", threads=THREADS)
+    for split in (0, 1):
+        b = nz.HipBackend()
+        b.set_option("air.degree_split", split)
+        _same(ref, b.prove_machine(comps, nz.default_config(**kw), seed=3, ad=b"z"))
+        b.close()
+
+
 def test_machine_prove_at_2pow18_v1_shaped(be, nz, oracle):
     """The shape of the reference's v1 machine: LOG_CONSTRAINT_DEGREE = 2 (reference components/mod.rs:12), a wide
     interaction tree, small extra components of other sizes (machine.rs:82-91) — scaled to 2^18 rows so that the oracle finishes."""

@@ -833,6 +833,59 @@ def test_air_jit_rejects_malformed_programs(be, nz):
 
 # ---------------- the prover session: stwo::prover::prove over recorded AIRs (nx_prover_*) ----------------------------------
 
+def test_air_subset_kernels_add_up_to_the_whole_program(be, oracle):
+    """nx_air_compile_subset: the kernel of the degree <= 3 constraints and the kernel of the others, run one after the other on the same
+    accumulator, give the whole program's result bit for bit (same alpha powers, same column table; the columns a part does not
+    read are passed as NULL), and nx_air_constraint_degrees names the split."""
+    import nexus_zkvm_amd as nx
+    from test_air_program_cpu import _mixed_degree_program, denominators
+    prog, n_cols = _mixed_degree_program()
+    deg = nx.air_constraint_degrees(prog, n_cols)
+    low, high = (deg <= 3).astype(np.uint8), (deg > 3).astype(np.uint8)
+    log, e = 7, 9
+    rng = np.random.default_rng(21)
+    cols = rng.integers(0, P, (n_cols, 1 << e), dtype=np.uint32)
+    pw = rng.integers(0, P, (prog.n_constraints, 4), dtype=np.uint32)
+    start = rng.integers(0, P, (4, 1 << e), dtype=np.uint32)
+    den = denominators(log, e)
+    d_cols = be.columns_from_host(cols)
+    ptrs = [d_cols.ptr.value + k * (4 << e) for k in range(n_cols)]
+    whole, parts = be.columns_from_host(start), be.columns_from_host(start)
+    k_all, k_low, k_high = be.compile_air(prog, n_cols), be.compile_air(prog, n_cols, low), be.compile_air(prog, n_cols, high)
+    k_all.eval(ptrs, pw, den, log, e, whole)
+    p_low = list(ptrs); p_low[6] = None            # column 6 is read by degree-5 / degree-4 constraints only
+    p_high = list(ptrs); p_high[3] = None          # column 3 by the cubic constraint only
+    k_low.eval(p_low, pw, den, log, e, parts)
+    k_high.eval(p_high, pw, den, log, e, parts)
+    ref = np.stack(oracle.eval_constraint_program(prog, list(cols), pw, den, log, e, acc4=list(start)))
+    assert np.array_equal(whole.to_cpu(), ref) and np.array_equal(parts.to_cpu(), ref)
+    for k in (k_all, k_low, k_high):
+        k.close()
+
+
+@pytest.mark.parametrize("logs,bounds", [((10, 8), (2, 1)), ((6, 7), None)])
+def test_degree_split_does_not_change_a_byte(nz, oracle, logs, bounds):
+    """The degree-aware composition ("air.degree_split": constraints of degree <= 3 on the committed evaluations, the rest on the 4x
+    domain, only the columns they read re-extended) gives the proof of the plain evaluation on the 4x domain — and of the oracle,
+    which only knows the plain one — byte for byte, also when the +2 component has no high-degree constraint at all."""
+    from test_prover_session_cpu import build_mixed_air
+    ocfg = oracle.default_cfg(pow_bits=2, log_constraint_degree=2, log_blowup=1)
+    cfg = _hip_cfg(nz, ocfg)
+    for hd in (True, False):
+        drive, _ = build_mixed_air(logs, lcd=2, bounds=bounds, high_degree=hd)
+        so = oracle.ProverSession(ocfg, max(logs))
+        ref = so.prove(drive(so, so.commit))
+        for split in (1, 0):
+            b = nz.HipBackend()
+            b.set_option("air.degree_split", split)
+            assert b.get_option("air.degree_split") == split
+            sh = b.prover_session(cfg, max(logs))
+            words = sh.prove(drive(sh, sh.commit))
+            assert np.array_equal(words, ref), (hd, split)
+            sh.close()
+            b.close()
+
+
 def _hip_cfg(nz, ocfg):
     return nz.default_config(pow_bits=int(ocfg[0]), log_blowup=int(ocfg[1]), n_queries=int(ocfg[2]), log_last_layer_degree_bound=int(ocfg[3]),
                              hash_mode=int(ocfg[4]), fri_alpha_mode=int(ocfg[5]), log_constraint_degree=int(ocfg[6]))
@@ -856,16 +909,19 @@ def test_session_proves_the_recorded_synthetic_machine_identically(be, nz, oracl
     s.close()
 
 
-@pytest.mark.parametrize("logs,lcd,bounds", [((5, 7), 1, None), ((6,), 2, None), ((7, 5, 6), 1, None), ((11, 9), 1, None),
-                                             ((12, 8, 10), 2, (1, 2, 1)),    # per-component bounds: big +1 components, one small +2 component
-                                             ((9, 9), 2, (2, 1))])
-def test_session_logup_air_matches_the_oracle_session(be, nz, oracle, logs, lcd, bounds):
+@pytest.mark.parametrize("logs,lcd,bounds,hd", [((5, 7), 1, None, False), ((6,), 2, None, False), ((7, 5, 6), 1, None, False), ((11, 9), 1, None, False),
+                                                ((12, 8, 10), 2, (1, 2, 1), False),    # per-component bounds: big +1 components, one small +2 component
+                                                ((9, 9), 2, (2, 1), False),
+                                                # degree-3 / degree-4 constraints under the +2 bound, base- and secure-field, interleaved with the
+                                                # degree-2 ones: the prover evaluates the two parts on different domains (air.degree_split)
+                                                ((10, 8), 2, (2, 1), True), ((7, 9, 6), 2, None, True)])
+def test_session_logup_air_matches_the_oracle_session(be, nz, oracle, logs, lcd, bounds, hd):
     """A multi-component AIR with a secure logup column at offsets [-1, 0] and lookup elements drawn from the session's
     channel: same draws, same roots, same proof bytes as the CPU oracle's session, and the oracle's verifier accepts."""
     from test_prover_session_cpu import build_mixed_air
     ocfg = oracle.default_cfg(pow_bits=2, log_constraint_degree=lcd, log_blowup=lcd)
     cfg = _hip_cfg(nz, ocfg)
-    drive, tree_logs = build_mixed_air(logs, lcd=lcd, bounds=bounds)
+    drive, tree_logs = build_mixed_air(logs, lcd=lcd, bounds=bounds, high_degree=hd)
     so = oracle.ProverSession(ocfg, max(logs))
     oroots = []
     ocomps = drive(so, lambda cols: oroots.append(so.commit(cols)))

@@ -59,7 +59,7 @@ def test_oracle_machine_proves_and_verifies(oracle, comps, kw):
     locs, a, b, d = [], 0, 0, 0
     for c in comps:
         locs.append((a, b, d)); a += c[1]; b += c[2]; d += c[3]
-    components = [M.machine_component(ap, c, l, z, alpha, sh) for c, l, sh in zip(comps, locs, shifts)]
+    components = [M.machine_component(ap, c, l, z, alpha, sh, int(cfg[6])) for c, l, sh in zip(comps, locs, shifts)]
     assert v.verify(components, words) is None
     bad = words.copy(); bad[len(bad) // 2] ^= 1
     v2, z2, a2, _ = _verify(comps, cfg, bad, ad)

@@ -77,9 +77,10 @@ def _roots_from_proof(words):
     return [w[n_hdr + 1 + 8 * t: n_hdr + 9 + 8 * t].copy() for t in range(4)]
 
 
-def build_mixed_air(logs=(5, 7), seed=3, lcd=1, bounds=None):
+def build_mixed_air(logs=(5, 7), seed=3, lcd=1, bounds=None, high_degree=False):
     """Two logup components of different sizes + the committed columns.  Returns (drive(session) -> components, tree_logs).
-    bounds: per-component log constraint-degree bounds (0 / None = the configuration's)."""
+    bounds: per-component log constraint-degree bounds (0 / None = the configuration's).  high_degree: the components whose bound is
+    2 also carry degree-3 and degree-4 constraints (base- and secure-field), interleaved with the degree-2 ones."""
     ap = _ap()
 
     def drive(sess, commit, tamper=None):
@@ -94,7 +95,8 @@ def build_mixed_air(logs=(5, 7), seed=3, lcd=1, bounds=None):
         for i, l in enumerate(logs):
             cols4, shift = X.logup_interaction_trace(l, mains[i][0], z, alpha)
             inter += cols4
-            comps.append(X.logup_component(ap, l, z, alpha, shift, main0=3 * i, inter0=4 * i))
+            hd = high_degree and ((bounds[i] if bounds and bounds[i] else lcd) >= 2)
+            comps.append(X.logup_component(ap, l, z, alpha, shift, main0=3 * i, inter0=4 * i, high_degree=hd))
             comps[-1].log_constraint_degree_bound = bounds[i] if bounds else 0
             sess.mix_felts(shift)
         commit(inter)
@@ -106,12 +108,14 @@ def build_mixed_air(logs=(5, 7), seed=3, lcd=1, bounds=None):
     return drive, tree_logs
 
 
-@pytest.mark.parametrize("logs,lcd,bounds", [((5, 7), 1, None), ((6,), 2, None), ((7, 5, 6), 1, None),
-                                             ((7, 5, 6), 2, (1, 2, 1)),      # per-component bounds: composition 2^8, not 2^9
-                                             ((6, 6), 2, (2, 1))])
-def test_logup_air_round_trip_and_rejections(logs, lcd, bounds):
+@pytest.mark.parametrize("logs,lcd,bounds,hd", [((5, 7), 1, None, False), ((6,), 2, None, False), ((7, 5, 6), 1, None, False),
+                                                ((7, 5, 6), 2, (1, 2, 1), False),      # per-component bounds: composition 2^8, not 2^9
+                                                ((6, 6), 2, (2, 1), False),
+                                                ((6, 5), 2, (2, 1), True),              # degree-3 / degree-4 constraints under the +2 bound
+                                                ((5, 6), 2, None, True)])
+def test_logup_air_round_trip_and_rejections(logs, lcd, bounds, hd):
     cfg = O.default_cfg(pow_bits=2, log_constraint_degree=lcd, log_blowup=lcd)
-    drive, tree_logs = build_mixed_air(logs, lcd=lcd, bounds=bounds)
+    drive, tree_logs = build_mixed_air(logs, lcd=lcd, bounds=bounds, high_degree=hd)
     s = O.ProverSession(cfg, max(logs))
     roots = []
     comps = drive(s, lambda cols: roots.append(s.commit(cols)))
@@ -135,7 +139,8 @@ def test_logup_air_round_trip_and_rejections(logs, lcd, bounds):
     assert verifier(comps, words, extra_mix=99)[0] is not None                     # different transcript
     # a verifier that assumes other lookup elements evaluates other constraints: OODS mismatch
     ap = _ap()
-    other = [X.logup_component(ap, l, (1, 2, 3, 4), alpha, np.asarray(c.program.econsts, np.uint32)[2], 3 * i, 4 * i) for i, (l, c) in enumerate(zip(logs, comps))]
+    other = [X.logup_component(ap, l, (1, 2, 3, 4), alpha, np.asarray(c.program.econsts, np.uint32)[2], 3 * i, 4 * i, high_degree=c.program.n_constraints > 2)
+             for i, (l, c) in enumerate(zip(logs, comps))]
     for o, c in zip(other, comps):
         o.log_constraint_degree_bound = c.log_constraint_degree_bound
     other[0] = ap.Component(other[0].log_size, other[0].program, other[0].cols + [(0, 0)], other[0].masks + [[0]], other[0].log_constraint_degree_bound)
