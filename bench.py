@@ -170,7 +170,8 @@ def main():
         # The reference's v1 machine shape: LOG_CONSTRAINT_DEGREE = 2 (reference prover/src/components/mod.rs:12: the
         # constraints are evaluated on a 2^(n+2) domain, every column re-evaluated there; twiddles for n+3, machine.rs:186-194),
         # ~250 logup columns ~ 1.0 k interaction base columns (chips/range_check/range256.rs:271-288 et al.), 8 extension components
-        # of other sizes (machine.rs:82-91).  Reported next to the headline, not instead of it.
+        # of other sizes (machine.rs:82-91).  Reported next to the headline, not instead of it.  A +2 component of the machine has
+        # degree-4 main-trace constraints (what the bound is for: sra.rs:267-307) and degree-2 logup constraints (components/mod.rs:53).
         try:
             # per component as in the reference: the main component's bound is +2 (components/mod.rs:12,44-45), every extension's +1
             # (extensions/multiplicity.rs:108-110, ram_init_final.rs:58-60)
@@ -180,7 +181,7 @@ def main():
             v1_el = timed(v1_comps, v1_cfg, v1_steps, 1)
             v1_words, v1_stats = prove(v1_comps, v1_cfg, 4243, want_stats=True)
             n_cols = sum(c[1] + c[2] + c[3] for c in v1_comps)
-            v1 = {"workload": "v1-shaped: 2^%d rows, %d preprocessed + %d main + %d interaction columns (%d logup columns), log_constraint_degree bound 2 for the main component, 1 for the 8 extension components of 2^8..2^15 rows"
+            v1 = {"workload": "v1-shaped: 2^%d rows, %d preprocessed + %d main + %d interaction columns (%d logup columns), log_constraint_degree bound 2 for the main component (its main-trace constraints are degree 4, its logup constraints degree 2 like finalize_logup's: degree-aware composition, DESIGN.md §6 item 22), 1 for the 8 extension components of 2^8..2^15 rows"
                   % (args.log_rows, args.n_pre, args.n_main, 4 * args.v1_logup, args.v1_logup),
                   "value": (1 << args.log_rows) * v1_steps / v1_el, "unit": "cycles/s", "ms_per_step": 1e3 * v1_el / v1_steps, "steps": v1_steps,
                   "n_columns": n_cols, "proof_words": int(len(v1_words)),

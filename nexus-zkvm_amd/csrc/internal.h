@@ -128,6 +128,9 @@ struct ColSet {
 #define NX_GLOBAL_AS __attribute__((address_space(1)))
 typedef uint32_t nx_v4u32 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t gld(const uint32_t* p) { return *(NX_GLOBAL_AS const uint32_t*)p; }
+// word at (uniform base) + a 32-bit BYTE offset: the `global_load_dword v, v_off, s[base]` form — no 64-bit address per load (a column is
+// at most 2^30 words, so the offset of any row fits 32 bits)
+__device__ __forceinline__ uint32_t gld_off(const uint32_t* base, uint32_t byte_off) { return *(NX_GLOBAL_AS const uint32_t*)((NX_GLOBAL_AS const char*)base + byte_off); }
 __device__ __forceinline__ uint4 gld4(const uint32_t* p) { const nx_v4u32 v = *(NX_GLOBAL_AS const nx_v4u32*)p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void gst(uint32_t* p, uint32_t v) { *(NX_GLOBAL_AS uint32_t*)p = v; }
 __device__ __forceinline__ void gst4(uint32_t* p, uint4 v) { nx_v4u32 w = {v.x, v.y, v.z, v.w}; *(NX_GLOBAL_AS nx_v4u32*)p = w; }

@@ -71,13 +71,15 @@ __device__ __forceinline__ void load_block16(const ColSet& cols, u32 n_cols, u32
 #pragma unroll
             for (int k = 0; k < 16; k++) p[k] = cols.base + (uint64_t)(c0 + k) * cols.stride;
         }
+        const u32 off = (u32)i << 2;          // rows < 2^30: one 32-bit byte offset for all 16 loads, the column bases stay in SGPRs
 #pragma unroll
-        for (int k = 0; k < 16; k++) dst[k] = gld(p[k] + i);
+        for (int k = 0; k < 16; k++) dst[k] = gld_off(p[k], off);
     } else {
+        const u32 off = (u32)i << 2;
 #pragma unroll
         for (int k = 0; k < 16; k++) p[k] = cols.col(min(c0 + k, n_cols - 1));
 #pragma unroll
-        for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? gld(p[k] + i) : 0u;
+        for (int k = 0; k < 16; k++) dst[k] = (c0 + k < n_cols) ? gld_off(p[k], off) : 0u;
     }
 }
 

@@ -1099,7 +1099,8 @@ static void release_split_cache(nx_ctx* ctx) {
 }
 int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g) {
     if (g.prepared) return NX_OK;
-    g.split = ctx->opt.air_degree_split && comp_log_cd(g.log_cd, cfg) > 1 && g.n_constraints > 0;
+    // not when the component's own domain is the committed one (bound == blowup): its evaluations are there already
+    g.split = ctx->opt.air_degree_split && comp_log_cd(g.log_cd, cfg) > 1 && comp_log_cd(g.log_cd, cfg) != cfg.log_blowup && g.n_constraints > 0;
     if (g.split) {
         // the analysis and the two kernels depend on the program only: once per context and AIR
         std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));

@@ -9,6 +9,7 @@ timeout 600 python bench.py --steps 20 > $O/bench.json 2> $O/bench.err; tail -1 
 python tools/rocprof_summary.py $O/kt_bench/kt_results.db $O/bench_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-v1-shaped --steps 3"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$O/kt_v1 -o kt -- python $R/bench.py --lcd 2 --n-logup 250 --extra-comps 8 --no-cpu-baseline --no-v1-shaped --steps 2 > /dev/null 2>&1)
 python tools/rocprof_summary.py $O/kt_v1/kt_results.db $O/v1_shaped_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --lcd 2 --n-logup 250 --extra-comps 8 --no-cpu-baseline --no-v1-shaped --steps 2"
+python tools/trace_gaps.py $O/kt_bench/kt_results.db 25 2 > $O/trace_gaps.txt 2>&1
 rm -rf $O/kt_bench $O/kt_v1
 timeout 400 python tools/pmc_traffic.py --out $O/fft_traffic.json > /dev/null 2>&1
 timeout 400 python tools/pmc_sq.py --opts fft.pipe=0 --out $O/fft_sq_counters.json > /dev/null 2>&1

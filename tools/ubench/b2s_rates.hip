@@ -10,9 +10,17 @@ template <int V> FI u32 rotr(u32 x, int r) {
     if (V == 2) return (x >> r) | (x << (32 - r));                             // let the compiler choose
     return __builtin_amdgcn_alignbit(x, x, r);
 }
+// rotr(d ^ a, 16) as two SDWA xors (VOP2 encodings with word selects): the halves of the xor land swapped
+FI u32 xor_rot16_sdwa(u32 d, u32 a) {
+    u32 t;
+    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(d), "v"(a));
+    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(t) : "v"(d), "v"(a));
+    return t;
+}
 template <int V> FI void G(u32& a, u32& b, u32& c, u32& d, u32 x, u32 y) {
     if (V == 3) { a = a + b; a = a + x; } else a = a + b + x;
-    d = rotr<V>(d ^ a, 16); c = c + d; b = rotr<V>(b ^ c, 12);
+    if (V == 4) d = xor_rot16_sdwa(d, a); else d = rotr<V>(d ^ a, 16);
+    c = c + d; b = rotr<V>(b ^ c, 12);
     if (V == 3) { a = a + b; a = a + y; } else a = a + b + y;
     d = rotr<V>(d ^ a, 8); c = c + d; b = rotr<V>(b ^ c, 7);
 }
@@ -42,7 +50,7 @@ template <int V> FI void compress(u32* h, const u32* m, u32 t0, u32 f0) {
     }
     for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
 }
-#define ITERS 64
+#define ITERS 1024   // ~15 ms per run: long enough for the clock to settle (the 64-iteration version measured the ramp)
 template <int V, int NCH> __global__ __launch_bounds__(256) void k(u32* out, u32 seed) {
     u32 h[NCH][8], m[16];
     for (int c = 0; c < NCH; c++) for (int i = 0; i < 8; i++) h[c][i] = threadIdx.x * 31 + i + c * 7 + seed;
@@ -57,10 +65,12 @@ template <int V, int NCH> __global__ __launch_bounds__(256) void k(u32* out, u32
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 template <int V, int NCH> void run(const char* name, int blocks_per_cu) {
-    u32* d; (void)hipMalloc(&d, 256 * 16 * 256 * 4);
+    u32* d = nullptr; hipError_t me = hipMalloc(&d, 256 * 16 * 256 * 4);
+    if (me != hipSuccess) { printf("hipMalloc: %s\n", hipGetErrorString(me)); return; }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     int blocks = 256 * blocks_per_cu;
     hipLaunchKernelGGL((k<V, NCH>), dim3(blocks), dim3(256), 0, 0, d, 1u);
+    hipLaunchKernelGGL((k<V, NCH>), dim3(blocks), dim3(256), 0, 0, d, 3u);
     (void)hipEventRecord(e0); hipLaunchKernelGGL((k<V, NCH>), dim3(blocks), dim3(256), 0, 0, d, 2u); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     double n = (double)blocks * 256 * ITERS * NCH;
@@ -68,8 +78,10 @@ template <int V, int NCH> void run(const char* name, int blocks_per_cu) {
     (void)hipFree(d);
 }
 int main() {
-    run<0, 1>("alignbit, add3 (current)", 8);
-    run<0, 1>("alignbit, add3 (current)", 4);
+    run<0, 1>("warm-up", 8);
+    for (int o : {1, 2, 4, 8}) run<0, 1>("alignbit, add3 (current)", o);      // latency- or issue-bound?
+    run<4, 1>("SDWA xor pair for rot16, alignbit, add3", 8);
+    run<4, 1>("SDWA xor pair for rot16, alignbit, add3", 4);
     run<1, 1>("perm for 16/8, add3", 8);
     run<2, 1>("shift/or rotate (compiler's choice)", 8);
     run<3, 1>("alignbit, two adds", 8);
