@@ -90,24 +90,62 @@ __global__ __launch_bounds__(256) void logup_col_kernel(LogupTupleFrac fa, Logup
 // no previous column is re-read, 16 bytes are written per column.  Descriptors live in device memory (flat pointer / alpha-power
 // tables), so the tuple width is not limited by the kernel argument size (the reference's widest relation has 200 elements).
 struct LogupBatchFrac { u32 first_col, n_cols, first_ap, pad; const u32* mult; QM31 z, scale; };
+// The QM31 inverse of a denominator is (conj-style) den^-1 = (a, -b) * D^-1 with D = a^2 - (2+i) b^2 in CM31 and D^-1 = conj(D) / N,
+// N = D.a^2 + D.b^2 in M31: the one expensive step is the M31 inverse of N (37 multiplications of the 57 of q_inv).  A lane walks
+// the fractions of its row in groups of LOGUP_GROUP and inverts the group's norms with ONE m_inv (Montgomery's trick on the M31 norms:
+// 3 multiplications per element): 57 -> 20 + 3 + 37/8 multiplications per fraction.  Same values: an inverse is unique; a zero
+// denominator (norm 0) still gives 0 like m_inv(0), and does not poison its group.
+constexpr int LOGUP_GROUP = 8;
 __global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* __restrict__ fr, u32 n_fracs, const u32* const* __restrict__ tuple_cols,
                                                          const u32* __restrict__ ap /*4 words each*/, u32* const* __restrict__ out /*4 per fraction*/, u32 n) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     QM31 run = q_zero();
-    for (u32 j = 0; j < n_fracs; j++) {
-        const LogupBatchFrac f = fr[j];
-        u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        for (u32 k = 0; k < f.n_cols; k++) {
-            const u32 v = gld(tuple_cols[f.first_col + k] + r);
-            const u32* a = ap + 4 * (size_t)(f.first_ap + k);
-            s0 = acc_mad(s0, a[0], v); s1 = acc_mad(s1, a[1], v); s2 = acc_mad(s2, a[2], v); s3 = acc_mad(s3, a[3], v);
-            if ((k & 3) == 3) { s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3); }
+    for (u32 j0 = 0; j0 < n_fracs; j0 += LOGUP_GROUP) {
+        QM31 den[LOGUP_GROUP]; CM31 dd[LOGUP_GROUP]; u32 nrm[LOGUP_GROUP], pre[LOGUP_GROUP];
+#pragma unroll
+        for (int g = 0; g < LOGUP_GROUP; g++) {
+            if (j0 + g < n_fracs) {                                   // uniform
+                const LogupBatchFrac f = fr[j0 + g];
+                u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                for (u32 k = 0; k < f.n_cols; k++) {
+                    const u32 v = gld(tuple_cols[f.first_col + k] + r);
+                    const u32* a = ap + 4 * (size_t)(f.first_ap + k);
+                    s0 = acc_mad(s0, a[0], v); s1 = acc_mad(s1, a[1], v); s2 = acc_mad(s2, a[2], v); s3 = acc_mad(s3, a[3], v);
+                    if ((k & 3) == 3) { s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3); }
+                }
+                den[g] = q_sub(qm(acc_final(s0), acc_final(s1), acc_final(s2), acc_final(s3)), f.z);
+                dd[g] = c_sub(c_mul(den[g].a, den[g].a), c_mul_R(c_mul(den[g].b, den[g].b)));
+                nrm[g] = m_add(m_sqr(dd[g].a), m_sqr(dd[g].b));
+            } else { den[g] = q_zero(); dd[g] = cm(0, 0); nrm[g] = 1; }
+            const u32 nz = nrm[g] ? nrm[g] : 1u;
+            pre[g] = g ? m_mul(pre[g - 1], nz) : nz;
         }
-        const QM31 den = q_sub(qm(acc_final(s0), acc_final(s1), acc_final(s2), acc_final(s3)), f.z);
-        const QM31 num = f.mult ? q_mul_m(f.scale, gld(f.mult + r)) : f.scale;
-        run = q_add(run, q_mul(num, q_inv(den)));
-        gst(out[4 * j] + r, run.a.a); gst(out[4 * j + 1] + r, run.a.b); gst(out[4 * j + 2] + r, run.b.a); gst(out[4 * j + 3] + r, run.b.b);
+        u32 inv = m_inv(pre[LOGUP_GROUP - 1]);
+#pragma unroll
+        for (int g = LOGUP_GROUP - 1; g >= 0; g--) {
+            const u32 nz = nrm[g] ? nrm[g] : 1u;
+            const u32 ni = g ? m_mul(inv, pre[g - 1]) : inv;          // 1 / nz
+            inv = m_mul(inv, nz);
+            pre[g] = nrm[g] ? ni : 0u;                                 // reused: 1 / norm (0 for a zero denominator, like m_inv)
+        }
+#pragma unroll
+        for (int g = 0; g < LOGUP_GROUP; g++) {
+            if (j0 + g < n_fracs) {
+                const u32 j = j0 + g;
+                const LogupBatchFrac f = fr[j];
+                const CM31 di = cm(m_mul(dd[g].a, pre[g]), m_mul(m_neg(dd[g].b), pre[g]));
+                QM31 qi; qi.a = c_mul(den[g].a, di); qi.b = c_mul(c_neg(den[g].b), di);
+                if ((f.scale.a.b | f.scale.b.a | f.scale.b.b) == 0) {          // uniform: a base-field numerator (+-1, a multiplicity): 4 products, not 16
+                    const u32 nm = f.mult ? m_mul(f.scale.a.a, gld(f.mult + r)) : f.scale.a.a;
+                    run = q_add(run, q_mul_m(qi, nm));
+                } else {
+                    const QM31 num = f.mult ? q_mul_m(f.scale, gld(f.mult + r)) : f.scale;
+                    run = q_add(run, q_mul(num, qi));
+                }
+                gst(out[4 * j] + r, run.a.a); gst(out[4 * j + 1] + r, run.a.b); gst(out[4 * j + 2] + r, run.b.a); gst(out[4 * j + 3] + r, run.b.b);
+            }
+        }
     }
 }
 

@@ -36,3 +36,18 @@ print("gap histogram:", {k: (v[0], round(v[1] / 1e6, 3)) for k, v in hist.items(
 print("largest gaps (us, at ms, after kernel -> before kernel):")
 for g, p, n, at in sorted(gaps, reverse=True)[:n_gaps]:
     print("  %8.1f  @%7.3f  %s -> %s" % (g / 1e3, at / 1e6, p[:48], n[:48]))
+
+# optional: list the launches of a window [from_ms, to_ms) of that prove, consecutive launches of one kernel merged
+if len(sys.argv) > 5:
+    lo, hi = float(sys.argv[4]) * 1e6 + t0, float(sys.argv[5]) * 1e6 + t0
+    print("launches in [%s, %s) ms:" % (sys.argv[4], sys.argv[5]))
+    run = None
+    for s, e, name in prove:
+        if s < lo or s >= hi:
+            continue
+        if run and run[0] == name:
+            run[1] += 1; run[2] += e - s; run[4] = e
+        else:
+            if run: print("  @%7.3f  %4d x %-60s %9.1f us busy, %9.1f us span" % ((run[3] - t0) / 1e6, run[1], run[0][:60], run[2] / 1e3, (run[4] - run[3]) / 1e3))
+            run = [name, 1, e - s, s, e]
+    if run: print("  @%7.3f  %4d x %-60s %9.1f us busy, %9.1f us span" % ((run[3] - t0) / 1e6, run[1], run[0][:60], run[2] / 1e3, (run[4] - run[3]) / 1e3))
