@@ -289,6 +289,23 @@ impl Session {
         Ok(v)
     }
     pub fn ctx(&self) -> *mut sys::nx_ctx { self.ctx }
+    /// Per-context policy (include/nexus_hip.h `nx_ctx_set_option`), e.g. `("air.degree_split", 0)` to evaluate every constraint on the
+    /// component's full domain like Stwo does.  No option changes a proof byte.
+    pub fn set_option(&mut self, name: &str, value: i64) -> Result<(), ProvingErrorKind> {
+        let c = std::ffi::CString::new(name).expect("option name");
+        check(self.ctx, unsafe { sys::nx_ctx_set_option(self.ctx, c.as_ptr(), value) })
+    }
+}
+impl RecordedComponent {
+    /// An upper bound of every constraint's degree in the trace columns: the smallest sound `log_constraint_degree_bound` is the e with
+    /// max degree <= 2^e + 1 (what a `FrameworkEval::max_constraint_log_degree_bound` must return, components/mod.rs:44-45).
+    pub fn constraint_degrees(&self) -> Vec<u32> {
+        let mut d = vec![0u32; self.n_constraints as usize];
+        let rc = unsafe { sys::nx_air_constraint_degrees(std::ptr::null_mut(), self.program.as_ptr(), self.program.len() as u32, self.n_regs, self.col_tree.len() as u32,
+                                                         (self.econsts.len() / 4) as u32, self.n_constraints, d.as_mut_ptr()) };
+        assert_eq!(rc, sys::NX_OK, "{}", last_error(std::ptr::null()));
+        d
+    }
 }
 impl Drop for Session { fn drop(&mut self) { unsafe { sys::nx_prover_destroy(self.p); sys::nx_ctx_destroy(self.ctx); } } }
 
