@@ -13,11 +13,11 @@ python tools/trace_gaps.py $O/kt_bench/kt_results.db 25 2 > $O/trace_gaps.txt 2>
 rm -rf $O/kt_bench $O/kt_v1
 timeout 400 python tools/pmc_traffic.py --out $O/fft_traffic.json > /dev/null 2>&1
 timeout 400 python tools/pmc_sq.py --opts fft.pipe=0 --out $O/fft_sq_counters.json > /dev/null 2>&1
-for n in 16 18 20 22 24; do timeout 300 python bench.py --log-rows $n --no-cpu-baseline --no-v1-shaped --steps 5 2>/dev/null | tail -1 | python -c "
+for n in 16 18 20 22 24; do st=20; [ $n -ge 22 ] && st=5; timeout 300 python bench.py --log-rows $n --no-cpu-baseline --no-v1-shaped --steps $st 2>/dev/null | tail -1 | python -c "
 import sys, json
 r = json.loads(sys.stdin.read())
 print(json.dumps({'log_rows': r['config']['log_n_rows'], 'ms_per_step': round(r['ms_per_step'], 3), 'cycles_per_s': r['value'], 'lde_ms': round(r['roofline']['kernel_ms'], 3), 'lde_alg_GBs': round(r['roofline']['achieved'], 1), 'stages_ms': r['stages_ms']}))" >> $O/bench_sizes.jsonl; done
 cat $O/bench_sizes.jsonl | cut -c 1-200
 bash tools/evidence.sh $O/evidence.jsonl > /dev/null 2>&1
-timeout 300 python tools/keccak_shaped.py --steps 3 > $O/keccak_shaped.json 2>/dev/null
+timeout 300 python tools/keccak_shaped.py --steps 5 > $O/keccak_shaped.json 2>/dev/null
 ls -la $O
