@@ -59,9 +59,9 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
 /* Per-context policy and tuning.  The NX_* environment variables only seed a new context's defaults; what a
  * context does is decided by its own options, so two contexts of one process may differ.  Names: "fft.pipe" (0/1: pipelined LDE
  * kernels of fft_pipe.hip, default 0), "fft.pipe_blocks_per_cu" (1..2), "fft.pipe_grid" (0 = automatic, else persistent blocks per launch), "fft.batch_cols",
- * "fft.streams" (1..4), "fri.dist_min_log" and "dist.chunks" (row-sharded prove: every GPU of a proof must use the same values),
- * "air.segment" (instruction budget of one generated AIR kernel), "air.degree_split" (1: degree-aware composition, see
- * nx_air_constraint_degrees).  Unknown names and out-of-range values are NX_ERR_ARG.
+ * "fft.streams" (1..4), "fri.dist_min_log", "dist.chunks" and "air.degree_split" (1: degree-aware composition, see
+ * nx_air_constraint_degrees) — row-sharded prove: every GPU of a proof must use the same values of these three, they shape the
+ * exchanges —, "air.segment" (instruction budget of one generated AIR kernel).  Unknown names and out-of-range values are NX_ERR_ARG.
  * None of them changes a result: proofs, roots and transforms are bit-identical under every setting. */
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value);
 int nx_ctx_get_option(const nx_ctx* ctx, const char* name, int64_t* value);
