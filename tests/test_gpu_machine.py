@@ -273,6 +273,45 @@ def test_session_driven_by_several_ranks(be, nz, oracle):
             _same(ref, w)
 
 
+def test_session_degree_split_on_several_ranks(be, nz, oracle):
+    """The degree-aware composition row-sharded: a +2 component whose degree-3 / degree-4 constraints (one of them secure-field, reading
+    the logup column at offset -1) are interleaved with the degree-2 ones.  The low part runs on every rank's rows of the committed
+    evaluations, the high part on re-extended columns handed out by an all-to-all (the masked one all-gathered); same bytes as the
+    oracle's plain evaluation on the 4x domain, on 1, 2 and 4 ranks, with the split on and off."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    log = 9
+    kw = dict(pow_bits=4, log_constraint_degree=2)
+    cfg, ocfg = nz.default_config(**kw), O.default_cfg(**kw)
+    nat, fin = AE.logup_main_trace(log, 43)
+
+    def drive(session, uploader):
+        session.mix_u64(log)
+        session.commit([])
+        uploader(fin)
+        z, alpha = session.draw_felt(), session.draw_felt()
+        inter, shift = AE.logup_interaction_trace(log, nat, z, alpha)
+        session.mix_felts(np.zeros(4, np.uint32))
+        uploader(inter)
+        return session.prove([AE.logup_component(ap, log, z, alpha, shift, high_degree=True)])
+
+    o = O.ProverSession(ocfg, log)
+    ref = drive(o, lambda cols: o.commit(cols))
+    s = be.prover_session(cfg, log)
+    _same(ref, drive(s, lambda cols: s.commit(cols)))
+    s.close()
+    for world, split in ((2, 1), (4, 1), (2, 0)):
+        def fn(b, comm, rank):
+            b.set_option("air.degree_split", split)
+            ss = b.prover_session(cfg, log)
+            ss.set_comm(comm)
+            out = drive(ss, lambda cols: ss.commit(cols))
+            ss.close()
+            return out
+        for w in _run_ranks(nz, world, fn):
+            _same(ref, w)
+
+
 def test_bench_two_processes_one_proof(tmp_path):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank) — over gloo with both ranks on this
     box's GPU, since RCCL refuses two ranks on one device: ONE row-sharded proof per step, one JSON line from rank 0."""
