@@ -87,12 +87,36 @@ __global__ __launch_bounds__(EVAL_THREADS) void eval_at_point_kernel(ColSet poly
 }
 
 // ------------------------------------------------------------------ K8: DEEP quotients ------
+__device__ __forceinline__ u32 get_lane4(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 struct QBatchDev {       // one ColumnSampleBatch, device-resident description
     u32 first, count;    // range in the flattened (col_idx, c) arrays
     u32 prx[2], pry[2], pix[2], piy[2];  // CM31 parts of the sample point
     u32 sum_a[4], sum_b[4];              // Σ alpha^k a_k , Σ alpha^k b_k   (QM31)
     u32 coeff[4];                        // alpha^{count}
 };
+
+// 1 / den_b(d) for the 4 domain points of a lane, den (CM31) = (Re p.x - d.x) Im p.y - (Re p.y - d.y) Im p.x: the four M31 norms are
+// inverted with ONE m_inv (Montgomery's trick; a zero denominator gives 0, as c_inv does, and leaves the other three alone)
+__device__ __forceinline__ void quot_den_inv4(const QBatchDev& B, const Pt dp[4], CM31 di[4]) {
+    const CM31 prx = cm(B.prx[0], B.prx[1]), pry = cm(B.pry[0], B.pry[1]), pix = cm(B.pix[0], B.pix[1]), piy = cm(B.piy[0], B.piy[1]);
+    CM31 den[4]; u32 nrm[4], pre[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        den[i] = c_sub(c_mul(c_sub(prx, cm(dp[i].x, 0)), piy), c_mul(c_sub(pry, cm(dp[i].y, 0)), pix));
+        nrm[i] = m_add(m_sqr(den[i].a), m_sqr(den[i].b));
+        const u32 nz = nrm[i] ? nrm[i] : 1u;
+        pre[i] = i ? m_mul(pre[i - 1], nz) : nz;
+    }
+    u32 inv = m_inv(pre[3]);
+#pragma unroll
+    for (int i = 3; i >= 0; i--) {
+        const u32 nz = nrm[i] ? nrm[i] : 1u;
+        const u32 ni = i ? m_mul(inv, pre[i - 1]) : inv;
+        inv = m_mul(inv, nz);
+        const u32 ninv = nrm[i] ? ni : 0u;
+        di[i] = cm(m_mul(den[i].a, ninv), m_mul(m_neg(den[i].b), ninv));
+    }
+}
 
 // Each lane owns 4 consecutive rows (one 16-byte read per column: 1 KB contiguous per wave and column instead of 256 B, which
 // is what lets ~440 concurrent column streams run near HBM speed).  In bit-reversed order the 4 domain points of rows
@@ -149,13 +173,97 @@ __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, u32
             }
         }
         const QM31 sa = q_load(B.sum_a), sb = q_load(B.sum_b), coeff = q_load(B.coeff);
-        const CM31 prx = cm(B.prx[0], B.prx[1]), pry = cm(B.pry[0], B.pry[1]), pix = cm(B.pix[0], B.pix[1]), piy = cm(B.piy[0], B.piy[1]);
+        CM31 di[4];
+        quot_den_inv4(B, dp, di);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             QM31 num = q_sub(qm(acc_final(n[i][0]), acc_final(n[i][1]), acc_final(n[i][2]), acc_final(n[i][3])), q_add(q_mul_m(sa, dp[i].y), sb));
-            // denominator (CM31): (Re p.x - d.x) Im p.y - (Re p.y - d.y) Im p.x
-            CM31 den = c_sub(c_mul(c_sub(prx, cm(dp[i].x, 0)), piy), c_mul(c_sub(pry, cm(dp[i].y, 0)), pix));
-            acc[i] = q_add(q_mul(acc[i], coeff), q_mul_c(num, c_inv(den)));
+            acc[i] = q_add(q_mul(acc[i], coeff), q_mul_c(num, di[i]));
+        }
+    }
+    *reinterpret_cast<uint4*>(o0 + r) = make_uint4(acc[0].a.a, acc[1].a.a, acc[2].a.a, acc[3].a.a);
+    *reinterpret_cast<uint4*>(o1 + r) = make_uint4(acc[0].a.b, acc[1].a.b, acc[2].a.b, acc[3].a.b);
+    *reinterpret_cast<uint4*>(o2 + r) = make_uint4(acc[0].b.a, acc[1].b.a, acc[2].b.a, acc[3].b.a);
+    *reinterpret_cast<uint4*>(o3 + r) = make_uint4(acc[0].b.b, acc[1].b.b, acc[2].b.b, acc[3].b.b);
+}
+
+// ---- the same quotients through the COEFFICIENTS (single GPU, wide size groups) -------------------------------------------------
+// A batch's numerator Σ_k c_k f_k(d) is linear in the columns, so it is the evaluation at d of ONE secure polynomial whose
+// coefficients are Σ_k c_k coef_k: combining the coefficient columns (half as long as their extensions at blowup 2), extending the
+// 4 coordinate columns per batch and finishing row by row reads half the bytes of the row-wise sum over the extensions — and gives the
+// same field elements, the arithmetic being exact.  Lane = 4 consecutive coefficients; out: [batch][coordinate] columns of n words.
+__global__ __launch_bounds__(256) void quotient_combine_kernel(ColSet polys, u32 n4, const QBatchDev* __restrict__ batches, u32 n_batches,
+                                                               const u32* __restrict__ col_idx, const u32* __restrict__ cks /*4 per entry*/,
+                                                               u32* __restrict__ out, size_t col_stride) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n4) return;
+    const u32 r = 4 * j;
+    for (u32 b = 0; b < n_batches; b++) {
+        const QBatchDev& B = batches[b];
+        u64 n[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) for (int q = 0; q < 4; q++) n[i][q] = 0;
+        const u32 end = B.first + B.count;
+        u32 k = B.first;
+        for (; k + 4 <= end; k += 4) {
+            uint4 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) f[u] = gld4(polys.col(col_idx[k + u]) + r);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const u32 c0 = cks[4 * (k + u)], c1 = cks[4 * (k + u) + 1], c2 = cks[4 * (k + u) + 2], c3 = cks[4 * (k + u) + 3];
+                const u32 fv[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    n[i][0] = acc_mad(n[i][0], c0, fv[i]); n[i][1] = acc_mad(n[i][1], c1, fv[i]);
+                    n[i][2] = acc_mad(n[i][2], c2, fv[i]); n[i][3] = acc_mad(n[i][3], c3, fv[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) for (int q = 0; q < 4; q++) n[i][q] = acc_fold(n[i][q]);
+        }
+        for (; k < end; k++) {
+            const uint4 f = gld4(polys.col(col_idx[k]) + r);
+            const u32 c0 = cks[4 * k], c1 = cks[4 * k + 1], c2 = cks[4 * k + 2], c3 = cks[4 * k + 3];
+            const u32 fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                n[i][0] = acc_mad(n[i][0], c0, fv[i]); n[i][1] = acc_mad(n[i][1], c1, fv[i]);
+                n[i][2] = acc_mad(n[i][2], c2, fv[i]); n[i][3] = acc_mad(n[i][3], c3, fv[i]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<uint4*>(out + (size_t)(4 * b + q) * col_stride + r) = make_uint4(acc_final(n[0][q]), acc_final(n[1][q]), acc_final(n[2][q]), acc_final(n[3][q]));
+    }
+}
+
+// rows 4j .. 4j+3 from the extended combinations: num_b = G_b(d) - (d.y Σ a + Σ b), acc = acc * alpha^count_b + num_b / den_b(d).  The
+// CM31 denominators of the 4 rows of a batch are inverted together (one m_inv for their 4 norms).
+__global__ __launch_bounds__(256) void quotient_finish_kernel(const u32* __restrict__ ext, size_t col_stride, int log, u32 n4, const QBatchDev* __restrict__ batches, u32 n_batches,
+                                                              u32* o0, u32* o1, u32* o2, u32* o3) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n4) return;
+    const u32 r = 4 * j;
+    Pt dp[4];
+    dp[0] = pt_from_index(circle_domain_index(log, bitrev(r, log)));
+    dp[1].x = dp[0].x; dp[1].y = m_neg(dp[0].y);
+    dp[2].x = m_neg(dp[0].x); dp[2].y = dp[1].y;
+    dp[3].x = dp[2].x; dp[3].y = dp[0].y;
+    QM31 acc[4] = {q_zero(), q_zero(), q_zero(), q_zero()};
+    for (u32 b = 0; b < n_batches; b++) {
+        const QBatchDev& B = batches[b];
+        uint4 g[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[q] = gld4(ext + (size_t)(4 * b + q) * col_stride + r);
+        const QM31 sa = q_load(B.sum_a), sb = q_load(B.sum_b), coeff = q_load(B.coeff);
+        CM31 di[4];
+        quot_den_inv4(B, dp, di);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const QM31 G = qm(get_lane4(g[0], i), get_lane4(g[1], i), get_lane4(g[2], i), get_lane4(g[3], i));
+            const QM31 num = q_sub(G, q_add(q_mul_m(sa, dp[i].y), sb));
+            acc[i] = q_add(q_mul(acc[i], coeff), q_mul_c(num, di[i]));
         }
     }
     *reinterpret_cast<uint4*>(o0 + r) = make_uint4(acc[0].a.a, acc[1].a.a, acc[2].a.a, acc[3].a.a);
@@ -424,18 +532,17 @@ extern "C" {
 // does, so that the partial accumulations of the GPUs sum to the full quotient).
 // row_begin / n_rows: the block of (bit-reversed) rows this call computes — the whole domain on one GPU, one contiguous block per GPU
 // in a row-sharded prove; d_cols and d_out4 then point at the BLOCK (n_rows words each).
-static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
-                                     uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
-                                     const uint32_t* values, const uint8_t* entry_local, int include_line, uint32_t* const* d_out4,
-                                     uint64_t row_begin, uint64_t n_rows) {
-    if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: bad log_size");
-    if (row_begin + n_rows > ((uint64_t)1 << log_size) || (log_size >= 2 && ((row_begin | n_rows) & 3))) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: row block outside the domain or not a multiple of 4 rows");
+// quotient_constants + ColumnSampleBatch descriptors of one size group (host): per batch the point, Σ alpha^k a_k, Σ alpha^k b_k and
+// alpha^count; per entry the column index and c_k = alpha^k (conj(p.y) - p.y)
+static int quotient_descriptors(nx_ctx* ctx, uint32_t n_cols, const uint32_t random_coeff[4], uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts,
+                                const uint32_t* col_idx, const uint32_t* values, const uint8_t* entry_local, int include_line,
+                                std::vector<QBatchDev>* hb_out, std::vector<uint32_t>* cks_out, std::vector<uint32_t>* lidx_out) {
     QM31 alpha = q_load(random_coeff);
     size_t total = 0;
     for (uint32_t b = 0; b < n_batches; b++) total += batch_counts[b];
-    std::vector<QBatchDev> hb(n_batches);
-    std::vector<uint32_t> cks; cks.reserve(4 * total);
-    std::vector<uint32_t> lidx; lidx.reserve(total);
+    std::vector<QBatchDev>& hb = *hb_out; hb.assign(n_batches, QBatchDev());
+    std::vector<uint32_t>& cks = *cks_out; cks.clear(); cks.reserve(4 * total);
+    std::vector<uint32_t>& lidx = *lidx_out; lidx.clear(); lidx.reserve(total);
     size_t k = 0;
     for (uint32_t b = 0; b < n_batches; b++) {
         QBatchDev& B = hb[b];
@@ -464,6 +571,17 @@ static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint3
         B.count = (uint32_t)lidx.size() - B.first;
         q_store(B.sum_a, sa); q_store(B.sum_b, sb); q_store(B.coeff, a_pow);
     }
+    return NX_OK;
+}
+
+static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4],
+                                     uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
+                                     const uint32_t* values, const uint8_t* entry_local, int include_line, uint32_t* const* d_out4,
+                                     uint64_t row_begin, uint64_t n_rows) {
+    if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: bad log_size");
+    if (row_begin + n_rows > ((uint64_t)1 << log_size) || (log_size >= 2 && ((row_begin | n_rows) & 3))) return set_err(ctx, NX_ERR_ARG, "nx_accumulate_quotients: row block outside the domain or not a multiple of 4 rows");
+    std::vector<QBatchDev> hb; std::vector<uint32_t> cks, lidx;
+    NX_TRY(quotient_descriptors(ctx, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, entry_local, include_line, &hb, &cks, &lidx));
     const size_t n_local = lidx.size();
     // descriptors, column indices, coefficients and the column pointer table travel in ONE stream-ordered copy through the pinned
     // staging ring (valid until the ring wraps, which synchronises): no allocation, no synchronisation per size group
@@ -498,6 +616,52 @@ int accumulate_quotients_rows(nx_ctx* ctx, uint32_t log_size, const uint32_t* co
                               const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx, const uint32_t* values, uint32_t* const* d_out4,
                               uint64_t row_begin, uint64_t n_rows) {
     return accumulate_quotients_impl(ctx, log_size, d_cols, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, nullptr, 1, d_out4, row_begin, n_rows);
+}
+
+// The quotients of one size group from the COEFFICIENT columns (d_polys: 2^log_coef words each, the polynomials whose extensions on
+// 2^log_size points the row-wise path reads): combine per batch, extend the 4 n_batches combinations, finish row by row.  Same values
+// as accumulate_quotients_rows on the extensions (exact arithmetic), about half the bytes at blowup 2.
+int accumulate_quotients_coeffs(nx_ctx* ctx, const nx_twiddles* tw, uint32_t log_size, uint32_t log_coef, const uint32_t* const* d_polys, uint32_t n_cols,
+                                const uint32_t random_coeff[4], uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
+                                const uint32_t* values, uint32_t* const* d_out4) {
+    if (log_coef < 2 || log_size <= log_coef || log_size > 30 || n_batches == 0) return set_err(ctx, NX_ERR_ARG, "accumulate_quotients_coeffs: bad shape");
+    std::vector<QBatchDev> hb; std::vector<uint32_t> cks, lidx;
+    NX_TRY(quotient_descriptors(ctx, n_cols, random_coeff, n_batches, points, batch_counts, col_idx, values, nullptr, 1, &hb, &cks, &lidx));
+    size_t bytes_b = hb.size() * sizeof(QBatchDev), bytes_i = lidx.size() * 4, bytes_c = cks.size() * 4, bytes_t = (size_t)n_cols * 8;
+    size_t off_i = (bytes_b + 15) & ~(size_t)15, off_c = off_i + ((bytes_i + 15) & ~(size_t)15), off_t = off_c + ((bytes_c + 15) & ~(size_t)15);
+    std::vector<uint8_t> host(off_t + bytes_t + 16, 0);
+    memcpy(host.data(), hb.data(), bytes_b);
+    if (bytes_i) memcpy(host.data() + off_i, lidx.data(), bytes_i);
+    if (bytes_c) memcpy(host.data() + off_c, cks.data(), bytes_c);
+    memcpy(host.data() + off_t, d_polys, bytes_t);
+    void* staged = nullptr;
+    NX_TRY(stage(ctx, host.data(), host.size(), &staged));
+    const uint8_t* blob = (const uint8_t*)staged;
+    ColSet cs; cs.base = nullptr; cs.stride = 0; cs.table = (uint32_t* const*)(blob + off_t);
+    const uint32_t nq = 4 * n_batches;
+    const size_t nc = (size_t)1 << log_coef, ne = (size_t)1 << log_size;
+    uint32_t* comb = nullptr; uint32_t* ext = nullptr;
+    NX_TRY(dev_alloc(ctx, (size_t)nq * nc * 4, (void**)&comb));
+    { int rc = dev_alloc(ctx, (size_t)nq * ne * 4, (void**)&ext); if (rc != NX_OK) { dev_free(ctx, comb); return rc; } }
+    int rc = NX_OK;
+    {
+        KTimer timer(ctx, NX_T_QUOT, ((uint64_t)n_cols * 4 + 16) * ne);     // the same algorithmic bytes as the row-wise path: what the stage computes
+        hipLaunchKernelGGL(quotient_combine_kernel, dim3((unsigned)((nc / 4 + 255) / 256)), dim3(256), 0, ctx->stream, cs, (u32)(nc / 4), (const QBatchDev*)blob, n_batches,
+                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), comb, nc);
+        if (hipGetLastError() != hipSuccess) rc = set_err(ctx, NX_ERR_HIP, "quotient_combine_kernel launch failed");
+    }
+    if (rc == NX_OK) {
+        std::vector<const uint32_t*> src(nq); std::vector<uint32_t*> dst(nq);
+        for (uint32_t q = 0; q < nq; q++) { src[q] = comb + (size_t)q * nc; dst[q] = ext + (size_t)q * ne; }
+        rc = nx_evaluate_batch(ctx, tw, src.data(), nq, log_coef, log_size - log_coef, dst.data());
+    }
+    if (rc == NX_OK) {
+        hipLaunchKernelGGL(quotient_finish_kernel, dim3((unsigned)((ne / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const u32*)ext, ne, (int)log_size, (u32)(ne / 4),
+                           (const QBatchDev*)blob, n_batches, d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+        if (hipGetLastError() != hipSuccess) rc = set_err(ctx, NX_ERR_HIP, "quotient_finish_kernel launch failed");
+    }
+    dev_free(ctx, comb); dev_free(ctx, ext);      // stream-ordered: reused only by later work on this stream
+    return rc;
 }
 }  // namespace nx
 extern "C" {

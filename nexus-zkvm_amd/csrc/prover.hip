@@ -975,8 +975,23 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         SecureColumn qc;
         if (D.on()) H_TRY(qc.alloc_rows(ctx, L, D.block(L), true)); else H_TRY(qc.alloc(ctx, L));
         uint32_t aw[4]; q_store(aw, q_coeff);
-        H_TRY(accumulate_quotients_rows(ctx, L, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(), cidx.data(), vals.data(), qc.c,
-                                        D.on() ? D.begin(L) : 0, qc.rows));                                                            // K8
+        // A wide group on one GPU goes through the coefficients (pcs.hip accumulate_quotients_coeffs: the numerators are linear in the
+        // columns): half the bytes of the row-wise sum at blowup 2, worth it from ~48 columns per sample point (the combinations cost an
+        // extension of 4 columns per point).  Row-sharded proves keep the row-wise path: their coefficients are column-sharded.
+        bool via_coeffs = !D.on() && ctx->opt.quotients_coeffs && L >= cfg.log_blowup + 2 && gcols.size() >= 48 * bpts.size();
+        std::vector<const uint32_t*> gpolys;
+        if (via_coeffs) {
+            for (size_t k = i; k < j && via_coeffs; k++) {
+                const auto& pl = cs.trees[all[k].t].polys[all[k].c];
+                if (!pl.ptr || pl.log + cfg.log_blowup != L) via_coeffs = false; else gpolys.push_back(pl.ptr);
+            }
+        }
+        if (via_coeffs)
+            H_TRY(accumulate_quotients_coeffs(ctx, tw, L, L - cfg.log_blowup, gpolys.data(), (uint32_t)gpolys.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(), cidx.data(),
+                                              vals.data(), qc.c));                                                                     // K8
+        else
+            H_TRY(accumulate_quotients_rows(ctx, L, gcols.data(), (uint32_t)gcols.size(), aw, (uint32_t)bpts.size(), fpts.data(), counts.data(), cidx.data(), vals.data(), qc.c,
+                                            D.on() ? D.begin(L) : 0, qc.rows));                                                        // K8
         quotients.push_back(std::move(qc));
         i = j;
     }

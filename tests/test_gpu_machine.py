@@ -83,6 +83,18 @@ def test_machine_degree_split_off_gives_the_same_bytes(nz, oracle):
         b.close()
 
 
+def test_machine_quotients_from_coefficients_or_rows(nz, oracle):
+    """"quotients.coeffs": the DEEP quotients of the wide size group accumulated from the coefficient columns (combine per sample point,
+    extend, finish row by row) or row-wise over the extensions like Stwo — the same proof, == the oracle's; also at blowup 4."""
+    for comps, kw in ((MACHINE_CASES[4][0], MACHINE_CASES[4][1]), ([(11, 5, 200, 16)], dict(pow_bits=3, log_blowup=2, n_queries=5))):
+        ref = M.prove_machine(comps, O.default_cfg(**kw), seed=8, ad=b"q", threads=THREADS)
+        for on in (1, 0):
+            b = nz.HipBackend()
+            b.set_option("quotients.coeffs", on)
+            _same(ref, b.prove_machine(comps, nz.default_config(**kw), seed=8, ad=b"q"))
+            b.close()
+
+
 def test_machine_prove_at_2pow18_v1_shaped(be, nz, oracle):
     """The shape of the reference's v1 machine: LOG_CONSTRAINT_DEGREE = 2 (reference components/mod.rs:12), a wide
     interaction tree, small extra components of other sizes (machine.rs:82-91) — scaled to 2^18 rows so that the oracle finishes."""
