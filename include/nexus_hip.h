@@ -62,7 +62,8 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
  * "fft.streams" (1..4), "fri.dist_min_log", "dist.chunks" and "air.degree_split" (1: degree-aware composition, see
  * nx_air_constraint_degrees) — row-sharded prove: every GPU of a proof must use the same values of these three, they shape the
  * exchanges —, "air.segment" (instruction budget of one generated AIR kernel), "quotients.coeffs" (1: the DEEP quotients of a wide
- * size group are accumulated from the coefficient columns — half the bytes at blowup 2; one GPU only).  Unknown names and out-of-range values are NX_ERR_ARG.
+ * size group are accumulated from the coefficient columns — half the bytes at blowup 2; one GPU only), "air.half_domain" (1: constraints
+ * of degree <= 2 are evaluated on the first half of the committed 2N-point domain; one GPU, blowup 2).  Unknown names and out-of-range values are NX_ERR_ARG.
  * None of them changes a result: proofs, roots and transforms are bit-identical under every setting. */
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value);
 int nx_ctx_get_option(const nx_ctx* ctx, const char* name, int64_t* value);

@@ -247,6 +247,7 @@ static nx_options options_from_env() {
     o.air_segment = std::max(200, env_int("NX_AIR_SEGMENT", 9000));
     o.air_degree_split = env_int("NX_AIR_DEGREE_SPLIT", 1) != 0;
     o.quotients_coeffs = env_int("NX_QUOTIENTS_COEFFS", 1) != 0;
+    o.air_half_domain = env_int("NX_AIR_HALF_DOMAIN", 1) != 0;
     return o;
 }
 struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
@@ -262,6 +263,7 @@ static const OptEntry k_options[] = {
     {"air.segment", &nx_options::air_segment, 200, 1 << 30},
     {"air.degree_split", &nx_options::air_degree_split, 0, 1},
     {"quotients.coeffs", &nx_options::quotients_coeffs, 0, 1},
+    {"air.half_domain", &nx_options::air_half_domain, 0, 1},
 };
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return set_err(ctx, NX_ERR_ARG, "nx_ctx_set_option: NULL argument");

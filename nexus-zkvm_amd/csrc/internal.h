@@ -22,6 +22,7 @@ struct nx_options {
     int dist_chunks;              // "dist.chunks": 0 = automatic; else column chunks of a row-sharded commit's exchange
     int air_segment;              // "air.segment": estimated-instruction budget of one generated AIR kernel
     int quotients_coeffs;         // "quotients.coeffs": DEEP quotients of wide size groups from the coefficient columns (single GPU)
+    int air_half_domain;          // "air.half_domain": constraints of degree <= 2 are evaluated on HALF of the committed 2N-point domain (single GPU, blowup 2)
     int air_degree_split;         // "air.degree_split": constraints of degree <= 3 of a component with a bound > 1 are evaluated on the log_size + 1 domain
 };
 
@@ -194,6 +195,7 @@ int fold_line_rows(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_
 int accumulate_quotients_rows(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4], uint32_t n_batches,
                               const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx, const uint32_t* values, uint32_t* const* d_out4,
                               uint64_t row_begin, uint64_t n_rows);
+int twiddles_first_half(nx_ctx* ctx, const nx_twiddles* tw, uint32_t n, nx_twiddles** out);   // fft.hip: the N-point domain inside the 2N-point one
 int accumulate_quotients_coeffs(nx_ctx* ctx, const nx_twiddles* tw, uint32_t log_size, uint32_t log_coef, const uint32_t* const* d_polys, uint32_t n_cols,
                                 const uint32_t random_coeff[4], uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
                                 const uint32_t* values, uint32_t* const* d_out4);

@@ -349,7 +349,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         for (uint32_t i = 0; i < n_comps && rc_local == NX_OK; i++) {
             GComponent g = machine_component(comps[i], locs[i], cfg);
             g.log_cd = comps[i].log_constraint_degree_bound;
-            rc_local = prepare_component_kernels(ctx, cfg, g);
+            rc_local = prepare_component_kernels(ctx, cfg, g, D.on());
         }
         if (D.on()) {
             std::vector<int32_t> all((size_t)D.world, 0);
@@ -477,7 +477,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         g.log_cd = comps[i].log_constraint_degree_bound;
         const QM31 shift = q_mul_m(claimed[i], m_inv((1u << comps[i].log_size) % P));
         memcpy(&g.econsts[0], z, 16); memcpy(&g.econsts[4], alpha, 16); q_store(&g.econsts[8], shift);
-        H_TRY(prepare_component_kernels(ctx, cfg, g));
+        H_TRY(prepare_component_kernels(ctx, cfg, g, D.on()));
         air.comps.push_back(std::move(g));
     }
     H_TRY(air.check(cs));

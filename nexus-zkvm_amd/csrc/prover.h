@@ -211,7 +211,9 @@ int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pa
 // per evaluation-domain size, this GPU's rows of the accumulation (whole on one GPU)
 int composition_accumulator(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, uint32_t e, SecureColumn** out);
 // DomainEvaluationAccumulator::finalize (row-sharded: all-gather of the accumulators first): 4 coefficient columns, replicated
-int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, DevBuf* out_polys, uint32_t* out_log);
+// coef (optional): per log size, contributions already in COEFFICIENT form (the half-domain parts), added after that size's interpolation
+int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, DevBuf* out_polys, uint32_t* out_log,
+                          std::map<uint32_t, SecureColumn>* coef = nullptr);
 std::vector<uint32_t> vanishing_denominators(uint32_t log_size, uint32_t e);
 QM31 coset_vanishing_q(uint32_t n, QPt p);
 QPt get_random_point(Blake2sChannel& ch);
@@ -235,16 +237,18 @@ struct GComponent {
     std::vector<std::pair<uint32_t, uint32_t>> cols;     // component column -> (tree, column in tree)
     std::vector<std::vector<int>> masks;                 // component column -> row offsets sampled
     const nx_air_kernel* kernel = nullptr; nx_air_kernel* owned = nullptr;
-    // degree-aware composition (prepare_component_kernels): the constraints of degree <= 3 ("low": evaluated on log_size + 1) and the
-    // others ("high": on log_size + bound), the columns each part reads, their kernels (context-cached)
-    struct Part { bool any = false; std::vector<uint8_t> select; std::vector<char> used; const nx_air_kernel* kernel = nullptr; };
-    bool split = false, prepared = false; Part low, high;
+    // degree-aware composition (prepare_component_kernels): the parts of the constraints, the columns each reads, their kernels (context-cached)
+    // where a part of the constraints is evaluated: on the component's own domain (log_size + bound), on the log_size + 1 domain
+    // (degree <= 3), or on the first half of the committed log_size + 1 domain (degree <= 2, see compute_composition)
+    enum { ON_FULL = 0, ON_LOW = 1, ON_HALF = 2 };
+    struct Part { int where = ON_FULL; bool whole = false; std::vector<uint8_t> select; std::vector<char> used; const nx_air_kernel* kernel = nullptr; };
+    bool prepared = false; std::vector<Part> parts;
 };
 // compiled kernels are cached per context and per (program, selection): one compilation serves every proof of an AIR
 int cached_air_kernel(nx_ctx* ctx, const GComponent& g, const uint8_t* select, const nx_air_kernel** out);
 // everything compute_composition will launch for this component, compiled now (a row-sharded prove votes on the result before its
 // first exchange): the whole program, or its low / high parts when the component's bound exceeds 1 and "air.degree_split" is on
-int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g);
+int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g, bool sharded);
 struct GenericAir : AirProver {
     nx_ctx* ctx; std::vector<GComponent> comps;
     std::vector<std::vector<std::vector<int>>> offs;     // tree -> column -> union of sampled offsets (first-appearance order)

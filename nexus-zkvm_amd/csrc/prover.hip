@@ -841,23 +841,46 @@ int composition_accumulator(CommitmentSchemeProver& cs, std::map<uint32_t, Secur
     return NX_OK;
 }
 
-// DomainEvaluationAccumulator::finalize — ascending size: lift the running polynomial, add, interpolate
-int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, DevBuf* out_polys, uint32_t* out_log) {
+// DomainEvaluationAccumulator::finalize — ascending size: lift the running polynomial, add, interpolate.  Contributions that are
+// already coefficients (`coef`) are added to that size's coefficients; a size that has only such a contribution takes the running
+// polynomial in coefficient form too (zero-extension = the same polynomial: its coefficients are added to the low part).
+int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, SecureColumn>& sub, DevBuf* out_polys, uint32_t* out_log, std::map<uint32_t, SecureColumn>* coef) {
     nx_ctx* ctx = cs.ctx;
     DevBuf cur; uint32_t cur_log = 0; bool have = false;
-    for (auto& kv : sub) {
-        uint32_t log = kv.first;
-        if (kv.second.block) { SecureColumn whole; H_TRY(gather_secure(ctx, cs.dist, kv.second, &whole)); kv.second = std::move(whole); }
-        SecureColumn& values = kv.second;
-        if (have) {
-            DevBuf lifted; H_TRY(lifted.alloc(ctx, (size_t)4 << log));
-            auto src = col_ptrs(cur.p, 4, cur_log), dst = col_ptrs(lifted.p, 4, log);
-            H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)src.data(), 4, cur_log, log - cur_log, dst.data()));
-            const u32* s4[4] = {dst[0], dst[1], dst[2], dst[3]};
-            H_TRY(secure_accumulate(ctx, values.c, s4, 1u << log));
-            H_TRY(nx_sync(ctx));
+    std::set<uint32_t> logs;
+    for (auto& kv : sub) logs.insert(kv.first);
+    if (coef) for (auto& kv : *coef) logs.insert(kv.first);
+    for (uint32_t log : logs) {
+        const bool has_evals = sub.count(log) != 0;
+        SecureColumn values;
+        if (has_evals) {
+            SecureColumn& sv = sub[log];
+            if (sv.block) { SecureColumn whole; H_TRY(gather_secure(ctx, cs.dist, sv, &whole)); sv = std::move(whole); }
+            values = std::move(sv);
+            if (have) {
+                DevBuf lifted; H_TRY(lifted.alloc(ctx, (size_t)4 << log));
+                auto src = col_ptrs(cur.p, 4, cur_log), dst = col_ptrs(lifted.p, 4, log);
+                H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)src.data(), 4, cur_log, log - cur_log, dst.data()));
+                const u32* s4[4] = {dst[0], dst[1], dst[2], dst[3]};
+                H_TRY(secure_accumulate(ctx, values.c, s4, 1u << log));
+                H_TRY(nx_sync(ctx));
+            }
+            H_TRY(nx_interpolate_batch(ctx, cs.tw, values.c, 4, log));
+            if (coef && coef->count(log)) {
+                SecureColumn& cv = (*coef)[log];
+                const u32* s4[4] = {cv.c[0], cv.c[1], cv.c[2], cv.c[3]};
+                H_TRY(secure_accumulate(ctx, values.c, s4, 1u << log));
+                H_TRY(nx_sync(ctx));                                  // cv is released with the map
+            }
+        } else {
+            values = std::move((*coef)[log]);
+            if (have) {
+                auto src = col_ptrs(cur.p, 4, cur_log);
+                const u32* s4[4] = {src[0], src[1], src[2], src[3]};
+                H_TRY(secure_accumulate(ctx, values.c, s4, 1u << cur_log));
+                H_TRY(nx_sync(ctx));
+            }
         }
-        H_TRY(nx_interpolate_batch(ctx, cs.tw, values.c, 4, log));
         cur = std::move(values.buf); cur_log = log; have = true;
     }
     *out_polys = std::move(cur); *out_log = cur_log;
@@ -1105,47 +1128,111 @@ void machine_kernels_release(nx_ctx* ctx) {   // nx_ctx_destroy: the modules bel
 // with e = 1): those constraints are evaluated there — on the committed evaluations when the blowup is 2 — and only the columns the
 // remaining constraints read are re-extended to log_size + bound.  finalize_accumulation lifts the small accumulator exactly like a
 // smaller component's, so the composition polynomial is the same, coefficient for coefficient.
-struct SplitCache { std::mutex mu; std::map<std::pair<nx_ctx*, std::string>, std::pair<GComponent::Part, GComponent::Part>> map; };
+struct SplitCache { std::mutex mu; std::map<std::pair<nx_ctx*, std::string>, std::vector<GComponent::Part>> map; };
 static SplitCache& split_cache() { static SplitCache c; return c; }
 static void release_split_cache(nx_ctx* ctx) {
     SplitCache& sc = split_cache();
     std::lock_guard<std::mutex> lk(sc.mu);
     for (auto it = sc.map.begin(); it != sc.map.end();) { if (it->first.first == ctx) it = sc.map.erase(it); else ++it; }
 }
-int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g) {
+// The plan of a component: which constraints are evaluated where (analysis and kernels depend on the program and on three switches
+// only: once per context and AIR).
+//  * degree <= 2 and the log_size + 1 domain is the committed one (blowup 2), one GPU: on the FIRST HALF of that domain ("air.half_domain");
+//  * degree <= 3 of a component whose bound exceeds 1: on the log_size + 1 domain ("air.degree_split"), unless the component's own
+//    domain is the committed one;
+//  * the rest (or everything): on the component's own domain.
+int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g, bool sharded) {
     if (g.prepared) return NX_OK;
-    // not when the component's own domain is the committed one (bound == blowup): its evaluations are there already
-    g.split = ctx->opt.air_degree_split && comp_log_cd(g.log_cd, cfg) > 1 && comp_log_cd(g.log_cd, cfg) != cfg.log_blowup && g.n_constraints > 0;
-    if (g.split) {
-        // the analysis and the two kernels depend on the program only: once per context and AIR
-        std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
-        key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs) + "|" + std::to_string(g.econsts.size() / 4);
-        SplitCache& sc = split_cache();
-        bool hit = false;
-        {
-            std::lock_guard<std::mutex> lk(sc.mu);
-            auto it = sc.map.find({ctx, key});
-            if (it != sc.map.end()) { g.low = it->second.first; g.high = it->second.second; hit = true; }
-        }
-        if (!hit) {
-            std::vector<uint32_t> deg;
-            air_constraint_degrees(g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, &deg);
-            if (deg.size() != g.n_constraints) return set_err(ctx, NX_ERR_ARG, "recorded AIR: constraint count mismatch");
-            g.low = GComponent::Part(); g.high = GComponent::Part();
-            g.low.select.assign(g.n_constraints, 0); g.high.select.assign(g.n_constraints, 0);
-            for (uint32_t j = 0; j < g.n_constraints; j++) { if (deg[j] <= 3) { g.low.select[j] = 1; g.low.any = true; } else { g.high.select[j] = 1; g.high.any = true; } }
-            for (GComponent::Part* part : {&g.low, &g.high}) {
-                if (!part->any || !g.low.any) continue;
-                air_subset_columns(g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), part->select.data(), &part->used);
-                H_TRY(cached_air_kernel(ctx, g, part->select.data(), &part->kernel));
-            }
-            std::lock_guard<std::mutex> lk(sc.mu);
-            sc.map.insert({{ctx, key}, {g.low, g.high}});
-        }
-        if (!g.low.any) g.split = false;              // nothing to move: the component is evaluated whole
+    const uint32_t bound = comp_log_cd(g.log_cd, cfg);
+    const bool can_half = ctx->opt.air_half_domain && !sharded && cfg.log_blowup == 1 && g.log_size >= 4 && g.n_constraints > 0;
+    const bool can_low = ctx->opt.air_degree_split && bound > 1 && bound != cfg.log_blowup && g.n_constraints > 0;
+    if (!can_half && !can_low) {
+        GComponent::Part whole; whole.whole = true; whole.where = GComponent::ON_FULL;
+        if (g.kernel) whole.kernel = g.kernel; else H_TRY(cached_air_kernel(ctx, g, nullptr, &whole.kernel));
+        g.parts.clear(); g.parts.push_back(std::move(whole));
+        g.prepared = true;
+        return NX_OK;
     }
-    if (!g.split && !g.kernel) H_TRY(cached_air_kernel(ctx, g, nullptr, &g.kernel));
+    std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
+    key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs) + "|" + std::to_string(g.econsts.size() / 4) + "|" + std::to_string(bound) + (can_half ? "|h" : "|-") + (can_low ? "l" : "-");
+    SplitCache& sc = split_cache();
+    {
+        std::lock_guard<std::mutex> lk(sc.mu);
+        auto it = sc.map.find({ctx, key});
+        if (it != sc.map.end()) { g.parts = it->second; g.prepared = true; return NX_OK; }
+    }
+    std::vector<uint32_t> deg;
+    air_constraint_degrees(g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, &deg);
+    if (deg.size() != g.n_constraints) return set_err(ctx, NX_ERR_ARG, "recorded AIR: constraint count mismatch");
+    // class of every constraint; a class nobody may take falls back to the next larger domain
+    int where_of[3];          // by degree class: <= 2, == 3, >= 4
+    where_of[2] = GComponent::ON_FULL;
+    where_of[1] = can_low ? GComponent::ON_LOW : GComponent::ON_FULL;
+    where_of[0] = can_half ? GComponent::ON_HALF : where_of[1];
+    std::vector<GComponent::Part> parts;
+    for (int where : {GComponent::ON_HALF, GComponent::ON_LOW, GComponent::ON_FULL}) {
+        GComponent::Part part; part.where = where; part.select.assign(g.n_constraints, 0);
+        bool any = false;
+        for (uint32_t j = 0; j < g.n_constraints; j++) { const int cls = deg[j] <= 2 ? 0 : deg[j] == 3 ? 1 : 2; if (where_of[cls] == where) { part.select[j] = 1; any = true; } }
+        if (any) parts.push_back(std::move(part));
+    }
+    if (parts.size() == 1 && parts[0].where == GComponent::ON_FULL) {        // nothing to move: the component is evaluated whole
+        parts[0].whole = true; parts[0].select.clear();
+        if (g.kernel) parts[0].kernel = g.kernel; else H_TRY(cached_air_kernel(ctx, g, nullptr, &parts[0].kernel));
+    } else {
+        for (auto& part : parts) {
+            air_subset_columns(g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), part.select.data(), &part.used);
+            bool all = true; for (uint8_t x : part.select) all = all && x;
+            H_TRY(cached_air_kernel(ctx, g, all ? nullptr : part.select.data(), &part.kernel));
+        }
+    }
+    g.parts = parts;
+    {
+        std::lock_guard<std::mutex> lk(sc.mu);
+        sc.map.insert({{ctx, key}, parts});
+    }
     g.prepared = true;
+    return NX_OK;
+}
+
+// acc[k][0] -= t[k] z0, acc[k][n] = t[k]: the half-domain interpolant becomes the quotient's coefficients (compute_composition)
+__global__ void half_fix_kernel(u32* c0, u32* c1, u32* c2, u32* c3, u32 n, u32 t0, u32 t1, u32 t2, u32 t3, u32 z0) {
+    if (threadIdx.x || blockIdx.x) return;
+    c0[0] = m_sub(c0[0], m_mul(t0, z0)); c1[0] = m_sub(c1[0], m_mul(t1, z0)); c2[0] = m_sub(c2[0], m_mul(t2, z0)); c3[0] = m_sub(c3[0], m_mul(t3, z0));
+    c0[n] = t0; c1[n] = t1; c2[n] = t2; c3[n] = t3;
+}
+
+// The quotient of constraints of degree <= 2 over columns of N = 2^n rows is Q0 + t Z with Q0 in the FFT space of N points, Z the
+// vanishing polynomial of the trace domain (the one basis function of the 2N-point space beyond the N-point one that a product of two
+// trace polynomials divided by Z can reach) and t a secure-field scalar.  Z is CONSTANT (z0) on the first half of the bit-reversed
+// 2N-point domain, and that half is itself an N-point circle domain (twiddles_first_half).  So the constraints are evaluated on the
+// first N rows of the committed columns only — half the bytes —, interpolated there (= Q0 + t z0), and t comes from one further row
+// w of the second half: t = (Q(w) - I(w)) / (Z(w) - z0).  The 2N coefficients [I - t z0 | t, 0 ...] are those of the plain
+// evaluation on all 2N rows, exactly.
+struct HalfGroup { SecureColumn acc; DevBuf extra; uint32_t n_extra = 0; };
+static int half_group_finish(nx_ctx* ctx, CommitmentSchemeProver& cs, uint32_t n, HalfGroup& hg, SecureColumn* out_coef) {
+    const uint32_t N = 1u << n;
+    nx_twiddles* sub_tw = nullptr;
+    H_TRY(twiddles_first_half(ctx, cs.tw, n, &sub_tw));
+    struct Guard { nx_twiddles* t; ~Guard() { nx_twiddles_destroy(t); } } guard{sub_tw};
+    H_TRY(nx_interpolate_batch(ctx, sub_tw, hg.acc.c, 4, n));
+    // I(w) and Q(w) for w = row N of the 2N-point domain
+    const Pt w = pt_from_index(circle_domain_index((int)n + 1, bitrev(N, (int)n + 1)));
+    uint32_t pts[32], idx[4] = {0, 1, 2, 3}, iw[16], qw[4];
+    for (int k = 0; k < 4; k++) { QPt qp; qp.x = q_from_m(w.x); qp.y = q_from_m(w.y); q_store(pts + 8 * k, qp.x); q_store(pts + 8 * k + 4, qp.y); }
+    const uint32_t* polys[4] = {hg.acc.c[0], hg.acc.c[1], hg.acc.c[2], hg.acc.c[3]};
+    H_TRY(nx_eval_at_points(ctx, polys, n, idx, pts, 4, iw));
+    for (int k = 0; k < 4; k++) H_TRY(nx_download(ctx, &qw[k], hg.extra.p + (size_t)k * hg.n_extra, 1));
+    const std::vector<uint32_t> den = vanishing_denominators(n, n + 1);      // 1/Z on the two halves
+    const u32 z0 = m_inv(den[0]), z1 = m_inv(den[1]);
+    const u32 dz = m_inv(m_sub(z1, z0));
+    u32 t[4];
+    for (int k = 0; k < 4; k++) t[k] = m_mul(m_sub(qw[k], iw[4 * k]), dz);
+    H_TRY(out_coef->alloc(ctx, n + 1));
+    H_TRY(nx_memset_zero(ctx, out_coef->buf.p, out_coef->buf.words));
+    for (int k = 0; k < 4; k++) H_TRY(nx_copy(ctx, out_coef->c[k], hg.acc.c[k], N));
+    hipLaunchKernelGGL(half_fix_kernel, dim3(1), dim3(64), 0, ctx->stream, out_coef->c[0], out_coef->c[1], out_coef->c[2], out_coef->c[3], N, t[0], t[1], t[2], t[3], z0);
+    if (hipGetLastError() != hipSuccess) return set_err(ctx, NX_ERR_HIP, "half_fix_kernel launch failed");
     return NX_OK;
 }
 
@@ -1155,6 +1242,7 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
     std::vector<QM31> powers(total);
     { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
     std::map<uint32_t, SecureColumn> sub;
+    std::map<uint32_t, HalfGroup> halves;                                     // by log_size: the half-domain parts of all components of that size
     size_t remaining = total;
     for (auto& c : comps) {
         const uint32_t e = c.log_size + comp_log_cd(c.log_cd, cs.cfg);      // per component; finalize_accumulation lifts to the largest
@@ -1164,29 +1252,51 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
         remaining -= nc;
         std::vector<char> masked(c.cols.size(), 0);
         for (size_t k = 0; k < c.cols.size(); k++) for (int o : c.masks[k]) if (o != 0) masked[k] = 1;
-        H_TRY(prepare_component_kernels(ctx, cs.cfg, c));
-        // one pass per part: (domain, kernel, columns read); an unsplit component is one part on its own domain
-        struct Pass { uint32_t e; const nx_air_kernel* k; const std::vector<char>* used; };
-        std::vector<Pass> passes;
-        if (c.split) {
+        H_TRY(prepare_component_kernels(ctx, cs.cfg, c, cs.dist.on()));
+        {   // the composition keeps the size the bound declares, whatever the parts need
             SecureColumn* whole = nullptr;
-            H_TRY(composition_accumulator(cs, sub, e, &whole));             // the composition keeps the size the bound declares, whatever the parts need
-            if (c.low.any) passes.push_back({c.log_size + 1, c.low.kernel, &c.low.used});
-            if (c.high.any) passes.push_back({e, c.high.kernel, &c.high.used});
-        } else passes.push_back({e, c.kernel, nullptr});
-        for (const Pass& ps : passes) {
-            const std::vector<uint32_t> den = vanishing_denominators(c.log_size, ps.e);
+            bool full_part = false; for (auto& part : c.parts) full_part = full_part || part.where == GComponent::ON_FULL;
+            if (!full_part) {
+                bool lower_only = true; for (auto& part : c.parts) lower_only = lower_only && part.where != GComponent::ON_FULL;
+                if (lower_only && e > c.log_size + 1) H_TRY(composition_accumulator(cs, sub, e, &whole));
+            }
+        }
+        for (const GComponent::Part& part : c.parts) {
+            const std::vector<char>* used = part.whole ? nullptr : &part.used;
+            if (part.where == GComponent::ON_HALF) {
+                const uint32_t n = c.log_size, N = 1u << n, el = n + 1;
+                HalfGroup& hg = halves[n];
+                if (!hg.acc.buf.p) {
+                    H_TRY(hg.acc.alloc(ctx, n));
+                    H_TRY(nx_memset_zero(ctx, hg.acc.buf.p, hg.acc.buf.words));
+                    hg.n_extra = std::min<uint32_t>(256, N);
+                    H_TRY(hg.extra.alloc(ctx, (size_t)4 * hg.n_extra));
+                    H_TRY(nx_memset_zero(ctx, hg.extra.p, hg.extra.words));
+                }
+                const std::vector<uint32_t> den = vanishing_denominators(n, el);
+                EvalDomainCols cols;
+                H_TRY(columns_on_eval_domain(cs, c.cols, n, el, masked, &cols, used));          // the committed evaluations (blowup 2)
+                uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = hg.acc.c[k];
+                H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, el, a4, 0, N));
+                uint32_t* x4[4]; for (int k = 0; k < 4; k++) x4[k] = hg.extra.p + (size_t)k * hg.n_extra - N;   // indexed with the global row: rows [N, N + n_extra)
+                H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, el, x4, N, hg.n_extra));
+                continue;
+            }
+            const uint32_t pe = part.where == GComponent::ON_LOW ? c.log_size + 1 : e;
+            const std::vector<uint32_t> den = vanishing_denominators(c.log_size, pe);
             EvalDomainCols cols;
-            H_TRY(columns_on_eval_domain(cs, c.cols, c.log_size, ps.e, masked, &cols, ps.used));
+            H_TRY(columns_on_eval_domain(cs, c.cols, c.log_size, pe, masked, &cols, used));
             SecureColumn* acc = nullptr;
-            H_TRY(composition_accumulator(cs, sub, ps.e, &acc));
-            const uint64_t rb = cs.dist.on() ? cs.dist.begin(ps.e) : 0;
+            H_TRY(composition_accumulator(cs, sub, pe, &acc));
+            const uint64_t rb = cs.dist.on() ? cs.dist.begin(pe) : 0;
             uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = bias_rows(acc->c[k], rb);
-            H_TRY(air_eval_rows(ctx, ps.k, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), c.log_size, ps.e, a4, (uint32_t)rb, (uint32_t)acc->rows));
+            H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), c.log_size, pe, a4, (uint32_t)rb, (uint32_t)acc->rows));
             // `cols` (the re-evaluated columns) is released here: stream-ordered frees, the kernel above was enqueued first
         }
     }
-    return finalize_accumulation(cs, sub, out_polys, out_log);
+    std::map<uint32_t, SecureColumn> coef;
+    for (auto& kv : halves) H_TRY(half_group_finish(ctx, cs, kv.first, kv.second, &coef[kv.first + 1]));
+    return finalize_accumulation(cs, sub, out_polys, out_log, coef.empty() ? nullptr : &coef);
 }
 
 void GenericAir::mask_points(QPt oods, MaskPoints* points) {

@@ -95,6 +95,20 @@ def test_machine_quotients_from_coefficients_or_rows(nz, oracle):
             b.close()
 
 
+def test_machine_half_domain_composition_on_and_off(nz, oracle):
+    """"air.half_domain": constraints of degree <= 2 evaluated on the first N rows of the committed 2N-point evaluations only (the
+    quotient is Q0 + t Z with Q0 in the N-point FFT space; Z is constant on that half, t comes from one further row) — the same proof as
+    the evaluation on all 2N rows, == the oracle's: a +1 machine (everything on the half), the v1 shape (transition and logup
+    constraints on the half, degree-4 ones on the 4x domain), several sizes in one statement."""
+    for comps, kw in ((MACHINE_CASES[1][0], MACHINE_CASES[1][1]), (MACHINE_CASES[-1][0], MACHINE_CASES[-1][1]), ([(9, 3, 12, 8), (9, 2, 5, 4), (6, 2, 4, 4)], dict(pow_bits=3))):
+        ref = M.prove_machine(comps, O.default_cfg(**kw), seed=12, ad=b"h", threads=THREADS)
+        for on in (1, 0):
+            b = nz.HipBackend()
+            b.set_option("air.half_domain", on)
+            _same(ref, b.prove_machine(comps, nz.default_config(**kw), seed=12, ad=b"h"))
+            b.close()
+
+
 def test_machine_prove_at_2pow18_v1_shaped(be, nz, oracle):
     """The shape of the reference's v1 machine: LOG_CONSTRAINT_DEGREE = 2 (reference components/mod.rs:12), a wide
     interaction tree, small extra components of other sizes (machine.rs:82-91) — scaled to 2^18 rows so that the oracle finishes."""
