@@ -1222,7 +1222,11 @@ static int half_group_finish(nx_ctx* ctx, CommitmentSchemeProver& cs, uint32_t n
     for (int k = 0; k < 4; k++) { QPt qp; qp.x = q_from_m(w.x); qp.y = q_from_m(w.y); q_store(pts + 8 * k, qp.x); q_store(pts + 8 * k + 4, qp.y); }
     const uint32_t* polys[4] = {hg.acc.c[0], hg.acc.c[1], hg.acc.c[2], hg.acc.c[3]};
     H_TRY(nx_eval_at_points(ctx, polys, n, idx, pts, 4, iw));
-    for (int k = 0; k < 4; k++) H_TRY(nx_download(ctx, &qw[k], hg.extra.p + (size_t)k * hg.n_extra, 1));
+    {   // one copy, one synchronisation: the whole scratch block (<= 4 KB)
+        std::vector<uint32_t> ex((size_t)4 * hg.n_extra);
+        H_TRY(nx_download(ctx, ex.data(), hg.extra.p, ex.size()));
+        for (int k = 0; k < 4; k++) qw[k] = ex[(size_t)k * hg.n_extra];
+    }
     const std::vector<uint32_t> den = vanishing_denominators(n, n + 1);      // 1/Z on the two halves
     const u32 z0 = m_inv(den[0]), z1 = m_inv(den[1]);
     const u32 dz = m_inv(m_sub(z1, z0));
