@@ -1209,7 +1209,7 @@ __global__ void half_fix_kernel(u32* c0, u32* c1, u32* c2, u32* c3, u32 n, u32 t
 // first N rows of the committed columns only — half the bytes —, interpolated there (= Q0 + t z0), and t comes from one further row
 // w of the second half: t = (Q(w) - I(w)) / (Z(w) - z0).  The 2N coefficients [I - t z0 | t, 0 ...] are those of the plain
 // evaluation on all 2N rows, exactly.
-struct HalfGroup { SecureColumn acc; DevBuf extra; uint32_t n_extra = 0; };
+struct HalfGroup { SecureColumn acc; uint32_t n_extra = 0; };     // acc: N + n_extra rows per coordinate — the half and a few rows of the second half, one launch
 static int half_group_finish(nx_ctx* ctx, CommitmentSchemeProver& cs, uint32_t n, HalfGroup& hg, SecureColumn* out_coef) {
     const uint32_t N = 1u << n;
     nx_twiddles* sub_tw = nullptr;
@@ -1222,10 +1222,10 @@ static int half_group_finish(nx_ctx* ctx, CommitmentSchemeProver& cs, uint32_t n
     for (int k = 0; k < 4; k++) { QPt qp; qp.x = q_from_m(w.x); qp.y = q_from_m(w.y); q_store(pts + 8 * k, qp.x); q_store(pts + 8 * k + 4, qp.y); }
     const uint32_t* polys[4] = {hg.acc.c[0], hg.acc.c[1], hg.acc.c[2], hg.acc.c[3]};
     H_TRY(nx_eval_at_points(ctx, polys, n, idx, pts, 4, iw));
-    {   // one copy, one synchronisation: the whole scratch block (<= 4 KB)
-        std::vector<uint32_t> ex((size_t)4 * hg.n_extra);
-        H_TRY(nx_download(ctx, ex.data(), hg.extra.p, ex.size()));
-        for (int k = 0; k < 4; k++) qw[k] = ex[(size_t)k * hg.n_extra];
+    {   // Q(w): row N of the four coordinates, one gather and one synchronisation
+        const uint32_t* gp[4] = {hg.acc.c[0], hg.acc.c[1], hg.acc.c[2], hg.acc.c[3]};
+        const uint64_t gi[4] = {N, N, N, N};
+        H_TRY(nx_gather(ctx, gp, gi, 4, qw));
     }
     const std::vector<uint32_t> den = vanishing_denominators(n, n + 1);      // 1/Z on the two halves
     const u32 z0 = m_inv(den[0]), z1 = m_inv(den[1]);
@@ -1271,19 +1271,15 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
                 const uint32_t n = c.log_size, N = 1u << n, el = n + 1;
                 HalfGroup& hg = halves[n];
                 if (!hg.acc.buf.p) {
-                    H_TRY(hg.acc.alloc(ctx, n));
+                    hg.n_extra = 4;                                  // row N is the one that is used; a multiple of 4 keeps the coordinates 16-byte aligned
+                    H_TRY(hg.acc.alloc_rows(ctx, n, (uint64_t)N + hg.n_extra, false));
                     H_TRY(nx_memset_zero(ctx, hg.acc.buf.p, hg.acc.buf.words));
-                    hg.n_extra = std::min<uint32_t>(256, N);
-                    H_TRY(hg.extra.alloc(ctx, (size_t)4 * hg.n_extra));
-                    H_TRY(nx_memset_zero(ctx, hg.extra.p, hg.extra.words));
                 }
                 const std::vector<uint32_t> den = vanishing_denominators(n, el);
                 EvalDomainCols cols;
                 H_TRY(columns_on_eval_domain(cs, c.cols, n, el, masked, &cols, used));          // the committed evaluations (blowup 2)
                 uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = hg.acc.c[k];
-                H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, el, a4, 0, N));
-                uint32_t* x4[4]; for (int k = 0; k < 4; k++) x4[k] = hg.extra.p + (size_t)k * hg.n_extra - N;   // indexed with the global row: rows [N, N + n_extra)
-                H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, el, x4, N, hg.n_extra));
+                H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, el, a4, 0, N + hg.n_extra));
                 continue;
             }
             const uint32_t pe = part.where == GComponent::ON_LOW ? c.log_size + 1 : e;
