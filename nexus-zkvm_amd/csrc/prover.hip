@@ -1257,13 +1257,11 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
         std::vector<char> masked(c.cols.size(), 0);
         for (size_t k = 0; k < c.cols.size(); k++) for (int o : c.masks[k]) if (o != 0) masked[k] = 1;
         H_TRY(prepare_component_kernels(ctx, cs.cfg, c, cs.dist.on()));
-        {   // the composition keeps the size the bound declares, whatever the parts need
-            SecureColumn* whole = nullptr;
-            bool full_part = false; for (auto& part : c.parts) full_part = full_part || part.where == GComponent::ON_FULL;
-            if (!full_part) {
-                bool lower_only = true; for (auto& part : c.parts) lower_only = lower_only && part.where != GComponent::ON_FULL;
-                if (lower_only && e > c.log_size + 1) H_TRY(composition_accumulator(cs, sub, e, &whole));
-            }
+        {   // the composition keeps the size the bound declares, whatever domains the parts are evaluated on
+            bool any_full = false;
+            for (auto& part : c.parts) any_full = any_full || part.where == GComponent::ON_FULL;
+            SecureColumn* declared = nullptr;
+            if (!any_full && e > c.log_size + 1) H_TRY(composition_accumulator(cs, sub, e, &declared));
         }
         for (const GComponent::Part& part : c.parts) {
             const std::vector<char>* used = part.whole ? nullptr : &part.used;
