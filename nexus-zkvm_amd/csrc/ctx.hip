@@ -228,7 +228,7 @@ int copy_columns(nx_ctx* ctx, uint32_t* const* h_dst, const uint32_t* const* h_s
 
 extern "C" {
 
-const char* nx_version(void) { return "nexus_hip 0.2 (gfx950)"; }
+const char* nx_version(void) { return "nexus_hip 0.3 (gfx950)"; }
 
 const char* nx_last_error(const nx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
