@@ -133,3 +133,44 @@ def test_linear_combinations_commute_with_extension(oracle):
         rows = sum(int(cks[k][q]) * ext[k] for k in range(7)) % P
         comb = sum(int(cks[k][q]) * cols[k].astype(object) for k in range(7)) % P
         assert np.array_equal(np.array(rows, np.uint32), T.evaluate(np.array(comb, np.uint32), n + 1))
+
+
+def test_degree_four_quotient_from_3n_plus_1_samples(oracle):
+    """The next lever (not built in the product): f = f0 + Z2 (f10 + t Z) for a degree-4 quotient — f0 from the
+    committed 2N rows, f10 from the first QUARTER of the 4N-point domain (itself an N-point domain: the first quarters of the 4N tables'
+    layers), t from one further row; 3N + 1 constraint evaluations instead of 4N, and an N-point transform per column instead of a 4N one."""
+    n, rng = 5, np.random.default_rng(9)
+    N = 1 << n
+    T = O.Twiddles(n + 2)
+    _, itw = _tables(T)
+    cols, cc = _vanishing_product_quotient(T, n, 4, rng)
+    inv = lambda x: pow(int(x) % P, P - 2, P)
+
+    def quotient_rows(e, rows):
+        den = denominators(n, n + e)
+        ev = [T.evaluate(c, n + e) for c in cols]
+        Cc = T.evaluate(cc, n + e)
+        out = []
+        for r in rows:
+            p = 1
+            for v in ev:
+                p = p * int(v[r]) % P
+            out.append((p - int(Cc[r])) % P * int(den[r >> n]) % P)
+        return out
+    full = [int(x) for x in T.interpolate(np.array(quotient_rows(2, range(4 * N)), np.uint32))]      # Stwo's way: all 4N rows
+    # the first quarter of the 4N-point domain is an N-point domain (first quarters of the layers)
+    assert sub_interpolate(T.evaluate(cols[0], n + 2)[:N], n, n + 2, itw) == [int(x) for x in cols[0]]
+    # 1. the committed 2N rows -> f0
+    f0 = T.interpolate(np.array(quotient_rows(1, range(2 * N)), np.uint32))
+    # 2. N rows of the first quarter + row N
+    f0_4n = T.evaluate(f0, n + 2)
+    z2 = inv(denominators(n + 1, n + 2)[0])                       # Z2 = vanishing polynomial of the committed domain: constant on the first half
+    d4 = denominators(n, n + 2)
+    z0, z1 = inv(d4[0]), inv(d4[1])                               # Z on the first and the second quarter
+    fq = quotient_rows(2, range(N + 1))
+    g = [(fq[r] - int(f0_4n[r])) % P * inv(z2) % P for r in range(N + 1)]
+    I = sub_interpolate(g[:N], n, n + 2, itw)
+    Iw = int(T.evaluate(np.array(I, np.uint32), n + 2)[N])
+    t = (g[N] - Iw) * inv(z1 - z0) % P
+    I[0] = (I[0] - t * z0) % P
+    assert [int(x) for x in f0] + I + [t] + [0] * (N - 1) == full
