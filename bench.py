@@ -191,6 +191,12 @@ def main():
         except Exception as e:   # noqa: BLE001 — the headline line must still be printed
             v1 = {"error": repr(e)[:300]}
 
+    prover_options = {}
+    for name in ("air.degree_split", "air.half_domain", "quotients.coeffs"):
+        try:
+            prover_options[name] = int(be.get_option(name))
+        except Exception:   # noqa: BLE001 — informational only
+            pass
     out = None
     if rank == 0:
         n_cycles = (1 << args.log_rows) * args.steps * (1 if sharded else world)
@@ -216,7 +222,10 @@ def main():
                        "log_n_rows": args.log_rows,
                        "parallelism": ("ONE proof on %d GPUs: column-parallel LDE, all-to-all into row blocks, local hashing / constraints / quotients / FRI folds" % world) if sharded
                        else ("1 independent proof per GPU" if world > 1 else "1 GPU"),
-                       "proof_words": int(len(words))},
+                       "proof_words": int(len(words)),
+                       # every byte of the proof is Stwo's: these only choose WHERE exact polynomial identities let the prover read fewer bytes
+                       # (0 = Stwo's evaluation order, same proof; profiles/r03_*_ab.log have both)
+                       "prover_options": prover_options},
             "roofline": roof,
             # the FFT is VALU-issue bound on gfx950, not HBM bound: butterflies of one prove's iFFT + LDE work
             # (n/2 * N per iFFT, n * N per 2x LDE: the trivial top layer is not computed) against the measured chip ceiling of the
