@@ -68,6 +68,9 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value);
 int nx_ctx_get_option(const nx_ctx* ctx, const char* name, int64_t* value);
 int nx_sync(nx_ctx* ctx);
+/* Hands the context's cached device blocks (freed columns kept for the next prove of the same shape) back to the driver:
+ * another context, process or library on the same GPU can then use that memory.  Synchronises the context. */
+int nx_ctx_trim(nx_ctx* ctx);
 void* nx_ctx_stream(nx_ctx* ctx); /* hipStream_t the context launches on                       */
 const char* nx_version(void);
 
@@ -291,6 +294,11 @@ int nx_machine_air_source(const nx_component_spec* comp, char** h_source);
 int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed,
                      const uint8_t* ad, size_t ad_len, const struct nx_comm* comm, uint32_t** proof_words, size_t* n_words,
                      nx_prove_stats* stats);
+/* `Proof.claimed_sum` of the last successful nx_prove_machine on this context (reference prover/src/machine.rs:93-98: the proof the
+ * reference returns carries the per-component logup claimed sums next to the StarkProof; a verifier mixes them before the interaction
+ * commitment, machine.rs:262 / :448-450, and nx_proof_serialize_stwo takes them): 4 words per component, in component order.
+ * Writes min(cap_components, n) entries and the count n.  Host only (no device work). */
+int nx_machine_claimed_sums(const nx_ctx* ctx, uint32_t* claimed_sums, uint32_t cap_components, uint32_t* n_components);
 
 /* ------------------------------------------- ONE proof on the GPUs of a node (BASELINE configs #4 / #5) ---------------
  * One process (or thread) per GPU calls the prove entry with the same arguments and its own nx_comm; W must be a power of two.

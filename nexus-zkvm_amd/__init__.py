@@ -456,6 +456,10 @@ class HipBackend:
     def sync(self):
         self._chk(self.L.nx_sync(self.ctx))
 
+    def trim(self):
+        """nx_ctx_trim: give the cached device blocks back to the driver (other contexts on this GPU can use them)."""
+        self._chk(self.L.nx_ctx_trim(self.ctx))
+
     def set_hash_mode(self, mode):
         self._chk(self.L.nx_ctx_set_hash_mode(self.ctx, mode))
 
@@ -823,6 +827,15 @@ class HipBackend:
         out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
         self.L.nx_free_host(words)
         return (out, stats.as_dict()) if want_stats else out
+
+    def machine_claimed_sums(self):
+        """`Proof.claimed_sum` of the last prove_machine on this context (reference machine.rs:93-98): (n_components, 4) uint32."""
+        n = C.c_uint32(0)
+        self._chk(self.L.nx_machine_claimed_sums(self.ctx, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 4), np.uint32)
+        if n.value:
+            self._chk(self.L.nx_machine_claimed_sums(self.ctx, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
 
     def prove_sharded(self, comps, comm, cfg=None, seed=1, ad=b"", want_stats=False):
         """One proof, columns sharded over the ranks of `comm` (an NxComm from make_comm); every rank calls this with the

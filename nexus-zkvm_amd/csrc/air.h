@@ -34,6 +34,7 @@ int air_eval_rows(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_
 void air_kernel_shape(const nx_air_kernel* k, uint32_t* n_cols, uint32_t* n_econsts, uint32_t* n_constraints);
 // degree-aware composition (air_jit.hip): an upper bound of every constraint's degree; the columns a subset of the constraints reads
 void air_constraint_degrees(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, std::vector<uint32_t>* out);
+void air_constraint_neighbours(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, std::vector<char>* out);   // per constraint: reads a column at a non-zero row offset
 void air_subset_columns(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, const uint8_t* select, std::vector<char>* used);
 
 }  // namespace nx

@@ -251,6 +251,32 @@ void air_constraint_degrees(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_
     }
 }
 
+// Per constraint: does its value depend on a column read at a non-zero row offset (the same forward pass as the degrees)?  A constraint
+// that reads only the current row can be evaluated on ANY set of points of the evaluation domain, e.g. an N-point sub-domain on
+// which only those columns were evaluated (prover.hip, the quarter-domain part of a degree-4 component).
+void air_constraint_neighbours(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, std::vector<char>* out) {
+    std::vector<char> f(n_regs + 4, 0);
+    out->clear();
+    auto fE = [&](uint32_t r) { return (char)(f[r] | f[r + 1] | f[r + 2] | f[r + 3]); };
+    auto setE = [&](uint32_t r, char v) { f[r] = f[r + 1] = f[r + 2] = f[r + 3] = v; };
+    for (uint32_t i = 0; i < n_instr; i++) {
+        const nx_cinstr& in = prog[i];
+        switch (in.op) {
+        case NX_C_LOAD: f[in.dst] = in.b != 0; break;
+        case NX_C_CONST: f[in.dst] = 0; break;
+        case NX_C_ADD: case NX_C_SUB: case NX_C_MUL: f[in.dst] = f[in.a] | f[in.b]; break;
+        case NX_C_NEG: f[in.dst] = f[in.a]; break;
+        case NX_C_CONSTE: setE(in.dst, 0); break;
+        case NX_C_LOADE: setE(in.dst, in.b != 0); break;
+        case NX_C_ADDE: case NX_C_SUBE: case NX_C_MULE: setE(in.dst, fE(in.a) | fE(in.b)); break;
+        case NX_C_MULEB: case NX_C_ADDEB: setE(in.dst, fE(in.a) | f[in.b]); break;
+        case NX_C_CONSTRAINT_B: out->push_back(f[in.a]); break;
+        case NX_C_CONSTRAINT_E: out->push_back(fE(in.a)); break;
+        default: break;
+        }
+    }
+}
+
 // The component columns the selected constraints read (the backward slices of generate_air_source).
 void air_subset_columns(const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, const uint8_t* select, std::vector<char>* used) {
     const ProgDeps pd = program_deps(prog, n_instr, n_regs);

@@ -248,6 +248,7 @@ static nx_options options_from_env() {
     o.air_degree_split = env_int("NX_AIR_DEGREE_SPLIT", 1) != 0;
     o.quotients_coeffs = env_int("NX_QUOTIENTS_COEFFS", 1) != 0;
     o.air_half_domain = env_int("NX_AIR_HALF_DOMAIN", 1) != 0;
+    o.air_quarter_domain = env_int("NX_AIR_QUARTER_DOMAIN", 1) != 0;
     return o;
 }
 struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
@@ -264,6 +265,7 @@ static const OptEntry k_options[] = {
     {"air.degree_split", &nx_options::air_degree_split, 0, 1},
     {"quotients.coeffs", &nx_options::quotients_coeffs, 0, 1},
     {"air.half_domain", &nx_options::air_half_domain, 0, 1},
+    {"air.quarter_domain", &nx_options::air_quarter_domain, 0, 1},
 };
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return set_err(ctx, NX_ERR_ARG, "nx_ctx_set_option: NULL argument");
@@ -342,6 +344,7 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode) {
 }
 
 int nx_sync(nx_ctx* ctx) { NX_GUARD(ctx); NX_HIP(ctx, hipStreamSynchronize(ctx->stream)); NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream)); return NX_OK; }
+int nx_ctx_trim(nx_ctx* ctx) { NX_GUARD(ctx); if (!ctx) return set_err(nullptr, NX_ERR_ARG, "nx_ctx_trim: NULL context"); NX_TRY(nx_sync(ctx)); dev_cache_release(ctx); return NX_OK; }
 void* nx_ctx_stream(nx_ctx* ctx) { return (void*)ctx->stream; }
 
 int nx_alloc(nx_ctx* ctx, size_t n_words, uint32_t** d_out) {

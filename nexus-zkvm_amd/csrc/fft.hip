@@ -516,19 +516,22 @@ namespace nx {
 // after the top layer of the 2^(n+1)-point transform of N coefficients both halves hold the same data, and the remaining layers act
 // on each half with its half of every table.  The result is laid out like a tree of log_half = n - 1, so every transform entry point
 // works on it unchanged: interpolating the first half of an extension returns the N coefficients.
+// depth d in general: the first 1 / 2^d of the bit-reversed CanonicCoset(n + d) domain, with the first 2^-d of every layer of the
+// size-2^(n+d) tables (d = 2: the first QUARTER of the 4N-point domain — the quarter-domain composition of prover.hip;
+// tests/test_exact_algebra_cpu.py::test_degree_four_quotient_from_3n_plus_1_samples checks the statement on the oracle).
 __global__ void sub_twiddle_kernel(const u32* __restrict__ s0, const u32* __restrict__ s1, const u32* __restrict__ s2, const u32* __restrict__ s3,
-                                   u32* __restrict__ d0, u32* __restrict__ d1, u32* __restrict__ d2, u32* __restrict__ d3, int n, int L) {
+                                   u32* __restrict__ d0, u32* __restrict__ d1, u32* __restrict__ d2, u32* __restrict__ d3, int n, int L, int depth) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x, half = 1u << (n - 1);
     if (i >= half) return;
     if (i + 1 == half) { d0[i] = 1; d1[i] = 1; d2[i] = 2; d3[i] = 2; return; }     // the pad word of a tree (never a twiddle)
     const u32 m = half - i;                                   // in (2^(K-1), 2^K], K = n - layer
     const int K = 32 - __builtin_clz(m - 1);
     const u32 h = (1u << K) - m;
-    const u32 src = (1u << L) - (1u << (K + 1)) + h;
+    const u32 src = (1u << L) - (1u << (K + depth)) + h;
     d0[i] = s0[src]; d1[i] = s1[src]; d2[i] = s2[src]; d3[i] = s3[src];
 }
-int twiddles_first_half(nx_ctx* ctx, const nx_twiddles* tw, uint32_t n, nx_twiddles** out) {
-    if (n < 3 || n > tw->log_half) return set_err(ctx, NX_ERR_ARG, "twiddles_first_half: need 3 <= n <= log_half of the source tree");
+int twiddles_first_part(nx_ctx* ctx, const nx_twiddles* tw, uint32_t n, uint32_t depth, nx_twiddles** out) {
+    if (depth < 1 || depth > 4 || n < 3 || n + depth - 1 > tw->log_half) return set_err(ctx, NX_ERR_ARG, "twiddles_first_part: need 1 <= depth <= 4 and 3 <= n <= log_half + 1 - depth of the source tree");
     nx_twiddles* t = new nx_twiddles();
     t->ctx = ctx; t->log_half = n - 1; t->d_tw = t->d_itw = t->d_tw2 = t->d_itw2 = nullptr;
     const size_t bytes = (size_t)4 << (n - 1);
@@ -539,7 +542,7 @@ int twiddles_first_half(nx_ctx* ctx, const nx_twiddles* tw, uint32_t n, nx_twidd
     if (rc != NX_OK) { dev_free(ctx, t->d_tw); dev_free(ctx, t->d_itw); dev_free(ctx, t->d_tw2); dev_free(ctx, t->d_itw2); delete t; return rc; }
     const u32 half = 1u << (n - 1);
     hipLaunchKernelGGL(sub_twiddle_kernel, dim3((half + 255) / 256), dim3(256), 0, ctx->stream, tw->d_tw, tw->d_itw, tw->d_tw2, tw->d_itw2, t->d_tw, t->d_itw, t->d_tw2, t->d_itw2,
-                       (int)n, (int)tw->log_half);
+                       (int)n, (int)tw->log_half, (int)depth);
     if (hipGetLastError() != hipSuccess) { nx_twiddles_destroy(t); return set_err(ctx, NX_ERR_HIP, "sub_twiddle_kernel launch failed"); }
     *out = t;
     return NX_OK;

@@ -23,6 +23,7 @@ struct nx_options {
     int air_segment;              // "air.segment": estimated-instruction budget of one generated AIR kernel
     int quotients_coeffs;         // "quotients.coeffs": DEEP quotients of wide size groups from the coefficient columns (single GPU)
     int air_half_domain;          // "air.half_domain": constraints of degree <= 2 are evaluated on HALF of the committed 2N-point domain (single GPU, blowup 2)
+    int air_quarter_domain;       // "air.quarter_domain": degree-4/5 constraints that read no neighbour row are evaluated on the committed 2N rows + the first QUARTER of the 4N-point domain (3N + 1 samples; single GPU, blowup 2, bound 2)
     int air_degree_split;         // "air.degree_split": constraints of degree <= 3 of a component with a bound > 1 are evaluated on the log_size + 1 domain
 };
 
@@ -60,6 +61,7 @@ struct nx_ctx {
     std::vector<hipEvent_t> event_pool;
     double kind_ms[4];
     uint64_t kind_bytes[4];
+    std::vector<uint32_t> last_claimed;   // nx_machine_claimed_sums: 4 words per component of the last nx_prove_machine
 };
 enum { NX_T_LDE = 0, NX_T_MERKLE = 1, NX_T_QUOT = 2, NX_T_OTHER = 3 };
 
@@ -195,7 +197,8 @@ int fold_line_rows(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_
 int accumulate_quotients_rows(nx_ctx* ctx, uint32_t log_size, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t random_coeff[4], uint32_t n_batches,
                               const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx, const uint32_t* values, uint32_t* const* d_out4,
                               uint64_t row_begin, uint64_t n_rows);
-int twiddles_first_half(nx_ctx* ctx, const nx_twiddles* tw, uint32_t n, nx_twiddles** out);   // fft.hip: the N-point domain inside the 2N-point one
+int twiddles_first_part(nx_ctx* ctx, const nx_twiddles* tw, uint32_t n, uint32_t depth, nx_twiddles** out);   // fft.hip: the N-point domain that is the first 1 / 2^depth of the 2^depth N-point one
+inline int twiddles_first_half(nx_ctx* ctx, const nx_twiddles* tw, uint32_t n, nx_twiddles** out) { return twiddles_first_part(ctx, tw, n, 1, out); }
 int accumulate_quotients_coeffs(nx_ctx* ctx, const nx_twiddles* tw, uint32_t log_size, uint32_t log_coef, const uint32_t* const* d_polys, uint32_t n_cols,
                                 const uint32_t random_coeff[4], uint32_t n_batches, const uint32_t* points, const uint32_t* batch_counts, const uint32_t* col_idx,
                                 const uint32_t* values, uint32_t* const* d_out4);

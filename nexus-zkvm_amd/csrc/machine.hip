@@ -482,6 +482,8 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     }
     H_TRY(air.check(cs));
     H_TRY(prove_core(ctx, cs, channel, cfg, tw, air, words, st, lap));               // machine.rs:286-290
+    ctx->last_claimed.resize(4 * (size_t)n_comps);                                    // Proof.claimed_sum (machine.rs:93-98, :291-296)
+    for (uint32_t i = 0; i < n_comps; i++) q_store(&ctx->last_claimed[4 * (size_t)i], claimed[i]);
     if (timed) finish_stats(ctx, st, t_start);
     return NX_OK;
 }
@@ -533,6 +535,14 @@ int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_com
     if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: NULL argument");
     std::vector<uint32_t> w;
     return hand_out(ctx, nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats), w, proof_words, n_words, "nx_prove_machine");
+}
+
+int nx_machine_claimed_sums(const nx_ctx* ctx, uint32_t* claimed_sums, uint32_t cap_components, uint32_t* n_components) {
+    if (!ctx || !n_components || (cap_components && !claimed_sums)) return set_err(nullptr, NX_ERR_ARG, "nx_machine_claimed_sums: NULL argument");
+    const uint32_t n = (uint32_t)(ctx->last_claimed.size() / 4);
+    if (n && cap_components) memcpy(claimed_sums, ctx->last_claimed.data(), (size_t)std::min(n, cap_components) * 16);
+    *n_components = n;
+    return NX_OK;
 }
 
 }  // extern "C"

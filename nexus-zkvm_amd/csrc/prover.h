@@ -239,8 +239,9 @@ struct GComponent {
     const nx_air_kernel* kernel = nullptr; nx_air_kernel* owned = nullptr;
     // degree-aware composition (prepare_component_kernels): the parts of the constraints, the columns each reads, their kernels (context-cached)
     // where a part of the constraints is evaluated: on the component's own domain (log_size + bound), on the log_size + 1 domain
-    // (degree <= 3), or on the first half of the committed log_size + 1 domain (degree <= 2, see compute_composition)
-    enum { ON_FULL = 0, ON_LOW = 1, ON_HALF = 2 };
+    // (degree <= 3), on the first half of the committed log_size + 1 domain (degree <= 2, see compute_composition), or — degree 4 / 5
+    // without neighbour rows, bound 2 — on the committed domain plus the first quarter of the log_size + 2 domain (3N + 1 samples)
+    enum { ON_FULL = 0, ON_LOW = 1, ON_HALF = 2, ON_QUARTER = 3 };   // ON_QUARTER: committed 2N rows + first quarter of the 4N-point domain (degree 4 / 5, no neighbour rows)
     struct Part { int where = ON_FULL; bool whole = false; std::vector<uint8_t> select; std::vector<char> used; const nx_air_kernel* kernel = nullptr; };
     bool prepared = false; std::vector<Part> parts;
 };

@@ -1146,7 +1146,8 @@ int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g, 
     const uint32_t bound = comp_log_cd(g.log_cd, cfg);
     const bool can_half = ctx->opt.air_half_domain && !sharded && cfg.log_blowup == 1 && g.log_size >= 4 && g.n_constraints > 0;
     const bool can_low = ctx->opt.air_degree_split && bound > 1 && bound != cfg.log_blowup && g.n_constraints > 0;
-    if (!can_half && !can_low) {
+    const bool can_quarter = ctx->opt.air_quarter_domain && !sharded && cfg.log_blowup == 1 && bound == 2 && g.log_size >= 4 && g.n_constraints > 0;
+    if (!can_half && !can_low && !can_quarter) {
         GComponent::Part whole; whole.whole = true; whole.where = GComponent::ON_FULL;
         if (g.kernel) whole.kernel = g.kernel; else H_TRY(cached_air_kernel(ctx, g, nullptr, &whole.kernel));
         g.parts.clear(); g.parts.push_back(std::move(whole));
@@ -1154,7 +1155,7 @@ int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g, 
         return NX_OK;
     }
     std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
-    key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs) + "|" + std::to_string(g.econsts.size() / 4) + "|" + std::to_string(bound) + (can_half ? "|h" : "|-") + (can_low ? "l" : "-");
+    key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs) + "|" + std::to_string(g.econsts.size() / 4) + "|" + std::to_string(bound) + (can_half ? "|h" : "|-") + (can_low ? "l" : "-") + (can_quarter ? "q" : "-");
     SplitCache& sc = split_cache();
     {
         std::lock_guard<std::mutex> lk(sc.mu);
@@ -1169,11 +1170,19 @@ int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g, 
     where_of[2] = GComponent::ON_FULL;
     where_of[1] = can_low ? GComponent::ON_LOW : GComponent::ON_FULL;
     where_of[0] = can_half ? GComponent::ON_HALF : where_of[1];
+    std::vector<int> where_c(g.n_constraints);
+    for (uint32_t j = 0; j < g.n_constraints; j++) where_c[j] = where_of[deg[j] <= 2 ? 0 : deg[j] == 3 ? 1 : 2];
+    if (can_quarter) {
+        // degree 4 / 5 (d <= 2^2 + 1: the quotient has 3N + 1 coefficients) that read the current row only: the sub-domain holds no neighbour rows
+        std::vector<char> nb;
+        air_constraint_neighbours(g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, &nb);
+        for (uint32_t j = 0; j < g.n_constraints; j++) if (where_c[j] == GComponent::ON_FULL && deg[j] >= 4 && deg[j] <= 5 && !nb[j]) where_c[j] = GComponent::ON_QUARTER;
+    }
     std::vector<GComponent::Part> parts;
-    for (int where : {GComponent::ON_HALF, GComponent::ON_LOW, GComponent::ON_FULL}) {
+    for (int where : {GComponent::ON_HALF, GComponent::ON_LOW, GComponent::ON_QUARTER, GComponent::ON_FULL}) {
         GComponent::Part part; part.where = where; part.select.assign(g.n_constraints, 0);
         bool any = false;
-        for (uint32_t j = 0; j < g.n_constraints; j++) { const int cls = deg[j] <= 2 ? 0 : deg[j] == 3 ? 1 : 2; if (where_of[cls] == where) { part.select[j] = 1; any = true; } }
+        for (uint32_t j = 0; j < g.n_constraints; j++) if (where_c[j] == where) { part.select[j] = 1; any = true; }
         if (any) parts.push_back(std::move(part));
     }
     if (parts.size() == 1 && parts[0].where == GComponent::ON_FULL) {        // nothing to move: the component is evaluated whole
@@ -1240,6 +1249,75 @@ static int half_group_finish(nx_ctx* ctx, CommitmentSchemeProver& cs, uint32_t n
     return NX_OK;
 }
 
+// out[i] = (a[i] + s1 b[i]) s2
+__global__ void axpy_scale_kernel(u32* __restrict__ out, const u32* __restrict__ a, const u32* __restrict__ b, u32 s1, u32 s2, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = m_mul(m_add(a[i], m_mul(s1, b[i])), s2);
+}
+static int axpy_scale(nx_ctx* ctx, u32* out, const u32* a, const u32* b, u32 s1, u32 s2, u32 n) {
+    hipLaunchKernelGGL(axpy_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, out, a, b, s1, s2, n);
+    if (hipGetLastError() != hipSuccess) return set_err(ctx, NX_ERR_HIP, "axpy_scale_kernel launch failed");
+    return NX_OK;
+}
+
+// The same decomposition one level up (tests/test_exact_algebra_cpu.py::
+// test_degree_four_quotient_from_3n_plus_1_samples states it on the oracle).  The quotient F of constraints of degree 4 / 5 over columns
+// of N rows lives in the 4N-point space with 3N + 1 coefficients:  F = F0 + Z2 (F10 + t Z),  F0 in the 2N-point space, Z2 the vanishing
+// polynomial of the committed 2N-point domain, F10 in the N-point space, Z the trace domain's vanishing polynomial, t a secure scalar.
+//  * Z2 = 0 on the committed domain: evaluating the constraints on the COMMITTED 2N rows (no extension at all) and interpolating gives F0;
+//  * the first QUARTER of the bit-reversed 4N-point domain is an N-point circle domain (twiddles_first_part, depth 2) on which Z2 and Z
+//    are constant (z2, z0): the columns are evaluated there by an N-point transform each instead of a 4N-point one, the constraints
+//    on N rows, and (F - F0) / z2 interpolated there is F10 + t z0;
+//  * one further row w (row N, second quarter: Z = z1) gives t = (G(w) - I(w)) / (z1 - z0); the columns' values at w are one
+//    eval_at_point sweep over their coefficients.
+// 3N + 1 constraint evaluations instead of 4N, and per column an N-point transform + one sweep instead of a 4N-point transform.  The
+// 4N coefficients [F0 | I - t z0 | t, 0 ...] are those of the plain evaluation on all 4N rows, exactly; they enter
+// finalize_accumulation as a coefficient-form contribution.  Only for constraints that read no neighbour row (the quarter holds none).
+struct QuarterGroup { SecureColumn acc2n, accq; };     // accq: N + 4 rows per coordinate (rows [0, N) of the quarter and row N)
+static int quarter_group_finish(nx_ctx* ctx, CommitmentSchemeProver& cs, uint32_t n, QuarterGroup& qg, SecureColumn* out_coef) {
+    const uint32_t N = 1u << n;
+    nx_twiddles* qtw = nullptr;
+    H_TRY(twiddles_first_part(ctx, cs.tw, n, 2, &qtw));
+    struct Guard { nx_twiddles* t; ~Guard() { nx_twiddles_destroy(t); } } guard{qtw};
+    H_TRY(nx_interpolate_batch(ctx, cs.tw, qg.acc2n.c, 4, n + 1));                          // F0: 2N coefficients per coordinate
+    const std::vector<uint32_t> d4 = vanishing_denominators(n, n + 2), d2 = vanishing_denominators(n + 1, n + 2);
+    const u32 z0 = m_inv(d4[0]), z1 = m_inv(d4[1]), inv_z2 = d2[0];
+    // F0 on the quarter: F0 = F0_lo + Z F0_hi with Z = z0 there
+    SecureColumn fq, f0q, g;
+    H_TRY(fq.alloc(ctx, n)); H_TRY(f0q.alloc(ctx, n)); H_TRY(g.alloc(ctx, n));
+    for (int k = 0; k < 4; k++) H_TRY(axpy_scale(ctx, fq.c[k], qg.acc2n.c[k], qg.acc2n.c[k] + N, z0, 1, N));
+    { const uint32_t* src[4] = {fq.c[0], fq.c[1], fq.c[2], fq.c[3]}; H_TRY(nx_evaluate_batch(ctx, qtw, src, 4, n, 0, f0q.c)); }
+    for (int k = 0; k < 4; k++) H_TRY(axpy_scale(ctx, g.c[k], qg.accq.c[k], f0q.c[k], P - 1, inv_z2, N));      // G = (F - F0) / z2 on the quarter
+    H_TRY(nx_interpolate_batch(ctx, qtw, g.c, 4, n));                                        // I = F10 + t z0
+    // the scalars at w = row N of the 4N-point domain
+    const Pt w = pt_from_index(circle_domain_index((int)n + 2, bitrev(N, (int)n + 2)));
+    uint32_t pts[12 * 8], idx[12], ev[12 * 4], fw[4];
+    const uint32_t* polys[12];
+    for (int k = 0; k < 4; k++) { polys[k] = qg.acc2n.c[k]; polys[4 + k] = qg.acc2n.c[k] + N; polys[8 + k] = g.c[k]; }
+    for (int i = 0; i < 12; i++) { idx[i] = (uint32_t)i; QPt qp; qp.x = q_from_m(w.x); qp.y = q_from_m(w.y); q_store(pts + 8 * i, qp.x); q_store(pts + 8 * i + 4, qp.y); }
+    H_TRY(nx_eval_at_points(ctx, polys, n, idx, pts, 12, ev));
+    {
+        const uint32_t* gp[4] = {qg.accq.c[0], qg.accq.c[1], qg.accq.c[2], qg.accq.c[3]};
+        const uint64_t gi[4] = {N, N, N, N};
+        H_TRY(nx_gather(ctx, gp, gi, 4, fw));
+    }
+    const u32 dz = m_inv(m_sub(z1, z0));
+    u32 t[4];
+    for (int k = 0; k < 4; k++) {
+        const u32 f0w = m_add(ev[4 * k], m_mul(z1, ev[4 * (4 + k)]));
+        const u32 gw = m_mul(m_sub(fw[k], f0w), inv_z2);
+        t[k] = m_mul(m_sub(gw, ev[4 * (8 + k)]), dz);
+    }
+    H_TRY(out_coef->alloc(ctx, n + 2));
+    H_TRY(nx_memset_zero(ctx, out_coef->buf.p, out_coef->buf.words));
+    for (int k = 0; k < 4; k++) { H_TRY(nx_copy(ctx, out_coef->c[k], qg.acc2n.c[k], 2 * (size_t)N)); H_TRY(nx_copy(ctx, out_coef->c[k] + 2 * (size_t)N, g.c[k], N)); }
+    hipLaunchKernelGGL(half_fix_kernel, dim3(1), dim3(64), 0, ctx->stream, out_coef->c[0] + 2 * (size_t)N, out_coef->c[1] + 2 * (size_t)N, out_coef->c[2] + 2 * (size_t)N,
+                       out_coef->c[3] + 2 * (size_t)N, N, t[0], t[1], t[2], t[3], z0);
+    if (hipGetLastError() != hipSuccess) return set_err(ctx, NX_ERR_HIP, "half_fix_kernel launch failed");
+    H_TRY(nx_sync(ctx));                                         // fq / f0q / g are released on return
+    return NX_OK;
+}
+
 int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coeff, DevBuf* out_polys, uint32_t* out_log) {
     size_t total = 0;
     for (auto& c : comps) total += c.n_constraints;
@@ -1247,6 +1325,9 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
     { QM31 a = q_one(); for (size_t i = 0; i < total; i++) { powers[i] = a; a = q_mul(a, random_coeff); } }
     std::map<uint32_t, SecureColumn> sub;
     std::map<uint32_t, HalfGroup> halves;                                     // by log_size: the half-domain parts of all components of that size
+    std::map<uint32_t, QuarterGroup> quarters;                                // by log_size: the quarter-domain parts (degree 4 / 5) of all components of that size
+    std::map<uint32_t, nx_twiddles*> qtw;                                     // quarter-domain twiddles by log_size
+    struct QtwGuard { std::map<uint32_t, nx_twiddles*>& m; ~QtwGuard() { for (auto& kv : m) nx_twiddles_destroy(kv.second); } } qtw_guard{qtw};
     size_t remaining = total;
     for (auto& c : comps) {
         const uint32_t e = c.log_size + comp_log_cd(c.log_cd, cs.cfg);      // per component; finalize_accumulation lifts to the largest
@@ -1258,8 +1339,8 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
         for (size_t k = 0; k < c.cols.size(); k++) for (int o : c.masks[k]) if (o != 0) masked[k] = 1;
         H_TRY(prepare_component_kernels(ctx, cs.cfg, c, cs.dist.on()));
         {   // the composition keeps the size the bound declares, whatever domains the parts are evaluated on
-            bool any_full = false;
-            for (auto& part : c.parts) any_full = any_full || part.where == GComponent::ON_FULL;
+            bool any_full = false;       // ... or a quarter part: its contribution has the declared size too (4N coefficients)
+            for (auto& part : c.parts) any_full = any_full || part.where == GComponent::ON_FULL || part.where == GComponent::ON_QUARTER;
             SecureColumn* declared = nullptr;
             if (!any_full && e > c.log_size + 1) H_TRY(composition_accumulator(cs, sub, e, &declared));
         }
@@ -1280,6 +1361,48 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
                 H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, el, a4, 0, N + hg.n_extra));
                 continue;
             }
+            if (part.where == GComponent::ON_QUARTER) {
+                const uint32_t n = c.log_size, N = 1u << n;
+                QuarterGroup& qg = quarters[n];
+                if (!qg.acc2n.buf.p) {
+                    H_TRY(qg.acc2n.alloc(ctx, n + 1)); H_TRY(nx_memset_zero(ctx, qg.acc2n.buf.p, qg.acc2n.buf.words));
+                    H_TRY(qg.accq.alloc_rows(ctx, n, (uint64_t)N + 4, false)); H_TRY(nx_memset_zero(ctx, qg.accq.buf.p, qg.accq.buf.words));
+                    H_TRY(twiddles_first_part(ctx, cs.tw, n, 2, &qtw[n]));
+                }
+                {   // 1. the committed 2N rows (Z2 vanishes there: what comes out is F0)
+                    const std::vector<uint32_t> den = vanishing_denominators(n, n + 1);
+                    EvalDomainCols cols;
+                    H_TRY(columns_on_eval_domain(cs, c.cols, n, n + 1, masked, &cols, used));
+                    H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 1, qg.acc2n.c, 0, 2 * N));
+                }
+                // 2. the columns the part reads, on the first quarter of the 4N-point domain (an N-point transform each) and at row N
+                std::vector<size_t> sel;
+                for (size_t k = 0; k < c.cols.size(); k++) if (!used || (k < used->size() && (*used)[k])) sel.push_back(k);
+                const size_t ns = sel.size();
+                std::vector<const uint32_t*> src(ns);
+                for (size_t i = 0; i < ns; i++) src[i] = cs.trees[c.cols[sel[i]].first].polys[c.cols[sel[i]].second].ptr;
+                DevBuf ext, wv; H_TRY(ext.alloc(ctx, std::max<size_t>(ns, 1) << n)); H_TRY(wv.alloc(ctx, std::max<size_t>(ns, 4)));
+                auto dst = col_ptrs(ext.p, (uint32_t)ns, n);
+                if (ns) H_TRY(nx_evaluate_batch(ctx, qtw[n], src.data(), (uint32_t)ns, n, 0, dst.data()));
+                const std::vector<uint32_t> den = vanishing_denominators(n, n + 2);
+                std::vector<const uint32_t*> ptrs(c.cols.size(), nullptr);
+                for (size_t i = 0; i < ns; i++) ptrs[sel[i]] = dst[i];
+                uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = qg.accq.c[k];
+                H_TRY(air_eval_rows(ctx, part.kernel, ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 2, a4, 0, N));
+                if (ns) {
+                    const Pt w = pt_from_index(circle_domain_index((int)n + 2, bitrev(N, (int)n + 2)));
+                    std::vector<uint32_t> pidx(ns), pts(8 * ns), ev(4 * ns), wh(ns);
+                    uint32_t pw8[8]; { QPt qp; qp.x = q_from_m(w.x); qp.y = q_from_m(w.y); q_store(pw8, qp.x); q_store(pw8 + 4, qp.y); }
+                    for (size_t i = 0; i < ns; i++) { pidx[i] = (uint32_t)i; memcpy(&pts[8 * i], pw8, 32); }
+                    H_TRY(nx_eval_at_points(ctx, src.data(), n, pidx.data(), pts.data(), (uint32_t)ns, ev.data()));
+                    for (size_t i = 0; i < ns; i++) wh[i] = ev[4 * i];                       // a base-field polynomial at a base-field point
+                    H_TRY(nx_upload(ctx, wv.p, wh.data(), ns));
+                    for (size_t i = 0; i < ns; i++) ptrs[sel[i]] = bias_rows((const uint32_t*)(wv.p + i), N);      // one-row "columns", indexed with the global row N
+                    H_TRY(air_eval_rows(ctx, part.kernel, ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 2, a4, N, 1));
+                    H_TRY(nx_sync(ctx));                                                   // ext / wv are released at the end of this block
+                }
+                continue;
+            }
             const uint32_t pe = part.where == GComponent::ON_LOW ? c.log_size + 1 : e;
             const std::vector<uint32_t> den = vanishing_denominators(c.log_size, pe);
             EvalDomainCols cols;
@@ -1294,6 +1417,16 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
     }
     std::map<uint32_t, SecureColumn> coef;
     for (auto& kv : halves) H_TRY(half_group_finish(ctx, cs, kv.first, kv.second, &coef[kv.first + 1]));
+    for (auto& kv : quarters) {
+        // components of 2N rows may have put a half-domain contribution at the same size: coefficient vectors add
+        SecureColumn q4;
+        H_TRY(quarter_group_finish(ctx, cs, kv.first, kv.second, &q4));
+        auto it = coef.find(kv.first + 2);
+        if (it == coef.end()) { coef[kv.first + 2] = std::move(q4); continue; }
+        const u32* s4[4] = {q4.c[0], q4.c[1], q4.c[2], q4.c[3]};
+        H_TRY(secure_accumulate(ctx, it->second.c, s4, 1u << (kv.first + 2)));
+        H_TRY(nx_sync(ctx));                                   // q4 is released here
+    }
     return finalize_accumulation(cs, sub, out_polys, out_log, coef.empty() ? nullptr : &coef);
 }
 

@@ -121,3 +121,40 @@ def prove_machine(comps, cfg, seed=1, ad=b"", threads=None):
         locs.append((a, b, d)); a += c[1]; b += c[2]; d += c[3]
     components = [machine_component(ap, c, l, z, alpha, sh, int(cfg[6])) for c, l, sh in zip(comps, locs, shifts)]
     return s.prove(components)                                # :286-290
+
+
+def verify_machine(comps, cfg, words, claimed, ad=b""):
+    """`nexus_vm_prover::verify` for the machine (reference prover/src/machine.rs:363-500) on the oracle's VERIFIER session: the
+    transcript prefix replayed from the proof's own commitments (:437-482: ad bytes, log sizes, preprocessed and main roots, lookup
+    elements, claimed sums, interaction root), the components rebuilt from the drawn lookup elements and the claimed sums
+    (`claimed`: (n_components, 4) words — `Proof.claimed_sum`, nx_machine_claimed_sums), then core::verifier::verify.  Costs KBs of
+    hashing whatever the trace size: the size-independent check of a proof the oracle PROVER could not reproduce in test time.
+    None when accepted, else the verifier's error text."""
+    import ref_emitter as ap
+    comps = [tuple(int(x) for x in c) for c in comps]
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    claimed = np.ascontiguousarray(claimed, dtype=np.uint32).reshape(len(comps), 4)
+    h = O.proof_header_words()
+    if int(words[h]) != 4:
+        return "proof does not hold 4 commitments"
+    roots = [words[h + 1 + 8 * t:h + 9 + 8 * t] for t in range(3)]
+    v = O.VerifierSession(cfg)
+    for byte in ad:
+        v.mix_u64(byte)
+    for c in comps:
+        v.mix_u64(c[0])
+    tree_logs = [[c[0] for c in comps for _ in range(c[1 + t])] for t in range(3)]
+    v.commit(roots[0], tree_logs[0])
+    v.commit(roots[1], tree_logs[1])
+    z, alpha = v.draw_felts(2)
+    v.mix_felts(claimed)
+    v.commit(roots[2], tree_logs[2])
+    locs, a, b, d = [], 0, 0, 0
+    for c in comps:
+        locs.append((a, b, d)); a += c[1]; b += c[2]; d += c[3]
+    shifts = []
+    for c, cs in zip(comps, claimed):
+        n_inv = pow((1 << c[0]) % P, P - 2, P)
+        shifts.append(np.array([(int(x) * n_inv) % P for x in cs], np.uint32))
+    components = [machine_component(ap, c, l, z, alpha, sh, int(cfg[6])) for c, l, sh in zip(comps, locs, shifts)]
+    return v.verify(components, words)
