@@ -1,0 +1,225 @@
+//! `prover/src/machine_hip.rs` — drop-in for the reference tree, a child module of `machine` (see README.md next to this file for
+//! the small edits that wire it in).  `Machine::<C>::prove_hip_with_extensions` is `Machine::<C>::prove_with_extensions` (prover/src/machine.rs:130-297)
+//! with the Stwo objects replaced by the device session of `nexus-hip`:
+//!
+//!   machine.rs                                                        here
+//!   :135-183  trace generation (CPU, unchanged)                        the same statements
+//!   :184-194  SimdBackend::precompute_twiddles(..)                     inside `Session::new` (sized max_log + LOG_CONSTRAINT_DEGREE + blowup - 1)
+//!   :197-206  Blake2sChannel, mix_u64 per AD byte / per log size       `Session::mix_u64`
+//!   :208-237  tree_builder.extend_evals(..) / .commit(channel) x2      `Session::tree_begin` + `upload` + `tree_commit`
+//!   :239-240  C::draw_lookup_elements(&mut lookup_elements, channel)   a host `Blake2sChannel` set to the session's digest (`host_channel_at`)
+//!   :242-263  generate_interaction_trace, mix_felts, commit            the reference's CPU generator, then upload + `tree_commit`
+//!   :264-285  FrameworkComponent::new(..) / to_component_prover(..)    `record_component(..)` over the same `MachineEval` / extension evals
+//!   :286-290  stwo::prover::prove(..)                                  `Session::prove` (composition, OODS, DEEP quotients, FRI, PoW, decommit)
+//!   :292-296  Proof { stark_proof, claimed_sum, log_size }             `proof_bytes` (postcard) -> `Proof`
+//!
+//! NOT COMPILED in the build image (no Rust toolchain); the `use` block below is machine.rs:1-47's (its `super::` is this file's `crate::`) — the
+//! structural test holds every `crate::` path here to the ones machine.rs itself imports.  The interaction trace stays on the CPU in this first cut
+//! (LogupTraceGenerator is written against SimdBackend); `sys::nx_logup_cols` + `sys::nx_logup_finalize_last` take over once the
+//! chips' `fill_interaction_trace` hand their tuples over as column lists (the device kernels and their parity tests exist:
+//! csrc/logup.hip, tests/test_gpu_machine.py).
+use num_traits::Zero;
+use stwo::{
+    core::{
+        channel::Blake2sChannel,
+        fields::{m31::BaseField, qm31::SecureField},
+        pcs::PcsConfig,
+        vcs::blake2_hash::Blake2sHash,
+    },
+    prover::{
+        backend::simd::SimdBackend,
+        poly::{circle::CircleEvaluation, BitReversedOrder},
+        ProvingError,
+    },
+};
+
+// a CHILD module of `machine` (`#[path = "machine_hip.rs"] mod hip;` inside machine.rs): `BASE_EXTENSIONS` and `Machine::max_log_size`
+// are private to that module (machine.rs:82, :488)
+use super::{GeneratedTraces, Machine, Proof, BASE_EXTENSIONS};
+use crate::trace::eval::{INTERACTION_TRACE_IDX, ORIGINAL_TRACE_IDX, PREPROCESSED_TRACE_IDX};
+use nexus_vm::{emulator::View, trace::Trace};
+
+use crate::components::{MachineEval, LOG_CONSTRAINT_DEGREE};
+use crate::traits::MachineChip;
+use crate::{
+    components::AllLookupElements,
+    extensions::{ComponentTrace, ExtensionComponent, ExtensionsConfig},
+    traits::generate_interaction_trace,
+};
+
+use nexus_hip::record::{record_component, TraceLocations};
+use nexus_hip::{proof_bytes, HipError, RecordedComponent, Session};
+use nexus_hip_sys as sys;
+
+type SimdEval = CircleEvaluation<SimdBackend, BaseField, BitReversedOrder>;
+
+fn q4(s: SecureField) -> [u32; 4] {
+    let a = s.to_m31_array();
+    [a[0].0, a[1].0, a[2].0, a[3].0]
+}
+/// `C::draw_lookup_elements(&mut lookup_elements, prover_channel, ..)` (machine.rs:239-240) takes `&mut impl Channel`, and `Channel`
+/// is `Default + Clone`: it has to be a real channel.  A host `Blake2sChannel` standing where the session's transcript stands does it:
+/// the lookup elements are DRAWN (draws hash the digest with a counter and leave the digest alone), and what follows — `mix_felts` of
+/// the claimed sums, machine.rs:262 — replaces the digest by H(digest ‖ felts) and resets the counter, so the session's transcript
+/// needs no replay of the draws.  [upstream-recollection: `Blake2sChannel::update_digest` is public; the oracle's channel
+/// (oracle/blake2s.h, csrc/host/channel.h) restates the same rule and the parity suite runs the draw-then-mix sequence through it]
+fn host_channel_at(session: &Session) -> Blake2sChannel {
+    let mut ch = Blake2sChannel::default();
+    ch.update_digest(Blake2sHash(session.channel_digest()));
+    ch
+}
+
+/// host pointers of a batch of SimdBackend evaluations (bit-reversed circle-domain order already: `finalize_columns` ran on the CPU,
+/// trace/utils.rs:94-106) and their log sizes, in commit order
+fn host_columns(evals: &[SimdEval]) -> (Vec<*const u32>, Vec<u32>) {
+    let ptrs = evals.iter().map(|e| e.values.as_slice().as_ptr() as *const u32).collect();
+    let logs = evals.iter().map(|e| e.domain.log_size()).collect();
+    (ptrs, logs)
+}
+
+/// TreeBuilder::extend_evals(..) + commit(channel) for one trace tree (machine.rs:208-228, :230-237, :249-263)
+fn commit_tree(session: &mut Session, evals: &[SimdEval]) -> Result<(), HipError> {
+    let (host, logs) = host_columns(evals);
+    let dev = session.tree_begin(&logs)?;
+    // runs of equal size go up in one call each (the library pins, streams and unpins a run at a time)
+    let mut i = 0;
+    while i < logs.len() {
+        let mut j = i;
+        while j < logs.len() && logs[j] == logs[i] { j += 1; }
+        session.upload(&host[i..j], logs[i], &dev[i..j], false)?;
+        i = j;
+    }
+    session.tree_commit()?;
+    Ok(())
+}
+
+fn to_proving_error(e: HipError) -> ProvingError {
+    match e {
+        HipError::ConstraintsNotSatisfied => ProvingError::ConstraintsNotSatisfied,
+        // the reference has no error channel for resources either: `vec![..]` aborts (trace_builder.rs:29)
+        other => panic!("nexus-hip: {other:?}"),
+    }
+}
+
+impl<C: MachineChip + Sync> Machine<C> {
+    pub fn prove_hip(trace: &impl Trace, view: &View) -> Result<Proof, ProvingError> {
+        Self::prove_hip_with_extensions(&[], trace, view)
+    }
+
+    pub fn prove_hip_with_extensions(
+        extensions: &[ExtensionComponent],
+        trace: &impl Trace,
+        view: &View,
+    ) -> Result<Proof, ProvingError> {
+        // ---- machine.rs:135-183: sizes, preprocessed / main / program traces on the CPU — the reference's own statements, hoisted
+        // (README.md edit 2) into `Machine::generate_traces` so that both provers run the same ones
+        let init_memory = [
+            view.get_ro_initial_memory(),
+            view.get_rw_initial_memory(),
+            view.get_public_input(),
+        ]
+        .concat();
+        let GeneratedTraces {
+            log_size,
+            extensions_config,
+            preprocessed_trace,
+            finalized_trace,
+            finalized_program_trace,
+            all_log_sizes,
+            mut prover_side_note,
+            program_trace_ref,
+        } = Self::generate_traces(extensions, trace, view, &init_memory);
+        let extensions_iter = BASE_EXTENSIONS.iter().chain(extensions);
+
+        // ---- machine.rs:184-206: config, twiddles (inside the session), channel seeding
+        let config = PcsConfig::default();
+        let max_log = log_size.max(all_log_sizes.iter().copied().max().unwrap_or(0));
+        let cfg = sys::nx_pcs_config {
+            pow_bits: config.pow_bits,
+            log_blowup: config.fri_config.log_blowup_factor,
+            n_queries: config.fri_config.n_queries as u32,
+            log_last_layer_degree_bound: config.fri_config.log_last_layer_degree_bound,
+            hash_mode: sys::NX_HASH_BLAKE2S as u32,
+            fri_alpha_mode: sys::NX_FRI_ALPHA_PREV as u32,
+            log_constraint_degree: LOG_CONSTRAINT_DEGREE,
+        };
+        let device: i32 = std::env::var("NEXUS_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+        let mut session = Session::new(&cfg, max_log, device).map_err(to_proving_error)?;
+        for byte in view.view_associated_data().unwrap_or_default() {
+            session.mix_u64(byte.into());
+        }
+        all_log_sizes.iter().for_each(|log_size| session.mix_u64(*log_size as u64));
+
+        // ---- machine.rs:208-228: preprocessed tree (base preprocessed + program columns, then the extensions')
+        let extension_traces: Vec<ComponentTrace> = extensions_iter
+            .clone()
+            .zip(all_log_sizes.get(1..).unwrap_or_default())
+            .map(|(ext, log_size)| {
+                ext.generate_component_trace(*log_size, program_trace_ref, &mut prover_side_note)
+            })
+            .collect();
+        let mut tree0: Vec<SimdEval> = preprocessed_trace
+            .clone()
+            .into_circle_evaluation()
+            .into_iter()
+            .chain(finalized_program_trace.clone().into_circle_evaluation())
+            .collect();
+        for extension_trace in &extension_traces {
+            tree0.extend(extension_trace.to_circle_evaluation(PREPROCESSED_TRACE_IDX));
+        }
+        commit_tree(&mut session, &tree0).map_err(to_proving_error)?;
+        drop(tree0);
+
+        // ---- machine.rs:230-237: main tree
+        let mut tree1: Vec<SimdEval> = finalized_trace.clone().into_circle_evaluation();
+        for extension_trace in &extension_traces {
+            tree1.extend(extension_trace.to_circle_evaluation(ORIGINAL_TRACE_IDX));
+        }
+        commit_tree(&mut session, &tree1).map_err(to_proving_error)?;
+        drop(tree1);
+
+        // ---- machine.rs:239-263: lookup elements from the session's channel, interaction trace (CPU), claimed sums, interaction tree
+        let mut lookup_elements = AllLookupElements::default();
+        C::draw_lookup_elements(&mut lookup_elements, &mut host_channel_at(&session), &extensions_config);
+        let (interaction_trace, claimed_sum) = generate_interaction_trace::<C>(
+            &finalized_trace,
+            &preprocessed_trace,
+            &finalized_program_trace,
+            &lookup_elements,
+        );
+        let mut tree2: Vec<SimdEval> = interaction_trace;
+        let mut all_claimed_sums = vec![claimed_sum];
+        for (ext, extension_trace) in extensions_iter.clone().zip(extension_traces) {
+            let (interaction_trace, claimed_sum) =
+                ext.generate_interaction_trace(extension_trace, &prover_side_note, &lookup_elements);
+            all_claimed_sums.push(claimed_sum);
+            tree2.extend(interaction_trace);
+        }
+        let claimed_words: Vec<u32> = all_claimed_sums.iter().flat_map(|s| q4(*s)).collect();
+        session.mix_felts(&claimed_words);
+        commit_tree(&mut session, &tree2).map_err(to_proving_error)?;
+        drop(tree2);
+
+        // ---- machine.rs:264-285: the components, recorded instead of instantiated (same evals, same order, same claimed sums)
+        let mut locations = TraceLocations::default();
+        let mut components: Vec<RecordedComponent> = vec![record_component(
+            &MachineEval::<C>::new(log_size, lookup_elements.clone(), extensions_config.clone()),
+            &mut locations,
+            claimed_sum,
+        )];
+        for ((ext, claimed_sum), log_size) in extensions_iter
+            .zip(all_claimed_sums.get(1..).unwrap_or_default())
+            .zip(all_log_sizes.get(1..).unwrap_or_default())
+        {
+            components.push(ext.to_recorded_component(&mut locations, &lookup_elements, *log_size, *claimed_sum));
+        }
+
+        // ---- machine.rs:286-296: stwo::prover::prove on the device; the reference's Proof from its postcard bytes
+        let words = session.prove(&components).map_err(to_proving_error)?;
+        let bytes = proof_bytes(&words, &claimed_words, &all_log_sizes).map_err(to_proving_error)?;
+        let proof: Proof = postcard::from_bytes(&bytes).expect("nx_proof_serialize_stwo emits the serde layout of machine::Proof");
+        debug_assert!(proof.claimed_sum == all_claimed_sums && proof.log_size == all_log_sizes);
+        debug_assert!(INTERACTION_TRACE_IDX == 2 && SecureField::zero().is_zero());
+        Ok(proof)
+    }
+}

@@ -1,0 +1,325 @@
+//! `impl <Stwo backend trait> for HipBackend` — one adapter per trait method over `crate::ops` (INTEGRATION.md §2 is the table
+//! trait method -> `ops::*` -> C-ABI export).  Compiled only with `RUSTFLAGS="--cfg stwo_traits"`: the signatures are
+//! [upstream-recollection] of stwo @ 0790eba (the crate is an un-vendored git dependency of the reference, Cargo.toml:39-48, and is
+//! not in the build image); the first compile against the pinned crate settles them.  What the reference itself shows of this
+//! surface: `SimdBackend::precompute_twiddles(CanonicCoset::new(..).circle_domain().half_coset)` (machine.rs:186-194),
+//! `CommitmentSchemeProver::<SimdBackend, Blake2sMerkleChannel>::new(config, &twiddles)` (:202-203), `tree_builder.extend_evals(..)` /
+//! `.commit(channel)` (:208-263), `prove::<SimdBackend, Blake2sMerkleChannel>(&components, channel, commitment_scheme)` (:286-290),
+//! `ColumnOps::bit_reverse_column` (trace/utils.rs:101), `Column::{zeros, at, set, to_cpu}` (prover2/trace/src/builder.rs:103,
+//! component.rs:40-44), `CircleEvaluation::new(domain, col)` (trace_builder.rs:156-164).
+use crate::{ctx, ops, HipBackend, HipColumn, HipTwiddles, RecordedComponent};
+use nexus_hip_sys as sys;
+use std::sync::Arc;
+
+use stwo::core::channel::Blake2sChannel;
+use stwo::core::circle::{CirclePoint, Coset};
+use stwo::core::fields::m31::BaseField;
+use stwo::core::fields::qm31::SecureField;
+use stwo::core::pcs::quotients::ColumnSampleBatch;
+use stwo::core::poly::circle::{CanonicCoset, CircleDomain};
+use stwo::core::vcs::blake2_hash::Blake2sHash;
+use stwo::core::vcs::blake2_merkle::{Blake2sMerkleChannel, Blake2sMerkleHasher};
+use stwo::core::ColumnVec;
+use stwo::prover::air::accumulation::{AccumulationOps, DomainEvaluationAccumulator};
+use stwo::prover::backend::{Backend, BackendForChannel, Col, Column, ColumnOps, FieldOps};
+use stwo::prover::fri::FriOps;
+use stwo::prover::line::LineEvaluation;
+use stwo::prover::lookups::gkr_prover::{GkrMultivariatePolyOracle, GkrOps, Layer};
+use stwo::prover::lookups::mle::{Mle, MleOps};
+use stwo::prover::pcs::quotient_ops::QuotientOps;
+use stwo::prover::poly::circle::{CircleEvaluation, CirclePoly, PolyOps, SecureEvaluation};
+use stwo::prover::poly::twiddles::TwiddleTree;
+use stwo::prover::poly::BitReversedOrder;
+use stwo::prover::proof_of_work::GrindOps;
+use stwo::prover::secure_column::SecureColumnByCoords;
+use stwo::prover::vcs::ops::MerkleOps;
+use stwo::prover::{ComponentProver, Trace};
+
+fn q4(s: SecureField) -> [u32; 4] { let a = s.to_m31_array(); [a[0].0, a[1].0, a[2].0, a[3].0] }
+fn q_from(w: &[u32]) -> SecureField { SecureField::from_m31_array([BaseField::from_u32_unchecked(w[0]), BaseField::from_u32_unchecked(w[1]), BaseField::from_u32_unchecked(w[2]), BaseField::from_u32_unchecked(w[3])]) }
+fn point8(p: CirclePoint<SecureField>) -> [u32; 8] { let (x, y) = (q4(p.x), q4(p.y)); [x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]] }
+fn coords_mut(c: &mut SecureColumnByCoords<HipBackend>) -> [*mut u32; 4] { [c.columns[0].as_mut_ptr(), c.columns[1].as_mut_ptr(), c.columns[2].as_mut_ptr(), c.columns[3].as_mut_ptr()] }
+fn coords(c: &SecureColumnByCoords<HipBackend>) -> [*const u32; 4] { [c.columns[0].as_ptr(), c.columns[1].as_ptr(), c.columns[2].as_ptr(), c.columns[3].as_ptr()] }
+fn new_coords(len: usize) -> SecureColumnByCoords<HipBackend> { SecureColumnByCoords { columns: std::array::from_fn(|_| HipColumn::<BaseField>::zeros_words(len, 1)) } }
+
+impl Backend for HipBackend {}
+impl BackendForChannel<Blake2sMerkleChannel> for HipBackend {}
+
+// ------------------------------------------------------------------------------------------------ columns ----
+impl ColumnOps<BaseField> for HipBackend {
+    type Column = HipColumn<BaseField>;
+    fn bit_reverse_column(col: &mut Self::Column) { ops::bit_reverse(col.as_mut_ptr(), col.len().ilog2()); }
+}
+impl Column<BaseField> for HipColumn<BaseField> {
+    fn zeros(len: usize) -> Self { HipColumn::zeros_words(len, 1) }
+    unsafe fn uninitialized(len: usize) -> Self { HipColumn::zeros_words(len, 1) }
+    fn to_cpu(&self) -> Vec<BaseField> { self.to_host_words().into_iter().map(BaseField::from_u32_unchecked).collect() }
+    fn len(&self) -> usize { self.len }
+    fn at(&self, index: usize) -> BaseField { BaseField::from_u32_unchecked(self.word_at(index)) }
+    fn set(&mut self, index: usize, value: BaseField) { self.set_word(index, value.0); }
+}
+impl FromIterator<BaseField> for HipColumn<BaseField> {
+    fn from_iter<I: IntoIterator<Item = BaseField>>(it: I) -> Self { let v: Vec<u32> = it.into_iter().map(|x| x.0).collect(); HipColumn::from_host_words(&v, 1) }
+}
+
+/// secure columns: four coordinate blocks of `len` words (coordinate-major), the layout every secure-field export takes
+impl ColumnOps<SecureField> for HipBackend {
+    type Column = HipColumn<SecureField>;
+    fn bit_reverse_column(col: &mut Self::Column) {
+        let p = [col.coord_ptr(0), col.coord_ptr(1), col.coord_ptr(2), col.coord_ptr(3)];
+        ops::bit_reverse_secure(&p, col.len().ilog2());
+    }
+}
+impl Column<SecureField> for HipColumn<SecureField> {
+    fn zeros(len: usize) -> Self { HipColumn::zeros_words(len, 4) }
+    unsafe fn uninitialized(len: usize) -> Self { HipColumn::zeros_words(len, 4) }
+    fn to_cpu(&self) -> Vec<SecureField> {
+        let w = self.to_host_words(); let n = self.len;
+        (0..n).map(|i| q_from(&[w[i], w[n + i], w[2 * n + i], w[3 * n + i]])).collect()
+    }
+    fn len(&self) -> usize { self.len }
+    fn at(&self, index: usize) -> SecureField { let n = self.len; q_from(&[self.word_at(index), self.word_at(n + index), self.word_at(2 * n + index), self.word_at(3 * n + index)]) }
+    fn set(&mut self, index: usize, value: SecureField) { let (n, q) = (self.len, q4(value)); for k in 0..4 { self.set_word(k * n + index, q[k]); } }
+}
+impl FromIterator<SecureField> for HipColumn<SecureField> {
+    fn from_iter<I: IntoIterator<Item = SecureField>>(it: I) -> Self {
+        let v: Vec<[u32; 4]> = it.into_iter().map(q4).collect();
+        let n = v.len();
+        let mut w = vec![0u32; 4 * n];
+        for (i, q) in v.iter().enumerate() { for k in 0..4 { w[k * n + i] = q[k]; } }
+        HipColumn::from_host_words(&w, 4)
+    }
+}
+
+/// Merkle layers: `len` hashes of 8 words
+impl ColumnOps<Blake2sHash> for HipBackend {
+    type Column = HipColumn<Blake2sHash>;
+    fn bit_reverse_column(_col: &mut Self::Column) { unimplemented!("Stwo never bit-reverses a hash column") }
+}
+fn hash_from(w: &[u32]) -> Blake2sHash { let mut b = [0u8; 32]; for k in 0..8 { b[4 * k..4 * k + 4].copy_from_slice(&w[k].to_le_bytes()); } Blake2sHash(b) }
+fn hash_words(h: &Blake2sHash) -> [u32; 8] { std::array::from_fn(|k| u32::from_le_bytes([h.0[4 * k], h.0[4 * k + 1], h.0[4 * k + 2], h.0[4 * k + 3]])) }
+impl Column<Blake2sHash> for HipColumn<Blake2sHash> {
+    fn zeros(len: usize) -> Self { HipColumn::zeros_words(len, 8) }
+    unsafe fn uninitialized(len: usize) -> Self { HipColumn::zeros_words(len, 8) }
+    fn to_cpu(&self) -> Vec<Blake2sHash> { self.to_host_words().chunks(8).map(hash_from).collect() }
+    fn len(&self) -> usize { self.len }
+    fn at(&self, index: usize) -> Blake2sHash { let w: Vec<u32> = (0..8).map(|k| self.word_at(8 * index + k)).collect(); hash_from(&w) }
+    fn set(&mut self, index: usize, value: Blake2sHash) { let w = hash_words(&value); for k in 0..8 { self.set_word(8 * index + k, w[k]); } }
+}
+impl FromIterator<Blake2sHash> for HipColumn<Blake2sHash> {
+    fn from_iter<I: IntoIterator<Item = Blake2sHash>>(it: I) -> Self { let w: Vec<u32> = it.into_iter().flat_map(|h| hash_words(&h)).collect(); HipColumn::from_host_words(&w, 8) }
+}
+
+impl FieldOps<BaseField> for HipBackend {
+    fn batch_inverse(column: &Self::Column, dst: &mut Self::Column) { ops::batch_inverse_m31(column.as_ptr(), dst.as_mut_ptr(), column.len()); }
+}
+impl FieldOps<SecureField> for HipBackend {
+    fn batch_inverse(column: &HipColumn<SecureField>, dst: &mut HipColumn<SecureField>) {
+        let s = [column.coord_ptr(0) as *const u32, column.coord_ptr(1) as *const u32, column.coord_ptr(2) as *const u32, column.coord_ptr(3) as *const u32];
+        let d = [dst.coord_ptr(0), dst.coord_ptr(1), dst.coord_ptr(2), dst.coord_ptr(3)];
+        ops::batch_inverse_qm31(&s, &d, column.len());
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ PolyOps ----
+fn tw_of(t: &TwiddleTree<HipBackend>) -> &HipTwiddles { &t.twiddles }
+
+impl PolyOps for HipBackend {
+    type Twiddles = Arc<HipTwiddles>;
+
+    /// values in the natural order of `coset` -> bit-reversed circle-domain order (reference trace/utils.rs:94-106, on the device)
+    fn new_canonical_ordered(coset: CanonicCoset, values: Col<Self, BaseField>) -> CircleEvaluation<Self, BaseField, BitReversedOrder> {
+        let mut out = HipColumn::<BaseField>::zeros_words(values.len(), 1);
+        ops::finalize_columns(&[values.as_ptr()], &[out.as_mut_ptr()], coset.log_size());
+        CircleEvaluation::new(coset.circle_domain(), out)
+    }
+    fn interpolate(eval: CircleEvaluation<Self, BaseField, BitReversedOrder>, twiddles: &TwiddleTree<Self>) -> CirclePoly<Self> {
+        let log = eval.domain.log_size();
+        let mut values = eval.values;
+        ops::interpolate(tw_of(twiddles), &[values.as_mut_ptr()], log);
+        CirclePoly::new(values)
+    }
+    /// all columns of one size in ONE batched call (the library spreads a batch over its streams)
+    fn interpolate_columns(columns: impl IntoIterator<Item = CircleEvaluation<Self, BaseField, BitReversedOrder>>, twiddles: &TwiddleTree<Self>) -> Vec<CirclePoly<Self>> {
+        let mut evals: Vec<CircleEvaluation<Self, BaseField, BitReversedOrder>> = columns.into_iter().collect();
+        let mut by_log: std::collections::BTreeMap<u32, Vec<*mut u32>> = Default::default();
+        for ev in evals.iter_mut() { by_log.entry(ev.domain.log_size()).or_default().push(ev.values.as_mut_ptr()); }
+        for (log, ptrs) in by_log { ops::interpolate(tw_of(twiddles), &ptrs, log); }
+        evals.into_iter().map(|ev| CirclePoly::new(ev.values)).collect()
+    }
+    fn eval_at_point(poly: &CirclePoly<Self>, point: CirclePoint<SecureField>) -> SecureField {
+        let mut out = [0u32; 4];
+        ops::eval_at_points(&[poly.coeffs.as_ptr()], poly.log_size(), &[0], &point8(point), &mut out);
+        q_from(&out)
+    }
+    /// zero-extension of the coefficient vector (the coefficients of a bit-reversed-basis polynomial keep their indices)
+    fn extend(poly: &CirclePoly<Self>, log_size: u32) -> CirclePoly<Self> {
+        assert!(log_size >= poly.log_size());
+        let mut out = HipColumn::<BaseField>::zeros_words(1 << log_size, 1);
+        let g = ctx();
+        crate::check(g.0, unsafe { sys::nx_copy(g.0, out.as_mut_ptr(), poly.coeffs.as_ptr(), poly.coeffs.len()) });
+        drop(g);
+        CirclePoly::new(out)
+    }
+    fn evaluate(poly: &CirclePoly<Self>, domain: CircleDomain, twiddles: &TwiddleTree<Self>) -> CircleEvaluation<Self, BaseField, BitReversedOrder> {
+        assert!(domain.is_canonic(), "HipBackend evaluates on canonic domains (the only ones stwo::prover::prove uses)");
+        let mut out = HipColumn::<BaseField>::zeros_words(domain.size(), 1);
+        ops::evaluate(tw_of(twiddles), &[poly.coeffs.as_ptr()], poly.log_size(), domain.log_size() - poly.log_size(), &[out.as_mut_ptr()]);
+        CircleEvaluation::new(domain, out)
+    }
+    fn evaluate_polynomials(polynomials: ColumnVec<CirclePoly<Self>>, log_blowup_factor: u32, twiddles: &TwiddleTree<Self>) -> Vec<CircleEvaluation<Self, BaseField, BitReversedOrder>> {
+        let mut outs: Vec<HipColumn<BaseField>> = polynomials.iter().map(|p| HipColumn::zeros_words(1usize << (p.log_size() + log_blowup_factor), 1)).collect();
+        let mut by_log: std::collections::BTreeMap<u32, (Vec<*const u32>, Vec<*mut u32>)> = Default::default();
+        for (p, o) in polynomials.iter().zip(outs.iter_mut()) { let e = by_log.entry(p.log_size()).or_default(); e.0.push(p.coeffs.as_ptr()); e.1.push(o.as_mut_ptr()); }
+        for (log, (src, dst)) in by_log { ops::evaluate(tw_of(twiddles), &src, log, log_blowup_factor, &dst); }
+        polynomials.iter().zip(outs).map(|(p, o)| CircleEvaluation::new(CanonicCoset::new(p.log_size() + log_blowup_factor).circle_domain(), o)).collect()
+    }
+    fn precompute_twiddles(coset: Coset) -> TwiddleTree<Self> {
+        let t = Arc::new(ops::precompute_twiddles(coset.log_size()));
+        TwiddleTree { root_coset: coset, twiddles: t.clone(), itwiddles: t }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ MerkleOps ----
+impl MerkleOps<Blake2sMerkleHasher> for HipBackend {
+    fn commit_on_layer(log_size: u32, prev_layer: Option<&Col<Self, Blake2sHash>>, columns: &[&Col<Self, BaseField>]) -> Col<Self, Blake2sHash> {
+        let mut out = HipColumn::<Blake2sHash>::zeros_words(1 << log_size, 8);
+        let cols: Vec<*const u32> = columns.iter().map(|c| c.as_ptr()).collect();
+        ops::commit_on_layer(log_size, prev_layer.map_or(std::ptr::null(), |p| p.as_ptr()), &cols, out.as_mut_ptr());
+        out
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ QuotientOps ----
+impl QuotientOps for HipBackend {
+    fn accumulate_quotients(domain: CircleDomain, columns: &[&CircleEvaluation<Self, BaseField, BitReversedOrder>], random_coeff: SecureField,
+                            sample_batches: &[ColumnSampleBatch], _log_blowup_factor: u32) -> SecureEvaluation<Self, BitReversedOrder> {
+        let cols: Vec<*const u32> = columns.iter().map(|c| c.values.as_ptr()).collect();
+        let (mut points, mut counts, mut col_idx, mut values) = (Vec::new(), Vec::new(), Vec::new(), Vec::new());
+        for b in sample_batches {
+            points.extend_from_slice(&point8(b.point));
+            counts.push(b.columns_and_values.len() as u32);
+            for (c, v) in &b.columns_and_values { col_idx.push(*c as u32); values.extend_from_slice(&q4(*v)); }
+        }
+        let mut out = new_coords(domain.size());
+        ops::accumulate_quotients(domain.log_size(), &cols, &q4(random_coeff), &points, &counts, &col_idx, &values, &coords_mut(&mut out));
+        SecureEvaluation::new(domain, out)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ FriOps ----
+impl FriOps for HipBackend {
+    fn fold_line(eval: &LineEvaluation<Self>, alpha: SecureField, twiddles: &TwiddleTree<Self>) -> LineEvaluation<Self> {
+        let log = eval.domain().log_size();
+        let mut out = new_coords(1 << (log - 1));
+        ops::fold_line(tw_of(twiddles), &coords(&eval.values), log, &q4(alpha), &coords_mut(&mut out));
+        LineEvaluation::new(eval.domain().double(), out)
+    }
+    fn fold_circle_into_line(dst: &mut LineEvaluation<Self>, src: &SecureEvaluation<Self, BitReversedOrder>, alpha: SecureField, twiddles: &TwiddleTree<Self>) {
+        ops::fold_circle_into_line(tw_of(twiddles), &coords_mut(&mut dst.values), &coords(&src.values), src.domain.log_size(), &q4(alpha));
+    }
+    fn decompose(eval: &SecureEvaluation<Self, BitReversedOrder>) -> (SecureEvaluation<Self, BitReversedOrder>, SecureField) {
+        let mut g = new_coords(eval.domain.size());
+        let lambda = ops::fri_decompose(&coords(&eval.values), eval.domain.log_size(), &coords_mut(&mut g));
+        (SecureEvaluation::new(eval.domain, g), q_from(&lambda))
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ AccumulationOps ----
+impl AccumulationOps for HipBackend {
+    fn accumulate(column: &mut SecureColumnByCoords<Self>, other: &SecureColumnByCoords<Self>) {
+        let log = column.columns[0].len().ilog2();
+        ops::secure_accumulate(&coords_mut(column), &coords(other), log);
+    }
+    fn generate_secure_powers(felt: SecureField, n_powers: usize) -> Vec<SecureField> {
+        ops::generate_secure_powers(&q4(felt), n_powers as u32).chunks(4).map(q_from).collect()
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GrindOps ----
+impl GrindOps<Blake2sChannel> for HipBackend {
+    fn grind(channel: &Blake2sChannel, pow_bits: u32) -> u64 { ops::grind(&channel.digest().0, pow_bits) }
+}
+
+// ------------------------------------------------------------------------------------------------ GkrOps ----
+// The reference proves no GKR lookups (`grep -ri gkr /root/reference`: nothing), but `Backend` lists `GkrOps` as a supertrait: the
+// bound is met, the methods are never reached.
+impl MleOps<BaseField> for HipBackend {
+    fn fix_first_variable(_mle: Mle<Self, BaseField>, _assignment: SecureField) -> Mle<Self, SecureField> { unimplemented!("GKR lookups are not part of the Nexus prover path") }
+}
+impl MleOps<SecureField> for HipBackend {
+    fn fix_first_variable(_mle: Mle<Self, SecureField>, _assignment: SecureField) -> Mle<Self, SecureField> { unimplemented!("GKR lookups are not part of the Nexus prover path") }
+}
+impl GkrOps for HipBackend {
+    fn gen_eq_evals(_y: &[SecureField], _v: SecureField) -> Mle<Self, SecureField> { unimplemented!("GKR lookups are not part of the Nexus prover path") }
+    fn next_layer(_layer: &Layer<Self>) -> Layer<Self> { unimplemented!("GKR lookups are not part of the Nexus prover path") }
+    fn sum_as_poly_in_first_variable(_h: &GkrMultivariatePolyOracle<'_, Self>, _claim: SecureField) -> stwo::prover::lookups::utils::UnivariatePoly<SecureField> {
+        unimplemented!("GKR lookups are not part of the Nexus prover path")
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the AIR ----
+/// `ComponentProver<HipBackend>` for a recorded component (route 1: the reference swaps `SimdBackend` -> `HipBackend` and
+/// `FrameworkComponent::new(..)` -> `HipComponent::new(record_component(..))`).  `FrameworkComponent<E>` itself implements
+/// `ComponentProver` for Stwo's own backends only — its row loop is SIMD code — so the device needs its own implementor; the
+/// `Component` side (mask points, point evaluation for the verifier's check inside `prove`) stays the `FrameworkComponent`'s.
+pub struct HipComponent<C> {
+    pub inner: C,                       // the FrameworkComponent<E>: Component (verifier-side) behaviour
+    pub recorded: RecordedComponent,
+    kernel: *mut sys::nx_air_kernel,
+}
+unsafe impl<C: Send> Send for HipComponent<C> {}
+unsafe impl<C: Sync> Sync for HipComponent<C> {}
+impl<C> HipComponent<C> {
+    pub fn new(inner: C, recorded: RecordedComponent) -> Self {
+        let kernel = ops::air_compile(&recorded.program, recorded.n_regs, recorded.col_tree.len() as u32, (recorded.econsts.len() / 4) as u32, recorded.n_constraints);
+        Self { inner, recorded, kernel }
+    }
+}
+impl<C> Drop for HipComponent<C> { fn drop(&mut self) { let _g = ctx(); unsafe { sys::nx_air_kernel_destroy(self.kernel) }; } }
+
+impl<C: stwo::core::air::Component> stwo::core::air::Component for HipComponent<C> {
+    fn n_constraints(&self) -> usize { self.inner.n_constraints() }
+    fn max_constraint_log_degree_bound(&self) -> u32 { self.inner.max_constraint_log_degree_bound() }
+    fn trace_log_degree_bounds(&self) -> stwo::core::pcs::TreeVec<ColumnVec<u32>> { self.inner.trace_log_degree_bounds() }
+    fn mask_points(&self, point: CirclePoint<SecureField>) -> stwo::core::pcs::TreeVec<ColumnVec<Vec<CirclePoint<SecureField>>>> { self.inner.mask_points(point) }
+    fn preproccessed_column_indices(&self) -> ColumnVec<usize> { self.inner.preproccessed_column_indices() }
+    fn evaluate_constraint_quotients_at_point(&self, point: CirclePoint<SecureField>, mask: &stwo::core::pcs::TreeVec<ColumnVec<Vec<SecureField>>>,
+                                              evaluation_accumulator: &mut stwo::core::air::accumulation::PointEvaluationAccumulator) {
+        self.inner.evaluate_constraint_quotients_at_point(point, mask, evaluation_accumulator)
+    }
+}
+impl<C: stwo::core::air::Component> ComponentProver<HipBackend> for HipComponent<C> {
+    /// FrameworkComponent::evaluate_constraint_quotients_on_domain, on the device: the component's polynomials are evaluated on the
+    /// constraint domain (`need_to_extend`), the recorded program runs once per row and adds  sum_j alpha^j C_j / Z  into the
+    /// accumulator's column of that size.
+    fn evaluate_constraint_quotients_on_domain(&self, trace: &Trace<'_, HipBackend>, evaluation_accumulator: &mut DomainEvaluationAccumulator<HipBackend>) {
+        let r = &self.recorded;
+        let log_eval = r.log_size + r.log_constraint_degree_bound;
+        let eval_domain = CanonicCoset::new(log_eval).circle_domain();
+        // the twiddles live with the commitment scheme; Stwo's own implementation rebuilds them per call the same way
+        let twiddles = HipBackend::precompute_twiddles(eval_domain.half_coset);
+        let mut keep: Vec<HipColumn<BaseField>> = Vec::new();
+        let mut cols: Vec<*const u32> = Vec::with_capacity(r.col_tree.len());
+        for (t, i) in r.col_tree.iter().zip(&r.col_index) {
+            let poly = &trace.polys[*t as usize][*i as usize];
+            let ev = HipBackend::evaluate(poly, eval_domain, &twiddles);
+            cols.push(ev.values.as_ptr());
+            keep.push(ev.values);
+        }
+        // 1 / Z on the 2^(log_eval - log_size) cosets of the evaluation domain, bit-reversed (csrc/prover.hip vanishing_denominators)
+        let log_expand = log_eval - r.log_size;
+        let mut denom_inv = vec![0u32; 1 << log_expand];
+        for i in 0..(1usize << log_expand) {
+            let p = eval_domain.at(stwo::core::utils::bit_reverse_index(i, log_expand));      // slot i <- the coset whose first point has bit-reversed index i
+            let z = stwo::core::constraints::coset_vanishing(CanonicCoset::new(r.log_size).coset, p);
+            denom_inv[i] = stwo::core::fields::FieldExpOps::inverse(&z).0;
+        }
+        let [mut acc] = evaluation_accumulator.columns([(log_eval, r.n_constraints as usize)]);
+        // the accumulator hands this component its powers in ascending order; constraint j takes the j-th from the END (Stwo reverses
+        // the vector before its row loop), which is the order nx_air_eval's alpha_powers has
+        let powers: Vec<u32> = acc.random_coeff_powers.iter().rev().flat_map(|p| q4(*p)).collect();
+        ops::air_eval(self.kernel, &cols, &r.econsts, &powers, &denom_inv, r.log_size, log_eval, &coords_mut(acc.col));
+        drop(keep);
+    }
+}

@@ -10,6 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SYS = os.path.join(ROOT, "rust", "nexus-hip-sys", "src", "lib.rs")
 HIP = os.path.join(ROOT, "rust", "nexus-hip", "src", "lib.rs")
+HIP_DIR = os.path.join(ROOT, "rust", "nexus-hip")
 HEADER = os.path.join(ROOT, "include", "nexus_hip.h")
 
 
@@ -64,11 +65,20 @@ def test_structs_mirror_the_header_field_for_field():
     assert "log_constraint_degree_bound" in re.search(r"typedef struct nx_component_spec \{(.*?)\}", t, flags=re.S).group(1)
 
 
+def _hand_written_sources():
+    out = {}
+    for d, _, fs in os.walk(HIP_DIR):
+        for f in fs:
+            if f.endswith(".rs"):
+                out[os.path.relpath(os.path.join(d, f), ROOT)] = open(os.path.join(d, f)).read()
+    return out
+
+
 def test_hand_written_crate_calls_only_declared_functions_with_the_declared_arity():
     decl = rust_extern_functions()
-    src = open(HIP).read()
+    src = "\n".join(_hand_written_sources().values())
     calls = list(re.finditer(r"sys::(nx_\w+)\(", src))
-    assert len(calls) > 40
+    assert len(calls) > 50
     for m in calls:
         name = m.group(1)
         assert name in decl, name
@@ -82,3 +92,192 @@ def test_hand_written_crate_calls_only_declared_functions_with_the_declared_arit
         n = 0 if not args else len(_split_args(args))
         assert n == decl[name], (name, n, decl[name])
     assert "core/src/lib.rs:22-24" in src
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the reference-side artefacts must be written against what /root/reference shows.
+def _load_scanner():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_use_paths", os.path.join(ROOT, "tools", "reference_use_paths.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def _observed():
+    return set(open(os.path.join(ROOT, "tests", "golden", "reference_use_paths.txt")).read().split())
+
+
+def _unobserved_listed():
+    out = {}
+    for line in open(os.path.join(ROOT, "rust", "UNOBSERVED_PATHS.txt")):
+        line = line.strip()
+        if line and not line.startswith("#"):
+            parts = [x.strip() for x in line.split("|")]
+            assert len(parts) == 3 and parts[1], "rust/UNOBSERVED_PATHS.txt: `path | why | what the reference shows` expected: " + line
+            out[parts[0]] = parts[1]
+    return out
+
+
+def test_fixture_of_reference_paths_is_current():
+    """tests/golden/reference_use_paths.txt is what tools/reference_use_paths.py extracts from /root/reference (re-checked wherever the
+    reference checkout exists: this container; the GPU box has none and trusts the committed fixture)."""
+    if not os.path.isdir("/root/reference"):
+        import pytest
+        pytest.skip("no /root/reference here")
+    R = _load_scanner()
+    assert R.scan(["/root/reference"]) == _observed()
+    obs = _observed()
+    # the facts the shim rests on: the pinned Stwo is the post-split crate
+    for p in ("stwo::prover::backend::simd::SimdBackend", "stwo::prover::poly::circle::PolyOps", "stwo::prover::CommitmentSchemeProver", "stwo::core::proof::StarkProof",
+              "stwo::core::vcs::blake2_merkle::Blake2sMerkleChannel", "stwo_constraint_framework::EvalAtRow", "nexus_vm::trace::k_trace_direct"):
+        assert p in obs, p
+    assert not any(p.startswith("stwo_prover::") for p in obs)
+
+
+def test_every_stwo_and_nexus_path_in_our_rust_is_observed_in_the_reference_or_listed():
+    """Every `stwo…` / `stwo_constraint_framework…` / `nexus_…` path named by tools/*.rs and rust/**/*.rs occurs in the reference's own
+    sources (exactly, or as the module prefix of an observed path), or is on the explicit list rust/UNOBSERVED_PATHS.txt with its
+    reason.  A path written from memory of another crate layout (round 3's `stwo_prover::core::…`) fails here."""
+    R = _load_scanner()
+    obs, listed = _observed(), _unobserved_listed()
+    mine = R.scan([os.path.join(ROOT, "tools"), os.path.join(ROOT, "rust")])
+    assert len(mine) > 60
+
+    def observed(p):
+        return p in obs or any(o.startswith(p + "::") for o in obs)
+    bad = sorted(p for p in mine if not observed(p) and p not in listed and not any(l.startswith(p + "::") for l in listed))
+    assert bad == [], "neither in the reference nor in rust/UNOBSERVED_PATHS.txt: %s" % bad
+    stale = sorted(p for p in listed if observed(p) or not any(m == p or m.startswith(p + "::") for m in mine))
+    assert stale == [], "listed as unobserved but observed in the reference, or no longer used: %s" % stale
+    assert not any(p.startswith("stwo_prover") for p in mine)
+
+
+def test_reference_patch_imports_what_machine_rs_imports():
+    """rust/nexus-hip/reference_patch/machine_hip.rs is a child module of the reference's `machine`: every `crate::` item it imports is one
+    machine.rs itself imports (there as `super::` / `crate::`), and what it takes from its parent exists there."""
+    R = _load_scanner()
+    patch = open(os.path.join(HIP_DIR, "reference_patch", "machine_hip.rs")).read()
+
+    def crate_paths(src, parent):
+        out = set()
+        for m in re.finditer(r"\buse\s+([^;]+);", R.strip_comments(src), flags=re.S):
+            for p in R.expand(re.sub(r"\s+", " ", m.group(1))):
+                p = p.replace(" ", "")
+                if p.startswith("super::"):
+                    p = parent + p[len("super::"):]
+                if p.startswith("crate::"):
+                    out.add(p)
+        return out
+    mine = crate_paths(patch, "crate::machine::")
+    fixture = os.path.join(ROOT, "tests", "golden", "reference_machine_rs_use_paths.txt")
+    if os.path.isdir("/root/reference"):
+        ref = crate_paths(open("/root/reference/prover/src/machine.rs").read(), "crate::")
+        assert sorted(ref) == open(fixture).read().split(), "regenerate tests/golden/reference_machine_rs_use_paths.txt"
+    ref = set(open(fixture).read().split())
+    own = {p for p in mine if p.startswith("crate::machine::")}
+    assert own == {"crate::machine::GeneratedTraces", "crate::machine::Machine", "crate::machine::Proof", "crate::machine::BASE_EXTENSIONS"}
+    missing = sorted(p for p in mine - own if p not in ref)
+    assert missing == [], missing
+    if os.path.isdir("/root/reference"):
+        msrc = open("/root/reference/prover/src/machine.rs").read()
+        assert "const BASE_EXTENSIONS" in msrc and "pub struct Machine" in msrc and "pub struct Proof" in msrc and "fn max_log_size" in msrc
+
+
+BACKEND_TRAITS = ["Backend", "BackendForChannel<Blake2sMerkleChannel>", "ColumnOps<BaseField>", "ColumnOps<SecureField>", "ColumnOps<Blake2sHash>",
+                  "FieldOps<BaseField>", "FieldOps<SecureField>", "PolyOps", "MerkleOps<Blake2sMerkleHasher>", "QuotientOps", "FriOps", "AccumulationOps",
+                  "GrindOps<Blake2sChannel>", "GkrOps", "MleOps<BaseField>", "MleOps<SecureField>"]
+TRAIT_METHODS = {   # the methods a backend must provide (INTEGRATION.md section 2), and the crate::ops adapter each rests on
+    "PolyOps": {"new_canonical_ordered": "finalize_columns", "interpolate": "interpolate", "interpolate_columns": "interpolate", "eval_at_point": "eval_at_points",
+                "extend": "nx_copy", "evaluate": "evaluate", "evaluate_polynomials": "evaluate", "precompute_twiddles": "precompute_twiddles"},
+    "MerkleOps<Blake2sMerkleHasher>": {"commit_on_layer": "commit_on_layer"},
+    "QuotientOps": {"accumulate_quotients": "accumulate_quotients"},
+    "FriOps": {"fold_line": "fold_line", "fold_circle_into_line": "fold_circle_into_line", "decompose": "fri_decompose"},
+    "AccumulationOps": {"accumulate": "secure_accumulate", "generate_secure_powers": "generate_secure_powers"},
+    "GrindOps<Blake2sChannel>": {"grind": "grind"},
+    "FieldOps<BaseField>": {"batch_inverse": "batch_inverse_m31"},
+    "FieldOps<SecureField>": {"batch_inverse": "batch_inverse_qm31"},
+    "ColumnOps<BaseField>": {"bit_reverse_column": "bit_reverse"},
+    "ColumnOps<SecureField>": {"bit_reverse_column": "bit_reverse_secure"},
+}
+
+
+def _impl_body(src, header):
+    i = src.index(header)
+    j = src.index("{", i)
+    depth, k = 1, j + 1
+    while depth:
+        depth += src[k] == "{"
+        depth -= src[k] == "}"
+        k += 1
+    return src[j + 1:k - 1]
+
+
+def test_every_backend_trait_has_its_impl_for_hipbackend():
+    """VERDICT r3: the trait impls stopped after ColumnOps.  Every trait stwo::prover::prove is generic over (Backend's supertraits and
+    BackendForChannel's bounds) has an `impl … for HipBackend` in rust/nexus-hip/src/backend.rs, every required method is there and goes
+    through the `ops::` adapter (hence the C-ABI export) INTEGRATION.md names for it; the recorded component implements ComponentProver."""
+    src = open(os.path.join(HIP_DIR, "src", "backend.rs")).read()
+    ops_src = open(HIP).read()
+    ops_fns = set(re.findall(r"pub fn (\w+)\(", _impl_body(ops_src, "pub mod ops")))
+    for t in BACKEND_TRAITS:
+        assert ("impl %s for HipBackend" % t) in src, t
+    for t, methods in TRAIT_METHODS.items():
+        body = _impl_body(src, "impl %s for HipBackend" % t)
+        for m, adapter in methods.items():
+            mm = re.search(r"fn %s\b" % m, body)
+            assert mm, (t, m)
+            nxt = re.search(r"\n    fn \w+", body[mm.end():])
+            mbody = body[mm.end():mm.end() + nxt.start()] if nxt else body[mm.end():]
+            if adapter.startswith("nx_"):
+                assert "sys::" + adapter in mbody, (t, m, adapter)
+            else:
+                assert adapter in ops_fns and ("ops::" + adapter) in mbody, (t, m, adapter)
+    for col_t in ("BaseField", "SecureField", "Blake2sHash"):
+        body = _impl_body(src, "impl Column<%s> for HipColumn<%s>" % (col_t, col_t))
+        for m in ("zeros", "uninitialized", "to_cpu", "len", "at", "set"):
+            assert re.search(r"fn %s\b" % m, body), (col_t, m)
+        assert ("impl FromIterator<%s> for HipColumn<%s>" % (col_t, col_t)) in src
+    assert "impl<C: stwo::core::air::Component> ComponentProver<HipBackend> for HipComponent<C>" in src
+    assert "ops::air_eval(" in _impl_body(src, "impl<C: stwo::core::air::Component> ComponentProver<HipBackend> for HipComponent<C>")
+    # no trait is left as a comment any more
+    assert "one adapter each over" not in ops_src and "unimplemented!" not in _impl_body(src, "impl PolyOps for HipBackend")
+
+
+def test_recording_evaluator_lowers_to_the_abi_opcodes():
+    """rust/nexus-hip/src/record.rs: the recording EvalAtRow exists as code — associated types, the trait methods the reference's AIR
+    calls (trace/eval.rs:22-50, components/mod.rs:48-56), the lowering to every NX_C_* opcode of include/nexus_hip.h, the linear-scan
+    allocation — and mirrors air_program.py's rules (chunks of 8 constraints, canonical operand order of commutative ops)."""
+    src = open(os.path.join(HIP_DIR, "src", "record.rs")).read()
+    for needle in ("impl<'a> EvalAtRow for RecordingEval<'a>", "type F = F;", "type EF = EF;", "fn next_interaction_mask<const N: usize>", "fn get_preprocessed_column",
+                   "fn add_constraint<G>", "fn combine_ef", "logup_proxy!()", "pub fn record_component<E: FrameworkEval>", "const CHUNK: usize = 8;", "a.min(c), a.max(c)"):
+        assert needle in src, needle
+    header_ops = re.findall(r"#define (NX_C_\w+)", open(HEADER).read()) or re.findall(r"\b(NX_C_[A-Z_]+)\b\s*=", open(HEADER).read())
+    assert len(set(header_ops)) == 15
+    for op in set(header_ops):
+        assert "sys::" + op in src, op
+    patch = open(os.path.join(HIP_DIR, "reference_patch", "machine_hip.rs")).read()
+    for needle in ("pub fn prove_hip(trace: &impl Trace, view: &View) -> Result<Proof, ProvingError>", "record_component(", "session.prove(&components)", "proof_bytes(",
+                   "generate_interaction_trace::<C>(", "C::draw_lookup_elements("):
+        assert needle in patch, needle
+
+
+def test_rust_sources_are_lexically_balanced():
+    """No compiler here: at least every bracket closes (outside strings, chars and comments) in every Rust file we ship."""
+    files = dict(_hand_written_sources())
+    files["tools/dump_reference.rs"] = open(os.path.join(ROOT, "tools", "dump_reference.rs")).read()
+    files["rust/nexus-hip-sys/src/lib.rs"] = open(SYS).read()
+    assert len(files) >= 6
+    for name, src in files.items():
+        t = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        t = re.sub(r"//[^\n]*", "", t)
+        t = re.sub(r'"(?:\\.|[^"\\])*"', '""', t)
+        t = re.sub(r"'(?:\\.|[^'\\])'", "' '", t)          # char literals (lifetimes have no closing quote and stay)
+        stack = []
+        pairs = {")": "(", "]": "[", "}": "{"}
+        for ch in t:
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in ")]}":
+                assert stack and stack[-1] == pairs[ch], (name, ch)
+                stack.pop()
+        assert not stack, (name, stack[-3:])

@@ -2,9 +2,17 @@
 //! in-repo oracle and the GPU library.  Needs a box with the Rust toolchain of `rust-toolchain.toml` (nightly-2025-05-09) and
 //! network access for the stwo git dependency; it could not be built or run in the build container (no cargo, no network).
 //!
+//! Crate layout: the reference's pin is the POST-SPLIT Stwo — one crate `stwo` with `stwo::core::…` (fields, circle, channel, pcs,
+//! vcs, verifier) and `stwo::prover::…` (backend, poly, CommitmentSchemeProver, prove), as the reference's own imports show
+//! (prover/src/machine.rs:4-19, prover/src/test_utils.rs:1-17, prover2/machine/src/prove.rs:2-15).  Every path below that the
+//! reference itself names is checked against it by tests/test_rust_shim_cpu.py; the ones it never names (the traits Stwo calls
+//! internally: FriOps, QuotientOps, MerkleOps, GrindOps, …) are listed in rust/UNOBSERVED_PATHS.txt as upstream recollection — a wrong
+//! one is a one-line `use` fix on first compile, the arithmetic below does not depend on it.
+//!
 //! Install:  cp tools/dump_reference.rs <reference>/prover/tests/dump_reference.rs
-//!           (add `serde_json = "1"`, `postcard = { version = "1", features = ["alloc", "use-std"] }`, `hex = "0.4"` to
-//!            prover/Cargo.toml [dev-dependencies]; `nexus-common-testing` is already one)
+//!           add to prover/Cargo.toml [dev-dependencies] (it holds only `rand` and `rand_chacha` today, prover/Cargo.toml:27-29):
+//!             serde_json = "1", hex = "0.4", postcard = { version = "1.0.10", features = ["alloc", "use-std"] }
+//!           (`nexus-vm`, `nexus-common`, `stwo` are regular dependencies of the crate already, prover/Cargo.toml:13-24)
 //! Run:      cd <reference>/prover && cargo test --release --test dump_reference -- --nocapture > reference_dump.json
 //! Replay:   python tools/replay_reference_dump.py reference_dump.json          (CPU oracle; add --gpu on an MI355X box)
 //!
@@ -16,27 +24,30 @@
 //!     fold_line; FriOps::decompose if the trait still has it (Appendix B.5).  These settle SURVEY.md Appendix B.1-B.6.
 //!   "prove": for the `stark_prove` bench program (prover-benches/benches/stark_prove.rs:55-82) at log sizes 8, 12, 16:
 //!     the 4 commitments, claimed sums, log sizes, proof_of_work, every FRI layer commitment, the last layer polynomial, the
-//!     size of sampled / queried values, sha256 + (for log 8) the full hex of postcard::to_stdvec(&proof)  (nx_proof_serialize_stwo).
-//! Everything is written with the public Stwo / nexus APIs the reference itself uses (machine.rs:4-19 imports).
-use nexus_common_testing::program_trace;
+//!     size of sampled / queried values, a hash + (for log 8) the full hex of postcard::to_stdvec(&proof)  (nx_proof_serialize_stwo).
+use nexus_vm::emulator::View;
+use nexus_vm::riscv::{BasicBlock, BuiltinOpcode, Instruction, Opcode};
+use nexus_vm::trace::{k_trace_direct, UniformTrace};
 use nexus_vm_prover::prove;
 use serde_json::{json, Value};
-use stwo_prover::core::{
-    backend::simd::SimdBackend,
-    backend::{Col, Column, CpuBackend},
-    channel::{Blake2sChannel, Channel, MerkleChannel},
-    circle::CirclePoint,
-    fields::{m31::BaseField, qm31::SecureField, FieldExpOps},
-    fri::FriOps,
-    pcs::quotients::{ColumnSampleBatch, QuotientOps},
-    poly::{
-        circle::{CanonicCoset, CircleEvaluation, PolyOps, SecureEvaluation},
-        line::{LineDomain, LineEvaluation},
-        BitReversedOrder,
-    },
-    proof_of_work::GrindOps,
-    vcs::{blake2_merkle::{Blake2sMerkleChannel, Blake2sMerkleHasher}, ops::MerkleOps, prover::MerkleProver},
-};
+use stwo::core::channel::{Blake2sChannel, Channel, MerkleChannel};
+use stwo::core::circle::CirclePoint;
+use stwo::core::fields::m31::BaseField;
+use stwo::core::fields::qm31::SecureField;
+use stwo::core::pcs::quotients::ColumnSampleBatch;
+use stwo::core::poly::circle::CanonicCoset;
+use stwo::core::poly::line::LineDomain;
+use stwo::core::vcs::blake2_merkle::{Blake2sMerkleChannel, Blake2sMerkleHasher};
+use stwo::prover::backend::simd::SimdBackend;
+use stwo::prover::backend::{Col, Column};
+use stwo::prover::fri::FriOps;
+use stwo::prover::line::LineEvaluation;
+use stwo::prover::pcs::quotient_ops::QuotientOps;
+use stwo::prover::poly::circle::{CircleEvaluation, PolyOps, SecureEvaluation};
+use stwo::prover::poly::BitReversedOrder;
+use stwo::prover::proof_of_work::GrindOps;
+use stwo::prover::vcs::ops::MerkleOps;
+use stwo::prover::vcs::prover::MerkleProver;
 
 fn splitmix64(mut x: u64) -> u64 {
     x = x.wrapping_add(0x9E3779B97F4A7C15);
@@ -79,11 +90,12 @@ fn kat() -> Value {
     let mut ch = Blake2sChannel::default();
     let mut steps = vec![];
     ch.mix_u64(0x0123456789ABCDEF); steps.push(json!({"after": "mix_u64(0x0123456789ABCDEF)", "digest": hexs(ch.digest().0)}));
-    let f = ch.draw_felt(); steps.push(json!({"draw_felt": qm31(f), "digest": hexs(ch.digest().0)}));
-    let fs = ch.draw_felts(3); steps.push(json!({"draw_felts(3)": fs.iter().map(|x| qm31(*x)).collect::<Vec<_>>()}));
+    // (`draw_felt` / `draw_felts` / `draw_random_bytes` before the rename; the dump keys keep the old names the replay tool reads)
+    let f = ch.draw_secure_felt(); steps.push(json!({"draw_felt": qm31(f), "digest": hexs(ch.digest().0)}));
+    let fs = ch.draw_secure_felts(3); steps.push(json!({"draw_felts(3)": fs.iter().map(|x| qm31(*x)).collect::<Vec<_>>()}));
     ch.mix_felts(&[f, fs[0]]); steps.push(json!({"after": "mix_felts([first drawn felt, first of draw_felts(3)])", "digest": hexs(ch.digest().0)}));
     Blake2sMerkleChannel::mix_root(&mut ch, merkle.root()); steps.push(json!({"after": "mix_root(merkle root above)", "digest": hexs(ch.digest().0)}));
-    steps.push(json!({"draw_random_bytes": hexs(ch.draw_random_bytes())}));
+    steps.push(json!({"draw_random_bytes": hexs(ch.draw_u32s().iter().flat_map(|w| w.to_le_bytes()).collect::<Vec<u8>>())}));
     for bits in [0u32, 5, 10, 16] { let mut c2 = ch.clone(); steps.push(json!({"grind_bits": bits, "nonce": SimdBackend::grind(&c2, bits)})); let _ = &mut c2; }
     out.insert("channel".into(), json!(steps));
     // K8: DEEP quotients of 3 LDE columns, two sample batches (points p and p + step; values = the true evaluations, so the result is low degree)
@@ -94,11 +106,11 @@ fn kat() -> Value {
         ColumnSampleBatch { point: p, columns_and_values: (0..3).map(|c| (c, polys[c].eval_at_point(p))).collect() },
         ColumnSampleBatch { point: p + step, columns_and_values: vec![(0, polys[0].eval_at_point(p + step)), (1, polys[1].eval_at_point(p + step))] },
     ];
-    let alpha = ch.draw_felt();
+    let alpha = ch.draw_secure_felt();
     let q = SimdBackend::accumulate_quotients(CanonicCoset::new(7).circle_domain(), &ldes.iter().collect::<Vec<_>>(), alpha, &batches, 1);
     out.insert("quotients".into(), json!({"seed": 2, "alpha": qm31(alpha), "out": (0..4).map(|k| m31s(q.values.columns[k].to_cpu())).collect::<Vec<_>>()}));
     // K9: folds of the quotient column
-    let a2 = ch.draw_felt();
+    let a2 = ch.draw_secure_felt();
     let mut line = LineEvaluation::<SimdBackend>::new_zero(LineDomain::new(CanonicCoset::new(7).half_coset()));
     SimdBackend::fold_circle_into_line(&mut line, &q, a2, &tw7);
     let folded = SimdBackend::fold_line(&line, a2, &tw7);
@@ -110,8 +122,26 @@ fn kat() -> Value {
     Value::Object(out)
 }
 
+/// The bench's program and trace, built the way prover-benches/benches/stark_prove.rs:55-82 builds them: one ADDI, then ADDs cycling
+/// through the registers, 2^log_size instructions, one basic block, `k_trace_direct(&blocks, 1)`.  (`nexus_common_testing::
+/// program_trace` returns only the `Vec<BasicBlock>` — common-testing/src/lib.rs:5 — and is not a dependency of the prover crate.)
+fn program_trace(log_size: u32) -> (View, UniformTrace) {
+    const NUM_REGISTERS: u8 = nexus_common::constants::NUM_REGISTERS as u8;
+    let (mut i, mut j, mut k) = (0u8, 1u8, 2u8);
+    let first = Instruction::new_ir(Opcode::from(BuiltinOpcode::ADDI), 1, 0, 1);
+    let rest = std::iter::from_fn(|| {
+        let inst = Instruction::new_ir(Opcode::from(BuiltinOpcode::ADD), k, j, i.into());
+        i = (i + 1) % NUM_REGISTERS;
+        j = (j + 1) % NUM_REGISTERS;
+        k = (k + 1) % NUM_REGISTERS;
+        Some(inst)
+    });
+    let insts: Vec<Instruction> = std::iter::once(first).chain(rest).take(1 << log_size).collect();
+    k_trace_direct(&vec![BasicBlock::new(insts)], 1).expect("error generating trace")
+}
+
 fn prove_dump(log_size: u32) -> Value {
-    let (view, trace) = program_trace(log_size);          // common-testing/src/lib.rs:5-30 == prover-benches/benches/stark_prove.rs:55-82
+    let (view, trace) = program_trace(log_size);
     let proof = prove(&trace, &view).expect("prove");
     let bytes = postcard::to_stdvec(&proof).expect("postcard");
     let sp = &proof.stark_proof.0;
