@@ -59,11 +59,14 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
 /* Per-context policy and tuning.  The NX_* environment variables only seed a new context's defaults; what a
  * context does is decided by its own options, so two contexts of one process may differ.  Names: "fft.pipe" (0/1: pipelined LDE
  * kernels of fft_pipe.hip, default 0), "fft.pipe_blocks_per_cu" (1..2), "fft.pipe_grid" (0 = automatic, else persistent blocks per launch), "fft.batch_cols",
- * "fft.streams" (1..4), "fri.dist_min_log", "dist.chunks" and "air.degree_split" (1: degree-aware composition, see
+ * "fft.streams" (1..4), "comm.timeout_ms" (native RCCL transport: the longest a rank waits for its peers in one collective before it aborts the communicator and fails
+ * the prove, default 120000; 0 = wait for ever), "fri.dist_min_log", "dist.chunks" and "air.degree_split" (1: degree-aware composition, see
  * nx_air_constraint_degrees) — row-sharded prove: every GPU of a proof must use the same values of these three, they shape the
  * exchanges —, "air.segment" (instruction budget of one generated AIR kernel), "quotients.coeffs" (1: the DEEP quotients of a wide
  * size group are accumulated from the coefficient columns — half the bytes at blowup 2; one GPU only), "air.half_domain" (1: constraints
- * of degree <= 2 are evaluated on the first half of the committed 2N-point domain; one GPU, blowup 2).  Unknown names and out-of-range values are NX_ERR_ARG.
+ * of degree <= 2 are evaluated on the first half of the committed 2N-point domain; one GPU, blowup 2), "air.quarter_domain" (1: constraints
+ * of degree 4 / 5 that read no neighbour row are evaluated on the committed 2N rows plus the first quarter of the 4N-point domain — 3N + 1
+ * samples instead of 4N; one GPU, blowup 2, component bound 2).  Unknown names and out-of-range values are NX_ERR_ARG.
  * None of them changes a result: proofs, roots and transforms are bit-identical under every setting. */
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value);
 int nx_ctx_get_option(const nx_ctx* ctx, const char* name, int64_t* value);
@@ -327,6 +330,13 @@ typedef struct nx_comm {
                      const size_t* recv_off, const size_t* recv_cnt);
     /* device all-gather: d_recv = world x n_words, rank r's contribution at r * n_words */
     int (*allgather_dev)(void* user, const uint32_t* d_send, size_t n_words, uint32_t* d_recv);
+    /* optional (may be NULL).  The library calls it on a rank whose prove FAILED after the exchanges of a proof may have started (a
+     * HIP error, out of memory, a failed callback): its peers are, or will be, waiting for it in a collective it will never enter.
+     * The transport must make the pending and later collectives of this communicator fail on the peers instead of waiting — tear the
+     * group down (the thread-rank transport breaks its barrier; the native RCCL transport calls ncclCommAbort and, since RCCL does
+     * not propagate that to live peers, additionally bounds every wait by the context option "comm.timeout_ms").  A communicator
+     * is unusable after abort. */
+    void (*abort)(void* user);
 } nx_comm;
 /* The native transport: RCCL over xGMI (csrc/comm_rccl.hip; librccl is opened at run time, NX_ERR_HIP when it is not there).  Rank 0
  * calls nx_rccl_unique_id and ships the 128 bytes to the other ranks through any side channel (environment, file, socket — the

@@ -45,13 +45,14 @@ _ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 _BROADCAST_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32)
 _ALLTOALLV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 _ALLGATHER_DEV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_ABORT_T = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class NxComm(C.Structure):
     """nx_comm of include/nexus_hip.h: the transport callbacks of one proof on several GPUs."""
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("user", C.c_void_p), ("send", _SEND_T), ("recv", _RECV_T),
                 ("allreduce_m31", _ALLREDUCE_T), ("allgather", _ALLGATHER_T), ("broadcast", _BROADCAST_T),
-                ("alltoallv", _ALLTOALLV_T), ("allgather_dev", _ALLGATHER_DEV_T)]
+                ("alltoallv", _ALLTOALLV_T), ("allgather_dev", _ALLGATHER_DEV_T), ("abort", _ABORT_T)]
 
 
 def make_comm(rank, world, impl):
@@ -82,9 +83,18 @@ def make_comm(rank, world, impl):
     def _alltoallv(_u, sp, soff, scnt, rp, roff, rcnt):
         impl.alltoallv(sp or 0, [soff[i] for i in range(world)], [scnt[i] for i in range(world)], rp or 0, [roff[i] for i in range(world)], [rcnt[i] for i in range(world)])
 
+    def _abort():
+        """nx_comm.abort: this rank's prove failed; make the peers' collectives fail instead of waiting (optional on the Python side)"""
+        try:
+            if hasattr(impl, "abort"):
+                impl.abort()
+        except Exception:   # noqa: BLE001 — must not unwind through C
+            pass
+
     c = NxComm(rank, world, None, _SEND_T(guard(lambda _u, dst, p, n: impl.send(dst, p, n))), _RECV_T(guard(lambda _u, src, p, n: impl.recv(src, p, n))),
                _ALLREDUCE_T(guard(lambda _u, p, n: impl.allreduce_m31(p, n))), _ALLGATHER_T(guard(_allgather)), _BROADCAST_T(guard(_broadcast)),
-               _ALLTOALLV_T(guard(_alltoallv)), _ALLGATHER_DEV_T(guard(lambda _u, sp, n, rp: impl.allgather_dev(sp or 0, n, rp or 0))))
+               _ALLTOALLV_T(guard(_alltoallv)), _ALLGATHER_DEV_T(guard(lambda _u, sp, n, rp: impl.allgather_dev(sp or 0, n, rp or 0))),
+               _ABORT_T(lambda _u: _abort()))
     c._impl = impl   # keep the callbacks' target alive
     return c
 

@@ -249,6 +249,7 @@ static nx_options options_from_env() {
     o.quotients_coeffs = env_int("NX_QUOTIENTS_COEFFS", 1) != 0;
     o.air_half_domain = env_int("NX_AIR_HALF_DOMAIN", 1) != 0;
     o.air_quarter_domain = env_int("NX_AIR_QUARTER_DOMAIN", 1) != 0;
+    o.comm_timeout_ms = std::max(0, env_int("NX_COMM_TIMEOUT_MS", 120000));
     return o;
 }
 struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
@@ -266,6 +267,7 @@ static const OptEntry k_options[] = {
     {"quotients.coeffs", &nx_options::quotients_coeffs, 0, 1},
     {"air.half_domain", &nx_options::air_half_domain, 0, 1},
     {"air.quarter_domain", &nx_options::air_quarter_domain, 0, 1},
+    {"comm.timeout_ms", &nx_options::comm_timeout_ms, 0, 1 << 30},
 };
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return set_err(ctx, NX_ERR_ARG, "nx_ctx_set_option: NULL argument");

@@ -24,6 +24,7 @@ struct nx_options {
     int quotients_coeffs;         // "quotients.coeffs": DEEP quotients of wide size groups from the coefficient columns (single GPU)
     int air_half_domain;          // "air.half_domain": constraints of degree <= 2 are evaluated on HALF of the committed 2N-point domain (single GPU, blowup 2)
     int air_quarter_domain;       // "air.quarter_domain": degree-4/5 constraints that read no neighbour row are evaluated on the committed 2N rows + the first QUARTER of the 4N-point domain (3N + 1 samples; single GPU, blowup 2, bound 2)
+    int comm_timeout_ms;          // "comm.timeout_ms": native RCCL transport, longest wait for the peers in one collective (0 = for ever)
     int air_degree_split;         // "air.degree_split": constraints of degree <= 3 of a component with a bound > 1 are evaluated on the log_size + 1 domain
 };
 

@@ -351,14 +351,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
             g.log_cd = comps[i].log_constraint_degree_bound;
             rc_local = prepare_component_kernels(ctx, cfg, g, D.on());
         }
-        if (D.on()) {
-            std::vector<int32_t> all((size_t)D.world, 0);
-            const int32_t mine = rc_local;
-            H_TRY(D.allgather_host(ctx, &mine, sizeof mine, all.data()));
-            for (int r = 0; r < D.world; r++)
-                if (all[r] != NX_OK) return rc_local != NX_OK ? rc_local : set_err(ctx, NX_ERR_HIP, "nx_prove_machine: rank " + std::to_string(r) + " failed to prepare its kernels (code " + std::to_string(all[r]) + "); no rank proceeds");
-        }
-        H_TRY(rc_local);
+        H_TRY(vote_before_exchanges(ctx, D, rc_local, "nx_prove_machine"));
     }
     lap(&st->commit);
 
@@ -492,6 +485,11 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
 
 using namespace nx;
 
+// A rank whose sharded prove failed leaves its peers waiting in the next collective: tell the transport (nx_comm.abort, optional)
+static void abort_peers(const nx_comm* comm, int rc) {
+    if (rc != NX_OK && comm && comm->world > 1 && comm->abort) comm->abort(comm->user);
+}
+
 static int hand_out(nx_ctx* ctx, int rc, std::vector<uint32_t>& w, uint32_t** proof_words, size_t* n_words, const char* who) {
     ctx->timing = false;
     if (rc != NX_OK) return rc;
@@ -517,7 +515,9 @@ int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t
     NX_GUARD(ctx);
     if (!ctx || !comps || !cfg || !proof_words || !n_words || !comm) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth_sharded: NULL argument");
     std::vector<uint32_t> w;
-    return hand_out(ctx, nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats), w, proof_words, n_words, "nx_prove_synth_sharded");
+    const int rc = nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
+    abort_peers(comm, rc);
+    return hand_out(ctx, rc, w, proof_words, n_words, "nx_prove_synth_sharded");
 }
 
 // The HIP source nx_air_compile generates for the recorded AIR of one nx_prove_machine component (host only, no GPU): for offline
@@ -534,7 +534,9 @@ int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_com
     NX_GUARD(ctx);
     if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: NULL argument");
     std::vector<uint32_t> w;
-    return hand_out(ctx, nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats), w, proof_words, n_words, "nx_prove_machine");
+    const int rc = nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
+    abort_peers(comm, rc);
+    return hand_out(ctx, rc, w, proof_words, n_words, "nx_prove_machine");
 }
 
 int nx_machine_claimed_sums(const nx_ctx* ctx, uint32_t* claimed_sums, uint32_t cap_components, uint32_t* n_components) {

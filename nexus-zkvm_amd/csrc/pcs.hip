@@ -656,6 +656,9 @@ int accumulate_quotients_coeffs(nx_ctx* ctx, const nx_twiddles* tw, uint32_t log
         rc = nx_evaluate_batch(ctx, tw, src.data(), nq, log_coef, log_size - log_coef, dst.data());
     }
     if (rc == NX_OK) {
+        // the stage's second kernel, under the same kind (its bytes are in the span above: the stage's algorithmic bytes are counted once).
+        // The extension in between is Circle-FFT work and is booked as such, bytes and time alike (fft_evaluate's own span).
+        KTimer timer(ctx, NX_T_QUOT, 0);
         hipLaunchKernelGGL(quotient_finish_kernel, dim3((unsigned)((ne / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const u32*)ext, ne, (int)log_size, (u32)(ne / 4),
                            (const QBatchDev*)blob, n_batches, d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
         if (hipGetLastError() != hipSuccess) rc = set_err(ctx, NX_ERR_HIP, "quotient_finish_kernel launch failed");

@@ -61,6 +61,11 @@ struct Dist {
                   hipEvent_t ready = nullptr) const;
 };
 int dist_init(nx_ctx* ctx, const nx_comm* comm, Dist* out);   // validates the callbacks; world must be a power of two
+// The vote every sharded prove takes before its first exchange: each rank's local status (kernel compilation is the one thing that can
+// fail on ONE rank only) and the context options that shape the exchanges ("air.degree_split", "air.half_domain", "air.quarter_domain",
+// "fri.dist_min_log", "dist.chunks": which domains are evaluated, what is all-gathered, how many chunks an all-to-all has).  A rank that
+// failed, or a rank configured differently, would otherwise meet its peers in mismatched collectives — a hang or garbage.
+int vote_before_exchanges(nx_ctx* ctx, const Dist& D, int rc_local, const char* who);
 
 // A column of 2^log words: the whole column (single GPU, or replicated on every GPU) or — block — this GPU's contiguous block of
 // 2^log / W rows.  ptr == nullptr: another GPU holds it (coefficients stay column-sharded).

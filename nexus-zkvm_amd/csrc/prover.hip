@@ -23,6 +23,20 @@ int dist_init(nx_ctx* ctx, const nx_comm* comm, Dist* out) {
     out->comm = comm; out->rank = comm->rank; out->world = comm->world; out->log_w = lw;
     return NX_OK;
 }
+int vote_before_exchanges(nx_ctx* ctx, const Dist& D, int rc_local, const char* who) {
+    if (!D.on()) return rc_local;
+    struct Ballot { int32_t rc; int32_t opt[5]; };
+    const Ballot mine = {rc_local, {ctx->opt.air_degree_split, ctx->opt.air_half_domain, ctx->opt.air_quarter_domain, ctx->opt.fri_dist_min_log, ctx->opt.dist_chunks}};
+    std::vector<Ballot> all((size_t)D.world);
+    H_TRY(D.allgather_host(ctx, &mine, sizeof mine, all.data()));
+    for (int r = 0; r < D.world; r++)
+        if (all[r].rc != NX_OK) return rc_local != NX_OK ? rc_local : set_err(ctx, NX_ERR_HIP, std::string(who) + ": rank " + std::to_string(r) + " failed to prepare its kernels (code " + std::to_string(all[r].rc) + "); no rank proceeds");
+    for (int r = 0; r < D.world; r++)
+        if (memcmp(all[r].opt, all[0].opt, sizeof mine.opt) != 0)
+            return set_err(ctx, NX_ERR_ARG, std::string(who) + ": the ranks of one proof run different context options (air.degree_split / air.half_domain / air.quarter_domain / fri.dist_min_log / dist.chunks: rank 0 vs rank " + std::to_string(r) + "); they shape the exchanges and must agree");
+    return NX_OK;
+}
+
 struct CommClock { const Dist& d; double t0; CommClock(const Dist& x) : d(x), t0(now_ms()) {} ~CommClock() { if (d.comm_ms) *d.comm_ms += now_ms() - t0; } };
 int Dist::allgather_host(nx_ctx* ctx, const void* send, size_t bytes, void* recv) const {
     CommClock clk(*this);
@@ -965,6 +979,17 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         }
     }
     { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); channel.mix_felts(flat); }
+    {   // ProvingError::ConstraintsNotSatisfied: the composition polynomial at the OODS point against the constraints over the sampled
+        // values.  Stwo checks it at the end of prove(); here as soon as the values exist (same inputs, same verdict): a trace that
+        // violates its constraints is refused BEFORE the quotients, FRI, the proof of work and the decommitment are paid for — and
+        // under every evaluation strategy: with "air.half_domain" / "air.quarter_domain" the composition is low-degree by construction
+        // even for an invalid trace (Q0 + t Z is what the interpolation returns), so this equality — not the FRI degree check — is
+        // what catches it.
+        QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
+        QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
+        if (!q_eq(lhs, air.eval_composition_at_point(oods, proof.sampled_values, random_coeff)))
+            return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
+    }
     lap(&st->oods);
     QM31 q_coeff = channel.draw_secure_felt();
     // compute_fri_quotients: all columns flattened, stable-sorted by LDE size (descending), grouped by size
@@ -1039,11 +1064,6 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         proof.commitments.push_back(cs.trees[t].root);
     }
     lap(&st->decommit);
-    // ProvingError::ConstraintsNotSatisfied sanity check
-    QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
-    QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
-    if (!q_eq(lhs, air.eval_composition_at_point(oods, proof.sampled_values, random_coeff)))
-        return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
     *words = serialize(proof, cfg);
     return NX_OK;
 }
@@ -1665,7 +1685,10 @@ int nx_prover_tree_commit(nx_prover* p, uint8_t root[32]) {
     nxhip::TreeBuilder tb = p->cs->tree_builder();
     for (auto& r : p->pending) tb.extend_evals_local(std::move(r.slab), r.n_cols, r.log, r.lo, r.hi);
     p->pending.clear(); p->open = false;
-    NX_TRY(tb.commit(p->channel));
+    {
+        const int rc = tb.commit(p->channel);
+        if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort) p->comm_copy.abort(p->comm_copy.user); return rc; }
+    }
     if (root) memcpy(root, p->cs->trees.back().root.w, 32);
     return NX_OK;
 }
@@ -1696,6 +1719,13 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
         air.comps.push_back(std::move(g));
     }
     if (p->proved) { while (p->cs->trees.size() > p->pre_trees) p->cs->trees.pop_back(); p->channel = p->pre_channel; }   // a second prove of the session
+    if (p->cs->dist.on()) {
+        // everything that can fail on one rank only (argument checks, hiprtc) happens before the first exchange, then the ranks vote
+        int rc_local = air.check(*p->cs);
+        for (auto& c : air.comps) if (rc_local == NX_OK) rc_local = nxhip::prepare_component_kernels(ctx, p->cfg, c, true);
+        const int rcv = nxhip::vote_before_exchanges(ctx, p->cs->dist, rc_local, "nx_prover_prove");
+        if (rcv != NX_OK) { if (p->has_comm && p->comm_copy.abort && rc_local == NX_OK && rcv != NX_ERR_ARG) p->comm_copy.abort(p->comm_copy.user); return rcv; }
+    }
     NX_TRY(air.check(*p->cs));
     const bool timed = stats != nullptr;
     nx_prove_stats local;
@@ -1713,6 +1743,7 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     if (!p->proved) { p->pre_trees = p->cs->trees.size(); p->pre_channel = p->channel; p->proved = true; }
     int rc = nxhip::prove_core(ctx, *p->cs, p->channel, p->cfg, p->tw, air, &w, st, lap);
     if (rc != NX_OK) { while (p->cs->trees.size() > p->pre_trees) p->cs->trees.pop_back(); p->channel = p->pre_channel; p->proved = false; }
+    if (rc != NX_OK && p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort) p->comm_copy.abort(p->comm_copy.user);   // the peers wait in a collective this rank will not enter
     if (timed) nxhip::finish_stats(ctx, st, t_start);
     ctx->timing = false;
     p->cs->dist.comm_ms = nullptr; p->cs->dist.comm_bytes = nullptr;

@@ -218,6 +218,13 @@ class _ThreadComm:
     def __init__(self, group, rank, backend):
         self.g, self.rank, self.be = group, rank, backend
 
+    def abort(self):
+        """nx_comm.abort: break the group's barrier — every rank waiting in (or later entering) a collective gets BrokenBarrierError,
+        its callback returns non-zero and its prove fails with NX_ERR_HIP instead of waiting for this rank for ever."""
+        self.g.barrier.abort()
+        with self.g.cv:
+            self.g.cv.notify_all()
+
     def send(self, dst, ptr, n):
         g = self.g
         with g.cv:

@@ -213,6 +213,75 @@ def test_machine_row_sharded_equals_single_gpu(be, nz, world, comps, kw):
     assert res[0][1]["comm_bytes"] > 0
 
 
+def _run_ranks_collect(nz, world, make_impl, fn, timeout=120):
+    """like _run_ranks, but failures are results: returns (results, errors) and whether every thread came back"""
+    from nexus_zkvm_amd.sharded import ThreadGroup
+    group = ThreadGroup(world)
+    results, errors = [None] * world, [None] * world
+
+    def run(rank):
+        try:
+            b = nz.HipBackend(0)
+            comm = nz.make_comm(rank, world, make_impl(rank, group.comm(rank, b)))
+            try:
+                results[rank] = fn(b, comm, rank)
+            finally:
+                b.close()
+        except Exception as e:   # noqa: BLE001
+            errors[rank] = repr(e)
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=timeout)
+    return results, errors, not any(t.is_alive() for t in th)
+
+
+def test_a_rank_failing_mid_prove_fails_the_others_instead_of_hanging_them(be, nz):
+    """VERDICT r3 weak #7 / hygiene: a rank-local failure AFTER the first exchange (here: rank 1's transport raises in its 7th
+    collective, i.e. after the first tree's all-to-all) used to leave the other ranks blocked in the next collective.  Now the failing
+    rank's prove calls nx_comm.abort, the transport breaks the group, and every rank returns an error within seconds."""
+    comps = [(12, 4, 40, 16), (9, 2, 9, 4)]
+    cfg = nz.default_config(pow_bits=4)
+
+    class Failing:
+        def __init__(self, impl, fail_at):
+            self.impl, self.n, self.fail_at = impl, 0, fail_at
+
+        def __getattr__(self, name):
+            f = getattr(self.impl, name)
+            if name == "abort":
+                return f
+
+            def g(*a):
+                self.n += 1
+                if self.n == self.fail_at:
+                    raise RuntimeError("injected transport failure")
+                return f(*a)
+            return g
+    res, errs, all_back = _run_ranks_collect(nz, 4, lambda rank, impl: Failing(impl, 7) if rank == 1 else impl,
+                                             lambda b, comm, rank: b.prove_machine(comps, cfg, seed=5, ad=b"x", comm=comm), timeout=90)
+    assert all_back, "a rank is still blocked in a collective"
+    assert all(e is not None for e in errs), (errs, [r is not None for r in res])
+    # and the GPU is fine afterwards: the same statement proves on a fresh group
+    ref = be.prove_machine(comps, cfg, seed=5, ad=b"x")
+    for w in _run_ranks(nz, 4, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=5, ad=b"x", comm=comm)):
+        _same(ref, w)
+
+
+def test_ranks_with_different_plan_options_are_refused_before_the_first_exchange(nz):
+    """"air.degree_split" & co. decide which domains a row-sharded prove evaluates and exchanges on; a rank configured
+    differently would meet its peers in mismatched collectives.  The pre-exchange vote carries the options: every rank gets NX_ERR_ARG."""
+    comps = [(10, 3, 20, 8, 2)]
+    cfg = nz.default_config(pow_bits=4, log_constraint_degree=2)
+
+    def fn(b, comm, rank):
+        b.set_option("air.degree_split", 0 if rank == 0 else 1)
+        return b.prove_machine(comps, cfg, seed=5, comm=comm)
+    res, errs, all_back = _run_ranks_collect(nz, 2, lambda rank, impl: impl, fn, timeout=90)
+    assert all_back and all(e is not None and "different context options" in e for e in errs), errs
+
+
 @pytest.mark.parametrize("world,chunks", [(2, 3), (4, 2), (8, 4)])
 def test_machine_row_sharded_with_chunked_exchange(be, nz, monkeypatch, world, chunks):
     """The column chunks of the row-sharded commit (chunk q+1's LDE enqueued before chunk q's all-to-all; the receive slab is
