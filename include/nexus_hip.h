@@ -297,6 +297,15 @@ int nx_machine_air_source(const nx_component_spec* comp, char** h_source);
 int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed,
                      const uint8_t* ad, size_t ad_len, const struct nx_comm* comm, uint32_t** proof_words, size_t* n_words,
                      nx_prove_stats* stats);
+/* The same machine with its preprocessed and main traces handed over in HOST memory — the hand-over of the reference, whose trace builder
+ * fills `Vec<Vec<M31>>` on the CPU (prover/src/trace/trace_builder.rs:19-32) — instead of generated on the device: h_pre_cols / h_main_cols
+ * hold, component after component, the n_pre / n_main columns of 2^log_size words (natural coset order when coset_order != 0, else
+ * bit-reversed circle-domain order).  The two commits upload the columns in chunks and transform each chunk as it arrives
+ * (nx_prover_tree_commit_host describes the pipeline); the interaction trace is generated on the device as in nx_prove_machine.  One GPU.
+ * The proof equals nx_prove_machine's for the same trace, byte for byte.  This is what bench.py's `host_trace` block times. */
+int nx_prove_machine_host(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg,
+                          const uint32_t* const* h_pre_cols, const uint32_t* const* h_main_cols, int coset_order, const uint8_t* ad,
+                          size_t ad_len, uint32_t** proof_words, size_t* n_words, nx_prove_stats* stats);
 /* `Proof.claimed_sum` of the last successful nx_prove_machine on this context (reference prover/src/machine.rs:93-98: the proof the
  * reference returns carries the per-component logup claimed sums next to the StarkProof; a verifier mixes them before the interaction
  * commitment, machine.rs:262 / :448-450, and nx_proof_serialize_stwo takes them): 4 words per component, in component order.
@@ -444,6 +453,17 @@ int nx_prover_channel_digest(const nx_prover* prover, uint8_t digest[32]);
  * The columns then belong to the session (they hold the coefficients afterwards). */
 int nx_prover_tree_begin(nx_prover* prover, const uint32_t* log_sizes, uint32_t n_cols, uint32_t** d_cols_out);
 int nx_prover_tree_commit(nx_prover* prover, uint8_t root[32]);
+/* The same for a tree whose columns are in HOST memory — what the reference's trace builder hands over (`Vec<Vec<M31>>`,
+ * prover/src/trace/trace_builder.rs:19-32): h_cols[i] is the host source of column i of the tree begun with nx_prover_tree_begin
+ * (2^log_sizes[i] words; natural coset order when coset_order != 0 — R3's permutation then runs on the device — else bit-reversed
+ * circle-domain order).  The commit uploads the columns in chunks on a copy stream and transforms each chunk as soon as it has arrived:
+ * PCIe transfer, iFFT + LDE and leaf hashing overlap.  keep_idx / d_keep (n_keep entries, may be 0):
+ * columns whose EVALUATIONS are needed after the commit (the logup fractions read main-trace columns; the commit turns columns into
+ * coefficients in place) are cloned into d_keep[k] (2^log words, caller-allocated) on arrival — the reference's whole-trace clone
+ * (machine.rs:232), for the columns that need it.  Blocking like nx_prover_tree_commit; the host columns are free on return.
+ * A row-sharded session uploads its own columns first (no overlap) and commits as usual. */
+int nx_prover_tree_commit_host(nx_prover* prover, const uint32_t* const* h_cols, int coset_order, const uint32_t* keep_idx,
+                               uint32_t n_keep, uint32_t* const* d_keep, uint8_t root[32]);
 /* A component: what FrameworkComponent<E> is to Stwo (reference prover/src/components/mod.rs:15-57).  Column k of the program is
  * column col_index[k] of tree col_tree[k] (TraceLocationAllocator); it is sampled at the mask_count[k] row offsets listed next in
  * mask_offsets (InfoEvaluator, components/mod.rs:59-67) — every LOAD offset must be listed, every committed column must be

@@ -249,6 +249,21 @@ class ProverSession:
                 self.be._chk(self.be.L.nx_upload(self.be.ctx, C.c_void_p(d), c.ctypes.data_as(C.c_void_p), C.c_size_t(len(c))))
         return self.tree_commit()
 
+    def commit_host(self, cols, coset_order=False, keep=()):
+        """nx_prover_tree_commit_host: the tree's columns stay in HOST memory (numpy) and are uploaded chunk by chunk under the commit's
+        own transforms.  keep: column indices whose evaluations are cloned on arrival; returns (root, {index: DeviceColumns})."""
+        cols = [_u32(c) for c in cols]
+        logs = [int(np.log2(len(c))) for c in cols]
+        self.tree_begin(logs)
+        hp = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data for c in cols])
+        kept = {int(k): DeviceColumns(self.be, 1, logs[int(k)]) for k in keep}
+        ki = _u32(list(kept.keys()))
+        kd = (C.c_void_p * max(1, len(kept)))(*[d.ptr.value for d in kept.values()])
+        root = np.zeros(8, np.uint32)
+        self.be._chk(self.be.L.nx_prover_tree_commit_host(self.h, hp, int(bool(coset_order)), ki.ctypes.data_as(C.c_void_p) if len(kept) else None, len(kept),
+                                                         kd if len(kept) else None, root.ctypes.data_as(C.c_void_p)))
+        return root, kept
+
     def prove(self, components, kernels=None, want_stats=False):
         """components: air_program.Component list; kernels: optional AirKernel per component (compiled once, reused)."""
         arr = (AirComponentC * len(components))()
@@ -834,6 +849,23 @@ class HipBackend:
         adb = (C.c_uint8 * max(1, len(ad)))(*ad)
         self._chk(self.L.nx_prove_machine(self.ctx, self._comps(comps), len(comps), C.byref(cfg), C.c_uint64(seed), adb, C.c_size_t(len(ad)),
                                           C.byref(comm) if comm is not None else None, C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
+        out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
+        self.L.nx_free_host(words)
+        return (out, stats.as_dict()) if want_stats else out
+
+    def prove_machine_host(self, comps, cfg, pre_cols, main_cols, ad=b"", coset_order=False, want_stats=False):
+        """nx_prove_machine_host: the machine's preprocessed / main traces from HOST memory (lists of contiguous uint32 arrays, component
+        after component), uploaded under the commits' own transforms.  Same proof as prove_machine for the same trace."""
+        cfg = cfg or default_config()
+        keep = [np.ascontiguousarray(c, dtype=np.uint32) for c in list(pre_cols) + list(main_cols)]
+        n_pre = len(pre_cols)
+        pp = (C.c_void_p * max(1, n_pre))(*[c.ctypes.data for c in keep[:n_pre]])
+        mp = (C.c_void_p * max(1, len(keep) - n_pre))(*[c.ctypes.data for c in keep[n_pre:]])
+        words, n = C.POINTER(C.c_uint32)(), C.c_size_t(0)
+        stats = ProveStats()
+        adb = (C.c_uint8 * max(1, len(ad)))(*ad)
+        self._chk(self.L.nx_prove_machine_host(self.ctx, self._comps(comps), len(comps), C.byref(cfg), pp, mp, int(bool(coset_order)), adb, C.c_size_t(len(ad)),
+                                               C.byref(words), C.byref(n), C.byref(stats) if want_stats else None))
         out = np.ctypeslib.as_array(words, shape=(n.value,)).copy()
         self.L.nx_free_host(words)
         return (out, stats.as_dict()) if want_stats else out

@@ -306,6 +306,8 @@ int nx_ctx_create(int device, nx_ctx** out) {
     NX_HIP(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->cur = c->stream;
     NX_HIP(nullptr, hipStreamCreateWithFlags(&c->hash_stream, hipStreamNonBlocking));
+    NX_HIP(nullptr, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    NX_HIP(nullptr, hipStreamCreateWithFlags(&c->perm_stream, hipStreamNonBlocking));
     NX_HIP(nullptr, hipEventCreateWithFlags(&c->hash_ev, hipEventDisableTiming));
     NX_HIP(nullptr, hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     for (int i = 0; i < 3; i++) {
@@ -335,6 +337,7 @@ void nx_ctx_destroy(nx_ctx* ctx) {
     for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(ctx->side[i]); (void)hipEventDestroy(ctx->join_ev[i]); }
     (void)hipEventDestroy(ctx->fork_ev);
     (void)hipStreamDestroy(ctx->hash_stream); (void)hipEventDestroy(ctx->hash_ev);
+    (void)hipStreamDestroy(ctx->copy_stream); (void)hipStreamDestroy(ctx->perm_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

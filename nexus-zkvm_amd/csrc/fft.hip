@@ -653,6 +653,67 @@ int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_col
     return NX_OK;
 }
 
+}  // extern "C" (re-opened below)
+namespace nx {
+int HostFeed::begin(nx_ctx* c, uint32_t log_size, int coset) {
+    ctx = c; log = log_size; coset_order = coset; n_done = 0;
+    if (log_size < 1 || log_size > 30) return set_err(c, NX_ERR_ARG, "host feed: bad log_size");
+    for (int k = 0; k < 2; k++) {
+        if (coset_order) NX_TRY(dev_alloc(ctx, (size_t)4 << log, (void**)&d_tmp[k]));
+        NX_HIP(ctx, hipEventCreateWithFlags(&copied[k], hipEventDisableTiming));
+        NX_HIP(ctx, hipEventCreateWithFlags(&consumed[k], hipEventDisableTiming));
+    }
+    return NX_OK;
+}
+int HostFeed::chunk(const uint32_t* const* h_cols, uint32_t* const* d_cols, uint32_t n_cols, hipEvent_t* ready) {
+    const size_t n = (size_t)1 << log, bytes = n * 4;
+    for (uint32_t c = 0; c < n_cols; c++) {
+        if (!h_cols[c] || !d_cols[c]) return set_err(ctx, NX_ERR_ARG, "host feed: NULL column");
+        if (hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back(h_cols[c]);
+        else (void)hipGetLastError();                                            // falls back to a pageable copy
+        const int k = (int)(n_done & 1);
+        if (!coset_order) {
+            NX_HIP(ctx, hipMemcpyAsync(d_cols[c], h_cols[c], bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        } else {
+            if (n_done >= 2) NX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, consumed[k], 0));      // the permutation of column n_done - 2 has read d_tmp[k]
+            NX_HIP(ctx, hipMemcpyAsync(d_tmp[k], h_cols[c], bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+            NX_HIP(ctx, hipEventRecord(copied[k], ctx->copy_stream));
+            NX_HIP(ctx, hipStreamWaitEvent(ctx->perm_stream, copied[k], 0));
+            ColSet s1, d1; s1.base = d_tmp[k]; s1.stride = 0; s1.table = nullptr; d1.base = d_cols[c]; d1.stride = 0; d1.table = nullptr;
+            hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, ctx->perm_stream, s1, d1, 1u, (int)log);
+            NX_LAUNCH_CHECK(ctx);
+            NX_HIP(ctx, hipEventRecord(consumed[k], ctx->perm_stream));
+        }
+        n_done++;
+    }
+    hipEvent_t ev = nullptr;
+    NX_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    events.push_back(ev);
+    NX_HIP(ctx, hipEventRecord(ev, coset_order ? ctx->perm_stream : ctx->copy_stream));
+    *ready = ev;
+    return NX_OK;
+}
+int HostFeed::finish() {
+    if (!ctx) return NX_OK;
+    hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->perm_stream);
+    for (const uint32_t* h : pinned) (void)hipHostUnregister((void*)h);
+    pinned.clear();
+    for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+    events.clear();
+    for (int k = 0; k < 2; k++) {
+        if (copied[k]) (void)hipEventDestroy(copied[k]);
+        if (consumed[k]) (void)hipEventDestroy(consumed[k]);
+        copied[k] = consumed[k] = nullptr;
+        if (d_tmp[k]) { dev_free(ctx, d_tmp[k]); d_tmp[k] = nullptr; }
+    }
+    nx_ctx* c = ctx; ctx = nullptr;
+    if (e1 != hipSuccess) return hip_fail(c, e1, "host feed (copy stream)", __FILE__, __LINE__);
+    if (e2 != hipSuccess) return hip_fail(c, e2, "host feed (permutation stream)", __FILE__, __LINE__);
+    return NX_OK;
+}
+}  // namespace nx
+extern "C" {
+
 int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst) {
     NX_GUARD(ctx);
     uint32_t* d_tmp = nullptr;

@@ -37,6 +37,7 @@ struct nx_ctx {
     hipStream_t side[3];
     hipEvent_t fork_ev, join_ev[3];
     hipStream_t cur;   // stream the FFT launchers enqueue on (== stream outside a forked region)
+    hipStream_t copy_stream, perm_stream;   // host-trace feed (HostFeed): PCIe copies / the R3 permutation behind them, next to the commit's kernels
     hipStream_t hash_stream;   // leaf hashing of finished column groups runs here, next to the LDE of the next group
     hipEvent_t hash_ev;
     int hash_mode;
@@ -165,6 +166,20 @@ void dev_cache_release(nx_ctx* ctx);
 
 // n_cols columns of n_words words each, dst[k] <- src[k], one launch (ctx.hip)
 int copy_columns(nx_ctx* ctx, uint32_t* const* h_dst, const uint32_t* const* h_src, uint32_t n_cols, size_t n_words);
+// A host-resident trace fed to the device WHILE the commitment transforms what has arrived (fft.hip): columns
+// are pinned in place, copied on ctx->copy_stream and — coset_order — permuted into bit-reversed circle-domain order on
+// ctx->perm_stream (R3 fused); chunk() returns an event that fires when its columns are in place, so the consumer orders its own
+// stream behind it (hipStreamWaitEvent) and the host never waits.  finish() drains both streams and unpins (also on the error paths).
+struct HostFeed {
+    nx_ctx* ctx = nullptr; int coset_order = 0; uint32_t log = 0;
+    uint32_t* d_tmp[2] = {nullptr, nullptr}; hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    uint64_t n_done = 0;
+    std::vector<const uint32_t*> pinned; std::vector<hipEvent_t> events;
+    int begin(nx_ctx* c, uint32_t log_size, int coset);
+    int chunk(const uint32_t* const* h_cols, uint32_t* const* d_cols, uint32_t n_cols, hipEvent_t* ready);
+    int finish();
+    ~HostFeed() { (void)finish(); }
+};
 int transpose_blocks(nx_ctx* ctx, uint32_t* full, uint64_t col_stride, uint32_t* blocks, uint32_t n_cols, uint64_t rows, uint32_t world, bool unpack);
 
 // Event-pair span on ctx->stream, recorded only when ctx->timing is on; resolved by timing_flush.

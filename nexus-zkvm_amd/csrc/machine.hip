@@ -315,8 +315,11 @@ static std::set<uint32_t> logup_main_columns(const nx_component_spec& c) {
     return s;
 }
 
+// host: the preprocessed and the main trace handed over in HOST memory (component after component, column after column; NULL = generate
+// them on the device from `seed`): the commits then upload them chunk by chunk under their own transforms (TreeBuilder::extend_evals_host)
+struct HostTrace { const uint32_t* const* pre = nullptr; const uint32_t* const* main = nullptr; int coset_order = 0; };
 static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
-                         size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st) {
+                         size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st, const HostTrace* host = nullptr) {
     PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
     H_TRY(check_components(ctx, comps, n_comps, ucfg));
     for (uint32_t i = 0; i < n_comps; i++) if (comps[i].n_inter % 4) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: n_inter = 4 x (number of logup columns)");
@@ -355,7 +358,15 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     }
     lap(&st->commit);
 
-    { TreeBuilder tb = cs.tree_builder(); H_TRY(fill_and_extend(cs, tb, comps, n_comps, 0, seed, 0)); lap(&st->trace_gen); H_TRY(tb.commit(channel)); lap(&st->commit); }   // :208-228
+    if (host && D.on()) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine_host: one GPU (a row-sharded session takes host columns through nx_prover_tree_commit_host)");
+    if (host) {
+        TreeBuilder tb = cs.tree_builder();
+        for (uint32_t i = 0; i < n_comps; i++) {
+            DevBuf slab; H_TRY(slab.alloc(ctx, (size_t)comps[i].n_pre << comps[i].log_size));
+            tb.extend_evals_host(std::move(slab), comps[i].n_pre, comps[i].log_size, host->pre + locs[i].pre0, host->coset_order);
+        }
+        H_TRY(tb.commit(channel)); lap(&st->commit);
+    } else { TreeBuilder tb = cs.tree_builder(); H_TRY(fill_and_extend(cs, tb, comps, n_comps, 0, seed, 0)); lap(&st->trace_gen); H_TRY(tb.commit(channel)); lap(&st->commit); }   // :208-228
 
     // The main trace is consumed by its commitment (the columns become coefficients), and the interaction trace needs its
     // evaluations afterwards: the reference clones the whole finalized trace (machine.rs:232); here only the columns the logup
@@ -375,9 +386,20 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
             if (hi > lo) {
                 H_TRY(slab.alloc(ctx, (size_t)(hi - lo) << log));
                 auto p = col_ptrs(slab.p, hi - lo, log);
-                H_TRY(synth_fill_range(ctx, c, i, 1, seed, 0, lo, hi - lo, p.data(), 0, 1u << log));
+                if (!host) H_TRY(synth_fill_range(ctx, c, i, 1, seed, 0, lo, hi - lo, p.data(), 0, 1u << log));
             }
             const std::set<uint32_t> need = logup_main_columns(c);
+            if (host) {
+                // the columns the logup fractions read are cloned as they arrive (keep list); the slab is filled by the commit
+                std::vector<std::pair<uint32_t, uint32_t*>> keep;
+                if (!need.empty()) {
+                    H_TRY(kept[i].alloc(ctx, need.size() << log));
+                    size_t q = 0;
+                    for (uint32_t k : need) { uint32_t* dst = kept[i].p + (q++ << log); keep.push_back({k, dst}); kept_ptr[i][k] = dst; }
+                }
+                tb.extend_evals_host(std::move(slab), c.n_main, log, host->main + locs[i].main0, host->coset_order, keep);
+                continue;
+            }
             if (!need.empty()) {
                 if (D.on() && log < (uint32_t)D.log_w + 2) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: every trace column needs at least 4 rows per GPU");
                 const uint64_t nb = D.on() ? D.block(log) : ((uint64_t)1 << log);
@@ -537,6 +559,16 @@ int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_com
     const int rc = nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
     abort_peers(comm, rc);
     return hand_out(ctx, rc, w, proof_words, n_words, "nx_prove_machine");
+}
+
+int nx_prove_machine_host(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, const uint32_t* const* h_pre_cols,
+                          const uint32_t* const* h_main_cols, int coset_order, const uint8_t* ad, size_t ad_len, uint32_t** proof_words, size_t* n_words,
+                          nx_prove_stats* stats) {
+    NX_GUARD(ctx);
+    if (!ctx || !comps || !cfg || !proof_words || !n_words || !h_pre_cols || !h_main_cols) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine_host: NULL argument");
+    nxhip::HostTrace host; host.pre = h_pre_cols; host.main = h_main_cols; host.coset_order = coset_order;
+    std::vector<uint32_t> w;
+    return hand_out(ctx, nxhip::prove_machine(ctx, comps, n_comps, cfg, 0, ad, ad_len, nullptr, &w, stats, &host), w, proof_words, n_words, "nx_prove_machine_host");
 }
 
 int nx_machine_claimed_sums(const nx_ctx* ctx, uint32_t* claimed_sums, uint32_t cap_components, uint32_t* n_components) {

@@ -150,10 +150,24 @@ class CommitmentSchemeProver;
 // TreeBuilder::{extend_evals, extend_polys, commit}
 class TreeBuilder {
   public:
-    struct Group { DevBuf slab; uint32_t n_cols, log; bool is_evals; uint32_t lo, hi; };   // slab: columns [lo, hi) of the group's n_cols (all of them on one GPU)
+    struct Group {
+        DevBuf slab; uint32_t n_cols, log; bool is_evals; uint32_t lo, hi;   // slab: columns [lo, hi) of the group's n_cols (all of them on one GPU)
+        // host-resident source (extend_evals_host): the slab is FILLED by the commit, from these host columns, while it transforms
+        std::vector<const uint32_t*> host; int coset_order = 0;
+        std::vector<std::pair<uint32_t, uint32_t*>> keep;                    // (column of the group, device buffer): its evaluations, cloned before the transform (R4)
+    };
     explicit TreeBuilder(CommitmentSchemeProver& c) : cs(c) {}
     // slab: n_cols contiguous columns of 2^log words (bit-reversed evaluations on CanonicCoset(log).circle_domain())
     void extend_evals(DevBuf&& slab, uint32_t n_cols, uint32_t log) { push(std::move(slab), n_cols, log, true, 0, n_cols); }
+    // The trace is in HOST memory (what the reference's trace builder hands over, prover/src/trace/trace_builder.rs:19-32): commit()
+    // uploads it in column chunks on the copy stream — pinned in place, R3's permutation on the device when coset_order — and runs each
+    // chunk's iFFT + LDE as soon as the chunk has arrived, so the PCIe transfer and the transforms overlap (one GPU).  keep: columns whose
+    // evaluations are needed after the commit (the logup fractions read them): cloned on arrival, the reference's trace clone (machine.rs:232)
+    void extend_evals_host(DevBuf&& slab, uint32_t n_cols, uint32_t log, const uint32_t* const* h_cols, int coset_order,
+                           const std::vector<std::pair<uint32_t, uint32_t*>>& keep = {}) {
+        push(std::move(slab), n_cols, log, true, 0, n_cols);
+        groups.back().host.assign(h_cols, h_cols + n_cols); groups.back().coset_order = coset_order; groups.back().keep = keep;
+    }
     // row-sharded prove: the slab holds this GPU's columns [lo, hi) of the group (plan_local_columns)
     void extend_evals_local(DevBuf&& slab, uint32_t n_cols, uint32_t log, uint32_t lo, uint32_t hi) { push(std::move(slab), n_cols, log, true, lo, hi); }
     // coefficients, all n_cols of them on every GPU (the composition polynomial)

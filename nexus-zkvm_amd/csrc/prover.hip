@@ -3,6 +3,7 @@
 // recorded AIRs — see prover.h for the objects and for how one proof is spread over the GPUs of a node.
 #include "prover.h"
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <numeric>
@@ -236,6 +237,8 @@ int TreeBuilder::commit_single(Blake2sChannel& channel) {
     for (auto& g : groups) if (g.n_cols) max_el = std::max(max_el, g.log + cs.cfg.log_blowup);
     for (auto& g : groups) if (g.n_cols && g.log + cs.cfg.log_blowup == max_el) total_leaf_cols += g.n_cols;
     for (auto& g : groups) if (g.lo != 0 || g.hi != g.n_cols) return set_err(ctx, NX_ERR_ARG, "TreeBuilder: a column shard was handed to a single-GPU commitment scheme");
+    std::vector<std::unique_ptr<HostFeed>> feeds;      // one per run with host-resident columns; drained (and the host unpinned) before commit returns
+    struct FeedGuard { std::vector<std::unique_ptr<HostFeed>>& f; ~FeedGuard() { for (auto& x : f) (void)x->finish(); } } feed_guard{feeds};
     TreePipe tp;
     struct PipeGuard { nx_ctx* c; TreePipe* p; ~PipeGuard() { if (p->tree) { (void)nx_sync(c); nx_tree_destroy(p->tree); p->tree = nullptr; } } } guard{ctx, &tp};
     if (total_leaf_cols) { H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp)); tp.side_stream = pipe_group_cols() < (1u << 29); }
@@ -257,12 +260,43 @@ int TreeBuilder::commit_single(Blake2sChannel& channel) {
             for (size_t g = g0; g < g1; g++) { auto p = col_ptrs(groups[g].slab.p, groups[g].n_cols, log); in.insert(in.end(), p.begin(), p.end()); }
             auto out = col_ptrs(lde.p, n_run, el);
             const bool leaf = el == max_el;
-            const uint32_t step = leaf ? G : n_run;
+            // host-resident columns of this run: per column its host source, and what to clone on arrival
+            std::vector<const uint32_t*> hsrc(n_run, nullptr); std::vector<uint32_t*> keep_of(n_run, nullptr);
+            bool any_host = false; int coset_order = 0;
+            {
+                uint32_t off = 0;
+                for (size_t g = g0; g < g1; g++) {
+                    if (!groups[g].host.empty()) {
+                        if (any_host && coset_order != groups[g].coset_order) return set_err(ctx, NX_ERR_ARG, "TreeBuilder: the host columns of one run must share one order");
+                        any_host = true; coset_order = groups[g].coset_order;
+                        for (uint32_t k = 0; k < groups[g].n_cols; k++) hsrc[off + k] = groups[g].host[k];
+                        for (auto& kv : groups[g].keep) { if (kv.first >= groups[g].n_cols) return set_err(ctx, NX_ERR_ARG, "TreeBuilder: keep index outside the group"); keep_of[off + kv.first] = kv.second; }
+                    }
+                    off += groups[g].n_cols;
+                }
+            }
+            HostFeed* feed = nullptr;
+            if (any_host) { feeds.emplace_back(new HostFeed()); feed = feeds.back().get(); H_TRY(feed->begin(ctx, log, coset_order)); }
+            // chunks of 16 columns when the run is fed from the host (a chunk's transforms start when IT has arrived; 16 columns of 2^22
+            // rows are 5 ms of PCIe and 0.7 ms of transforms), else the whole run (or NX_PIPE_COLS groups) per call
+            const uint32_t step = any_host ? 16u : (leaf ? G : n_run);
             for (uint32_t c0 = 0; c0 < n_run; c0 += step) {
                 const uint32_t nb = std::min(step, n_run - c0);
+                if (any_host) {
+                    // contiguous sub-runs with a host source are uploaded; columns without one were filled by the caller
+                    for (uint32_t a = c0; a < c0 + nb;) {
+                        if (!hsrc[a]) { a++; continue; }
+                        uint32_t b2 = a; while (b2 < c0 + nb && hsrc[b2]) b2++;
+                        hipEvent_t ready = nullptr;
+                        H_TRY(feed->chunk(hsrc.data() + a, in.data() + a, b2 - a, &ready));
+                        NX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ready, 0));
+                        a = b2;
+                    }
+                    for (uint32_t a = c0; a < c0 + nb; a++) if (keep_of[a]) H_TRY(nx_copy(ctx, keep_of[a], in[a], (size_t)1 << log));       // Column::clone (R4)
+                }
                 if (is_evals) H_TRY(nx_lde_batch(ctx, cs.tw, in.data() + c0, nb, log, cs.cfg.log_blowup, out.data() + c0));   // K3 + K4
                 else H_TRY(nx_evaluate_batch(ctx, cs.tw, (const uint32_t* const*)in.data() + c0, nb, log, cs.cfg.log_blowup, out.data() + c0));  // K4
-                if (leaf) H_TRY(tree_pipe_absorb(ctx, &tp, (const uint32_t* const*)out.data() + c0, nb, false));                   // K5, leaf layer
+                if (leaf) H_TRY(tree_pipe_absorb(ctx, &tp, (const uint32_t* const*)out.data() + c0, nb, false));                   // K5, leaf layer (16-column blocks as they complete)
             }
             for (uint32_t i = 0; i < n_run; i++) {
                 t.polys.push_back({in[i], log, false}); t.evals.push_back({out[i], el, false}); t.owner.push_back(-1);
@@ -278,6 +312,7 @@ int TreeBuilder::commit_single(Blake2sChannel& channel) {
     else H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &t.merkle.local));
     H_TRY(nx_merkle_root(ctx, t.merkle.local, (uint8_t*)t.root.w));
     t.merkle.root = t.root;
+    for (auto& f : feeds) H_TRY(f->finish());                                                // the host columns are the caller's again
     channel.mix_root(t.root);                                                                // K6
     cs.trees.push_back(std::move(t));
     groups.clear();
@@ -1684,6 +1719,44 @@ int nx_prover_tree_commit(nx_prover* p, uint8_t root[32]) {
     if (!p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit: no tree was begun");
     nxhip::TreeBuilder tb = p->cs->tree_builder();
     for (auto& r : p->pending) tb.extend_evals_local(std::move(r.slab), r.n_cols, r.log, r.lo, r.hi);
+    p->pending.clear(); p->open = false;
+    {
+        const int rc = tb.commit(p->channel);
+        if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort) p->comm_copy.abort(p->comm_copy.user); return rc; }
+    }
+    if (root) memcpy(root, p->cs->trees.back().root.w, 32);
+    return NX_OK;
+}
+
+int nx_prover_tree_commit_host(nx_prover* p, const uint32_t* const* h_cols, int coset_order, const uint32_t* keep_idx, uint32_t n_keep, uint32_t* const* d_keep,
+                               uint8_t root[32]) {
+    NX_GUARD(p ? p->ctx : nullptr);
+    if (!p) return set_err(nullptr, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL prover");
+    if (!p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: no tree was begun");
+    uint32_t n_total = 0;
+    for (auto& r : p->pending) n_total += r.n_cols;
+    if ((n_total && !h_cols) || (n_keep && (!keep_idx || !d_keep))) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL argument");
+    for (uint32_t k = 0; k < n_keep; k++) if (keep_idx[k] >= n_total || !d_keep[k]) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: keep entry outside the tree (or NULL)");
+    const bool sharded = p->cs->dist.on();
+    nxhip::TreeBuilder tb = p->cs->tree_builder();
+    uint32_t first = 0;
+    for (auto& r : p->pending) {
+        if (sharded) {
+            // this GPU's columns of the run, uploaded before the commit (the exchange-bound sharded commit gains nothing from the overlap)
+            std::vector<const uint32_t*> hs; std::vector<uint32_t*> ds;
+            for (uint32_t k = r.lo; k < r.hi; k++) { if (!h_cols[first + k]) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL host column"); hs.push_back(h_cols[first + k]); ds.push_back(r.slab.p + ((size_t)(k - r.lo) << r.log)); }
+            if (!hs.empty()) NX_TRY(nx_upload_columns(p->ctx, hs.data(), (uint32_t)hs.size(), r.log, ds.data(), coset_order));
+            for (uint32_t k = 0; k < n_keep; k++)
+                if (keep_idx[k] >= first + r.lo && keep_idx[k] < first + r.hi) NX_TRY(nx_copy(p->ctx, d_keep[k], r.slab.p + ((size_t)(keep_idx[k] - first - r.lo) << r.log), (size_t)1 << r.log));
+            tb.extend_evals_local(std::move(r.slab), r.n_cols, r.log, r.lo, r.hi);
+        } else {
+            for (uint32_t k = 0; k < r.n_cols; k++) if (!h_cols[first + k]) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL host column");
+            std::vector<std::pair<uint32_t, uint32_t*>> keep;
+            for (uint32_t k = 0; k < n_keep; k++) if (keep_idx[k] >= first && keep_idx[k] < first + r.n_cols) keep.push_back({keep_idx[k] - first, d_keep[k]});
+            tb.extend_evals_host(std::move(r.slab), r.n_cols, r.log, h_cols + first, coset_order, keep);
+        }
+        first += r.n_cols;
+    }
     p->pending.clear(); p->open = false;
     {
         const int rc = tb.commit(p->channel);

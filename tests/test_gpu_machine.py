@@ -308,6 +308,61 @@ def test_machine_row_sharded_default_fri_switch(be, nz, monkeypatch, world):
         _same(ref, res[r])
 
 
+def test_machine_from_a_host_resident_trace_equals_the_device_generated_one(be, nz, oracle):
+    """the reference hands its trace over in HOST memory (trace_builder.rs:19-32).
+    nx_prove_machine_host takes the preprocessed and main traces from host arrays and uploads them in chunks UNDER the commits' own
+    transforms (TreeBuilder::extend_evals_host): same trace -> the same proof as nx_prove_machine generates on the device (which the
+    tests above tie to the oracle), in both host orders — bit-reversed circle-domain evaluations, and the natural coset order of the
+    reference's `Vec<Vec<M31>>` with R3's permutation on the device; several components, sizes below and above a 16-column chunk."""
+    for comps, kw in (([(12, 27, 90, 32), (9, 3, 20, 8), (6, 2, 5, 4)], dict(pow_bits=5)), ([(11, 3, 17, 8, 2), (11, 2, 33, 4, 1)], dict(pow_bits=4, log_constraint_degree=2))):
+        cfg = nz.default_config(**kw)
+        ref = be.prove_machine(comps, cfg, seed=41, ad=b"host")
+        pre = [c for s in be.synth_fill_tree(comps, 0, 41) for c in s.to_cpu()]
+        main = [c for s in be.synth_fill_tree(comps, 1, 41) for c in s.to_cpu()]
+        _same(ref, be.prove_machine_host(comps, cfg, pre, main, ad=b"host"))
+
+        def natural(col):        # the coset-order column whose finalize_columns image is `col`
+            n = len(col)
+            idx = O.finalize_column(np.arange(n, dtype=np.uint32))
+            nat = np.zeros(n, np.uint32); nat[idx] = col
+            return nat
+        words, st = be.prove_machine_host(comps, cfg, [natural(c) for c in pre], [natural(c) for c in main], ad=b"host", coset_order=True, want_stats=True)
+        _same(ref, words)
+        assert st["total"] > 0
+
+
+def test_session_commit_from_host_columns_with_kept_evaluations(be, nz, oracle):
+    """nx_prover_tree_commit_host through the session: the root equals the plain commit's, the kept columns are the evaluations as they
+    arrived (the commit itself turns the tree's columns into coefficients), and the prove that follows gives the oracle session's bytes."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    log = 10
+    kw = dict(pow_bits=4)
+    cfg, ocfg = nz.default_config(**kw), O.default_cfg(**kw)
+    nat, fin = AE.logup_main_trace(log, 44)
+
+    def drive(session, commit_main):
+        session.mix_u64(log)
+        session.commit([])
+        commit_main(fin)
+        z, alpha = session.draw_felt(), session.draw_felt()
+        inter, shift = AE.logup_interaction_trace(log, nat, z, alpha)
+        session.mix_felts(np.zeros(4, np.uint32))
+        session.commit(inter)
+        return session.prove([AE.logup_component(ap, log, z, alpha, shift)])
+    o = O.ProverSession(ocfg, log)
+    ref = drive(o, lambda cols: o.commit(cols))
+    s = be.prover_session(cfg, log)
+    kept = {}
+
+    def from_host(cols):
+        root, k = s.commit_host(cols, keep=(0, len(cols) - 1))
+        kept.update(k)
+    _same(ref, drive(s, from_host))
+    assert np.array_equal(kept[0].to_cpu()[0], fin[0]) and np.array_equal(kept[len(fin) - 1].to_cpu()[0], fin[-1])
+    s.close()
+
+
 def test_config5_keccak_shaped_machine(be, nz, oracle):
     """BASELINE config #5 shape (two keccak round components of 16 and 8 rows per instance, byte-lane main columns, 4
     logup columns per lane-level lookup, so the interaction tree is the widest one): real logup columns and the recorded AIR on the
