@@ -57,8 +57,7 @@ void nx_ctx_destroy(nx_ctx* ctx);
 const char* nx_last_error(const nx_ctx* ctx); /* ctx may be NULL: last global error               */
 int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
 /* Per-context policy and tuning.  The NX_* environment variables only seed a new context's defaults; what a
- * context does is decided by its own options, so two contexts of one process may differ.  Names: "fft.pipe" (0/1: pipelined LDE
- * kernels of fft_pipe.hip, default 0), "fft.pipe_blocks_per_cu" (1..2), "fft.pipe_grid" (0 = automatic, else persistent blocks per launch), "fft.batch_cols",
+ * context does is decided by its own options, so two contexts of one process may differ.  Names: "fft.batch_cols" (2^22-row columns per launch of the LDE),
  * "fft.streams" (1..4), "comm.timeout_ms" (native RCCL transport: the longest a rank waits for its peers in one collective before it aborts the communicator and fails
  * the prove, default 120000; 0 = wait for ever), "fri.dist_min_log", "dist.chunks" and "air.degree_split" (1: degree-aware composition, see
  * nx_air_constraint_degrees) — row-sharded prove: every GPU of a proof must use the same values of these three, they shape the
@@ -355,6 +354,16 @@ typedef struct nx_comm {
 int nx_rccl_unique_id(uint8_t id[128]);
 int nx_comm_rccl_create(nx_ctx* ctx, const uint8_t unique_id[128], int32_t rank, int32_t world, nx_comm** out);
 void nx_comm_rccl_destroy(nx_comm* comm);
+/* The in-process transport (csrc/comm_local.hip): ONE process drives the GPUs of a node with one thread per GPU — each thread its own
+ * context and its own communicator of one shared group — and the collectives are rendezvous of those threads plus device-to-device copies
+ * every rank pulls from its peers (peer to peer over xGMI between two devices; plain copies when several contexts share one GPU, which is
+ * how the test-suite runs the 2 / 4 / 8-rank proofs on a one-GPU box).  No RCCL, no second process.  abort() breaks the group: every
+ * waiting and later collective fails on every rank; waits are bounded by "comm.timeout_ms".  The group outlives its communicators. */
+typedef struct nx_comm_group nx_comm_group;
+int nx_comm_group_create(int32_t world, nx_comm_group** out);
+void nx_comm_group_destroy(nx_comm_group* group);
+int nx_comm_local_create(nx_comm_group* group, nx_ctx* ctx, int32_t rank, nx_comm** out);
+void nx_comm_local_destroy(nx_comm* comm);
 /* Which columns of a tree a GPU transforms: groups = (column count, log size) per component in commit order; consecutive groups
  * of one size form a run whose columns are cut into `world` contiguous balanced ranges; lo/hi[i] = this rank's [lo, hi) of group i.
  * Host arithmetic only (no context, no GPU). */
@@ -433,7 +442,9 @@ int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_inst
  * main tree (:230-237), draw lookup elements (:239-240), build the interaction trace (nx_logup_*), mix the claimed sums (:262),
  * commit the interaction tree (:263) — and nx_prover_prove runs CommitmentSchemeProver / stwo::prover::prove (:286-290) on the
  * device: composition polynomial (nx_air_eval), OODS sampling, DEEP quotients, FRI, proof of work, decommitment.  The proof is
- * in the NXP1 word format of nx_prove_synth.  Exactly three trace trees. */
+ * in the NXP1 word format of nx_prove_synth.  The session proves the trace trees it was given — the reference commits three
+ * (preprocessed, main, interaction), Stwo's prove takes any TreeVec; a component column names its tree by index —; the composition
+ * polynomial's tree follows them. */
 typedef struct nx_prover nx_prover;
 int nx_prover_create(nx_ctx* ctx, const nx_pcs_config* cfg, uint32_t max_log_size, nx_prover** out);
 void nx_prover_destroy(nx_prover* prover);

@@ -23,6 +23,23 @@ HASH_BLAKE2S, HASH_BLAKE2S_RAW0 = 0, 1
 FRI_ALPHA_PREV, FRI_ALPHA_FIRST = 0, 1
 
 
+class LocalGroup:
+    """nx_comm_group: the shared board of the in-process transport (one per proof; HipBackend.local_comm(group, rank) per thread)."""
+
+    def __init__(self, world):
+        self.world = int(world)
+        self.h = C.c_void_p()
+        L = load_library()
+        rc = L.nx_comm_group_create(self.world, C.byref(self.h))
+        if rc != 0:
+            raise NexusHipError(f"nx_comm_group_create failed ({rc}): {L.nx_last_error(None).decode()}")
+
+    def close(self):
+        if self.h:
+            load_library().nx_comm_group_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class NexusHipError(RuntimeError):
     pass
 
@@ -337,7 +354,10 @@ def load_library():
     L.nx_free_host.argtypes = [C.c_void_p]
     L.nx_air_kernel_destroy.argtypes = [C.c_void_p]
     L.nx_prover_destroy.argtypes = [C.c_void_p]
-    for name in ("nx_ctx_destroy", "nx_twiddles_destroy", "nx_tree_destroy", "nx_free_host", "nx_air_kernel_destroy", "nx_prover_destroy"):
+    L.nx_comm_group_destroy.argtypes = [C.c_void_p]
+    L.nx_comm_local_destroy.argtypes = [C.c_void_p]
+    for name in ("nx_ctx_destroy", "nx_twiddles_destroy", "nx_tree_destroy", "nx_free_host", "nx_air_kernel_destroy", "nx_prover_destroy", "nx_comm_group_destroy",
+                 "nx_comm_local_destroy", "nx_comm_rccl_destroy"):
         getattr(L, name).restype = None
     _lib = L
     return L
@@ -501,8 +521,20 @@ class HipBackend:
     def free_rccl_comm(self, comm):
         self.L.nx_comm_rccl_destroy(comm._native)
 
+    def local_comm(self, group, rank):
+        """The in-process transport (csrc/comm_local.hip) as an NxComm: `group` = LocalGroup(world) shared by the threads of one proof,
+        one thread per rank with a HipBackend of its own.  No Python in the data path.  Free with free_local_comm."""
+        p = C.c_void_p()
+        self._chk(self.L.nx_comm_local_create(group.h, self.ctx, int(rank), C.byref(p)))
+        comm = NxComm.from_address(p.value)
+        comm._native, comm._group = p, group
+        return comm
+
+    def free_local_comm(self, comm):
+        self.L.nx_comm_local_destroy(comm._native)
+
     def set_option(self, name, value):
-        """Per-context policy / tuning (nx_ctx_set_option): "fft.pipe", "fft.pipe_grid", "fft.batch_cols", "fft.streams",
+        """Per-context policy / tuning (nx_ctx_set_option): "fft.batch_cols", "fft.streams",
         "fri.dist_min_log", "dist.chunks", "air.segment", ...  The NX_* environment variables only seed a new context's defaults."""
         self._chk(self.L.nx_ctx_set_option(self.ctx, name.encode(), C.c_int64(int(value))))
 

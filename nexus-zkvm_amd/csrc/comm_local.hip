@@ -1,0 +1,204 @@
+// The in-process transport of a row-sharded prove: ONE process, one thread per GPU (or several contexts on one GPU), no RCCL.
+// Every collective of nx_comm is a rendezvous of the W threads on a shared board (mutex + condition variable) plus device-to-device
+// copies that each rank PULLS from its peers' buffers on a stream of its own — hipMemcpyAsync between two devices of one process goes
+// over xGMI peer to peer once peer access is enabled, which nx_comm_local_create does for the devices of the group.  This is the
+// transport a single-process prover farm uses on one node, and what the GPU test-suite runs the 2 / 4 / 8-rank proofs on (the Python
+// ThreadGroup of sharded.py is the same protocol with the interpreter's lock in every collective: tools/thread_ranks_bench.py measures
+// both).  A rank that fails calls abort(): the board is marked broken and every waiting or later rendezvous returns an error; waits are
+// also bounded by the context option "comm.timeout_ms".
+#include "internal.h"
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string.h>
+
+struct nx_comm_group {
+    int world = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    struct Slot { const void* p = nullptr; const size_t* off = nullptr; const size_t* cnt = nullptr; size_t n = 0; };
+    std::vector<Slot> slot;
+    std::vector<int> device;          // device of every rank's context (peer access is enabled pairwise at create)
+    std::vector<std::pair<const uint32_t*, size_t>> mail;      // point-to-point board, index src * world + dst
+};
+
+namespace nx {
+namespace {
+
+struct LocalComm {
+    nx_comm iface;            // FIRST member: nx_comm* <-> LocalComm*
+    nx_ctx* ctx = nullptr;
+    nx_comm_group* g = nullptr;
+    hipStream_t stream = nullptr;
+    int rank = 0;
+};
+
+// all ranks arrive, all leave; 0 ok, 1 when the group is broken or the wait timed out (the group is broken then)
+static int rendezvous(LocalComm* c) {
+    nx_comm_group* g = c->g;
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->broken) return 1;
+    const uint64_t gen = g->generation;
+    if (++g->arrived == g->world) { g->arrived = 0; g->generation++; g->cv.notify_all(); return 0; }
+    const int limit_ms = c->ctx->opt.comm_timeout_ms;
+    auto done = [&] { return g->generation != gen || g->broken; };
+    if (limit_ms > 0) {
+        if (!g->cv.wait_for(lk, std::chrono::milliseconds(limit_ms), done)) { g->broken = true; g->cv.notify_all(); }
+    } else g->cv.wait(lk, done);
+    return g->generation != gen && !g->broken ? 0 : 1;
+}
+static int fail(LocalComm* c, const char* what) { (void)set_err(c->ctx, NX_ERR_HIP, std::string("local transport: ") + what); return 1; }
+#define L_MEET(c) do { if (rendezvous(c)) return fail(c, "a peer failed or did not arrive in time (group broken)"); } while (0)
+#define L_HIP(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(c, hipGetErrorString(e__)); } while (0)
+
+static int cb_allgather(void* user, const void* h_send, size_t bytes, void* h_recv) {
+    LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
+    g->slot[c->rank].p = h_send;
+    L_MEET(c);
+    for (int r = 0; r < g->world; r++) memcpy((uint8_t*)h_recv + (size_t)r * bytes, g->slot[r].p, bytes);
+    L_MEET(c);                                   // nobody reuses its send buffer before everyone has read it
+    return 0;
+}
+static int cb_broadcast(void* user, void* h_buf, size_t bytes, int32_t root) {
+    LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
+    if (c->rank == root) g->slot[root].p = h_buf;
+    L_MEET(c);
+    if (c->rank != root) memcpy(h_buf, g->slot[root].p, bytes);
+    L_MEET(c);
+    return 0;
+}
+static int cb_allgather_dev(void* user, const uint32_t* d_send, size_t n_words, uint32_t* d_recv) {
+    LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
+    DeviceGuard dg(c->ctx);
+    g->slot[c->rank].p = d_send;
+    L_MEET(c);
+    for (int k = 0; k < g->world && n_words; k++) {
+        const int r = (c->rank + k) % g->world;          // every rank starts with a different peer: the pulls spread over the links
+        L_HIP(c, hipMemcpyAsync(d_recv + (size_t)r * n_words, g->slot[r].p, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    L_HIP(c, hipStreamSynchronize(c->stream));
+    L_MEET(c);
+    return 0;
+}
+static int cb_alltoallv(void* user, const uint32_t* d_send, const size_t* soff, const size_t* scnt, uint32_t* d_recv, const size_t* roff, const size_t* rcnt) {
+    LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
+    DeviceGuard dg(c->ctx);
+    nx_comm_group::Slot& mine = g->slot[c->rank];
+    mine.p = d_send; mine.off = soff; mine.cnt = scnt;
+    L_MEET(c);
+    for (int k = 0; k < g->world; k++) {
+        const int r = (c->rank + k) % g->world;
+        const nx_comm_group::Slot& s = g->slot[r];
+        if (s.cnt[c->rank] != rcnt[r]) return fail(c, "all-to-all: a peer sends a different count than this rank expects");
+        if (rcnt[r]) L_HIP(c, hipMemcpyAsync(d_recv + roff[r], (const uint32_t*)s.p + s.off[c->rank], rcnt[r] * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    L_HIP(c, hipStreamSynchronize(c->stream));
+    L_MEET(c);
+    return 0;
+}
+// point to point (the ring commit protocol): the receiver pulls
+static int cb_send(void* user, int32_t dst, const uint32_t* d_buf, size_t n_words) {
+    LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
+    if (nx_sync(c->ctx) != NX_OK) return 1;
+    std::unique_lock<std::mutex> lk(g->mu);
+    auto& m = g->mail[(size_t)c->rank * g->world + dst];
+    m = {d_buf, n_words};
+    g->cv.notify_all();
+    g->cv.wait(lk, [&] { return m.first == nullptr || g->broken; });       // the receiver copied it
+    return g->broken ? fail(c, "group broken") : 0;
+}
+static int cb_recv(void* user, int32_t src, uint32_t* d_buf, size_t n_words) {
+    LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
+    DeviceGuard dg(c->ctx);
+    const uint32_t* from = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        auto& m = g->mail[(size_t)src * g->world + c->rank];
+        g->cv.wait(lk, [&] { return m.first != nullptr || g->broken; });
+        if (g->broken) return fail(c, "group broken");
+        if (m.second != n_words) return fail(c, "recv: the sender announced a different length");
+        from = m.first;
+    }
+    L_HIP(c, hipMemcpyAsync(d_buf, from, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
+    L_HIP(c, hipStreamSynchronize(c->stream));
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->mail[(size_t)src * g->world + c->rank] = {nullptr, 0};
+    g->cv.notify_all();
+    return 0;
+}
+// sum mod p over the ranks: everyone snapshots its buffer, then adds the peers' snapshots
+static int cb_allreduce_m31(void* user, uint32_t* d_buf, size_t n_words) {
+    LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
+    DeviceGuard dg(c->ctx);
+    uint32_t* snap = nullptr;
+    if (nx_alloc(c->ctx, std::max<size_t>(n_words, 1), &snap) != NX_OK) return 1;
+    int rc = nx_copy(c->ctx, snap, d_buf, n_words);
+    if (rc == NX_OK) rc = nx_sync(c->ctx);
+    g->slot[c->rank].p = snap;
+    if (rendezvous(c)) rc = NX_ERR_HIP;
+    for (int r = 0; r < g->world && rc == NX_OK; r++) if (r != c->rank) rc = nx_m31_add_into(c->ctx, d_buf, (const uint32_t*)g->slot[r].p, n_words);
+    if (rc == NX_OK) rc = nx_sync(c->ctx);
+    if (rendezvous(c) && rc == NX_OK) rc = NX_ERR_HIP;
+    (void)nx_free(c->ctx, snap);
+    return rc == NX_OK ? 0 : 1;
+}
+static void cb_abort(void* user) {
+    LocalComm* c = (LocalComm*)user;
+    std::lock_guard<std::mutex> lk(c->g->mu);
+    c->g->broken = true;
+    c->g->cv.notify_all();
+}
+
+}  // namespace
+}  // namespace nx
+
+using namespace nx;
+
+extern "C" {
+
+int nx_comm_group_create(int32_t world, nx_comm_group** out) {
+    if (!out || world < 1 || world > 64) return set_err(nullptr, NX_ERR_ARG, "nx_comm_group_create: 1 <= world <= 64 required");
+    nx_comm_group* g = new nx_comm_group();
+    g->world = world; g->slot.resize(world); g->device.assign(world, -1); g->mail.assign((size_t)world * world, {nullptr, 0});
+    *out = g;
+    return NX_OK;
+}
+void nx_comm_group_destroy(nx_comm_group* g) { delete g; }
+
+int nx_comm_local_create(nx_comm_group* g, nx_ctx* ctx, int32_t rank, nx_comm** out) {
+    NX_GUARD(ctx);
+    if (!g || !ctx || !out || rank < 0 || rank >= g->world) return set_err(ctx, NX_ERR_ARG, "nx_comm_local_create: bad argument");
+    LocalComm* c = new LocalComm();
+    c->ctx = ctx; c->g = g; c->rank = rank;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_err(ctx, NX_ERR_HIP, "nx_comm_local_create: hipStreamCreate failed"); }
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->device[rank] = ctx->device;
+    }
+    {   // pulls read the peers' memory directly: peer access from this context's device to every other GPU of the node (xGMI); a
+        // device that is already enabled, or not reachable, is not an error here — a copy that cannot go peer to peer is staged by the runtime
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); n_dev = 0; }
+        for (int d = 0; d < n_dev; d++) if (d != ctx->device && hipDeviceEnablePeerAccess(d, 0) != hipSuccess) (void)hipGetLastError();
+    }
+    memset(&c->iface, 0, sizeof c->iface);
+    c->iface.rank = rank; c->iface.world = g->world; c->iface.user = c;
+    c->iface.send = cb_send; c->iface.recv = cb_recv; c->iface.allreduce_m31 = cb_allreduce_m31;
+    c->iface.allgather = cb_allgather; c->iface.broadcast = cb_broadcast;
+    c->iface.alltoallv = cb_alltoallv; c->iface.allgather_dev = cb_allgather_dev; c->iface.abort = cb_abort;
+    *out = &c->iface;
+    return NX_OK;
+}
+void nx_comm_local_destroy(nx_comm* comm) {
+    if (!comm) return;
+    LocalComm* c = (LocalComm*)comm->user;
+    DeviceGuard g(c->ctx);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+}  // extern "C"

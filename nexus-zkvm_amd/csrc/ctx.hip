@@ -236,10 +236,6 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 static nx_options options_from_env() {
     nx_options o;
-    o.fft_pipe = env_int("NX_FFT_PIPE", 0) != 0;   // opt-in: measured 7-9 % slower than fft13.hip at 2^22 rows (profiles/r03_fft_pipe_*)
-    o.fft_tile = env_int("NX_FFT_TILE", 0) != 0;
-    o.fft_pipe_blocks_per_cu = clampi(env_int("NX_FFT_PGRID", 2), 1, 2);
-    o.fft_pipe_grid = 0;
     o.fft_batch_cols = std::max(1, env_int("NX_FFT_BATCH", 2));
     o.fft_streams = clampi(env_int("NX_FFT_STREAMS", 2), 1, 4);
     o.fri_dist_min_log = std::max(0, env_int("NX_FRI_DIST_MIN_LOG", 21));
@@ -254,10 +250,6 @@ static nx_options options_from_env() {
 }
 struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
 static const OptEntry k_options[] = {
-    {"fft.pipe", &nx_options::fft_pipe, 0, 1},
-    {"fft.tile", &nx_options::fft_tile, 0, 1},
-    {"fft.pipe_blocks_per_cu", &nx_options::fft_pipe_blocks_per_cu, 1, 2},
-    {"fft.pipe_grid", &nx_options::fft_pipe_grid, 0, 1 << 20},
     {"fft.batch_cols", &nx_options::fft_batch_cols, 1, 256},
     {"fft.streams", &nx_options::fft_streams, 1, 4},
     {"fri.dist_min_log", &nx_options::fri_dist_min_log, 0, 31},

@@ -435,14 +435,6 @@ int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, ui
     for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += bc, bi++) {
         u32 nb = std::min<u32>(bc, n_cols - c0);
         streams_pick(ctx, (int)bi, ns);
-        if (log_expand == 1 && !g_tune.legacy && ctx->opt.fft_tile && fft_pipe_supports((int)log_size)) {
-            rc = fft_tile_lde(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, sub_colset(out, c0));   // conflict-free rounds, one item per block (fft_pipe.hip)
-            continue;
-        }
-        if (log_expand == 1 && !g_tune.legacy && ctx->opt.fft_pipe && fft_pipe_supports((int)log_size)) {
-            rc = fft_pipe_lde(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, sub_colset(out, c0));   // persistent, LDS-DMA pipelined (fft_pipe.hip)
-            continue;
-        }
         if (log_expand == 1 && log_size >= 14 && !g_tune.legacy && fft13_lde_fused_enabled()) {
             rc = fft13_lde(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, sub_colset(out, c0));   // middle passes fused (fft13.hip)
             continue;

@@ -59,14 +59,6 @@ __device__ __forceinline__ uint2 gload2(const u32* p) { const v2u32 v = *(NX_GLO
 __device__ __forceinline__ u32 gload1(const u32* p) { return *(NX_GLOBAL const u32*)p; }
 __device__ __forceinline__ void gstore4(u32* p, uint4 v) { v4u32 w = {v.x, v.y, v.z, v.w}; *(NX_GLOBAL v4u32*)p = w; }
 
-#ifdef NX_FFT_TRACE   // tools/fft_trace.py: per-block phase times (100 MHz wall clock), summed per kernel kind; never in the product build
-__device__ unsigned long long g_trace13[4][8];
-#define TRACE_MARK(slot) do { if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); atomicAdd(&g_trace13[(INV ? 2 : 0) + (FIRST ? 1 : 0)][slot], t_ - t_prev_); t_prev_ = t_; } } while (0)
-#define TRACE_BEGIN() unsigned long long t_prev_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_trace13[(INV ? 2 : 0) + (FIRST ? 1 : 0)][7], 1ull)
-#else
-#define TRACE_MARK(slot) do {} while (0)
-#define TRACE_BEGIN() do {} while (0)
-#endif
 
 __device__ __forceinline__ u32 pad13(u32 t) { return t + (t >> 4); }
 
@@ -224,7 +216,6 @@ __global__ __launch_bounds__(T13_ROWS >> RB, CB == 1 ? NX_FFT_MINWAVES1 : NX_FFT
     constexpr int MAXR = (T13_S - 1 + RB - 1) / RB;       // full rounds in a 13-layer pass
     extern __shared__ __attribute__((aligned(16))) u32 lds13[];
     Row<CB>* lds = reinterpret_cast<Row<CB>*>(lds13);
-    TRACE_BEGIN();
 
     const int K = FIRST ? T13_S : (KT ? KT : a.K), B = FIRST ? 0 : (KT ? T13_S - KT : a.B), lo = FIRST ? 0 : a.lo;
     const int lb = lo - B;
@@ -324,7 +315,6 @@ __global__ __launch_bounds__(T13_ROWS >> RB, CB == 1 ? NX_FFT_MINWAVES1 : NX_FFT
             }
         }
         __syncthreads();
-        TRACE_MARK(0);
 
         // step j of the round sequence uses twiddle registers (j even ? twA : twB) and requests step j+1's into the other set
         if (INV) {
@@ -356,7 +346,6 @@ __global__ __launch_bounds__(T13_ROWS >> RB, CB == 1 ? NX_FFT_MINWAVES1 : NX_FFT
             if (rem) rem_round13<RB, CB, NT, false>(lds, a, rem, B, tile_base);
         }
 
-        TRACE_MARK(1);
         if (INV) {
             // top layer fused into the store; the 1/N scale rides on it (one multiply per output instead of two)
             const u32 sc2 = a.scale << 1, tes2 = (a.scale ? m_mul(te, a.scale) : te) << 1;
@@ -395,12 +384,7 @@ __global__ __launch_bounds__(T13_ROWS >> RB, CB == 1 ? NX_FFT_MINWAVES1 : NX_FFT
                     if (live[k]) gstore4(d[k] + g, make_uint4(x0.c[k], x1.c[k], x2.c[k], x3.c[k]));
             }
         }
-        TRACE_MARK(2);
     }
-#ifdef NX_FFT_TRACE
-    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): until this wave's stores are acknowledged
-    TRACE_MARK(3);
-#endif
 }
 
 // ---- the fused middle of an LDE with blow-up 2 ---------------------------------------------------------------------------------
@@ -637,14 +621,6 @@ int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n_cols,
     }
     return NX_OK;
 }
-
-#ifdef NX_FFT_TRACE
-extern "C" int nx_fft13_trace_read(unsigned long long* out32, int reset) {
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_trace13), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace13), z, sizeof z) != hipSuccess) return 1; }
-    return 0;
-}
-#endif
 
 template <int RB, int KT>
 static int launch_mid_t(nx_ctx* ctx, const PassMid& m) {

@@ -12,10 +12,6 @@
 // Per-context tuning / sharding policy (nx_ctx_set_option).  The environment variables of DESIGN.md §6.1 are only the DEFAULTS a new
 // context starts from: two contexts of one process can run different settings.
 struct nx_options {
-    int fft_pipe;                 // "fft.pipe": 1 = pipelined LDE kernels (fft_pipe.hip) where they apply, 0 = fft13.hip
-    int fft_tile;                 // "fft.tile": 1 = the tile kernels of fft_pipe.hip (conflict-free rounds, one item per block); wins over fft.pipe
-    int fft_pipe_blocks_per_cu;   // "fft.pipe_blocks_per_cu": persistent blocks per CU and launch (1 or 2); "fft.pipe_grid" caps the grid outright
-    int fft_pipe_grid;            // 0 = blocks_per_cu * CUs; else the number of persistent blocks (rounded down to a multiple of 8)
     int fft_batch_cols;           // "fft.batch_cols": 2^22-row columns per launch (scaled up for smaller columns)
     int fft_streams;              // "fft.streams": concurrent streams of the column batches (1..4)
     int fri_dist_min_log;         // "fri.dist_min_log": row-sharded prove, FRI layers below this many rows run replicated
@@ -243,11 +239,5 @@ int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_
 int fft13_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n, ColSet out);   // blow-up 2, n >= 14: middle passes fused
 bool fft13_lde_fused_enabled();
 
-// pipelined schedule (fft_pipe.hip): persistent blocks, LDS-DMA double buffering; LDE of 2^17 .. 2^22 rows with blow-up 2
-bool fft_pipe_supports(int n);
-int fft_pipe_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n, ColSet out);
-int fft_tile_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n, ColSet out);   // the same rounds, one item per block ("fft.tile")
-int fft_pipe_ifirst(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n);    // layers [0, 13) of the iFFT, in place
-int fft_pipe_ffirst(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n);    // layers [13, 0) of the FFT, in place
 
 }  // namespace nx

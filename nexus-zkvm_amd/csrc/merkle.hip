@@ -62,11 +62,6 @@ __device__ __forceinline__ void b2s_compress(u32 h[8], const u32 m[16], u32 t0, 
 // 16 consecutive columns of one 64-byte message block at row i: the column addresses first (one uniform branch, wide scalar loads of
 // the pointer table), then 16 global loads issued back to back; columns past n_cols read as zero (the padded last block)
 __device__ __forceinline__ void load_block16(const ColSet& cols, u32 n_cols, u32 c0, u64 i, u32* dst) {
-#ifdef NX_MERKLE_ABL_NOLOAD   // ablation build (tools/ab/merkle_noload.sh): the message words without memory traffic — wrong hashes, timing only
-#pragma unroll
-    for (int k = 0; k < 16; k++) dst[k] = c0 + k + (u32)i;
-    return;
-#endif
     const u32* p[16];
     if (c0 + 16 <= n_cols) {
         if (cols.table) {

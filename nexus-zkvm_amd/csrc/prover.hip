@@ -950,6 +950,9 @@ void finish_stats(nx_ctx* ctx, nx_prove_stats* st, double t_start) {
 int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel, const PcsConfig& cfg, const nx_twiddles* tw, AirProver& air,
                std::vector<uint32_t>* words, nx_prove_stats* st, Lap& lap) {
     const Dist& D = cs.dist;
+    // T trace trees are committed (the reference: 3 — preprocessed, main, interaction, machine.rs:208-263; Stwo takes any TreeVec and so
+    // does this prover: the count is whatever the session committed); the composition polynomial's tree is number T
+    const int T = (int)cs.trees.size();
     // ---------------- stwo::prover::prove ----------------
     QM31 random_coeff = channel.draw_secure_felt();
     DevBuf comp_polys; uint32_t clog = 0;
@@ -961,21 +964,21 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
 
     MaskPoints points;                                                    // tree -> column -> points
     air.mask_points(oods, &points);
-    points.resize(4);
-    points[3].assign(4, std::vector<QPt>{oods});
+    points.resize(T + 1);
+    points[T].assign(4, std::vector<QPt>{oods});
 
     // ---------------- prove_values ----------------
     Proof proof;
-    proof.sampled_values.resize(4);
+    proof.sampled_values.resize(T + 1);
     {   // every tree and size is enqueued first; ONE synchronisation collects all the sampled values (K7).  Row-sharded: each GPU
         // samples the polynomials it holds; the values (KBs) are all-gathered.
         struct Pending { std::vector<uint32_t> out; std::vector<std::pair<uint32_t, uint32_t>> where; int t; };
         std::vector<Pending> pend;
         std::vector<EvalJob> jobs;
         size_t n_req = 0;
-        for (int t = 0; t < 4; t++) { std::set<uint32_t> logs; for (auto& c : cs.trees[t].polys) logs.insert(c.log); n_req += logs.size(); }
+        for (int t = 0; t <= T; t++) { std::set<uint32_t> logs; for (auto& c : cs.trees[t].polys) logs.insert(c.log); n_req += logs.size(); }
         pend.reserve(n_req);                                       // `out` buffers must not move while jobs point into them
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t <= T; t++) {
             auto& tr = cs.trees[t];
             proof.sampled_values[t].resize(tr.polys.size());
             for (uint32_t c = 0; c < tr.polys.size(); c++) proof.sampled_values[t][c].assign(points[t][c].size(), q_zero());
@@ -1003,11 +1006,11 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
             for (size_t i = 0; i < pd.where.size(); i++) proof.sampled_values[pd.t][pd.where[i].first][pd.where[i].second] = q_load(&pd.out[4 * i]);
         if (D.on()) {
             std::vector<uint32_t> mine;
-            for (int t = 0; t < 4; t++) for (auto& col : proof.sampled_values[t]) for (auto& v : col) { uint32_t w[4]; q_store(w, v); mine.insert(mine.end(), w, w + 4); }
+            for (int t = 0; t <= T; t++) for (auto& col : proof.sampled_values[t]) for (auto& v : col) { uint32_t w[4]; q_store(w, v); mine.insert(mine.end(), w, w + 4); }
             std::vector<uint32_t> everyone(mine.size() * (size_t)D.world);
             H_TRY(D.allgather_host(ctx, mine.data(), mine.size() * 4, everyone.data()));
             size_t slot = 0;
-            for (int t = 0; t < 4; t++) for (uint32_t c = 0; c < proof.sampled_values[t].size(); c++) {
+            for (int t = 0; t <= T; t++) for (uint32_t c = 0; c < proof.sampled_values[t].size(); c++) {
                 const int r = cs.trees[t].owner[c];
                 for (auto& v : proof.sampled_values[t][c]) { if (r >= 0) v = q_load(&everyone[(size_t)r * mine.size() + 4 * slot]); slot++; }
             }
@@ -1020,7 +1023,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         // under every evaluation strategy: with "air.half_domain" / "air.quarter_domain" the composition is low-degree by construction
         // even for an invalid trace (Q0 + t Z is what the interpolation returns), so this equality — not the FRI degree check — is
         // what catches it.
-        QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
+        QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[T][k][0];
         QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
         if (!q_eq(lhs, air.eval_composition_at_point(oods, proof.sampled_values, random_coeff)))
             return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
@@ -1030,7 +1033,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     // compute_fri_quotients: all columns flattened, stable-sorted by LDE size (descending), grouped by size
     struct Flat { const uint32_t* ptr; uint32_t log; int t; uint32_t c; };
     std::vector<Flat> all;
-    for (int t = 0; t < 4; t++) for (uint32_t c = 0; c < cs.trees[t].evals.size(); c++) all.push_back({cs.trees[t].evals[c].ptr, cs.trees[t].evals[c].log, t, c});
+    for (int t = 0; t <= T; t++) for (uint32_t c = 0; c < cs.trees[t].evals.size(); c++) all.push_back({cs.trees[t].evals[c].ptr, cs.trees[t].evals[c].log, t, c});
     std::stable_sort(all.begin(), all.end(), [](const Flat& a, const Flat& b) { return a.log > b.log; });
     std::vector<SecureColumn> quotients;
     for (size_t i = 0; i < all.size();) {
@@ -1089,12 +1092,12 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     fri.draw_queries(channel, &qpos);
     GatherBatch gb; gb.dist = &D;
     fri.decommit_plan(&gb);
-    DecommitPlan tree_plans[4];
-    for (int t = 0; t < 4; t++) tree_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, cs.trees[t].evals, &gb);
+    std::vector<DecommitPlan> tree_plans(T + 1);
+    for (int t = 0; t <= T; t++) tree_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, cs.trees[t].evals, &gb);
     H_TRY(gb.run(ctx));
     fri.decommit_fill(gb, &proof);
-    proof.decommitments.resize(4); proof.queried_values.resize(4);
-    for (int t = 0; t < 4; t++) {
+    proof.decommitments.resize(T + 1); proof.queried_values.resize(T + 1);
+    for (int t = 0; t <= T; t++) {
         merkle_decommit_fill(tree_plans[t], gb, &proof.queried_values[t], &proof.decommitments[t]);
         proof.commitments.push_back(cs.trees[t].root);
     }
@@ -1110,16 +1113,17 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
 
 // the consistency rules of oracle-side gair_check: every committed column claimed, sizes agree, loads inside the masks
 int GenericAir::check(const CommitmentSchemeProver& cs) {
-    if (cs.trees.size() != 3) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: exactly three trace trees (preprocessed, main, interaction) must be committed first");
+    if (cs.trees.empty()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: at least one trace tree must be committed first");
+    const int NT = (int)cs.trees.size();                 // the reference commits 3 (preprocessed, main, interaction); the count is the session's
     if (comps.empty()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: no components");
-    tree_logs.assign(3, {}); offs.assign(3, {});
-    std::vector<std::vector<char>> claimed(3);
-    for (int t = 0; t < 3; t++) { for (auto& c : cs.trees[t].polys) tree_logs[t].push_back(c.log); claimed[t].assign(tree_logs[t].size(), 0); offs[t].resize(tree_logs[t].size()); }
+    tree_logs.assign(NT, {}); offs.assign(NT, {});
+    std::vector<std::vector<char>> claimed(NT);
+    for (int t = 0; t < NT; t++) { for (auto& c : cs.trees[t].polys) tree_logs[t].push_back(c.log); claimed[t].assign(tree_logs[t].size(), 0); offs[t].resize(tree_logs[t].size()); }
     for (auto& c : comps) {
         if (c.masks.size() != c.cols.size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: one mask list per component column required");
         for (size_t k = 0; k < c.cols.size(); k++) {
             const uint32_t t = c.cols[k].first, i = c.cols[k].second;
-            if (t > 2 || i >= tree_logs[t].size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column outside the committed trees");
+            if (t >= (uint32_t)NT || i >= tree_logs[t].size()) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column outside the committed trees");
             if (tree_logs[t][i] != c.log_size) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: component column of a different log size than the component");
             claimed[t][i] = 1;
             for (int o : c.masks[k]) if (std::find(offs[t][i].begin(), offs[t][i].end(), o) == offs[t][i].end()) offs[t][i].push_back(o);
@@ -1146,7 +1150,7 @@ int GenericAir::check(const CommitmentSchemeProver& cs) {
         }
         if (n_c != c.n_constraints) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: constraint count mismatch");
     }
-    for (int t = 0; t < 3; t++) for (char x : claimed[t]) if (!x) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: a committed column is claimed by no component");
+    for (int t = 0; t < NT; t++) for (char x : claimed[t]) if (!x) return set_err(ctx, NX_ERR_ARG, "nx_prover_prove: a committed column is claimed by no component");
     return NX_OK;
 }
 
@@ -1486,8 +1490,8 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
 }
 
 void GenericAir::mask_points(QPt oods, MaskPoints* points) {
-    points->assign(3, {});
-    for (int t = 0; t < 3; t++)
+    points->assign(offs.size(), {});
+    for (size_t t = 0; t < offs.size(); t++)
         for (size_t c = 0; c < offs[t].size(); c++) {
             std::vector<QPt> pts;
             for (int o : offs[t][c]) {
@@ -1695,7 +1699,8 @@ int nx_prover_tree_begin(nx_prover* p, const uint32_t* log_sizes, uint32_t n_col
     NX_GUARD(p ? p->ctx : nullptr);
     if (!p || (n_cols && (!log_sizes || !d_cols_out))) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_tree_begin: NULL argument");
     if (p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: the previous tree was not committed");
-    if (p->cs->trees.size() >= 3) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: the three trace trees are already committed");
+    if (p->proved) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: the session has proved; its trace trees are fixed");
+    if (p->cs->trees.size() >= 16) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: at most 16 trace trees");
     for (uint32_t i = 0; i < n_cols; i++) if (log_sizes[i] < 1 || log_sizes[i] > p->max_log) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_begin: column log size outside [1, max_log_size]");
     p->pending.clear();
     const nxhip::Dist& D = p->cs->dist;

@@ -55,18 +55,19 @@ static inline bool gair_decode(const u32* w, size_t n, GAir& air) {
     return i == n;
 }
 
-// "" when the components are consistent with trees of the given column log sizes (3 trace trees).
+// "" when the components are consistent with trees of the given column log sizes (any number of trace trees >= 1; the reference has 3).
 static inline std::string gair_check(const GAir& air, const std::vector<std::vector<int>>& tree_logs) {
-    if (tree_logs.size() < 3) return "three trace trees (preprocessed, main, interaction) must be committed";
+    if (tree_logs.empty()) return "at least one trace tree must be committed";
+    const int NT = (int)tree_logs.size();
     if (air.comps.empty()) return "no components";
-    std::vector<std::vector<char>> claimed(3);
-    for (int t = 0; t < 3; t++) claimed[t].assign(tree_logs[t].size(), 0);
+    std::vector<std::vector<char>> claimed(NT);
+    for (int t = 0; t < NT; t++) claimed[t].assign(tree_logs[t].size(), 0);
     for (auto& c : air.comps) {
         if (c.cols.size() != c.masks.size()) return "cols / masks length mismatch";
         if (c.log_cd < 0 || c.log_cd > 2) return "component log constraint-degree bound outside {0 (default), 1, 2}";
         for (size_t k = 0; k < c.cols.size(); k++) {
             int t = c.cols[k].first, i = c.cols[k].second;
-            if (t < 0 || t > 2 || i < 0 || (size_t)i >= tree_logs[t].size()) return "component column outside the committed trees";
+            if (t < 0 || t >= NT || i < 0 || (size_t)i >= tree_logs[t].size()) return "component column outside the committed trees";
             if (tree_logs[t][i] != c.log_size) return "component column of a different log size than the component";
             claimed[t][i] = 1;
         }
@@ -84,7 +85,7 @@ static inline std::string gair_check(const GAir& air, const std::vector<std::vec
         }
         if (n_c != c.n_constraints) return "constraint count mismatch";
     }
-    for (int t = 0; t < 3; t++) for (char x : claimed[t]) if (!x) return "a committed column is claimed by no component";
+    for (int t = 0; t < NT; t++) for (char x : claimed[t]) if (!x) return "a committed column is claimed by no component";
     return "";
 }
 
@@ -96,8 +97,8 @@ static inline QPt g_offset_point(QPt oods, int log_size, int offset) {
 
 // per tree, per column: the union (first-appearance order) of the offsets the components sample it at
 static inline std::vector<std::vector<std::vector<int>>> g_mask_offsets(const GAir& air, const std::vector<size_t>& n_cols) {
-    std::vector<std::vector<std::vector<int>>> r(3);
-    for (int t = 0; t < 3; t++) r[t].resize(n_cols[t]);
+    std::vector<std::vector<std::vector<int>>> r(n_cols.size());
+    for (size_t t = 0; t < n_cols.size(); t++) r[t].resize(n_cols[t]);
     for (auto& c : air.comps)
         for (size_t k = 0; k < c.cols.size(); k++) {
             auto& dst = r[c.cols[k].first][c.cols[k].second];
@@ -110,12 +111,12 @@ static inline AirHooks g_hooks(const GAir& air, const PcsConfig& cfg, const std:
     AirHooks h;
     h.composition_log = 0;
     for (auto& c : air.comps) h.composition_log = std::max(h.composition_log, c.log_size + (c.log_cd > 0 ? c.log_cd : cfg.log_constraint_degree));
-    std::vector<size_t> n_cols = {tree_logs[0].size(), tree_logs[1].size(), tree_logs[2].size()};
+    std::vector<size_t> n_cols; for (auto& t : tree_logs) n_cols.push_back(t.size());
     auto offs = std::make_shared<std::vector<std::vector<std::vector<int>>>>(g_mask_offsets(air, n_cols));
     auto logs = std::make_shared<std::vector<std::vector<int>>>(tree_logs);
     h.mask_points = [offs, logs](QPt oods) {
-        MaskPoints r(3);
-        for (int t = 0; t < 3; t++)
+        MaskPoints r(offs->size());
+        for (size_t t = 0; t < offs->size(); t++)
             for (size_t c = 0; c < (*offs)[t].size(); c++) {
                 std::vector<QPt> pts; for (int o : (*offs)[t][c]) pts.push_back(g_offset_point(oods, (*logs)[t][c], o));
                 r[t].push_back(pts);
@@ -205,7 +206,7 @@ struct ProverSession {
     Proof prove(const GAir& air) {
         std::vector<std::vector<int>> tree_logs;
         for (auto& t : cs.trees) tree_logs.push_back(t.logs);
-        std::string e = cs.trees.size() == 3 ? gair_check(air, tree_logs) : "exactly three trace trees must be committed before prove";
+        std::string e = gair_check(air, tree_logs);
         if (!e.empty()) throw e;
         return prove_core(cs, ch, cfg, tw, g_hooks(air, cfg, tree_logs), cs.n_threads);
     }
@@ -216,11 +217,10 @@ struct VerifierSession {
     std::vector<std::vector<int>> tree_logs; std::vector<Hash> roots;
     void commit(const Hash& root, const std::vector<int>& logs) { ch.mix_root(root); roots.push_back(root); tree_logs.push_back(logs); }   // CommitmentSchemeVerifier::commit
     std::string verify(const GAir& air, const Proof& proof) {
-        if (tree_logs.size() != 3) return "exactly three trace trees must be committed before verify";
         std::string e = gair_check(air, tree_logs);
         if (!e.empty()) return "InvalidStructure: " + e;
-        if (proof.commitments.size() != 4) return "InvalidStructure";
-        for (int t = 0; t < 3; t++) if (memcmp(proof.commitments[t].w, roots[t].w, 32)) return "CommitmentMismatch";
+        if (proof.commitments.size() != tree_logs.size() + 1) return "InvalidStructure";
+        for (size_t t = 0; t < tree_logs.size(); t++) if (memcmp(proof.commitments[t].w, roots[t].w, 32)) return "CommitmentMismatch";
         return verify_core(ch, cfg, proof, tree_logs, g_hooks(air, cfg, tree_logs));
     }
 };

@@ -683,20 +683,22 @@ static inline Proof prove_synth(const AirSpec& air, const PcsConfig& cfg, u64 se
 }
 
 static inline Proof prove_core(CommitmentSchemeProver& cs, Channel& ch, const PcsConfig& cfg, const Twiddles& tw, const AirHooks& air, int n_threads) {
-    // ---- stwo::prover::prove ----
+    // ---- stwo::prover::prove ----  (T trace trees are committed: the reference has 3 — preprocessed, main, interaction, machine.rs:208-263 —
+    // Stwo itself takes any TreeVec; the composition polynomial's tree is number T)
+    const int T = (int)cs.trees.size();
     QM31 random_coeff = ch.draw_secure_felt();
     std::vector<std::vector<u32>> comp = air.compute_composition(tw, cs.trees, random_coeff, n_threads);
     int clog = air.composition_log;
-    cs.commit_polys(comp, std::vector<int>(4, clog), ch);                  // tree 3
+    cs.commit_polys(comp, std::vector<int>(4, clog), ch);                  // tree T
     QPt oods = get_random_point(ch);
     auto points = air.mask_points(oods);
-    points.resize(4); points[3].assign(4, std::vector<QPt>{oods});
+    points.resize(T + 1); points[T].assign(4, std::vector<QPt>{oods});
 
     // ---- prove_values ----
     Proof proof; proof.config = cfg;
-    std::vector<std::vector<std::vector<PointSample>>> samples(4);
-    proof.sampled_values.resize(4);
-    for (int t = 0; t < 4; t++) {
+    std::vector<std::vector<std::vector<PointSample>>> samples(T + 1);
+    proof.sampled_values.resize(T + 1);
+    for (int t = 0; t <= T; t++) {
         size_t nc = cs.trees[t].polys.size();
         samples[t].resize(nc); proof.sampled_values[t].resize(nc);
         parallel_for(nc, n_threads, [&](size_t c) {
@@ -711,7 +713,7 @@ static inline Proof prove_core(CommitmentSchemeProver& cs, Channel& ch, const Pc
     // compute_fri_quotients: all columns, sorted by LDE log size descending (stable), grouped
     struct CRef { const u32* data; int log; const std::vector<PointSample>* s; };
     std::vector<CRef> all;
-    for (int t = 0; t < 4; t++) for (size_t c = 0; c < cs.trees[t].evals.size(); c++)
+    for (int t = 0; t <= T; t++) for (size_t c = 0; c < cs.trees[t].evals.size(); c++)
         all.push_back({cs.trees[t].evals[c].data(), cs.trees[t].logs[c] + (int)cfg.log_blowup, &samples[t][c]});
     std::stable_sort(all.begin(), all.end(), [](const CRef& a, const CRef& b) { return a.log > b.log; });
     std::vector<SecureCols> quotients;
@@ -726,15 +728,15 @@ static inline Proof prove_core(CommitmentSchemeProver& cs, Channel& ch, const Pc
     proof.proof_of_work = ch.grind(cfg.pow_bits);
     ch.mix_u64(proof.proof_of_work);
     std::map<int, std::vector<size_t>> qpos = fri_decommit(ch, cfg, fri, proof);
-    proof.decommitments.resize(4); proof.queried_values.resize(4);
-    for (int t = 0; t < 4; t++) {
+    proof.decommitments.resize(T + 1); proof.queried_values.resize(T + 1);
+    for (int t = 0; t <= T; t++) {
         std::vector<ColRef> refs;
         for (size_t c = 0; c < cs.trees[t].evals.size(); c++) refs.push_back({cs.trees[t].evals[c].data(), cs.trees[t].logs[c] + (int)cfg.log_blowup});
         merkle_decommit(cs.trees[t].merkle, qpos, refs, proof.queried_values[t], proof.decommitments[t]);
         proof.commitments.push_back(cs.trees[t].merkle.root());
     }
     // sanity check of stwo prover/mod.rs::prove
-    QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
+    QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[T][k][0];
     if (!qm31_eq(from_partial_evals(ce), air.eval_composition_at_point(oods, proof.sampled_values, random_coeff)))
         throw std::string("ConstraintsNotSatisfied");
     return proof;
@@ -752,7 +754,7 @@ static inline std::string verify_synth(const AirSpec& air, const PcsConfig& cfg,
     for (size_t i = 0; i < ad_len; i++) ch.mix_u64(ad[i]);
     for (auto& c : air.comps) ch.mix_u64((u64)c.log_size);
     // column log sizes per tree (polynomial degree bounds)
-    std::vector<std::vector<int>> tree_logs(4);
+    std::vector<std::vector<int>> tree_logs(3);
     for (auto& c : air.comps) {
         for (int k = 0; k < c.n_pre; k++) tree_logs[0].push_back(c.log_size);
         for (int k = 0; k < c.n_main; k++) tree_logs[1].push_back(c.log_size);
@@ -769,28 +771,29 @@ static inline std::string verify_synth(const AirSpec& air, const PcsConfig& cfg,
 
 // core/verifier.rs::verify from the point where the trace trees are in the transcript.
 static inline std::string verify_core(Channel& ch, const PcsConfig& cfg, const Proof& proof, std::vector<std::vector<int>> tree_logs, const AirHooks& air) {
-    if (proof.commitments.size() != 4 || proof.sampled_values.size() != 4) return "InvalidStructure";
+    const int T = (int)tree_logs.size();                       // trace trees in the transcript so far; the composition tree is number T
+    if ((int)proof.commitments.size() != T + 1 || (int)proof.sampled_values.size() != T + 1) return "InvalidStructure";
     if (proof.config.pow_bits != cfg.pow_bits || proof.config.log_blowup != cfg.log_blowup || proof.config.n_queries != cfg.n_queries ||
         proof.config.log_last_layer_degree_bound != cfg.log_last_layer_degree_bound) return "ConfigMismatch";
-    tree_logs.resize(4);
-    tree_logs[3].assign(4, air.composition_log);
+    tree_logs.resize(T + 1);
+    tree_logs[T].assign(4, air.composition_log);
     QM31 random_coeff = ch.draw_secure_felt();
-    ch.mix_root(proof.commitments[3]);
+    ch.mix_root(proof.commitments[T]);
     QPt oods = get_random_point(ch);
     auto points = air.mask_points(oods);
-    points.resize(4); points[3].assign(4, std::vector<QPt>{oods});
-    for (int t = 0; t < 4; t++) {
+    points.resize(T + 1); points[T].assign(4, std::vector<QPt>{oods});
+    for (int t = 0; t <= T; t++) {
         if (proof.sampled_values[t].size() != points[t].size()) return "InvalidStructure";
         for (size_t c = 0; c < points[t].size(); c++) if (proof.sampled_values[t][c].size() != points[t][c].size()) return "InvalidStructure";
     }
-    QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[3][k][0];
+    QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[T][k][0];
     if (!qm31_eq(from_partial_evals(ce), air.eval_composition_at_point(oods, proof.sampled_values, random_coeff))) return "OodsNotMatching";
     // verify_values
     { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); ch.mix_felts(flat.data(), flat.size()); }
     QM31 q_coeff = ch.draw_secure_felt();
     // FRI commit phase (FriVerifier::commit): column bounds = distinct LDE log sizes, descending
     std::set<int, std::greater<int>> size_set;
-    for (int t = 0; t < 4; t++) for (int l : tree_logs[t]) size_set.insert(l + (int)cfg.log_blowup);
+    for (int t = 0; t <= T; t++) for (int l : tree_logs[t]) size_set.insert(l + (int)cfg.log_blowup);
     std::vector<int> col_logs(size_set.begin(), size_set.end());
     ch.mix_root(proof.first_layer.commitment);
     QM31 first_alpha = ch.draw_secure_felt();
@@ -816,21 +819,21 @@ static inline std::string verify_core(Channel& ch, const PcsConfig& cfg, const P
     std::vector<size_t> queries = queries_generate(ch, max_log, cfg.n_queries);
     std::map<int, std::vector<size_t>> qpos;
     for (int l : col_logs) qpos[l] = queries_fold(queries, max_log - l);
-    // Merkle decommitments of the 4 trees
-    for (int t = 0; t < 4; t++) {
+    // Merkle decommitments of the T + 1 trees
+    for (int t = 0; t <= T; t++) {
         std::vector<int> lde_logs; for (int l : tree_logs[t]) lde_logs.push_back(l + (int)cfg.log_blowup);
         std::string e = merkle_verify(proof.commitments[t], lde_logs, qpos, proof.queried_values[t], proof.decommitments[t], cfg.hash_mode);
         if (!e.empty()) return "MerkleVerification(tree " + std::to_string(t) + "): " + e;
     }
     // fri_answers: quotient values at the queried positions, per size group (descending)
     // queried_values[t] order: by layer (descending size), by query position, by column.
-    std::vector<size_t> qv_pos(4, 0);
+    std::vector<size_t> qv_pos(T + 1, 0);
     std::vector<std::vector<QM31>> answers;  // per column-size group, per query
     for (int L : col_logs) {
         // columns of this size in flattened (tree, column) order
         std::vector<std::pair<int, size_t>> members;
         std::vector<std::vector<PointSample>> ms;
-        for (int t = 0; t < 4; t++) for (size_t c = 0; c < tree_logs[t].size(); c++) if (tree_logs[t][c] + (int)cfg.log_blowup == L) {
+        for (int t = 0; t <= T; t++) for (size_t c = 0; c < tree_logs[t].size(); c++) if (tree_logs[t][c] + (int)cfg.log_blowup == L) {
             members.push_back({t, c});
             std::vector<PointSample> s; for (size_t k = 0; k < points[t][c].size(); k++) s.push_back({points[t][c][k], proof.sampled_values[t][c][k]});
             ms.push_back(s);
@@ -838,11 +841,11 @@ static inline std::string verify_core(Channel& ch, const PcsConfig& cfg, const P
         std::vector<const std::vector<PointSample>*> msp; for (auto& s : ms) msp.push_back(&s);
         auto batches = sample_batches_new(msp);
         QuotientConstants qc = quotient_constants(batches, q_coeff);
-        std::vector<size_t> n_in_tree(4, 0); for (auto& m : members) n_in_tree[m.first]++;
+        std::vector<size_t> n_in_tree(T + 1, 0); for (auto& m : members) n_in_tree[m.first]++;
         std::vector<QM31> ans;
         for (size_t q : qpos[L]) {
             std::vector<u32> row;
-            for (int t = 0; t < 4; t++) for (size_t k = 0; k < n_in_tree[t]; k++) {
+            for (int t = 0; t <= T; t++) for (size_t k = 0; k < n_in_tree[t]; k++) {
                 if (qv_pos[t] >= proof.queried_values[t].size()) return "QueriedValuesTooShort";
                 row.push_back(proof.queried_values[t][qv_pos[t]++]);
             }

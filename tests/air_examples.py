@@ -92,3 +92,21 @@ def logup_component(ap, log, z, alpha, shift, main0=0, inter0=0, high_degree=Fal
         pb.add_constraint(((s_cur - s_prev + sh) * den - 1) * a * c)
     cols = [(1, main0), (1, main0 + 1), (1, main0 + 2)] + [(2, inter0 + k) for k in range(4)]
     return ap.Component(log, pb.build(), cols)
+
+
+def tree_count_statement(ap, n_trees, log=6, seed=11):
+    """The synthetic machine's AIR over 2 or 4 trace trees instead of the reference's 3 (Stwo takes any TreeVec; the session takes the
+    count it is given): n_trees == 2: preprocessed + main only (no interaction columns); n_trees == 4: the last six main columns live
+    in a FOURTH tree committed after the interaction tree.  Returns (trees: list of column lists in commit order, component)."""
+    n_pre, n_main, n_inter = 3, 20, (0 if n_trees == 2 else 8)
+    comps = [(log, n_pre, n_main, n_inter)]
+    pre, main = O.synth_tree_columns(comps, 0, seed), O.synth_tree_columns(comps, 1, seed)
+    comp = synthetic_component(ap, log, n_pre, n_main, n_inter)
+    if n_trees == 2:
+        return [pre, main], comp
+    inter = O.synth_tree_columns(comps, 2, seed, 5)
+    if n_trees == 3:
+        return [pre, main, inter], comp
+    split = n_main - 6
+    cols = [(3, i - split) if (t == 1 and i >= split) else (t, i) for t, i in comp.cols]
+    return [pre, main[:split], inter, main[split:]], ap.Component(log, comp.program, cols, comp.masks)

@@ -165,29 +165,43 @@ def test_machine_whole_proof_byte_equal_at_2pow22_headline(be, nz, oracle):
     be.trim()
 
 
-def _run_ranks(nz, world, fn):
+def _run_ranks(nz, world, fn, transport="native"):
+    """W thread-ranks on this box's GPU, one context each.  transport "native": the library's in-process transport (csrc/comm_local.hip —
+    rendezvous + peer copies, no Python in a collective); "python": sharded.ThreadGroup behind the callback trampoline (the same
+    protocol; what rounds 1-3 ran, kept on a few cases so that the Python-callback route of nx_comm stays covered)."""
     from nexus_zkvm_amd.sharded import ThreadGroup
-    group = ThreadGroup(world)
+    group = nz.LocalGroup(world) if transport == "native" else ThreadGroup(world)
     results, errors = [None] * world, []
 
     def run(rank):
+        b = comm = None
         try:
             b = nz.HipBackend(0)
-            comm = nz.make_comm(rank, world, group.comm(rank, b))
+            comm = b.local_comm(group, rank) if transport == "native" else nz.make_comm(rank, world, group.comm(rank, b))
             results[rank] = fn(b, comm, rank)
-            b.close()
         except Exception as e:   # noqa: BLE001
             import traceback
             errors.append((rank, repr(e), traceback.format_exc()))
             try:
-                group.barrier.abort()
+                if transport == "native":
+                    if comm is not None:
+                        comm.abort(comm.user)
+                else:
+                    group.barrier.abort()
             except Exception:
                 pass
+        finally:
+            if transport == "native" and comm is not None:
+                b.free_local_comm(comm)
+            if b is not None:
+                b.close()
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
     for t in th:
         t.join(timeout=600)
+    if transport == "native":
+        group.close()
     assert not errors, errors
     return results
 
@@ -207,10 +221,11 @@ def test_machine_row_sharded_equals_single_gpu(be, nz, world, comps, kw):
     single-GPU bytes (which test_machine_prove_bit_exact_vs_oracle ties to the oracle)."""
     cfg = nz.default_config(**kw)
     ref = be.prove_machine(comps, cfg, seed=31, ad=b"m")
-    res = _run_ranks(nz, world, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=31, ad=b"m", comm=comm, want_stats=True))
-    for r in range(world):
-        _same(ref, res[r][0])
-    assert res[0][1]["comm_bytes"] > 0
+    for transport in (("native", "python") if world <= 4 and len(comps) == 1 else ("native",)):
+        res = _run_ranks(nz, world, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=31, ad=b"m", comm=comm, want_stats=True), transport=transport)
+        for r in range(world):
+            _same(ref, res[r][0])
+        assert res[0][1]["comm_bytes"] > 0
 
 
 def _run_ranks_collect(nz, world, make_impl, fn, timeout=120):
@@ -267,6 +282,44 @@ def test_a_rank_failing_mid_prove_fails_the_others_instead_of_hanging_them(be, n
     ref = be.prove_machine(comps, cfg, seed=5, ad=b"x")
     for w in _run_ranks(nz, 4, lambda b, comm, rank: b.prove_machine(comps, cfg, seed=5, ad=b"x", comm=comm)):
         _same(ref, w)
+
+
+def test_native_transport_abort_and_timeout(nz):
+    """The in-process transport's own failure handling: (1) a rank that never joins — the others leave their first collective after
+    "comm.timeout_ms" with an error instead of waiting for ever; (2) abort() called on one communicator fails the peers' pending
+    rendezvous at once."""
+    import time
+    comps = [(10, 3, 12, 4)]
+    cfg = nz.default_config(pow_bits=4)
+    group = nz.LocalGroup(2)
+    b = nz.HipBackend(0)
+    b.set_option("comm.timeout_ms", 1500)
+    comm = b.local_comm(group, 0)
+    t0 = time.perf_counter()
+    with pytest.raises(nz.NexusHipError):
+        b.prove_machine(comps, cfg, seed=1, comm=comm)              # rank 1 never shows up
+    assert 1.0 < time.perf_counter() - t0 < 30
+    b.free_local_comm(comm); b.close(); group.close()
+    group = nz.LocalGroup(2)
+    out = {}
+
+    def waiter():
+        bb = nz.HipBackend(0)
+        c = bb.local_comm(group, 0)
+        try:
+            bb.prove_machine(comps, cfg, seed=1, comm=c)
+            out["err"] = None
+        except nz.NexusHipError as e:
+            out["err"] = repr(e)
+        bb.free_local_comm(c); bb.close()
+    th = threading.Thread(target=waiter, daemon=True); th.start()
+    time.sleep(1.0)
+    b1 = nz.HipBackend(0)
+    c1 = b1.local_comm(group, 1)
+    c1.abort(c1.user)                                               # "my prove failed": the peer must not keep waiting
+    th.join(timeout=30)
+    assert not th.is_alive() and out["err"] is not None
+    b1.free_local_comm(c1); b1.close(); group.close()
 
 
 def test_ranks_with_different_plan_options_are_refused_before_the_first_exchange(nz):

@@ -166,5 +166,37 @@ def test_prover_refuses_an_invalid_trace_and_malformed_airs():
         s.prove([ap.Component(c0.log_size, c0.program, comps[0].cols, [[0]] * len(comps[0].cols))])
     s = O.ProverSession(cfg, 5)
     s.commit([np.zeros(32, np.uint32)])
-    with pytest.raises(RuntimeError, match="three trace trees"):
+    with pytest.raises(RuntimeError, match="outside the committed trees"):          # one tree committed, the components name three
         s.prove(comps)
+
+
+@pytest.mark.parametrize("n_trees", [2, 3, 4])
+def test_sessions_take_the_tree_count_they_are_given(n_trees):
+    """VERDICT r3 hygiene: the prover hard-coded "exactly three trace trees".  The reference commits three (machine.rs:208-263) but
+    Stwo's prove takes any TreeVec: the session now proves whatever was committed — here 2 trees (no interaction tree), 3, and 4 (some
+    main columns in a fourth tree) — and the verifier session accepts exactly that statement (and not a proof of another tree count)."""
+    ap = _ap()
+    cfg = O.default_cfg(pow_bits=3)
+    trees, comp = X.tree_count_statement(ap, n_trees)
+    s = O.ProverSession(cfg, comp.log_size)
+    s.mix_u64(n_trees)
+    roots = [s.commit(t) for t in trees]
+    words = s.prove([comp])
+    assert int(words[O.proof_header_words()]) == n_trees + 1
+    v = O.VerifierSession(cfg)
+    v.mix_u64(n_trees)
+    for r, t in zip(roots, trees):
+        v.commit(r, [comp.log_size] * len(t))
+    assert v.verify([comp], words) is None
+    bad = words.copy(); bad[len(bad) // 2] ^= 1
+    v2 = O.VerifierSession(cfg)
+    v2.mix_u64(n_trees)
+    for r, t in zip(roots, trees):
+        v2.commit(r, [comp.log_size] * len(t))
+    assert v2.verify([comp], bad) is not None
+    if n_trees > 2:                                    # a verifier that saw fewer trees refuses the proof's structure
+        v3 = O.VerifierSession(cfg)
+        v3.mix_u64(n_trees)
+        for r, t in list(zip(roots, trees))[:-1]:
+            v3.commit(r, [comp.log_size] * len(t))
+        assert v3.verify([comp], words) is not None

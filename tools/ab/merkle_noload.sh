@@ -1,6 +1,7 @@
 #!/bin/bash
 # Merkle commit of 347 columns x 2^23 rows: the shipped build against the ablation build whose message words come from registers
-# (libnexus_hip_abl.so: merkle.hip compiled with -DNX_MERKLE_ABL_NOLOAD; wrong hashes, timing only)
+# (libnexus_hip_abl.so: a scratch copy of csrc with tools/ab/patches/merkle_noload.patch applied, compiled with -DNX_MERKLE_ABL_NOLOAD;
+#  wrong hashes by design, timing only — the ablation is not in the product sources)
 for round in 1 2 3; do
   for lib in real noload; do
     if [ $lib = noload ]; then export NX_LIB=$PWD/nexus-zkvm_amd/libnexus_hip_abl.so; else unset NX_LIB; fi

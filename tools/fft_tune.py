@@ -1,6 +1,6 @@
 """Micro-benchmark of the fused LDE (iFFT + FFT) and Merkle commit for tuning; prints one JSON line per option set.
 usage: fft_tune.py LOG NCOLS REPS [name=value,name=value ...]   each further argument is one set of nx_ctx_set_option settings
-(e.g. fft.pipe=0  fft.pipe=1,fft.batch_cols=4,fft.streams=1); without any, the context's defaults."""
+(e.g. fft.batch_cols=4,fft.streams=1  fft.batch_cols=2,fft.streams=2); without any, the context's defaults."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +19,7 @@ import ctypes as _C
 if os.environ.get("FFT_TUNE_ZEROS") == "1":      # DVFS probe: all-zero data toggles far fewer bits (MI355X_MICROARCH.md: the chip clocks to its power budget)
     be._chk(be.L.nx_memset_zero(be.ctx, cols.ptr, _C.c_size_t(ncols << log)))
 be.sync()
-defaults = {k: be.get_option(k) for k in ("fft.pipe", "fft.tile", "fft.pipe_blocks_per_cu", "fft.pipe_grid", "fft.batch_cols", "fft.streams")}
+defaults = {k: be.get_option(k) for k in ("fft.batch_cols", "fft.streams")}
 rounds = int(os.environ.get("FFT_TUNE_ROUNDS", "1"))     # > 1: the option sets are cycled A/B/C/A/B/C ... and min / median are reported per set
 samples = {st: [] for st in sets}
 for st in (sets * rounds if rounds > 1 else []):

@@ -41,35 +41,43 @@ class Counting:
         return g
 
 
+NATIVE = os.environ.get("NX_RANKS_TRANSPORT", "native") == "native"     # "python": sharded.ThreadGroup behind the callback trampoline (rounds 1-3)
+
+
 def run_world(world):
-    group = ThreadGroup(world)
+    group = nz.LocalGroup(world) if NATIVE else ThreadGroup(world)
     times, stats, same, errors, counts = [1e9] * world, [None] * world, [False] * world, [], {}
+    start = threading.Barrier(world)
 
     def run(rank):
         try:
             b = nz.HipBackend(0)
-            cnt = Counting(group.comm(rank, b))
-            comm = nz.make_comm(rank, world, cnt)
+            if NATIVE:
+                cnt, comm = None, b.local_comm(group, rank)
+            else:
+                cnt = Counting(group.comm(rank, b))
+                comm = nz.make_comm(rank, world, cnt)
             for rep in range(REPS + 1):
-                b.sync(); group.barrier.wait(); t0 = time.perf_counter()
+                b.sync(); start.wait(); t0 = time.perf_counter()
                 w = b.prove_machine(comps, cfg, seed=77, comm=comm)
-                b.sync(); group.barrier.wait()
+                b.sync(); start.wait()
                 if rep: times[rank] = min(times[rank], time.perf_counter() - t0)
             same[rank] = bool(np.array_equal(w, ref))
-            cnt.on = True
+            if cnt: cnt.on = True
             stats[rank] = b.prove_machine(comps, cfg, seed=77, comm=comm, want_stats=True)[1]
-            if rank == 0: counts.update(cnt.calls)
+            if rank == 0 and cnt: counts.update(cnt.calls)
+            if NATIVE: b.free_local_comm(comm)
             b.close()
         except Exception as e:   # noqa: BLE001
             errors.append((rank, repr(e)))
-            try: group.barrier.abort()
+            try: start.abort()
             except Exception: pass
     th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in th: t.start()
     for t in th: t.join(timeout=900)
     if errors: return {"errors": errors}
     s = stats[0]
-    return {"ms": max(times) * 1e3, "same_proof_bytes": all(same), "rank0_stages_ms": {k: round(v, 3) for k, v in s.items() if isinstance(v, float) and k not in ("comm_ms",)},
+    return {"transport": "native (csrc/comm_local.hip)" if NATIVE else "python (sharded.ThreadGroup)", "ms": max(times) * 1e3, "same_proof_bytes": all(same), "rank0_stages_ms": {k: round(v, 3) for k, v in s.items() if isinstance(v, float) and k not in ("comm_ms",)},
             "rank0_comm_ms": s.get("comm_ms"), "rank0_comm_bytes": s.get("comm_bytes"),
             "rank0_collectives": counts, "rank0_collective_calls": sum(counts.values())}
 
