@@ -6,9 +6,9 @@
 //!   :135-183  trace generation (CPU, unchanged)                        the same statements
 //!   :184-194  SimdBackend::precompute_twiddles(..)                     inside `Session::new` (sized max_log + LOG_CONSTRAINT_DEGREE + blowup - 1)
 //!   :197-206  Blake2sChannel, mix_u64 per AD byte / per log size       `Session::mix_u64`
-//!   :208-237  tree_builder.extend_evals(..) / .commit(channel) x2      `Session::tree_begin` + `upload` + `tree_commit`
+//!   :208-237  tree_builder.extend_evals(..) / .commit(channel) x2      `Session::tree_begin` + `tree_commit_host` (upload under the transforms)
 //!   :239-240  C::draw_lookup_elements(&mut lookup_elements, channel)   a host `Blake2sChannel` set to the session's digest (`host_channel_at`)
-//!   :242-263  generate_interaction_trace, mix_felts, commit            the reference's CPU generator, then upload + `tree_commit`
+//!   :242-263  generate_interaction_trace, mix_felts, commit            the reference's CPU generator, then `tree_commit_host`
 //!   :264-285  FrameworkComponent::new(..) / to_component_prover(..)    `record_component(..)` over the same `MachineEval` / extension evals
 //!   :286-290  stwo::prover::prove(..)                                  `Session::prove` (composition, OODS, DEEP quotients, FRI, PoW, decommit)
 //!   :292-296  Proof { stark_proof, claimed_sum, log_size }             `proof_bytes` (postcard) -> `Proof`
@@ -77,19 +77,12 @@ fn host_columns(evals: &[SimdEval]) -> (Vec<*const u32>, Vec<u32>) {
     (ptrs, logs)
 }
 
-/// TreeBuilder::extend_evals(..) + commit(channel) for one trace tree (machine.rs:208-228, :230-237, :249-263)
+/// TreeBuilder::extend_evals(..) + commit(channel) for one trace tree (machine.rs:208-228, :230-237, :249-263): the columns stay in the
+/// SimdBackend evaluations' memory and go up in chunks under the commit's own transforms (nx_prover_tree_commit_host)
 fn commit_tree(session: &mut Session, evals: &[SimdEval]) -> Result<(), HipError> {
     let (host, logs) = host_columns(evals);
-    let dev = session.tree_begin(&logs)?;
-    // runs of equal size go up in one call each (the library pins, streams and unpins a run at a time)
-    let mut i = 0;
-    while i < logs.len() {
-        let mut j = i;
-        while j < logs.len() && logs[j] == logs[i] { j += 1; }
-        session.upload(&host[i..j], logs[i], &dev[i..j], false)?;
-        i = j;
-    }
-    session.tree_commit()?;
+    session.tree_begin(&logs)?;
+    session.tree_commit_host(&host, false, &[])?;
     Ok(())
 }
 

@@ -315,6 +315,16 @@ impl Session {
     }
     /// TreeBuilder::commit: interpolate, extend, Merkle-commit, mix the root
     pub fn tree_commit(&mut self) -> Result<[u8; 32], HipError> { let mut r = [0u8; 32]; try_check(self.ctx, unsafe { sys::nx_prover_tree_commit(self.p, r.as_mut_ptr()) })?; Ok(r) }
+    /// TreeBuilder::extend_evals + commit for a tree whose columns are in HOST memory (begun with `tree_begin`): pinned in place, uploaded
+    /// in chunks on a copy stream WHILE the commit transforms and hashes the chunks that have arrived.  `keep`: (column of the tree, device
+    /// buffer of 2^log words) — the evaluations of these columns are cloned on arrival (the commit turns the tree's columns into coefficients).
+    pub fn tree_commit_host(&mut self, host_cols: &[*const u32], coset_order: bool, keep: &[(u32, *mut u32)]) -> Result<[u8; 32], HipError> {
+        let idx: Vec<u32> = keep.iter().map(|k| k.0).collect();
+        let dst: Vec<*mut u32> = keep.iter().map(|k| k.1).collect();
+        let mut r = [0u8; 32];
+        try_check(self.ctx, unsafe { sys::nx_prover_tree_commit_host(self.p, host_cols.as_ptr(), coset_order as i32, idx.as_ptr(), idx.len() as u32, dst.as_ptr(), r.as_mut_ptr()) })?;
+        Ok(r)
+    }
     /// stwo::prover::prove (machine.rs:286-290): NXP1 proof words
     pub fn prove(&mut self, comps: &[RecordedComponent]) -> Result<Vec<u32>, HipError> {
         let raw: Vec<sys::nx_air_component> = comps.iter().map(|c| sys::nx_air_component {
