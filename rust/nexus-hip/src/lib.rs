@@ -273,7 +273,21 @@ pub struct RecordedComponent {
 /// machine.rs:184-296 on the device, on a context of the session's own (several sessions may prove concurrently, one per thread).
 /// Order of calls = the reference's transcript: `mix_u64` (:198-206), `tree_begin` / fill / `tree_commit` per trace tree (:208-263)
 /// with `draw_felts` (:239-240) and `mix_felts` (:262) in between, `prove` (:286-290).
-pub struct Session { ctx: *mut sys::nx_ctx, p: *mut sys::nx_prover, comm: *mut sys::nx_comm }
+pub struct Session { ctx: *mut sys::nx_ctx, p: *mut sys::nx_prover, comm: *mut sys::nx_comm, comm_is_local: bool }
+
+/// The shared board of the in-process transport (csrc/comm_local.hip): one per proof, shared (`Arc`) by the threads that prove it — one
+/// thread per GPU, each with its own `Session` and `Session::set_local_comm(&group, rank)`.  No RCCL, no second process.
+pub struct LocalGroup(*mut sys::nx_comm_group, pub i32);
+unsafe impl Send for LocalGroup {}
+unsafe impl Sync for LocalGroup {}
+impl LocalGroup {
+    pub fn new(world: i32) -> Result<Self, HipError> {
+        let mut g = std::ptr::null_mut();
+        try_check(std::ptr::null(), unsafe { sys::nx_comm_group_create(world, &mut g) })?;
+        Ok(Self(g, world))
+    }
+}
+impl Drop for LocalGroup { fn drop(&mut self) { unsafe { sys::nx_comm_group_destroy(self.0) } } }
 impl Session {
     pub fn new(cfg: &sys::nx_pcs_config, max_log_size: u32, device: i32) -> Result<Self, HipError> {
         let mut c = std::ptr::null_mut();
@@ -283,7 +297,7 @@ impl Session {
             unsafe { sys::nx_ctx_destroy(c) };
             return Err(e);
         }
-        Ok(Self { ctx: c, p, comm: std::ptr::null_mut() })
+        Ok(Self { ctx: c, p, comm: std::ptr::null_mut(), comm_is_local: false })
     }
     /// one proof on the GPUs of a node: the native RCCL transport (csrc/comm_rccl.hip); `unique_id` from rank 0's `rccl_unique_id()`.
     /// The communicator belongs to the session and is destroyed with it (after the prover, which refers to it).
@@ -296,6 +310,18 @@ impl Session {
             return Err(e);
         }
         self.comm = comm;
+        Ok(())
+    }
+    /// one proof on the GPUs of a node from ONE process: this session is rank `rank` of `group` (the group must outlive the session)
+    pub fn set_local_comm(&mut self, group: &LocalGroup, rank: i32) -> Result<(), HipError> {
+        if !self.comm.is_null() { return Err(HipError::Argument("the session already has a communicator".into())); }
+        let mut comm = std::ptr::null_mut();
+        try_check(self.ctx, unsafe { sys::nx_comm_local_create(group.0, self.ctx, rank, &mut comm) })?;
+        if let Err(e) = try_check(self.ctx, unsafe { sys::nx_prover_set_comm(self.p, comm) }) {
+            unsafe { sys::nx_comm_local_destroy(comm) };
+            return Err(e);
+        }
+        self.comm = comm; self.comm_is_local = true;
         Ok(())
     }
     pub fn mix_u64(&mut self, v: u64) { check(self.ctx, unsafe { sys::nx_prover_mix_u64(self.p, v) }); }
@@ -363,7 +389,7 @@ impl Drop for Session {
     fn drop(&mut self) {
         unsafe {
             sys::nx_prover_destroy(self.p);
-            if !self.comm.is_null() { sys::nx_comm_rccl_destroy(self.comm); }
+            if !self.comm.is_null() { if self.comm_is_local { sys::nx_comm_local_destroy(self.comm) } else { sys::nx_comm_rccl_destroy(self.comm) } }
             sys::nx_ctx_destroy(self.ctx);
         }
     }
