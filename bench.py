@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--one-proof", action="store_true", help="N > 1: ONE row-sharded proof on all GPUs (strong scaling) instead of one independent proof per GPU")
     ap.add_argument("--no-host-trace", action="store_true", help="skip the host-resident-trace measurement (host_trace block)")
     ap.add_argument("--no-one-proof", action="store_true", help="N > 1, default mode: do not also try ONE row-sharded proof on the N GPUs after the headline")
-    ap.add_argument("--one-proof-timeout", type=int, default=240, help="seconds after which the additional one-proof attempt is abandoned (its block then holds an error)")
+    ap.add_argument("--one-proof-timeout", type=int, default=120, help="seconds after which the additional one-proof attempt is abandoned (its block then holds an error)")
     ap.add_argument("--legacy-synth", action="store_true", help="prove the round-1 machine (synthetic interaction fill, hand-written constraint kernel)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 path on a 1-GPU box)")
     ap.add_argument("--transport", default=None, choices=["rccl-native", "torch"],

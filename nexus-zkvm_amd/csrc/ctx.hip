@@ -246,6 +246,14 @@ static nx_options options_from_env() {
     o.air_half_domain = env_int("NX_AIR_HALF_DOMAIN", 1) != 0;
     o.air_quarter_domain = env_int("NX_AIR_QUARTER_DOMAIN", 1) != 0;
     o.comm_timeout_ms = std::max(0, env_int("NX_COMM_TIMEOUT_MS", 120000));
+    o.fft_kmax = clampi(env_int("NX_FFT_KMAX", 9), 1, 11);
+    o.fft_fused = env_int("NX_FFT_FUSED", 1) != 0;
+    o.merkle_subtree = clampi(env_int("NX_MERKLE_SUBTREE", 17), 0, 30);
+    { int x = env_int("NX_PIPE_COLS", 0); o.commit_pipe_cols = x < 16 ? 0 : (x / 16) * 16; }
+    o.fri_device_channel = env_int("NX_FRI_DEVICE_CHANNEL", 1) != 0;
+    o.fri_tail = env_int("NX_FRI_TAIL", 1) != 0;
+    o.logup_scan_tiled = env_int("NX_LOGUP_SCAN_TILED", 1) != 0;
+    o.logup_per_column = env_int("NX_LOGUP_PER_COLUMN", 0) != 0;
     return o;
 }
 struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
@@ -260,6 +268,14 @@ static const OptEntry k_options[] = {
     {"air.half_domain", &nx_options::air_half_domain, 0, 1},
     {"air.quarter_domain", &nx_options::air_quarter_domain, 0, 1},
     {"comm.timeout_ms", &nx_options::comm_timeout_ms, 0, 1 << 30},
+    {"fft.kmax", &nx_options::fft_kmax, 1, 11},
+    {"fft.fused", &nx_options::fft_fused, 0, 1},
+    {"merkle.subtree", &nx_options::merkle_subtree, 0, 30},
+    {"commit.pipe_cols", &nx_options::commit_pipe_cols, 0, 1 << 20},
+    {"fri.device_channel", &nx_options::fri_device_channel, 0, 1},
+    {"fri.tail", &nx_options::fri_tail, 0, 1},
+    {"logup.scan_tiled", &nx_options::logup_scan_tiled, 0, 1},
+    {"logup.per_column", &nx_options::logup_per_column, 0, 1},
 };
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return set_err(ctx, NX_ERR_ARG, "nx_ctx_set_option: NULL argument");

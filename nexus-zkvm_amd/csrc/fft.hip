@@ -246,24 +246,12 @@ __global__ void fft_tiny_kernel(ColSet src, ColSet dst, u32 n_cols, int n, int l
 }
 
 // ---- planning ----
-struct FftTune { int smax, bmax, threads, legacy; };   // columns per launch and streams are per-context options (nx_ctx_set_option)
-static FftTune g_tune = {13, 5, 256, 0};   // 2 streams x 2 columns in flight: the working set of a batch (48 MiB per column at 2^22) stays in the 256 MiB Infinity Cache between its four passes
-static std::once_flag g_tune_once;
-// Read once per process, under std::call_once: contexts on several host threads (one per GPU, tools/concurrent_proves.py, ThreadGroup)
-// plan their first transform concurrently and must all see the fully clamped values.
-static void tune_init() {
-    std::call_once(g_tune_once, []() {
-        FftTune t = g_tune;
-        if (const char* e = getenv("NX_FFT_SMAX")) t.smax = atoi(e);
-        if (const char* e = getenv("NX_FFT_B")) t.bmax = atoi(e);
-        if (const char* e = getenv("NX_FFT_THREADS")) t.threads = atoi(e);
-        if (const char* e = getenv("NX_FFT_LEGACY")) t.legacy = atoi(e);
-        t.smax = std::max(6, std::min(t.smax, 15));
-        t.bmax = std::max(2, std::min(t.bmax, 6));
-        if (t.threads != 128 && t.threads != 256 && t.threads != 512 && t.threads != 1024) t.threads = 256;
-        g_tune = t;
-    });
-}
+// The pass shapes of the transforms below 2^13 points (everything larger is fft13.hip): one LDS-resident pass of up to 2^13 rows,
+// later passes with 5 contiguity bits, 256-lane blocks.  (Rounds 1-2 tuned these through NX_FFT_SMAX / _B / _THREADS and kept the whole
+// pre-fft13 path behind NX_FFT_LEGACY; the measurements are settled — DESIGN.md section 6 — and the knobs are gone.)
+struct FftTune { int smax, bmax, threads, legacy; };
+static constexpr FftTune g_tune = {13, 5, 256, 0};
+static inline void tune_init() {}
 
 struct PassPlan { int lo, hi, B; };
 static int rounds_of(int k) { return (k + 3) / 4; }
@@ -435,7 +423,7 @@ int fft_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, ui
     for (u32 c0 = 0, bi = 0; c0 < n_cols && rc == NX_OK; c0 += bc, bi++) {
         u32 nb = std::min<u32>(bc, n_cols - c0);
         streams_pick(ctx, (int)bi, ns);
-        if (log_expand == 1 && log_size >= 14 && !g_tune.legacy && fft13_lde_fused_enabled()) {
+        if (log_expand == 1 && log_size >= 14 && ctx->opt.fft_fused) {
             rc = fft13_lde(ctx, tw, sub_colset(cols, c0), nb, (int)log_size, sub_colset(out, c0));   // middle passes fused (fft13.hip)
             continue;
         }

@@ -4,8 +4,8 @@
 //  * a pass owns 13 index bits: K butterfly layers [lo, lo+K) plus B = 13-K low bits that only make
 //    the global accesses contiguous (runs of 2^B words, B = 0 for the pass that holds layers [0,13)).
 //    2^22 points = 2 passes (13 + 9 layers); each pass is one HBM round trip.
-//  * a block transforms the same 2^13-row tile of CB columns: CB = 1 by default (34 KB of LDS, 58-70 VGPRs,
-//    3-4 blocks per CU); CB = 2 (NX_FFT_CB=2) holds (col0, col1) pairs, 64-bit LDS accesses, 2 blocks per CU.
+//  * a block transforms one 2^13-row tile of one column (34 KB of LDS, 58-70 VGPRs, 3-4 blocks per CU).  (Column PAIRS per block
+//    with 64-bit LDS accesses were measured slower in rounds 1-2 and are gone.)
 //  * 4 layers per LDS round trip (radix-16 in registers); the pass's top layer is fused into the
 //    global<->LDS staging (its twiddle is uniform over the tile); the layer count K is a template constant.
 //  * the twiddles of a round are requested one round ahead from DOUBLED tables (2t: what the doubled-factor
@@ -533,16 +533,11 @@ __global__ __launch_bounds__(T13_ROWS >> RB, 1) void lde_mid_kernel(PassMid m) {
 
 // ---- planning: layers [0, m) -> the FIRST pass [0, 13) plus passes of <= kmax layers (runs of 2^(13-kmax) words) ----
 struct Plan13 { int lo, K, B; };
-static int plan13_kmax() {
-    static const int v = []() { const char* e = getenv("NX_FFT_KMAX"); return e ? std::max(1, std::min(11, atoi(e))) : 9; }();   // thread-safe (C++11 static init)
-    return v;
-}
-static std::vector<Plan13> plan13(int m) {
+static std::vector<Plan13> plan13(int m, int kmax) {
     std::vector<Plan13> p;
     p.push_back({0, T13_S, 0});
     int rest = m - T13_S;
     if (rest <= 0) return p;
-    const int kmax = plan13_kmax();
     int nhi = (rest + kmax - 1) / kmax, lo = T13_S;
     for (int i = 0; i < nhi; i++) {
         int k = rest / nhi + (i < rest % nhi ? 1 : 0);
@@ -552,13 +547,8 @@ static std::vector<Plan13> plan13(int m) {
     return p;
 }
 
-struct Shape13 { int cb; };   // radix-8 rounds (RB = 3) measured slower in every shape and are no longer built
-// one column per block: 34 KB tiles, 58-70 VGPRs -> 3-4 blocks per CU; measured 3 % faster than column pairs (2 blocks per CU)
-static const Shape13& shape13() {
-    static const Shape13 s = []() { Shape13 v = {1}; if (const char* e = getenv("NX_FFT_CB")) v.cb = atoi(e) == 1 ? 1 : 2; return v; }();   // thread-safe
-    return s;
-}
-
+// one column per block (CB = 1: 34 KB tiles, 58-70 VGPRs, 3-4 blocks per CU) measured 3 % faster than column pairs (CB = 2, b64 LDS, 2 blocks per
+// CU); radix-8 rounds (RB = 3) slower in every shape: neither is instantiated any more (the kernel stays generic in CB / RB)
 template <bool INV, bool FIRST, int CB, int RB, int KT>
 static int launch13_t(nx_ctx* ctx, const Pass13& a) {
     static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
@@ -591,15 +581,13 @@ static int launch13_k(nx_ctx* ctx, bool first, const Pass13& a) {
 }
 
 static int launch13(nx_ctx* ctx, bool inv, bool first, Pass13 a) {
-    const int cb = a.n_cols == 1 ? 1 : shape13().cb;
-    a.n_groups = (a.n_cols + cb - 1) / cb;
-    if (cb == 2) return inv ? launch13_k<true, 2, 4>(ctx, first, a) : launch13_k<false, 2, 4>(ctx, first, a);
+    a.n_groups = a.n_cols;
     return inv ? launch13_k<true, 1, 4>(ctx, first, a) : launch13_k<false, 1, 4>(ctx, first, a);
 }
 
 // in-place iFFT of n_cols columns of 2^n words (n >= 13)
 int fft13_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_cols, int n) {
-    std::vector<Plan13> plan = plan13(n);
+    std::vector<Plan13> plan = plan13(n, ctx->opt.fft_kmax);
     for (size_t i = 0; i < plan.size(); i++) {
         Pass13 a; a.src = cols; a.dst = cols; a.tw = tw->d_itw2; a.tw_log = tw->log_half; a.n = n; a.log_in = n;
         a.lo = plan[i].lo; a.K = plan[i].K; a.B = plan[i].B; a.scale = i + 1 == plan.size() ? m_inv(1u << n) : 0;
@@ -611,7 +599,7 @@ int fft13_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_col
 
 // FFT of 2^log_in coefficients per column onto 2^n points (n >= log_in >= 13); out may alias polys when n == log_in
 int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n_cols, int log_in, int n, ColSet out) {
-    std::vector<Plan13> plan = plan13(log_in);
+    std::vector<Plan13> plan = plan13(log_in, ctx->opt.fft_kmax);
     for (size_t k = plan.size(); k-- > 0;) {
         const bool top = k + 1 == plan.size();
         Pass13 a; a.src = top ? polys : out; a.dst = out; a.tw = tw->d_tw2; a.tw_log = tw->log_half; a.n = n; a.log_in = top ? log_in : n;
@@ -649,15 +637,10 @@ static int launch_mid(nx_ctx* ctx, const PassMid& m) {
     }
 }
 
-bool fft13_lde_fused_enabled() {
-    static const bool v = []() { const char* e = getenv("NX_FFT_FUSED"); return e ? (atoi(e) != 0) : true; }();
-    return v;
-}
-
 // iFFT in place (coefficients stay in `cols`) + FFT onto 2^(n+1) points in `out`, n >= 14: every pass as in fft13_interpolate /
 // fft13_evaluate except the inverse transform's last pass and the forward transform's first pass, which are one launch.
 int fft13_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, u32 n_cols, int n, ColSet out) {
-    std::vector<Plan13> plan = plan13(n);
+    std::vector<Plan13> plan = plan13(n, ctx->opt.fft_kmax);
     const size_t P = plan.size();
     if (P < 2) return set_err(ctx, NX_ERR_ARG, "fft13_lde: needs at least two passes");
     for (size_t i = 0; i + 1 < P; i++) {

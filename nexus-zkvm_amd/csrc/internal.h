@@ -21,6 +21,16 @@ struct nx_options {
     int air_half_domain;          // "air.half_domain": constraints of degree <= 2 are evaluated on HALF of the committed 2N-point domain (single GPU, blowup 2)
     int air_quarter_domain;       // "air.quarter_domain": degree-4/5 constraints that read no neighbour row are evaluated on the committed 2N rows + the first QUARTER of the 4N-point domain (3N + 1 samples; single GPU, blowup 2, bound 2)
     int comm_timeout_ms;          // "comm.timeout_ms": native RCCL transport, longest wait for the peers in one collective (0 = for ever)
+    // schedule choices that were A/B'd and settled (DESIGN.md section 6.1 lists the measurements); kept as options — not as getenv calls spread over
+    // the kernels' launchers — so that a tool can still flip one on ONE context
+    int fft_kmax;                 // "fft.kmax": most layers of a non-FIRST pass (runs of 2^(13-K) words), 1..11
+    int fft_fused;                // "fft.fused": fused LDE middle launch (lde_mid_kernel)
+    int merkle_subtree;           // "merkle.subtree": highest tree level built by the fused subtree launch (0 = one launch per level)
+    int commit_pipe_cols;         // "commit.pipe_cols": leaf hashing of finished column groups of this many columns beside the next group's LDE (0 = off)
+    int fri_device_channel;       // "fri.device_channel": FRI commit phase with the channel on the device
+    int fri_tail;                 // "fri.tail": last FRI layers in one launch
+    int logup_scan_tiled;         // "logup.scan_tiled": finalize_last as coalesced tiles
+    int logup_per_column;         // "logup.per_column": one nx_logup_col launch per column instead of nx_logup_cols
     int air_degree_split;         // "air.degree_split": constraints of degree <= 3 of a component with a bound > 1 are evaluated on the log_size + 1 domain
 };
 
@@ -237,7 +247,6 @@ int streams_join(nx_ctx* ctx, int n_streams);
 int fft13_interpolate(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n);
 int fft13_evaluate(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, uint32_t n_cols, int log_in, int n, ColSet out);
 int fft13_lde(nx_ctx* ctx, const nx_twiddles* tw, ColSet cols, uint32_t n_cols, int n, ColSet out);   // blow-up 2, n >= 14: middle passes fused
-bool fft13_lde_fused_enabled();
 
 
 }  // namespace nx

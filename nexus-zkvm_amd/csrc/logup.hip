@@ -457,8 +457,7 @@ int nx_logup_finalize_last_batch(nx_ctx* ctx, uint32_t log_size, uint32_t* const
     if (n_cols == 0) return NX_OK;
     if (n_cols > 65535) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: at most 65535 columns per call");
     // coalesced tiles from 2^13 rows (NX_LOGUP_SCAN_TILED=0: the per-row gather kernels at every size, kept for A/B and small columns)
-    static const bool tiled_on = []() { const char* e = getenv("NX_LOGUP_SCAN_TILED"); return !e || atoi(e) != 0; }();
-    const bool tiled = tiled_on && log_size >= (uint32_t)SC_MIN_LOG && n_cols * 4 <= 65535;
+    const bool tiled = ctx->opt.logup_scan_tiled && log_size >= (uint32_t)SC_MIN_LOG && n_cols * 4 <= 65535;
     const u32 n = 1u << log_size, n_blocks = tiled ? 1u << (log_size - 1 - SC_H) : (n + SCAN_BLOCK - 1) / SCAN_BLOCK;   // tiled: one total per 128-pair segment
     std::vector<Sec4> h(n_cols);
     for (u32 k = 0; k < n_cols; k++) for (int q = 0; q < 4; q++) { if (!d_cols4[4 * k + q]) return set_err(ctx, NX_ERR_ARG, "nx_logup_finalize_last: NULL column"); h[k].c[q] = d_cols4[4 * k + q]; }

@@ -295,7 +295,7 @@ static int logup_columns(nx_ctx* ctx, const nx_component_spec& c, uint32_t log_r
     const uint32_t L = c.n_inter / 4;
     static const uint32_t one[4] = {1, 0, 0, 0}, minus_one[4] = {P - 1, 0, 0, 0};
     uint32_t ap[8] = {1, 0, 0, 0, alpha[0], alpha[1], alpha[2], alpha[3]};     // LookupElements alpha powers [1, alpha]
-    static const bool per_column = []() { const char* e = getenv("NX_LOGUP_PER_COLUMN"); return e && atoi(e) != 0; }();   // A/B: one nx_logup_col launch per column
+    const bool per_column = ctx->opt.logup_per_column != 0;   // A/B: one nx_logup_col launch per column
     std::vector<nx_logup_frac> fr(L);
     std::vector<const uint32_t*> tuples(2 * (size_t)L);
     for (uint32_t j = 0; j < L; j++) {

@@ -561,7 +561,7 @@ static int build_inner_layers(nx_ctx* ctx, nx_tree* t, uint32_t max_log, const s
     int smallest_col_log = n ? (int)logs[n - 1] : (int)max_log;
     int top_fused = std::min(10, std::min((int)max_log - 1, smallest_col_log - 1));
     // levels [top_fused + 1, SUBTREE_TOP] without injected columns: one launch (merkle_subtree_kernel) instead of one per level
-    static const int SUBTREE_TOP = []() { const char* e = getenv("NX_MERKLE_SUBTREE"); return e ? atoi(e) : 17; }();   // 0 = off; thread-safe
+    const int SUBTREE_TOP = ctx->opt.merkle_subtree;   // 0 = off
     for (int log = (int)max_log - 1; log >= 0; log--) {
         if (log == top_fused && log >= 1) {
             NX_TRY(launch_merkle_top(ctx, buf, log));

@@ -223,10 +223,7 @@ void plan_local_columns(const std::vector<std::pair<uint32_t, uint32_t>>& groups
 // Blake2s chain per row over the largest columns in commit order, so it is built incrementally: as soon as a group of
 // columns is extended, its 16-column blocks are absorbed on the hash stream while the main stream already extends the next
 // group (tree_pipe_* in merkle.hip).
-static uint32_t pipe_group_cols() {
-    static const int v = []() { const char* e = getenv("NX_PIPE_COLS"); int x = e ? atoi(e) : 0; if (x < 16) x = 1 << 30; return (x / 16) * 16; }();   // thread-safe
-    return (uint32_t)v;
-}
+static uint32_t pipe_group_cols(const nx_ctx* ctx) { return ctx->opt.commit_pipe_cols >= 16 ? (uint32_t)ctx->opt.commit_pipe_cols : (1u << 30); }
 
 int TreeBuilder::commit(Blake2sChannel& channel) { return cs.dist.on() ? commit_dist(channel) : commit_single(channel); }
 
@@ -241,9 +238,9 @@ int TreeBuilder::commit_single(Blake2sChannel& channel) {
     struct FeedGuard { std::vector<std::unique_ptr<HostFeed>>& f; ~FeedGuard() { for (auto& x : f) (void)x->finish(); } } feed_guard{feeds};
     TreePipe tp;
     struct PipeGuard { nx_ctx* c; TreePipe* p; ~PipeGuard() { if (p->tree) { (void)nx_sync(c); nx_tree_destroy(p->tree); p->tree = nullptr; } } } guard{ctx, &tp};
-    if (total_leaf_cols) { H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp)); tp.side_stream = pipe_group_cols() < (1u << 29); }
+    if (total_leaf_cols) { H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp)); tp.side_stream = pipe_group_cols(ctx) < (1u << 29); }
     std::vector<const uint32_t*> small_cols; std::vector<uint32_t> small_logs;
-    const uint32_t G = pipe_group_cols();
+    const uint32_t G = pipe_group_cols(ctx);
     // consecutive groups of one size (the components of a prover2-style statement) are extended by ONE batch call: a tree of 55 small
     // components is 6 calls, not 55 (each call forks/joins the FFT streams and is launch-bound below ~2^16 rows)
     for (size_t g0 = 0; g0 < groups.size();) {
@@ -499,8 +496,7 @@ class FriProver {
     // the host reads the roots and the channel state back once, before the last layer.  NX_FRI_DEVICE_CHANNEL=0: the per-layer host
     // channel (same transcript; kept for A/B).  Row-sharded: every layer's root needs the W subtree roots, so the host channel.
     int commit(Blake2sChannel& channel, std::vector<SecureColumn>&& cols) {
-        static const bool dev_channel = []() { const char* e = getenv("NX_FRI_DEVICE_CHANNEL"); return !e || atoi(e) != 0; }();
-        if (D.on() || !dev_channel) return commit_host_channel(channel, std::move(cols));
+        if (D.on() || !ctx->opt.fri_device_channel) return commit_host_channel(channel, std::move(cols));
         columns = std::move(cols);
         if (columns.empty()) return set_err(ctx, NX_ERR_ARG, "fri: no columns");
         const uint32_t last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
@@ -526,7 +522,7 @@ class FriProver {
         SecureColumn layer; H_TRY(layer.alloc(ctx, layer_log));
         H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
         size_t ci = 0;
-        static const bool use_tail = []() { const char* e = getenv("NX_FRI_TAIL"); return !e || atoi(e) != 0; }();
+        const bool use_tail = ctx->opt.fri_tail != 0;
         while (layer_log > last_log) {
             const int j = (int)inner.size() + 1;   // record of the layer committed in this iteration
             if (use_tail && ci == columns.size() && layer_log <= (uint32_t)FRI_TAIL_LOG && layer_log - last_log <= (uint32_t)FRI_TAIL_MAX_LAYERS) {
