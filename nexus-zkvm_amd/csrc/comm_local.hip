@@ -50,7 +50,24 @@ static int rendezvous(LocalComm* c) {
     } else g->cv.wait(lk, done);
     return g->generation != gen && !g->broken ? 0 : 1;
 }
-static int fail(LocalComm* c, const char* what) { (void)set_err(c->ctx, NX_ERR_HIP, std::string("local transport: ") + what); return 1; }
+// every failure of one rank breaks the group: its peers' waits return at once instead of running into the timeout
+static int fail(LocalComm* c, const char* what) {
+    {
+        std::lock_guard<std::mutex> lk(c->g->mu);
+        c->g->broken = true;
+        c->g->cv.notify_all();
+    }
+    (void)set_err(c->ctx, NX_ERR_HIP, std::string("local transport: ") + what);
+    return 1;
+}
+// a wait on the board's condition variable, bounded by "comm.timeout_ms" like the rendezvous; false = timed out (the caller fails -> group broken)
+template <class Pred>
+static bool wait_bounded(LocalComm* c, std::unique_lock<std::mutex>& lk, Pred done) {
+    const int limit_ms = c->ctx->opt.comm_timeout_ms;
+    if (limit_ms > 0) return c->g->cv.wait_for(lk, std::chrono::milliseconds(limit_ms), done);
+    c->g->cv.wait(lk, done);
+    return true;
+}
 #define L_MEET(c) do { if (rendezvous(c)) return fail(c, "a peer failed or did not arrive in time (group broken)"); } while (0)
 #define L_HIP(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(c, hipGetErrorString(e__)); } while (0)
 
@@ -102,26 +119,36 @@ static int cb_alltoallv(void* user, const uint32_t* d_send, const size_t* soff, 
 // point to point (the ring commit protocol): the receiver pulls
 static int cb_send(void* user, int32_t dst, const uint32_t* d_buf, size_t n_words) {
     LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
-    if (nx_sync(c->ctx) != NX_OK) return 1;
-    std::unique_lock<std::mutex> lk(g->mu);
-    auto& m = g->mail[(size_t)c->rank * g->world + dst];
-    m = {d_buf, n_words};
-    g->cv.notify_all();
-    g->cv.wait(lk, [&] { return m.first == nullptr || g->broken; });       // the receiver copied it
-    return g->broken ? fail(c, "group broken") : 0;
+    if (dst < 0 || dst >= g->world || dst == c->rank) return fail(c, "send: bad destination rank");
+    if (nx_sync(c->ctx) != NX_OK) return fail(c, "send: the context's stream failed");
+    bool in_time, broken;
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        auto& m = g->mail[(size_t)c->rank * g->world + dst];
+        m = {d_buf, n_words};
+        g->cv.notify_all();
+        in_time = wait_bounded(c, lk, [&] { return m.first == nullptr || g->broken; });       // the receiver copied it
+        broken = g->broken;
+        if (!in_time || broken) m = {nullptr, 0};
+    }
+    if (!in_time) return fail(c, "send: the receiver did not arrive in time");
+    return broken ? fail(c, "group broken") : 0;
 }
 static int cb_recv(void* user, int32_t src, uint32_t* d_buf, size_t n_words) {
     LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
     DeviceGuard dg(c->ctx);
+    if (src < 0 || src >= g->world || src == c->rank) return fail(c, "recv: bad source rank");
     const uint32_t* from = nullptr;
+    const char* why = nullptr;
     {
         std::unique_lock<std::mutex> lk(g->mu);
         auto& m = g->mail[(size_t)src * g->world + c->rank];
-        g->cv.wait(lk, [&] { return m.first != nullptr || g->broken; });
-        if (g->broken) return fail(c, "group broken");
-        if (m.second != n_words) return fail(c, "recv: the sender announced a different length");
-        from = m.first;
+        if (!wait_bounded(c, lk, [&] { return m.first != nullptr || g->broken; })) why = "recv: the sender did not arrive in time";
+        else if (g->broken) why = "group broken";
+        else if (m.second != n_words) why = "recv: the sender announced a different length";
+        else from = m.first;
     }
+    if (why) return fail(c, why);
     L_HIP(c, hipMemcpyAsync(d_buf, from, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
     L_HIP(c, hipStreamSynchronize(c->stream));
     std::unique_lock<std::mutex> lk(g->mu);

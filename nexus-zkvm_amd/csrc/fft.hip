@@ -643,6 +643,14 @@ int HostFeed::begin(nx_ctx* c, uint32_t log_size, int coset) {
         NX_HIP(ctx, hipEventCreateWithFlags(&copied[k], hipEventDisableTiming));
         NX_HIP(ctx, hipEventCreateWithFlags(&consumed[k], hipEventDisableTiming));
     }
+    // the destination columns (and d_tmp) come from the context's block cache, whose frees are ordered on ctx->stream only: the feed's
+    // streams start behind everything the context has queued so far
+    hipEvent_t here = nullptr;
+    NX_HIP(ctx, hipEventCreateWithFlags(&here, hipEventDisableTiming));
+    events.push_back(here);
+    NX_HIP(ctx, hipEventRecord(here, ctx->stream));
+    NX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, here, 0));
+    NX_HIP(ctx, hipStreamWaitEvent(ctx->perm_stream, here, 0));
     return NX_OK;
 }
 int HostFeed::chunk(const uint32_t* const* h_cols, uint32_t* const* d_cols, uint32_t n_cols, hipEvent_t* ready) {

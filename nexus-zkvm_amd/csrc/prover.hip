@@ -1739,30 +1739,32 @@ int nx_prover_tree_commit_host(nx_prover* p, const uint32_t* const* h_cols, int 
     if ((n_total && !h_cols) || (n_keep && (!keep_idx || !d_keep))) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL argument");
     for (uint32_t k = 0; k < n_keep; k++) if (keep_idx[k] >= n_total || !d_keep[k]) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: keep entry outside the tree (or NULL)");
     const bool sharded = p->cs->dist.on();
-    nxhip::TreeBuilder tb = p->cs->tree_builder();
-    uint32_t first = 0;
-    for (auto& r : p->pending) {
-        if (sharded) {
-            // this GPU's columns of the run, uploaded before the commit (the exchange-bound sharded commit gains nothing from the overlap)
-            std::vector<const uint32_t*> hs; std::vector<uint32_t*> ds;
-            for (uint32_t k = r.lo; k < r.hi; k++) { if (!h_cols[first + k]) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL host column"); hs.push_back(h_cols[first + k]); ds.push_back(r.slab.p + ((size_t)(k - r.lo) << r.log)); }
-            if (!hs.empty()) NX_TRY(nx_upload_columns(p->ctx, hs.data(), (uint32_t)hs.size(), r.log, ds.data(), coset_order));
-            for (uint32_t k = 0; k < n_keep; k++)
-                if (keep_idx[k] >= first + r.lo && keep_idx[k] < first + r.hi) NX_TRY(nx_copy(p->ctx, d_keep[k], r.slab.p + ((size_t)(keep_idx[k] - first - r.lo) << r.log), (size_t)1 << r.log));
-            tb.extend_evals_local(std::move(r.slab), r.n_cols, r.log, r.lo, r.hi);
-        } else {
-            for (uint32_t k = 0; k < r.n_cols; k++) if (!h_cols[first + k]) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL host column");
-            std::vector<std::pair<uint32_t, uint32_t*>> keep;
-            for (uint32_t k = 0; k < n_keep; k++) if (keep_idx[k] >= first && keep_idx[k] < first + r.n_cols) keep.push_back({keep_idx[k] - first, d_keep[k]});
-            tb.extend_evals_host(std::move(r.slab), r.n_cols, r.log, h_cols + first, coset_order, keep);
+    // a rank that fails here (before or inside the commit) tells its peers, which are in — or about to enter — the commit's exchanges
+    auto run = [&]() -> int {
+        nxhip::TreeBuilder tb = p->cs->tree_builder();
+        uint32_t first = 0;
+        for (auto& r : p->pending) {
+            if (sharded) {
+                // this GPU's columns of the run, uploaded before the commit (the exchange-bound sharded commit gains nothing from the overlap)
+                std::vector<const uint32_t*> hs; std::vector<uint32_t*> ds;
+                for (uint32_t k = r.lo; k < r.hi; k++) { if (!h_cols[first + k]) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL host column"); hs.push_back(h_cols[first + k]); ds.push_back(r.slab.p + ((size_t)(k - r.lo) << r.log)); }
+                if (!hs.empty()) NX_TRY(nx_upload_columns(p->ctx, hs.data(), (uint32_t)hs.size(), r.log, ds.data(), coset_order));
+                for (uint32_t k = 0; k < n_keep; k++)
+                    if (keep_idx[k] >= first + r.lo && keep_idx[k] < first + r.hi) NX_TRY(nx_copy(p->ctx, d_keep[k], r.slab.p + ((size_t)(keep_idx[k] - first - r.lo) << r.log), (size_t)1 << r.log));
+                tb.extend_evals_local(std::move(r.slab), r.n_cols, r.log, r.lo, r.hi);
+            } else {
+                for (uint32_t k = 0; k < r.n_cols; k++) if (!h_cols[first + k]) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_commit_host: NULL host column");
+                std::vector<std::pair<uint32_t, uint32_t*>> keep;
+                for (uint32_t k = 0; k < n_keep; k++) if (keep_idx[k] >= first && keep_idx[k] < first + r.n_cols) keep.push_back({keep_idx[k] - first, d_keep[k]});
+                tb.extend_evals_host(std::move(r.slab), r.n_cols, r.log, h_cols + first, coset_order, keep);
+            }
+            first += r.n_cols;
         }
-        first += r.n_cols;
-    }
+        return tb.commit(p->channel);
+    };
+    const int rc = run();
     p->pending.clear(); p->open = false;
-    {
-        const int rc = tb.commit(p->channel);
-        if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort) p->comm_copy.abort(p->comm_copy.user); return rc; }
-    }
+    if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort) p->comm_copy.abort(p->comm_copy.user); return rc; }
     if (root) memcpy(root, p->cs->trees.back().root.w, 32);
     return NX_OK;
 }
