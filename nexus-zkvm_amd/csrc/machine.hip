@@ -344,29 +344,17 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     if (comm) { H_TRY(dist_init(ctx, comm, &cs.dist)); cs.dist.comm_ms = &st->comm_ms; cs.dist.comm_bytes = &st->comm_bytes; }
     const Dist& D = cs.dist;
     for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
-    {
-        // Everything that can fail on ONE rank only before the exchanges start — the hiprtc compilation of the components' kernels
-        // (the text does not depend on the proof: lookup elements and claimed sums are run-time constants) — happens here, followed
-        // by a vote: a rank that failed must not leave its peers blocked in the first all-to-all.
-        int rc_local = NX_OK;
-        for (uint32_t i = 0; i < n_comps && rc_local == NX_OK; i++) {
-            GComponent g = machine_component(comps[i], locs[i], cfg);
-            g.log_cd = comps[i].log_constraint_degree_bound;
-            rc_local = prepare_component_kernels(ctx, cfg, g, D.on());
-        }
-        H_TRY(vote_before_exchanges(ctx, D, rc_local, "nx_prove_machine"));
-    }
-    lap(&st->commit);
-
     if (host && D.on()) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine_host: one GPU (a row-sharded session takes host columns through nx_prover_tree_commit_host)");
+    // The fills of the preprocessed and the main trace are queued FIRST (they depend on nothing), the host work of the prove's start —
+    // assembling the components' programs, looking their kernels up, the vote of a row-sharded prove — runs while the GPU fills, and
+    // only then the two commits (each ends in the synchronisation that fetches its root): the GPU does not idle through the set-up.
+    TreeBuilder tb0 = cs.tree_builder(), tb1 = cs.tree_builder();
     if (host) {
-        TreeBuilder tb = cs.tree_builder();
         for (uint32_t i = 0; i < n_comps; i++) {
             DevBuf slab; H_TRY(slab.alloc(ctx, (size_t)comps[i].n_pre << comps[i].log_size));
-            tb.extend_evals_host(std::move(slab), comps[i].n_pre, comps[i].log_size, host->pre + locs[i].pre0, host->coset_order);
+            tb0.extend_evals_host(std::move(slab), comps[i].n_pre, comps[i].log_size, host->pre + locs[i].pre0, host->coset_order);
         }
-        H_TRY(tb.commit(channel)); lap(&st->commit);
-    } else { TreeBuilder tb = cs.tree_builder(); H_TRY(fill_and_extend(cs, tb, comps, n_comps, 0, seed, 0)); lap(&st->trace_gen); H_TRY(tb.commit(channel)); lap(&st->commit); }   // :208-228
+    } else H_TRY(fill_and_extend(cs, tb0, comps, n_comps, 0, seed, 0));                // machine.rs:208-228
 
     // The main trace is consumed by its commitment (the columns become coefficients), and the interaction trace needs its
     // evaluations afterwards: the reference clones the whole finalized trace (machine.rs:232); here only the columns the logup
@@ -375,7 +363,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     std::vector<DevBuf> kept(n_comps);
     std::vector<std::map<uint32_t, const uint32_t*>> kept_ptr(n_comps);
     {
-        TreeBuilder tb = cs.tree_builder();
+        TreeBuilder& tb = tb1;
         std::vector<std::pair<uint32_t, uint32_t>> groups, local;
         for (uint32_t i = 0; i < n_comps; i++) groups.push_back({comps[i].n_main, comps[i].log_size});
         plan_local_columns(groups, D, &local);
@@ -416,10 +404,23 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
             }
             tb.extend_evals_local(std::move(slab), c.n_main, log, lo, hi);
         }
-        lap(&st->trace_gen);
-        H_TRY(tb.commit(channel));                                                    // machine.rs:230-237
-        lap(&st->commit);
     }
+    {
+        // Everything that can fail on ONE rank only before the exchanges start — the hiprtc compilation of the components' kernels
+        // (the text does not depend on the proof: lookup elements and claimed sums are run-time constants) — happens here, followed
+        // by a vote: a rank that failed must not leave its peers blocked in the first all-to-all.
+        int rc_local = NX_OK;
+        for (uint32_t i = 0; i < n_comps && rc_local == NX_OK; i++) {
+            GComponent g = machine_component(comps[i], locs[i], cfg);
+            g.log_cd = comps[i].log_constraint_degree_bound;
+            rc_local = prepare_component_kernels(ctx, cfg, g, D.on());
+        }
+        H_TRY(vote_before_exchanges(ctx, D, rc_local, "nx_prove_machine"));
+    }
+    lap(&st->trace_gen);
+    H_TRY(tb0.commit(channel));                                                       // machine.rs:208-228
+    H_TRY(tb1.commit(channel));                                                       // machine.rs:230-237
+    lap(&st->commit);
 
     // machine.rs:239-247: draw_lookup_elements, generate_interaction_trace
     uint32_t z[4], alpha[4];
@@ -482,10 +483,10 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     kept.clear();
     lap(&st->interaction);
     channel.mix_felts(claimed);                                                       // machine.rs:262
-    H_TRY(tb2.commit(channel));                                                       // machine.rs:263
-    lap(&st->commit);
+    H_TRY(tb2.commit_begin());                                                        // machine.rs:263, queued; its root is fetched below
 
-    // machine.rs:265-285: the components (recorded programs; lookup elements and claimed-sum shifts are run-time constants)
+    // machine.rs:265-285: the components (recorded programs; lookup elements and claimed-sum shifts are run-time constants), assembled
+    // while the GPU builds the interaction tree
     GenericAir air; air.ctx = ctx;
     for (uint32_t i = 0; i < n_comps; i++) {
         GComponent g = machine_component(comps[i], locs[i], cfg);
@@ -495,6 +496,8 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         H_TRY(prepare_component_kernels(ctx, cfg, g, D.on()));
         air.comps.push_back(std::move(g));
     }
+    H_TRY(tb2.commit_end(channel));
+    lap(&st->commit);
     H_TRY(air.check(cs));
     H_TRY(prove_core(ctx, cs, channel, cfg, tw, air, words, st, lap));               // machine.rs:286-290
     ctx->last_claimed.resize(4 * (size_t)n_comps);                                    // Proof.claimed_sum (machine.rs:93-98, :291-296)

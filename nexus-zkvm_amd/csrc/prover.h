@@ -13,6 +13,7 @@
 // single-GPU prover.
 #pragma once
 #include "internal.h"
+#include <memory>
 #include "air.h"
 #include "host/channel.h"
 #include <algorithm>
@@ -172,13 +173,23 @@ class TreeBuilder {
     void extend_evals_local(DevBuf&& slab, uint32_t n_cols, uint32_t log, uint32_t lo, uint32_t hi) { push(std::move(slab), n_cols, log, true, lo, hi); }
     // coefficients, all n_cols of them on every GPU (the composition polynomial)
     void extend_polys(DevBuf&& slab, uint32_t n_cols, uint32_t log) { push(std::move(slab), n_cols, log, false, 0, n_cols); }
-    int commit(Blake2sChannel& channel);
+    int commit(Blake2sChannel& channel) { int rc = commit_begin(); return rc != NX_OK ? rc : commit_end(channel); }
+    // The two halves of commit, for callers with host work that does not depend on the root (assembling the next stage's descriptors,
+    // looking kernels up): commit_begin queues the whole tree build — transforms, hashing, host-feed chunks — and returns; commit_end
+    // downloads the root (the one synchronisation of a commit) and mixes it into the channel.  Whatever the caller mixes between the
+    // two enters the transcript BEFORE the root, as it would before a one-piece commit.  Row-sharded: the exchanges synchronise with
+    // the host anyway; commit_begin does nothing and commit_end is the whole commit.
+    int commit_begin();
+    int commit_end(Blake2sChannel& channel);
+    TreeBuilder(TreeBuilder&&) = default;
+    ~TreeBuilder() { for (auto& f : feeds) (void)f->finish(); }
   private:
     void push(DevBuf&& slab, uint32_t n, uint32_t log, bool ev, uint32_t lo, uint32_t hi) { Group g; g.slab = std::move(slab); g.n_cols = n; g.log = log; g.is_evals = ev; g.lo = lo; g.hi = hi; groups.push_back(std::move(g)); }
-    int commit_single(Blake2sChannel& channel);
     int commit_dist(Blake2sChannel& channel);
     CommitmentSchemeProver& cs;
     std::vector<Group> groups;
+    std::vector<std::unique_ptr<nx::HostFeed>> feeds;      // one per run with host-resident columns; drained (and the host unpinned) by commit_end
+    bool begun = false;
 };
 
 // The share of every group of a tree this GPU transforms: consecutive groups of one size form a run, a run's columns are cut into W

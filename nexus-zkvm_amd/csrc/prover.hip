@@ -225,17 +225,29 @@ void plan_local_columns(const std::vector<std::pair<uint32_t, uint32_t>>& groups
 // group (tree_pipe_* in merkle.hip).
 static uint32_t pipe_group_cols(const nx_ctx* ctx) { return ctx->opt.commit_pipe_cols >= 16 ? (uint32_t)ctx->opt.commit_pipe_cols : (1u << 30); }
 
-int TreeBuilder::commit(Blake2sChannel& channel) { return cs.dist.on() ? commit_dist(channel) : commit_single(channel); }
-
-int TreeBuilder::commit_single(Blake2sChannel& channel) {
+int TreeBuilder::commit_end(Blake2sChannel& channel) {
+    if (cs.dist.on()) return commit_dist(channel);
     nx_ctx* ctx = cs.ctx;
+    if (!begun) return set_err(ctx, NX_ERR_ARG, "TreeBuilder::commit_end without commit_begin");
+    begun = false;
+    CommitmentTreeProver& t = cs.trees.back();
+    H_TRY(nx_merkle_root(ctx, t.merkle.local, (uint8_t*)t.root.w));                          // the commit's synchronisation
+    t.merkle.root = t.root;
+    for (auto& f : feeds) H_TRY(f->finish());                                                // the host columns are the caller's again
+    feeds.clear();
+    channel.mix_root(t.root);                                                                // K6
+    return NX_OK;
+}
+
+int TreeBuilder::commit_begin() {
+    if (cs.dist.on()) return NX_OK;
+    nx_ctx* ctx = cs.ctx;
+    if (begun) return set_err(ctx, NX_ERR_ARG, "TreeBuilder::commit_begin twice");
     CommitmentTreeProver t;
     uint32_t max_el = 0, total_leaf_cols = 0;
     for (auto& g : groups) if (g.n_cols) max_el = std::max(max_el, g.log + cs.cfg.log_blowup);
     for (auto& g : groups) if (g.n_cols && g.log + cs.cfg.log_blowup == max_el) total_leaf_cols += g.n_cols;
     for (auto& g : groups) if (g.lo != 0 || g.hi != g.n_cols) return set_err(ctx, NX_ERR_ARG, "TreeBuilder: a column shard was handed to a single-GPU commitment scheme");
-    std::vector<std::unique_ptr<HostFeed>> feeds;      // one per run with host-resident columns; drained (and the host unpinned) before commit returns
-    struct FeedGuard { std::vector<std::unique_ptr<HostFeed>>& f; ~FeedGuard() { for (auto& x : f) (void)x->finish(); } } feed_guard{feeds};
     TreePipe tp;
     struct PipeGuard { nx_ctx* c; TreePipe* p; ~PipeGuard() { if (p->tree) { (void)nx_sync(c); nx_tree_destroy(p->tree); p->tree = nullptr; } } } guard{ctx, &tp};
     if (total_leaf_cols) { H_TRY(tree_pipe_begin(ctx, max_el, total_leaf_cols, &tp)); tp.side_stream = pipe_group_cols(ctx) < (1u << 29); }
@@ -307,12 +319,9 @@ int TreeBuilder::commit_single(Blake2sChannel& channel) {
     t.merkle.n_layers = max_el + 1;
     if (total_leaf_cols) H_TRY(tree_pipe_finish(ctx, &tp, small_cols.data(), small_logs.data(), (uint32_t)small_cols.size(), &t.merkle.local));   // K5, inner layers
     else H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &t.merkle.local));
-    H_TRY(nx_merkle_root(ctx, t.merkle.local, (uint8_t*)t.root.w));
-    t.merkle.root = t.root;
-    for (auto& f : feeds) H_TRY(f->finish());                                                // the host columns are the caller's again
-    channel.mix_root(t.root);                                                                // K6
     cs.trees.push_back(std::move(t));
     groups.clear();
+    begun = true;
     return NX_OK;
 }
 
