@@ -190,6 +190,7 @@ class TreeBuilder {
     std::vector<Group> groups;
     std::vector<std::unique_ptr<nx::HostFeed>> feeds;      // one per run with host-resident columns; drained (and the host unpinned) by commit_end
     bool begun = false;
+    size_t tree_index = 0;                                   // of the tree commit_begin appended to cs.trees
 };
 
 // The share of every group of a tree this GPU transforms: consecutive groups of one size form a run, a run's columns are cut into W

@@ -230,7 +230,7 @@ int TreeBuilder::commit_end(Blake2sChannel& channel) {
     nx_ctx* ctx = cs.ctx;
     if (!begun) return set_err(ctx, NX_ERR_ARG, "TreeBuilder::commit_end without commit_begin");
     begun = false;
-    CommitmentTreeProver& t = cs.trees.back();
+    CommitmentTreeProver& t = cs.trees[tree_index];          // not necessarily the last: a caller may begin the next tree before ending this one
     H_TRY(nx_merkle_root(ctx, t.merkle.local, (uint8_t*)t.root.w));                          // the commit's synchronisation
     t.merkle.root = t.root;
     for (auto& f : feeds) H_TRY(f->finish());                                                // the host columns are the caller's again
@@ -319,6 +319,7 @@ int TreeBuilder::commit_begin() {
     t.merkle.n_layers = max_el + 1;
     if (total_leaf_cols) H_TRY(tree_pipe_finish(ctx, &tp, small_cols.data(), small_logs.data(), (uint32_t)small_cols.size(), &t.merkle.local));   // K5, inner layers
     else H_TRY(nx_merkle_commit(ctx, nullptr, nullptr, 0, &t.merkle.local));
+    tree_index = cs.trees.size();
     cs.trees.push_back(std::move(t));
     groups.clear();
     begun = true;
