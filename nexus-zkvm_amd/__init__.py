@@ -586,6 +586,17 @@ class HipBackend:
         self._chk(self.L.nx_upload_columns(self.ctx, hp, len(cols), log, out.col_ptrs(), 1 if coset_order else 0))
         return out
 
+    def host_pin(self, arr):
+        """nx_host_pin: registers a contiguous host array with the driver once (a trace buffer reused across proofs); the entry points
+        that take host columns then skip their own per-call pinning of it.  Undo with host_unpin before the array is freed."""
+        a = np.ascontiguousarray(arr)
+        if a is not arr and not np.shares_memory(a, arr):
+            raise ValueError("host_pin needs a contiguous array (it pins the memory in place)")
+        self._chk(self.L.nx_host_pin(self.ctx, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)))
+
+    def host_unpin(self, arr):
+        self._chk(self.L.nx_host_unpin(self.ctx, C.c_void_p(np.ascontiguousarray(arr).ctypes.data)))
+
     # ---- PolyOps ----
     def precompute_twiddles(self, log_half_coset):
         return Twiddles(self, log_half_coset)

@@ -605,7 +605,7 @@ int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_col
     std::vector<bool> registered(n_cols, false);
     for (uint32_t c = 0; c < n_cols && rc == NX_OK && e == hipSuccess; c++) {
         const int k = c & 1;
-        registered[c] = hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess;   // falls back to a pageable copy
+        registered[c] = !host_pinned_by_owner(ctx, h_cols[c], bytes) && hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess;   // else pinned by its owner, or a pageable copy
         if (!registered[c]) (void)hipGetLastError();
         uint32_t* dst = coset_order ? d_tmp[k] : d_cols[c];
         if (coset_order && c >= 2) e = hipStreamWaitEvent(copy_stream, consumed[k], 0);      // the permute kernel of column c-2 has read d_tmp[k]
@@ -657,11 +657,14 @@ int HostFeed::chunk(const uint32_t* const* h_cols, uint32_t* const* d_cols, uint
     const size_t n = (size_t)1 << log, bytes = n * 4;
     for (uint32_t c = 0; c < n_cols; c++) {
         if (!h_cols[c] || !d_cols[c]) return set_err(ctx, NX_ERR_ARG, "host feed: NULL column");
-        if (hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back(h_cols[c]);
+        if (host_pinned_by_owner(ctx, h_cols[c], bytes)) {}                      // pinned once by its owner (nx_host_pin)
+        else if (hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back(h_cols[c]);
         else (void)hipGetLastError();                                            // falls back to a pageable copy
         const int k = (int)(n_done & 1);
         if (!coset_order) {
-            NX_HIP(ctx, hipMemcpyAsync(d_cols[c], h_cols[c], bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+            // no permutation to run: the second stream carries every other column's copy (two DMA queues in flight: 136.6 -> 132.7 ms
+            // for the 374-column headline trace, bench.py host_trace)
+            NX_HIP(ctx, hipMemcpyAsync(d_cols[c], h_cols[c], bytes, hipMemcpyHostToDevice, (n_done & 1) ? ctx->perm_stream : ctx->copy_stream));
         } else {
             if (n_done >= 2) NX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, consumed[k], 0));      // the permutation of column n_done - 2 has read d_tmp[k]
             NX_HIP(ctx, hipMemcpyAsync(d_tmp[k], h_cols[c], bytes, hipMemcpyHostToDevice, ctx->copy_stream));
@@ -677,6 +680,13 @@ int HostFeed::chunk(const uint32_t* const* h_cols, uint32_t* const* d_cols, uint
     hipEvent_t ev = nullptr;
     NX_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     events.push_back(ev);
+    if (!coset_order) {                                     // the chunk is ready when both queues are through it
+        hipEvent_t evp = nullptr;
+        NX_HIP(ctx, hipEventCreateWithFlags(&evp, hipEventDisableTiming));
+        events.push_back(evp);
+        NX_HIP(ctx, hipEventRecord(evp, ctx->perm_stream));
+        NX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, evp, 0));
+    }
     NX_HIP(ctx, hipEventRecord(ev, coset_order ? ctx->perm_stream : ctx->copy_stream));
     *ready = ev;
     return NX_OK;
@@ -701,6 +711,30 @@ int HostFeed::finish() {
 }
 }  // namespace nx
 extern "C" {
+
+int nx_host_pin(nx_ctx* ctx, const void* h, size_t bytes) {
+    NX_GUARD(ctx);
+    if (!ctx || !h || !bytes) return set_err(ctx, NX_ERR_ARG, "nx_host_pin: NULL / empty range");
+    {   // (the runtime accepts a second registration of a range and the first hipHostUnregister then drops both: the book is kept here)
+        auto it = ctx->owner_pinned.upper_bound((const uint8_t*)h);
+        if (it != ctx->owner_pinned.end() && it->first < (const uint8_t*)h + bytes) return set_err(ctx, NX_ERR_ARG, "nx_host_pin: the range overlaps a pinned one");
+        if (it != ctx->owner_pinned.begin()) { --it; if (it->first + it->second > (const uint8_t*)h) return set_err(ctx, NX_ERR_ARG, "nx_host_pin: the range overlaps a pinned one"); }
+    }
+    NX_HIP(ctx, hipHostRegister((void*)h, bytes, hipHostRegisterDefault));
+    ctx->owner_pinned[(const uint8_t*)h] = bytes;
+    return NX_OK;
+}
+int nx_host_unpin(nx_ctx* ctx, const void* h) {
+    NX_GUARD(ctx);
+    if (!ctx || !h) return set_err(ctx, NX_ERR_ARG, "nx_host_unpin: NULL argument");
+    auto it = ctx->owner_pinned.find((const uint8_t*)h);
+    if (it == ctx->owner_pinned.end()) return set_err(ctx, NX_ERR_ARG, "nx_host_unpin: not the start of a range pinned with nx_host_pin on this context");
+    NX_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));      // nothing of this context may still be reading it
+    NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->owner_pinned.erase(it);
+    NX_HIP(ctx, hipHostUnregister((void*)h));
+    return NX_OK;
+}
 
 int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst) {
     NX_GUARD(ctx);

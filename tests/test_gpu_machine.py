@@ -373,6 +373,25 @@ def test_machine_from_a_host_resident_trace_equals_the_device_generated_one(be, 
         pre = [c for s in be.synth_fill_tree(comps, 0, 41) for c in s.to_cpu()]
         main = [c for s in be.synth_fill_tree(comps, 1, 41) for c in s.to_cpu()]
         _same(ref, be.prove_machine_host(comps, cfg, pre, main, ad=b"host"))
+        # columns their owner pinned once (nx_host_pin: a trace buffer reused across proofs): the entry point skips its own pinning, same proof;
+        # one registration may cover many columns (a single trace slab) and a range is not pinned twice
+        slab = np.concatenate(main)
+        views, off = [], 0
+        for c in main:
+            views.append(slab[off:off + len(c)]); off += len(c)
+        be.host_pin(slab)
+        for c in pre:
+            be.host_pin(c)
+        try:
+            with pytest.raises(nz.NexusHipError):
+                be.host_pin(pre[0])
+            _same(ref, be.prove_machine_host(comps, cfg, pre, views, ad=b"host"))
+            _same(ref, be.prove_machine_host(comps, cfg, pre, views, ad=b"host"))
+        finally:
+            be.host_unpin(slab)
+            for c in pre:
+                be.host_unpin(c)
+        _same(ref, be.prove_machine_host(comps, cfg, pre, main, ad=b"host"))
 
         def natural(col):        # the coset-order column whose finalize_columns image is `col`
             n = len(col)
