@@ -339,6 +339,14 @@ impl Session {
     pub fn upload(&mut self, host_cols: &[*const u32], log_size: u32, dev_cols: &[*mut u32], coset_order: bool) -> Result<(), HipError> {
         try_check(self.ctx, unsafe { sys::nx_upload_columns(self.ctx, host_cols.as_ptr(), host_cols.len() as u32, log_size, dev_cols.as_ptr(), coset_order as i32) })
     }
+    /// A trace slab that is reused from proof to proof: pinned once by its owner (`nx_host_pin`); `upload` / `tree_commit_host` then skip
+    /// their per-call pinning of columns inside it.  Undo with `unpin_host` before the slab is dropped.
+    pub fn pin_host(&mut self, slab: &[u32]) -> Result<(), HipError> {
+        try_check(self.ctx, unsafe { sys::nx_host_pin(self.ctx, slab.as_ptr() as *const core::ffi::c_void, core::mem::size_of_val(slab)) })
+    }
+    pub fn unpin_host(&mut self, slab: &[u32]) -> Result<(), HipError> {
+        try_check(self.ctx, unsafe { sys::nx_host_unpin(self.ctx, slab.as_ptr() as *const core::ffi::c_void) })
+    }
     /// TreeBuilder::commit: interpolate, extend, Merkle-commit, mix the root
     pub fn tree_commit(&mut self) -> Result<[u8; 32], HipError> { let mut r = [0u8; 32]; try_check(self.ctx, unsafe { sys::nx_prover_tree_commit(self.p, r.as_mut_ptr()) })?; Ok(r) }
     /// TreeBuilder::extend_evals + commit for a tree whose columns are in HOST memory (begun with `tree_begin`): pinned in place, uploaded
