@@ -115,8 +115,9 @@ int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_col
  * [h, h + bytes) with the driver (hipHostRegister; the memory stays where it is), nx_host_unpin releases it.  Every entry point that takes
  * host columns (nx_upload_columns, nx_prover_tree_commit_host, nx_prove_machine_host) recognises pinned columns and skips its own
  * pin / unpin of them — the per-proof cost of pinning 6 GB of trace is what separates 135 ms from the PCIe floor in bench.py's
- * host_trace block.  Pinning is an optimisation only: results never depend on it.  Ranges pinned on one context must not overlap
- * (NX_ERR_ARG); nx_host_unpin takes the start of a pinned range and waits for the context's copies out of it. */
+ * host_trace block.  Pinning is an optimisation only: results never depend on it.  Pinned ranges must not overlap (NX_ERR_ARG; the
+ * book is process-wide, any context recognises them); nx_host_unpin takes the start of a pinned range and waits for the calling
+ * context's copies out of it. */
 int nx_host_pin(nx_ctx* ctx, const void* h, size_t bytes);
 int nx_host_unpin(nx_ctx* ctx, const void* h);
 

@@ -605,7 +605,7 @@ int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_col
     std::vector<bool> registered(n_cols, false);
     for (uint32_t c = 0; c < n_cols && rc == NX_OK && e == hipSuccess; c++) {
         const int k = c & 1;
-        registered[c] = !host_pinned_by_owner(ctx, h_cols[c], bytes) && hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess;   // else pinned by its owner, or a pageable copy
+        registered[c] = !host_pinned_by_owner(h_cols[c], bytes) && hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess;   // else pinned by its owner, or a pageable copy
         if (!registered[c]) (void)hipGetLastError();
         uint32_t* dst = coset_order ? d_tmp[k] : d_cols[c];
         if (coset_order && c >= 2) e = hipStreamWaitEvent(copy_stream, consumed[k], 0);      // the permute kernel of column c-2 has read d_tmp[k]
@@ -657,7 +657,7 @@ int HostFeed::chunk(const uint32_t* const* h_cols, uint32_t* const* d_cols, uint
     const size_t n = (size_t)1 << log, bytes = n * 4;
     for (uint32_t c = 0; c < n_cols; c++) {
         if (!h_cols[c] || !d_cols[c]) return set_err(ctx, NX_ERR_ARG, "host feed: NULL column");
-        if (host_pinned_by_owner(ctx, h_cols[c], bytes)) {}                      // pinned once by its owner (nx_host_pin)
+        if (host_pinned_by_owner(h_cols[c], bytes)) {}                      // pinned once by its owner (nx_host_pin)
         else if (hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back(h_cols[c]);
         else (void)hipGetLastError();                                            // falls back to a pageable copy
         const int k = (int)(n_done & 1);
@@ -712,26 +712,46 @@ int HostFeed::finish() {
 }  // namespace nx
 extern "C" {
 
+}  // extern "C" (re-opened below)
+namespace nx {
+// (the runtime accepts a second registration of a range, and the first hipHostUnregister then drops both: the book is kept here,
+// process-wide because the registration is)
+struct PinBook { std::mutex mu; std::map<const uint8_t*, size_t> ranges; };
+static PinBook& pin_book() { static PinBook b; return b; }
+bool host_pinned_by_owner(const void* p, size_t bytes) {
+    PinBook& b = pin_book();
+    std::lock_guard<std::mutex> lk(b.mu);
+    auto it = b.ranges.upper_bound((const uint8_t*)p);
+    if (it == b.ranges.begin()) return false;
+    --it;
+    return (const uint8_t*)p + bytes <= it->first + it->second;
+}
+}  // namespace nx
+extern "C" {
+
 int nx_host_pin(nx_ctx* ctx, const void* h, size_t bytes) {
     NX_GUARD(ctx);
     if (!ctx || !h || !bytes) return set_err(ctx, NX_ERR_ARG, "nx_host_pin: NULL / empty range");
-    {   // (the runtime accepts a second registration of a range and the first hipHostUnregister then drops both: the book is kept here)
-        auto it = ctx->owner_pinned.upper_bound((const uint8_t*)h);
-        if (it != ctx->owner_pinned.end() && it->first < (const uint8_t*)h + bytes) return set_err(ctx, NX_ERR_ARG, "nx_host_pin: the range overlaps a pinned one");
-        if (it != ctx->owner_pinned.begin()) { --it; if (it->first + it->second > (const uint8_t*)h) return set_err(ctx, NX_ERR_ARG, "nx_host_pin: the range overlaps a pinned one"); }
-    }
+    PinBook& b = pin_book();
+    std::lock_guard<std::mutex> lk(b.mu);
+    auto it = b.ranges.upper_bound((const uint8_t*)h);
+    if (it != b.ranges.end() && it->first < (const uint8_t*)h + bytes) return set_err(ctx, NX_ERR_ARG, "nx_host_pin: the range overlaps a pinned one");
+    if (it != b.ranges.begin()) { --it; if (it->first + it->second > (const uint8_t*)h) return set_err(ctx, NX_ERR_ARG, "nx_host_pin: the range overlaps a pinned one"); }
     NX_HIP(ctx, hipHostRegister((void*)h, bytes, hipHostRegisterDefault));
-    ctx->owner_pinned[(const uint8_t*)h] = bytes;
+    b.ranges[(const uint8_t*)h] = bytes;
     return NX_OK;
 }
 int nx_host_unpin(nx_ctx* ctx, const void* h) {
     NX_GUARD(ctx);
     if (!ctx || !h) return set_err(ctx, NX_ERR_ARG, "nx_host_unpin: NULL argument");
-    auto it = ctx->owner_pinned.find((const uint8_t*)h);
-    if (it == ctx->owner_pinned.end()) return set_err(ctx, NX_ERR_ARG, "nx_host_unpin: not the start of a range pinned with nx_host_pin on this context");
     NX_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));      // nothing of this context may still be reading it
+    NX_HIP(ctx, hipStreamSynchronize(ctx->perm_stream));
     NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->owner_pinned.erase(it);
+    PinBook& b = pin_book();
+    std::lock_guard<std::mutex> lk(b.mu);
+    auto it = b.ranges.find((const uint8_t*)h);
+    if (it == b.ranges.end()) return set_err(ctx, NX_ERR_ARG, "nx_host_unpin: not the start of a range pinned with nx_host_pin");
+    b.ranges.erase(it);
     NX_HIP(ctx, hipHostUnregister((void*)h));
     return NX_OK;
 }

@@ -43,7 +43,6 @@ struct nx_ctx {
     hipStream_t side[3];
     hipEvent_t fork_ev, join_ev[3];
     hipStream_t cur;   // stream the FFT launchers enqueue on (== stream outside a forked region)
-    std::map<const uint8_t*, size_t> owner_pinned;   // host ranges their owner pinned (nx_host_pin): the host-column entry points neither pin nor unpin inside them
     hipStream_t copy_stream, perm_stream;   // host-trace feed (HostFeed): PCIe copies / the R3 permutation behind them, next to the commit's kernels
     hipStream_t hash_stream;   // leaf hashing of finished column groups runs here, next to the LDE of the next group
     hipEvent_t hash_ev;
@@ -177,12 +176,9 @@ int copy_columns(nx_ctx* ctx, uint32_t* const* h_dst, const uint32_t* const* h_s
 // are pinned in place, copied on ctx->copy_stream and — coset_order — permuted into bit-reversed circle-domain order on
 // ctx->perm_stream (R3 fused); chunk() returns an event that fires when its columns are in place, so the consumer orders its own
 // stream behind it (hipStreamWaitEvent) and the host never waits.  finish() drains both streams and unpins (also on the error paths).
-inline bool host_pinned_by_owner(const nx_ctx* ctx, const void* p, size_t bytes) {
-    auto it = ctx->owner_pinned.upper_bound((const uint8_t*)p);
-    if (it == ctx->owner_pinned.begin()) return false;
-    --it;
-    return (const uint8_t*)p + bytes <= it->first + it->second;
-}
+// host ranges their owner pinned (nx_host_pin; process-wide like the driver's registration): the host-column entry points neither pin nor
+// unpin inside them
+bool host_pinned_by_owner(const void* p, size_t bytes);
 struct HostFeed {
     nx_ctx* ctx = nullptr; int coset_order = 0; uint32_t log = 0;
     uint32_t* d_tmp[2] = {nullptr, nullptr}; hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
