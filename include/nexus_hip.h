@@ -67,7 +67,8 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
  * of degree 4 / 5 that read no neighbour row are evaluated on the committed 2N rows plus the first quarter of the 4N-point domain — 3N + 1
  * samples instead of 4N; one GPU, blowup 2, component bound 2).  Kernel-shape switches kept for A/B measurement (defaults are the
  * measured best): "fft.kmax" (most layers of a non-first FFT pass, 1..11), "fft.fused" (fused middle launch of the LDE), "merkle.subtree"
- * (highest level built by the fused sub-tree launch; 0 = one launch per level), "commit.pipe_cols" (leaf hashing beside the LDE in
+ * (highest level built by the fused sub-tree launch; 0 = one launch per level), "merkle.pair_levels" (two node-only levels per launch
+ * above it), "commit.pipe_cols" (leaf hashing beside the LDE in
  * groups of this many columns; 0 = off), "fri.device_channel", "fri.tail", "logup.scan_tiled", "logup.per_column".
  * Unknown names and out-of-range values are NX_ERR_ARG.
  * None of them changes a result: proofs, roots and transforms are bit-identical under every setting. */

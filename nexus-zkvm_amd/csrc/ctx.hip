@@ -249,6 +249,7 @@ static nx_options options_from_env() {
     o.fft_kmax = clampi(env_int("NX_FFT_KMAX", 9), 1, 11);
     o.fft_fused = env_int("NX_FFT_FUSED", 1) != 0;
     o.merkle_subtree = clampi(env_int("NX_MERKLE_SUBTREE", 17), 0, 30);
+    o.merkle_pair_levels = env_int("NX_MERKLE_PAIR_LEVELS", 1) != 0;
     { int x = env_int("NX_PIPE_COLS", 0); o.commit_pipe_cols = x < 16 ? 0 : (x / 16) * 16; }
     o.fri_device_channel = env_int("NX_FRI_DEVICE_CHANNEL", 1) != 0;
     o.fri_tail = env_int("NX_FRI_TAIL", 1) != 0;
@@ -271,6 +272,7 @@ static const OptEntry k_options[] = {
     {"fft.kmax", &nx_options::fft_kmax, 1, 11},
     {"fft.fused", &nx_options::fft_fused, 0, 1},
     {"merkle.subtree", &nx_options::merkle_subtree, 0, 30},
+    {"merkle.pair_levels", &nx_options::merkle_pair_levels, 0, 1},
     {"commit.pipe_cols", &nx_options::commit_pipe_cols, 0, 1 << 20},
     {"fri.device_channel", &nx_options::fri_device_channel, 0, 1},
     {"fri.tail", &nx_options::fri_tail, 0, 1},

@@ -25,7 +25,7 @@ struct nx_options {
     // the kernels' launchers — so that a tool can still flip one on ONE context
     int fft_kmax;                 // "fft.kmax": most layers of a non-FIRST pass (runs of 2^(13-K) words), 1..11
     int fft_fused;                // "fft.fused": fused LDE middle launch (lde_mid_kernel)
-    int merkle_subtree;           // "merkle.subtree": highest tree level built by the fused subtree launch (0 = one launch per level)
+    int merkle_subtree; int merkle_pair_levels;           // "merkle.subtree": highest tree level built by the fused subtree launch (0 = one launch per level)
     int commit_pipe_cols;         // "commit.pipe_cols": leaf hashing of finished column groups of this many columns beside the next group's LDE (0 = off)
     int fri_device_channel;       // "fri.device_channel": FRI commit phase with the channel on the device
     int fri_tail;                 // "fri.tail": last FRI layers in one launch

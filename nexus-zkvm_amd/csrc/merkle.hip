@@ -135,6 +135,44 @@ __global__ __launch_bounds__(256) void merkle_layer_kernel(ColSet cols, u32 n_co
 }
 
 
+// TWO node-only levels in one launch: lane i reads the four nodes prev[4i .. 4i + 3] (128 contiguous bytes), writes the two nodes of the
+// level in between and node i of the level above them.  The same three compressions as two launches of merkle_layer_kernel, without reading
+// the middle level back and with half the launches' ramps and tails (the level launches sit at 29-32 G compressions/s against the 39.5 of
+// the compression loop: DESIGN.md section 6 item 23).
+template <int MODE>
+__global__ __launch_bounds__(256) void merkle_pair_levels_kernel(const u32* __restrict__ prev, u32* __restrict__ mid, u32* __restrict__ out, u32 n_nodes) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const u32* p = prev + (size_t)i * 32;
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = gld4(p + 4 * k);
+    u32 top[16];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        u32 h[8], m[16];
+#pragma unroll
+        for (int k = 0; k < 8; k++) h[k] = MODE == 0 ? B2S_IV_D[k] : 0u;
+        if (MODE == 0) h[0] ^= 0x01010020u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint4 w = v[4 * half + k]; m[4 * k] = w.x; m[4 * k + 1] = w.y; m[4 * k + 2] = w.z; m[4 * k + 3] = w.w; }
+        if (MODE == 0) b2s_compress(h, m, 64, 0xFFFFFFFFu); else b2s_compress(h, m, 0, 0);
+        uint4* o = reinterpret_cast<uint4*>(mid + ((size_t)2 * i + half) * 8);
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) top[8 * half + k] = h[k];
+    }
+    u32 h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = MODE == 0 ? B2S_IV_D[k] : 0u;
+    if (MODE == 0) h[0] ^= 0x01010020u;
+    if (MODE == 0) b2s_compress(h, top, 64, 0xFFFFFFFFu); else b2s_compress(h, top, 0, 0);
+    uint4* o = reinterpret_cast<uint4*>(out + (size_t)i * 8);
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
 // One column shard of a leaf layer: continue (or start) the per-row chaining state over this shard's columns.
 // `first`: the shard starts at column 0 (state = IV); `last`: it holds the layer's last column (finalisation).
 template <int MODE>
@@ -570,6 +608,16 @@ static int build_inner_layers(nx_ctx* ctx, nx_tree* t, uint32_t max_log, const s
         if (top_fused >= 1 && log <= SUBTREE_TOP && log - top_fused >= 2 && log - top_fused <= 7 && smallest_col_log > log) {
             NX_TRY(launch_merkle_subtree(ctx, buf, log + 1, log - top_fused));       // levels log .. top_fused + 1
             log = top_fused + 1;
+            continue;
+        }
+        // two node-only levels (log and log - 1) above the fused region: one launch for both
+        if (ctx->opt.merkle_pair_levels && log >= 13 && log - 1 > top_fused && !(top_fused >= 1 && log - 1 <= SUBTREE_TOP && log - 1 - top_fused >= 2 && log - 1 - top_fused <= 7)
+            && (ci >= n || (int)logs[ci] < log - 1)) {
+            const u32 nn = 1u << (log - 1);
+            if (ctx->hash_mode == NX_HASH_BLAKE2S) hipLaunchKernelGGL(merkle_pair_levels_kernel<0>, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, t->layers[log + 1], t->layers[log], t->layers[log - 1], nn);
+            else hipLaunchKernelGGL(merkle_pair_levels_kernel<1>, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, t->layers[log + 1], t->layers[log], t->layers[log - 1], nn);
+            NX_LAUNCH_CHECK(ctx);
+            log -= 1;
             continue;
         }
         size_t c0 = ci;
