@@ -55,6 +55,41 @@ def lde_roofline(stats, log_rows, n_cols_total):
 STAGES = ("trace_gen", "commit", "interaction", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")
 
 
+def _arm_guardian(fallback):
+    """A child process that prints `fallback` (one JSON line) on this process's stdout if this process dies before _disarm_guardian: the
+    child only waits on a pipe — end-of-file without the disarm byte means the parent is gone.  Returns the pipe's write end."""
+    sys.stdout.flush(); sys.stderr.flush()
+    r, w = os.pipe()
+    line = (json.dumps(fallback) + "\n").encode()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            os.close(w)
+            try:
+                os.setsid()             # a launcher that signals the worker's process group does not take the guardian with it
+            except OSError:
+                pass
+            got = os.read(r, 1)
+            if not got:
+                os.write(1, line)
+        finally:
+            os._exit(0)
+    os.close(r)
+    return (w, pid)
+
+
+def _disarm_guardian(guard):
+    if guard is None:
+        return
+    w, pid = guard
+    try:
+        os.write(w, b"x")
+        os.close(w)
+        os.waitpid(pid, 0)
+    except OSError:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,61 +234,6 @@ def main():
         except Exception as e:   # noqa: BLE001 — the headline line must still be printed
             v1 = {"error": repr(e)[:300]}
 
-    # N > 1, default mode: `value` above is N independent proofs.  The SAME run then also tries ONE row-sharded proof on the N GPUs
-    # (DESIGN.md section 7) and reports it in a block of its own: the strong-scaling number and the RCCL bring-up result of whatever
-    # multi-GPU box the driver has, at no risk to the headline — every failure, on any rank, ends as {"error": ...}, and a collective
-    # that never returns (a peer died before entering it) is cut off by a watchdog: the line is still printed, every rank still exits 0.
-    one_proof = None
-    hung = False
-    if world > 1 and not sharded and not args.no_one_proof and not args.legacy_synth:
-        import threading
-        box = {}
-
-        def attempt():
-            try:
-                import numpy as np
-                torch.cuda.set_device(local_rank)
-                if world & (world - 1):
-                    raise RuntimeError("a row-sharded proof needs a power-of-two number of GPUs")
-                if os.environ.get("NX_BENCH_ONE_PROOF_FAULT") == str(rank):      # test hook: this rank fails alone, its peers meet a missing partner
-                    raise RuntimeError("injected fault on rank %d" % rank)
-                c = make_comm()
-                chk = [(min(args.log_rows, 16), args.n_pre, args.n_main, n_inter)]
-                mine = be.prove_machine(chk, cfg, seed=77, comm=c)
-                solo = be.prove_machine(chk, cfg, seed=77)
-                ok = torch.tensor([1 if (len(mine) == len(solo) and np.array_equal(mine, solo)) else 0], dtype=torch.int32, device="cuda")
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if not int(ok.item()):
-                    raise RuntimeError("a rank's row-sharded proof of the 2^%d-row check statement differs from the single-GPU proof" % chk[0][0])
-                steps1 = max(1, min(3, args.steps))
-                be.prove_machine(comps, cfg, seed=1500, comm=c)                      # warm-up
-                barrier()
-                t0 = time.perf_counter()
-                for k in range(steps1):
-                    w1 = be.prove_machine(comps, cfg, seed=2000 + k, comm=c)
-                barrier()
-                el1 = time.perf_counter() - t0
-                t = torch.tensor([el1], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el1 = float(t.item())
-                _, st1 = be.prove_machine(comps, cfg, seed=4242, comm=c, want_stats=True)
-                box["ok"] = {"scaling": "strong", "value": (1 << args.log_rows) * steps1 / el1, "unit": "cycles/s", "ms_per_step": 1e3 * el1 / steps1, "steps": steps1,
-                             "equals_single_gpu": True, "check": "2^%d-row statement, every rank's bytes == its own single-GPU proof" % chk[0][0],
-                             "proof_words": int(len(w1)), "stages_ms": {k: round(st1[k], 3) for k in STAGES},
-                             "xgmi": {"transport": transport, "bytes_sent_per_gpu_per_proof": int(st1["comm_bytes"]), "ms_in_collectives_per_proof": round(st1["comm_ms"], 3)}}
-            except BaseException as e:   # noqa: BLE001 — the headline must survive anything here
-                box["err"] = repr(e)[:400]
-
-        th = threading.Thread(target=attempt, daemon=True)
-        th.start()
-        th.join(timeout=args.one_proof_timeout)
-        if th.is_alive():
-            hung = True
-            one_proof = {"error": "no result after %d s (a collective did not return; a peer may have failed before entering it)" % args.one_proof_timeout}
-        else:
-            # a rank that failed alone must not leave the others' blocks looking fine: agree on the outcome (bounded by the same watchdog idea)
-            one_proof = box.get("ok") or {"error": box.get("err", "unknown")}
-
     # The reference hands its trace over in HOST memory (prover/src/trace/trace_builder.rs:19-32).  `value` above has the trace generated in
     # HBM; this block times the same proof from a host-resident preprocessed + main trace, uploaded chunk by chunk UNDER the commits' own
     # transforms (nx_prove_machine_host).  PCIe-inclusive, reported next to the headline, never as `value`.
@@ -353,10 +333,70 @@ def main():
                            "collectives": "one all-to-all per trace tree (LDE columns -> row blocks), all-gather of W subtree roots per tree, of the columns read at a non-zero mask offset, of the composition accumulator and of the FRI tail; sampled / queried values (KBs)"}
         if host_trace is not None:
             out["host_trace"] = host_trace
-        if one_proof is not None:
-            out["one_proof"] = one_proof
         if v1 is not None:
             out["config_v1_shaped"] = v1
+    # N > 1, default mode: `value` above is N independent proofs.  The SAME run then also tries ONE row-sharded proof on the N GPUs
+    # (DESIGN.md section 7) and reports it in a block of its own: the strong-scaling number and the RCCL bring-up result of whatever
+    # multi-GPU box the driver has, at no risk to the headline — every failure, on any rank, ends as {"error": ...}, and a collective
+    # that never returns (a peer died before entering it) is cut off by a watchdog: the line is still printed, every rank still exits 0.
+    one_proof = None
+    hung = False
+    if world > 1 and not sharded and not args.no_one_proof and not args.legacy_synth:
+        import threading
+        box = {}
+        # the attempt drives RCCL paths no 1-GPU box has ever run: if THIS process dies in it (a fault inside a collective, or the launcher
+        # killing rank 0 because a peer died) a guardian child still prints the finished headline line, with the block reporting the death
+        guard = _arm_guardian(dict(out, one_proof={"error": "rank 0 did not survive the attempt (crashed, or was killed by the launcher after a peer died)"})) if rank == 0 else None
+
+        def attempt():
+            try:
+                import numpy as np
+                torch.cuda.set_device(local_rank)
+                if world & (world - 1):
+                    raise RuntimeError("a row-sharded proof needs a power-of-two number of GPUs")
+                if os.environ.get("NX_BENCH_ONE_PROOF_FAULT") == str(rank):      # test hook: this rank fails alone, its peers meet a missing partner
+                    raise RuntimeError("injected fault on rank %d" % rank)
+                c = make_comm()
+                chk = [(min(args.log_rows, 16), args.n_pre, args.n_main, n_inter)]
+                mine = be.prove_machine(chk, cfg, seed=77, comm=c)
+                solo = be.prove_machine(chk, cfg, seed=77)
+                ok = torch.tensor([1 if (len(mine) == len(solo) and np.array_equal(mine, solo)) else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if not int(ok.item()):
+                    raise RuntimeError("a rank's row-sharded proof of the 2^%d-row check statement differs from the single-GPU proof" % chk[0][0])
+                steps1 = max(1, min(3, args.steps))
+                be.prove_machine(comps, cfg, seed=1500, comm=c)                      # warm-up
+                barrier()
+                t0 = time.perf_counter()
+                for k in range(steps1):
+                    w1 = be.prove_machine(comps, cfg, seed=2000 + k, comm=c)
+                barrier()
+                el1 = time.perf_counter() - t0
+                t = torch.tensor([el1], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el1 = float(t.item())
+                _, st1 = be.prove_machine(comps, cfg, seed=4242, comm=c, want_stats=True)
+                box["ok"] = {"scaling": "strong", "value": (1 << args.log_rows) * steps1 / el1, "unit": "cycles/s", "ms_per_step": 1e3 * el1 / steps1, "steps": steps1,
+                             "equals_single_gpu": True, "check": "2^%d-row statement, every rank's bytes == its own single-GPU proof" % chk[0][0],
+                             "proof_words": int(len(w1)), "stages_ms": {k: round(st1[k], 3) for k in STAGES},
+                             "xgmi": {"transport": transport, "bytes_sent_per_gpu_per_proof": int(st1["comm_bytes"]), "ms_in_collectives_per_proof": round(st1["comm_ms"], 3)}}
+            except BaseException as e:   # noqa: BLE001 — the headline must survive anything here
+                box["err"] = repr(e)[:400]
+
+        th = threading.Thread(target=attempt, daemon=True)
+        th.start()
+        th.join(timeout=args.one_proof_timeout)
+        if th.is_alive():
+            hung = True
+            one_proof = {"error": "no result after %d s (a collective did not return; a peer may have failed before entering it)" % args.one_proof_timeout}
+        else:
+            # a rank that failed alone must not leave the others' blocks looking fine: agree on the outcome (bounded by the same watchdog idea)
+            one_proof = box.get("ok") or {"error": box.get("err", "unknown")}
+        _disarm_guardian(guard)
+
+    if rank == 0:
+        if one_proof is not None:
+            out["one_proof"] = one_proof
         if not args.no_cpu_baseline and world == 1:
             import oracle_lib as O   # checker / baseline only — never part of the measured GPU path
             import numpy as np
