@@ -353,38 +353,47 @@ void nx_ctx_destroy(nx_ctx* ctx) {
 }
 
 int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode) {
+    if (!ctx) return set_err(nullptr, NX_ERR_ARG, "nx_ctx_set_hash_mode: NULL context");
     if (mode != NX_HASH_BLAKE2S && mode != NX_HASH_BLAKE2S_RAW0) return set_err(ctx, NX_ERR_ARG, "bad hash mode");
     ctx->hash_mode = mode;
     return NX_OK;
 }
 
-int nx_sync(nx_ctx* ctx) { NX_GUARD(ctx); NX_HIP(ctx, hipStreamSynchronize(ctx->stream)); NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream)); return NX_OK; }
+int nx_sync(nx_ctx* ctx) { NX_GUARD(ctx); if (!ctx) return set_err(nullptr, NX_ERR_ARG, "nx_sync: NULL context"); NX_HIP(ctx, hipStreamSynchronize(ctx->stream)); NX_HIP(ctx, hipStreamSynchronize(ctx->hash_stream)); return NX_OK; }
 int nx_ctx_trim(nx_ctx* ctx) { NX_GUARD(ctx); if (!ctx) return set_err(nullptr, NX_ERR_ARG, "nx_ctx_trim: NULL context"); NX_TRY(nx_sync(ctx)); dev_cache_release(ctx); return NX_OK; }
-void* nx_ctx_stream(nx_ctx* ctx) { return (void*)ctx->stream; }
+void* nx_ctx_stream(nx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int nx_alloc(nx_ctx* ctx, size_t n_words, uint32_t** d_out) {
     NX_GUARD(ctx);
+    if (!ctx || !d_out) return set_err(ctx, NX_ERR_ARG, "nx_alloc: NULL argument");
     *d_out = nullptr;
     return dev_alloc(ctx, n_words * 4, (void**)d_out);
 }
 int nx_free(nx_ctx* ctx, uint32_t* d_ptr) {
     NX_GUARD(ctx);
+    if (!ctx) return set_err(nullptr, NX_ERR_ARG, "nx_free: NULL context");
     dev_free(ctx, d_ptr);
     return NX_OK;
 }
 int nx_memset_zero(nx_ctx* ctx, uint32_t* d_ptr, size_t n_words) {
     NX_GUARD(ctx);
+    if (!ctx || (!d_ptr && n_words)) return set_err(ctx, NX_ERR_ARG, "nx_memset_zero: NULL argument");
+    if (!n_words) return NX_OK;
     NX_HIP(ctx, hipMemsetAsync(d_ptr, 0, n_words * 4, ctx->stream));
     return NX_OK;
 }
 int nx_upload(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* h_src, size_t n_words) {
     NX_GUARD(ctx);
+    if (!ctx || ((!d_dst || !h_src) && n_words)) return set_err(ctx, NX_ERR_ARG, "nx_upload: NULL argument");
+    if (!n_words) return NX_OK;
     NX_HIP(ctx, hipMemcpyAsync(d_dst, h_src, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
     NX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_src may be pageable and reused by the caller
     return NX_OK;
 }
 int nx_download(nx_ctx* ctx, uint32_t* h_dst, const uint32_t* d_src, size_t n_words) {
     NX_GUARD(ctx);
+    if (!ctx || ((!h_dst || !d_src) && n_words)) return set_err(ctx, NX_ERR_ARG, "nx_download: NULL argument");
+    if (!n_words) return NX_OK;
     NX_HIP(ctx, hipMemcpyAsync(h_dst, d_src, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NX_OK;
@@ -392,6 +401,7 @@ int nx_download(nx_ctx* ctx, uint32_t* h_dst, const uint32_t* d_src, size_t n_wo
 
 int nx_copy(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words) {
     NX_GUARD(ctx);
+    if (!ctx || ((!d_dst || !d_src) && n_words)) return set_err(ctx, NX_ERR_ARG, "nx_copy: NULL argument");
     if (n_words == 0) return NX_OK;
     if ((n_words & 3) || ((uintptr_t)d_dst & 15) || ((uintptr_t)d_src & 15)) {
         NX_HIP(ctx, hipMemcpyAsync(d_dst, d_src, n_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -429,6 +439,7 @@ int nx_m31_narrow(nx_ctx* ctx, uint32_t* d_dst, const uint64_t* d_src, size_t n_
 
 int nx_gather(nx_ctx* ctx, const uint32_t* const* d_ptrs, const uint64_t* index, size_t n, uint32_t* h_out) {
     NX_GUARD(ctx);
+    if (!ctx || ((!d_ptrs || !index || !h_out) && n)) return set_err(ctx, NX_ERR_ARG, "nx_gather: NULL argument");
     if (n == 0) return NX_OK;
     uint8_t* d = nullptr;
     size_t bytes = n * (8 + 8 + 4);

@@ -539,6 +539,7 @@ void nx_twiddles_destroy(nx_twiddles* tw) {
 
 int nx_twiddles_download(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* h_tw, uint32_t* h_itw) {
     NX_GUARD(ctx);
+    if (!ctx || !tw || !h_tw || !h_itw) return set_err(ctx, NX_ERR_ARG, "nx_twiddles_download: NULL argument");
     NX_TRY(nx_download(ctx, h_tw, tw->d_tw, (size_t)1 << tw->log_half));
     return nx_download(ctx, h_itw, tw->d_itw, (size_t)1 << tw->log_half);
 }
@@ -562,6 +563,8 @@ int nx_evaluate_batch(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const*
 
 int nx_bit_reverse(nx_ctx* ctx, uint32_t* d_col, uint32_t log_size) {
     NX_GUARD(ctx);
+    if (!ctx || !d_col) return set_err(ctx, NX_ERR_ARG, "nx_bit_reverse: NULL argument");
+    if (log_size > 31) return set_err(ctx, NX_ERR_ARG, "nx_bit_reverse: log_size too large");
     u32 n = 1u << log_size;
     hipLaunchKernelGGL(bit_reverse_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_col, (int)log_size);
     NX_LAUNCH_CHECK(ctx);
@@ -758,6 +761,8 @@ int nx_host_unpin(nx_ctx* ctx, const void* h) {
 
 int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_size, uint32_t* d_dst) {
     NX_GUARD(ctx);
+    if (!ctx || !h_natural || !d_dst) return set_err(ctx, NX_ERR_ARG, "nx_upload_coset_order: NULL argument");
+    if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_upload_coset_order: bad log_size");
     uint32_t* d_tmp = nullptr;
     size_t n = (size_t)1 << log_size;
     NX_TRY(dev_alloc(ctx, n * 4, (void**)&d_tmp));

@@ -793,10 +793,11 @@ int nx_merkle_from_leaves(nx_ctx* ctx, const uint32_t* d_leaf_digests, uint32_t 
 
 int nx_merkle_root(nx_ctx* ctx, const nx_tree* tree, uint8_t root[32]) {
     NX_GUARD(ctx);
+    if (!ctx || !tree || !root || tree->layers.empty()) return set_err(ctx, NX_ERR_ARG, "nx_merkle_root: NULL argument");
     return nx_download(ctx, (uint32_t*)root, tree->layers[0], 8);
 }
-uint32_t nx_merkle_n_layers(const nx_tree* tree) { return (uint32_t)tree->layers.size(); }
-const uint32_t* nx_merkle_layer(const nx_tree* tree, uint32_t k) { return k < tree->layers.size() ? tree->layers[k] : nullptr; }
+uint32_t nx_merkle_n_layers(const nx_tree* tree) { return tree ? (uint32_t)tree->layers.size() : 0; }
+const uint32_t* nx_merkle_layer(const nx_tree* tree, uint32_t k) { return tree && k < tree->layers.size() ? tree->layers[k] : nullptr; }
 
 void nx_tree_destroy(nx_tree* tree) {
     NX_GUARD(tree ? tree->ctx : nullptr);
@@ -807,6 +808,7 @@ void nx_tree_destroy(nx_tree* tree) {
 
 int nx_grind(nx_ctx* ctx, const uint8_t digest[32], uint32_t pow_bits, uint64_t* nonce) {
     NX_GUARD(ctx);
+    if (!ctx || !digest || !nonce) return set_err(ctx, NX_ERR_ARG, "nx_grind: NULL argument");
     if (pow_bits > 64) return set_err(ctx, NX_ERR_ARG, "nx_grind: pow_bits > 64");
     struct { uint32_t d[8]; unsigned long long res; } h;
     memcpy(h.d, digest, 32);

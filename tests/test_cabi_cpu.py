@@ -54,3 +54,40 @@ def test_header_is_plain_c99_and_the_c_example_links(tmp_path):
     lib_dir = os.path.join(root, "nexus-zkvm_amd")
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "session_prove.c"),
                     "-L" + lib_dir, "-lnexus_hip", "-Wl,-rpath," + lib_dir, "-o", str(tmp_path / "session_prove")], check=True)
+
+
+def test_null_arguments_are_errors_not_crashes():
+    """The boundary's error behaviour needs no GPU: EVERY export, called with all-zero arguments (NULL context, NULL pointers, zero sizes),
+    returns — an error code, NULL or 0 — instead of taking its caller down (the reference's `vec![]` would abort on a failed allocation,
+    trace_builder.rs:29; a C ABI must not).  Each call runs in its own process: a crash is a test failure naming the function."""
+    import re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "nexus_hip.h")).read(), flags=re.S)
+    protos = re.findall(r"^\s*(?:int|void|const char\*|uint32_t|const uint32_t\*|void\*)\s+(nx_\w+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.M | re.S)
+    assert len(protos) >= 90
+    child = ("import sys, ctypes as C\nsys.path.insert(0, %r)\nimport nexus_zkvm_amd as nz\nL = nz.load_library()\n"
+             "for spec in sys.argv[1:]:\n    name, n = spec.split(':'); f = getattr(L, name); f.restype = C.c_int64; f.argtypes = [C.c_void_p] * int(n)\n"
+             "    print('call', name, flush=True); f(*[C.c_void_p(0) for _ in range(int(n))])\nprint('done')\n") % root
+    specs = []
+    for name, params in protos:
+        params = params.strip()
+        specs.append("%s:%d" % (name, 0 if params in ("", "void") else len(params.split(","))))
+    r = subprocess.run([sys.executable, "-c", child] + specs, capture_output=True, text=True, timeout=300)
+    last = [l for l in r.stdout.splitlines() if l.startswith("call ")]
+    assert r.returncode == 0 and r.stdout.strip().endswith("done"), "crashed in %s (rc %d)" % (last[-1] if last else "?", r.returncode)
+    # ... and the documented error code where there is one to give
+    import nexus_zkvm_amd as nz
+    L = nz.load_library()
+    n32 = C.c_uint32(0)
+    out = C.c_void_p()
+    for name, call in {
+        "nx_host_pin": lambda: L.nx_host_pin(None, None, C.c_size_t(0)),
+        "nx_alloc": lambda: L.nx_alloc(None, C.c_size_t(16), None),
+        "nx_sync": lambda: L.nx_sync(None),
+        "nx_grind": lambda: L.nx_grind(None, None, 0, None),
+        "nx_comm_group_create": lambda: L.nx_comm_group_create(0, C.byref(out)),
+        "nx_machine_claimed_sums": lambda: L.nx_machine_claimed_sums(None, None, 0, C.byref(n32)),
+        "nx_prover_tree_commit_host": lambda: L.nx_prover_tree_commit_host(None, None, 0, None, 0, None, None),
+    }.items():
+        assert call() == -2, name                        # NX_ERR_ARG
+        assert L.nx_last_error(None), name
