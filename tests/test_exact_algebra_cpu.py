@@ -174,3 +174,29 @@ def test_degree_four_quotient_from_3n_plus_1_samples(oracle):
     t = (g[N] - Iw) * inv(z1 - z0) % P
     I[0] = (I[0] - t * z0) % P
     assert [int(x) for x in f0] + I + [t] + [0] * (N - 1) == full
+
+
+def test_neighbour_rows_of_the_first_quarter_are_the_second_quarter(oracle):
+    """The next lever of the quarter-domain composition: a constraint of degree 4 / 5 that reads a neighbour row
+    (mask offset +-1) is kept on the 4N-point domain today.  The first quarter of the bit-reversed 4N-point domain is +-(g + <g_{N/2}>)
+    with g of order 8N; the trace step has order N, and g + g_N lands in the coset whose bit-reversed positions are the SECOND quarter
+    (index bits 10 below the top), an even multiple of the step back in the first.  So the neighbour reads of the quarter-domain rows
+    need one more N-point transform per neighbour-read column (the second quarter), not the 4N-point extension.  Checked with the
+    oracle's own evaluator: the values a LOAD at offset +-1 / +-2 sees on rows [0, N) of the 4N-point domain are exactly the column's
+    extension values at rows [N, 2N) / [0, N), each once."""
+    import nexus_zkvm_amd.air_program as ap
+    for n in (4, 6):
+        N = 1 << n
+        rng = np.random.default_rng(n)
+        T = O.Twiddles(n + 2)
+        co = T.interpolate(rng.integers(0, P, N, dtype=np.uint32))
+        E = T.evaluate(co, n + 2)
+        assert len(set(int(v) for v in E)) == 4 * N          # distinct values: positions can be read off
+        pos = {int(v): i for i, v in enumerate(E)}
+        for off, quarter in ((1, 1), (-1, 1), (2, 0), (-2, 0), (3, 1)):
+            b = ap.ProgramBuilder()
+            (x,) = b.next_trace_mask(0, (off,))
+            b.add_constraint(x)
+            seen = O.eval_constraint_program(b.build(), [E], [1, 0, 0, 0], np.ones(4 * N, np.uint32), n, n + 2)[0]
+            idx = [pos[int(v)] for v in seen[:N]]
+            assert sorted(idx) == list(range(quarter * N, (quarter + 1) * N)), (n, off)
