@@ -255,7 +255,23 @@ typedef struct nx_component_spec {
      * shifts 2, prover2/machine/src/framework/traits/builtin.rs:23, composition size = the maximum, prove.rs:44-48).
      * 0 = nx_pcs_config.log_constraint_degree; otherwise 1 <= bound <= that field (the twiddle tree is sized by the config's). */
     uint32_t log_constraint_degree_bound;
+    /* nx_prove_machine only — how the component's F logup fractions fill its L = n_inter / 4 logup columns (NX_LOGUP_* below). */
+    uint32_t logup_mode;
 } nx_component_spec;
+/* nx_component_spec.logup_mode, a bit set:
+ *   0                 one fraction per column, F = L: EvalAtRow::finalize_logup as the v1 main component and the multiplicity tables
+ *                     use it (reference prover/src/components/mod.rs:53, prover/src/extensions/multiplicity.rs:123) — degree-2 constraints;
+ *   NX_LOGUP_PAIRS    two fractions per column, F = 2 L: finalize_logup_in_pairs (reference prover/src/extensions/keccak/round/
+ *                     constraints.rs:116, keccak/memory_check/constraints.rs:125, extensions/final_reg.rs:112, every prover2 component:
+ *                     prover2/machine/src/components/.../mod.rs) over columns built pairwise, (a d + b c) / (b d), by
+ *                     LogupTraceBuilder::add_to_relation_with (prover2/machine/src/lookups/logup_trace_builder.rs:86-101) — the
+ *                     constraint (S_j - S_{j-1}) d0 d1 - (n0 d1 + n1 d0) has degree 3 under the bound +1;
+ *   NX_LOGUP_ODD      with PAIRS: F = 2 L - 1, the last column holds the one left-over fraction (LogupTraceBuilder::finalize,
+ *                     logup_trace_builder.rs:110-117; finalize_logup_in_pairs with an odd number of add_to_relation calls);
+ *   NX_LOGUP_TABLE    the table side of a lookup: every tuple reads PREPROCESSED columns (get_preprocessed_column) and every numerator is
+ *                     a negated multiplicity column of the main trace (reference prover/src/extensions/multiplicity.rs:111-124,
+ *                     extensions/keccak/bitwise_table/mod.rs). */
+enum { NX_LOGUP_PAIRS = 1, NX_LOGUP_ODD = 2, NX_LOGUP_TABLE = 4 };
 
 typedef struct nx_pcs_config {
     uint32_t pow_bits, log_blowup, n_queries, log_last_layer_degree_bound; /* PcsConfig / FriConfig */
@@ -307,6 +323,12 @@ int nx_proof_serialize_stwo(const uint32_t* proof_words, size_t n_words, const u
 struct nx_comm;
 /* The HIP source nx_air_compile generates for the recorded AIR of one such component (host only; free with nx_free_host). */
 int nx_machine_air_source(const nx_component_spec* comp, char** h_source);
+/* The recorded program itself (host only): what nx_prove_machine hands to nx_air_compile for this component under a configuration
+ * whose log_constraint_degree is cfg_log_constraint_degree — so that a CPU checker can run the product's emission through its own
+ * interpreter.  Secure constants: [z, alpha, claimed / N, 0].  *h_program: free with nx_free_host. */
+struct nx_cinstr;
+int nx_machine_air_program(const nx_component_spec* comp, uint32_t cfg_log_constraint_degree, struct nx_cinstr** h_program,
+                           uint32_t* n_instr, uint32_t* n_regs, uint32_t* n_constraints);
 int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed,
                      const uint8_t* ad, size_t ad_len, const struct nx_comm* comm, uint32_t** proof_words, size_t* n_words,
                      nx_prove_stats* stats);
@@ -537,6 +559,13 @@ int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, co
 /* The n_cols logup columns of a component in ONE launch: column j = sum over i <= j of fraction i(row), i.e. what n_cols calls of
  * nx_logup_col with d_prev4 = the previous column produce, reading every tuple column once.  d_out: 4 n_cols coordinate columns. */
 int nx_logup_cols(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, uint32_t n_cols, uint32_t* const* d_out);
+/* The general form, stwo-constraint-framework's finalize_logup_batched on the trace side: fraction i belongs to batch batching[i]
+ * (any order; every batch 0 .. n_cols - 1 must hold at least one fraction), column j = sum of the fractions of batches <= j — the
+ * merged fraction (a d + b c) / (b d) of a pair (LogupTraceBuilder::add_to_relation_with, reference prover2/machine/src/lookups/
+ * logup_trace_builder.rs:86-101) is the sum of its two fractions.  batching NULL = in pairs (i / 2: finalize_logup_in_pairs; an odd
+ * n_fracs leaves the last column one fraction).  One launch; every tuple column is read once.  d_out: 4 n_cols coordinate columns. */
+int nx_logup_cols_batched(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, uint32_t n_fracs, const uint32_t* batching,
+                          uint32_t n_cols, uint32_t* const* d_out);
 /* LogupTraceGenerator::finalize_last on the last column (in place): claimed_sum = sum over all rows; the column becomes
  * the inclusive prefix sum, in natural coset order, of (value - claimed_sum / 2^log_size). */
 int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_col4, uint32_t claimed_sum[4]);

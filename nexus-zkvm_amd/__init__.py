@@ -46,7 +46,11 @@ class NexusHipError(RuntimeError):
 
 class ComponentSpec(C.Structure):
     _fields_ = [("log_size", C.c_uint32), ("n_pre", C.c_uint32), ("n_main", C.c_uint32), ("n_inter", C.c_uint32),
-                ("log_constraint_degree_bound", C.c_uint32)]   # 0 = the config's log_constraint_degree
+                ("log_constraint_degree_bound", C.c_uint32),   # 0 = the config's log_constraint_degree
+                ("logup_mode", C.c_uint32)]                    # nx_prove_machine: LOGUP_PAIRS | LOGUP_ODD | LOGUP_TABLE (0: one fraction per column)
+
+
+LOGUP_PAIRS, LOGUP_ODD, LOGUP_TABLE = 1, 2, 4                   # nx_component_spec.logup_mode (include/nexus_hip.h NX_LOGUP_*)
 
 
 class PcsConfig(C.Structure):
@@ -821,6 +825,26 @@ class HipBackend:
         self._chk(self.L.nx_logup_cols(self.ctx, log, arr, len(fracs), ptrs))
         return outs
 
+    def logup_cols_batched(self, fracs, batching=None, n_cols=None):
+        """finalize_logup_batched on the trace side (nx_logup_cols_batched): fraction i belongs to batch batching[i] (None: in pairs,
+        i // 2), column j = the sum of the fractions of batches <= j.  Returns one 4-column DeviceColumns per logup column."""
+        keep, arr = [], (LogupFrac * len(fracs))()
+        for i, f in enumerate(fracs):
+            t = f["tuple"]
+            ptrs = t.col_ptrs(); ap = _u32(f["alphas"]).reshape(-1); z = _u32(f["z"]); sc = _u32(f.get("scale", (1, 0, 0, 0)))
+            keep.extend([ptrs, ap, z, sc])
+            m = f.get("mult")
+            arr[i] = LogupFrac(C.cast(ptrs, C.c_void_p), t.n_cols, ap.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                               m.ptr if m is not None else None, sc.ctypes.data_as(C.c_void_p))
+        log = fracs[0]["tuple"].log_size
+        if n_cols is None:
+            n_cols = (len(fracs) + 1) // 2 if batching is None else max(batching) + 1
+        outs = [DeviceColumns(self, 4, log) for _ in range(n_cols)]
+        ptrs = (C.c_void_p * (4 * n_cols))(*[o.ptr.value + k * (4 << log) for o in outs for k in range(4)])
+        b = None if batching is None else _u32(batching)
+        self._chk(self.L.nx_logup_cols_batched(self.ctx, log, arr, len(fracs), b.ctypes.data_as(C.c_void_p) if b is not None else None, n_cols, ptrs))
+        return outs
+
     def logup_finalize_last(self, col4):
         """LogupTraceGenerator::finalize_last in place; returns the claimed sum (4 words)."""
         cs = np.zeros(4, np.uint32)
@@ -857,7 +881,7 @@ class HipBackend:
     # ---- synthetic machine ----
     @staticmethod
     def _comps(comps):
-        return (ComponentSpec * len(comps))(*[ComponentSpec(*[int(x) for x in c]) for c in comps])   # 4- or 5-tuples (bound defaults to 0)
+        return (ComponentSpec * len(comps))(*[ComponentSpec(*[int(x) for x in c]) for c in comps])   # 4-, 5- or 6-tuples (bound and logup_mode default to 0)
 
     def synth_fill_tree(self, comps, tree, seed, inter_seed=0):
         sets = []

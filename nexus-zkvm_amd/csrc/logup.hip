@@ -14,6 +14,7 @@
 #include "internal.h"
 #include <algorithm>
 #include <string.h>
+#include <string>
 #include <stdlib.h>
 
 namespace nx {
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(256) void logup_col_kernel(LogupTupleFrac fa, Logup
 // running sum of the row's first j + 1 fractions, so a lane walks the fractions of its row once — every tuple column is read once,
 // no previous column is re-read, 16 bytes are written per column.  Descriptors live in device memory (flat pointer / alpha-power
 // tables), so the tuple width is not limited by the kernel argument size (the reference's widest relation has 200 elements).
-struct LogupBatchFrac { u32 first_col, n_cols, first_ap, pad; const u32* mult; QM31 z, scale; };
+// out_col: 1 + the logup column the running sum is stored to after this fraction (the last fraction of a batch), 0 = none
+struct LogupBatchFrac { u32 first_col, n_cols, first_ap, out_col; const u32* mult; QM31 z, scale; };
 // The QM31 inverse of a denominator is (conj-style) den^-1 = (a, -b) * D^-1 with D = a^2 - (2+i) b^2 in CM31 and D^-1 = conj(D) / N,
 // N = D.a^2 + D.b^2 in M31: the one expensive step is the M31 inverse of N (37 multiplications of the 57 of q_inv).  A lane walks
 // the fractions of its row in groups of LOGUP_GROUP and inverts the group's norms with ONE m_inv (Montgomery's trick on the M31 norms:
@@ -97,7 +99,7 @@ struct LogupBatchFrac { u32 first_col, n_cols, first_ap, pad; const u32* mult; Q
 // denominator (norm 0) still gives 0 like m_inv(0), and does not poison its group.
 constexpr int LOGUP_GROUP = 8;
 __global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* __restrict__ fr, u32 n_fracs, const u32* const* __restrict__ tuple_cols,
-                                                         const u32* __restrict__ ap /*4 words each*/, u32* const* __restrict__ out /*4 per fraction*/, u32 n) {
+                                                         const u32* __restrict__ ap /*4 words each*/, u32* const* __restrict__ out /*4 per logup column*/, u32 n) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     QM31 run = q_zero();
@@ -143,7 +145,10 @@ __global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* _
                     const QM31 num = f.mult ? q_mul_m(f.scale, gld(f.mult + r)) : f.scale;
                     run = q_add(run, q_mul(num, qi));
                 }
-                gst(out[4 * j] + r, run.a.a); gst(out[4 * j + 1] + r, run.a.b); gst(out[4 * j + 2] + r, run.b.a); gst(out[4 * j + 3] + r, run.b.b);
+                if (f.out_col) {                                               // uniform: the batch is complete (finalize_logup_batched: one column per batch)
+                    const u32 oc = f.out_col - 1;
+                    gst(out[4 * oc] + r, run.a.a); gst(out[4 * oc + 1] + r, run.a.b); gst(out[4 * oc + 2] + r, run.b.a); gst(out[4 * oc + 3] + r, run.b.b);
+                }
             }
         }
     }
@@ -401,24 +406,38 @@ int nx_logup_col(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* frac_a, co
 }
 
 
-// n_cols logup columns of one component in one launch: column j = sum over i <= j of fraction i (what n_cols calls of nx_logup_col
-// with d_prev4 = the previous column produce).  d_out: 4 n_cols coordinate columns.
-int nx_logup_cols(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, uint32_t n_cols, uint32_t* const* d_out) {
-    NX_GUARD(ctx);
-    if (!ctx || (n_cols && (!fracs || !d_out))) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: NULL argument");
-    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: log_size too large");
-    if (!n_cols) return NX_OK;
-    std::vector<LogupBatchFrac> h(n_cols);
-    std::vector<const u32*> cols; std::vector<u32> ap;
-    for (u32 j = 0; j < n_cols; j++) {
-        const nx_logup_frac& f = fracs[j];
-        if (!f.alpha_powers || !f.z || !f.scale || (f.n_tuple_cols && !f.d_tuple_cols)) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: incomplete fraction");
-        h[j].first_col = (u32)cols.size(); h[j].n_cols = f.n_tuple_cols; h[j].first_ap = (u32)(ap.size() / 4); h[j].pad = 0;
-        for (u32 k = 0; k < f.n_tuple_cols; k++) { if (!f.d_tuple_cols[k]) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: NULL tuple column"); cols.push_back(f.d_tuple_cols[k]); }
-        ap.insert(ap.end(), f.alpha_powers, f.alpha_powers + 4 * (size_t)f.n_tuple_cols);
-        h[j].mult = f.d_mult; h[j].z = q_load(f.z); h[j].scale = q_load(f.scale);
-        for (int q = 0; q < 4; q++) if (!d_out[4 * j + q]) return set_err(ctx, NX_ERR_ARG, "nx_logup_cols: NULL output column");
+// The logup columns of one component in one launch: fraction i belongs to batch batching[i], column j = the sum of the fractions of
+// batches <= j (finalize_logup_batched on the trace side).  The fractions are walked in batch order (a stable sort by batch: the sum
+// does not depend on the order inside a batch); the last fraction of a batch stores the running sum.  d_out: 4 n_cols coordinate columns.
+static int logup_cols_launch(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, uint32_t n_fracs, const uint32_t* batching, uint32_t n_cols, uint32_t* const* d_out,
+                             const char* who) {
+    if (!ctx || (n_fracs && !fracs) || (n_cols && !d_out)) return set_err(ctx, NX_ERR_ARG, std::string(who) + ": NULL argument");
+    if (log_size > 30) return set_err(ctx, NX_ERR_ARG, std::string(who) + ": log_size too large");
+    if (!n_cols && !n_fracs) return NX_OK;
+    if (!n_cols || n_fracs < n_cols) return set_err(ctx, NX_ERR_ARG, std::string(who) + ": every logup column needs at least one fraction");
+    std::vector<u32> order(n_fracs), batch(n_fracs);
+    for (u32 i = 0; i < n_fracs; i++) {
+        order[i] = i; batch[i] = batching ? batching[i] : i;
+        if (batch[i] >= n_cols) return set_err(ctx, NX_ERR_ARG, std::string(who) + ": batch index outside the logup columns");
     }
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return batch[a] < batch[b]; });
+    {
+        std::vector<char> seen(n_cols, 0);
+        for (u32 i = 0; i < n_fracs; i++) seen[batch[i]] = 1;
+        for (u32 j = 0; j < n_cols; j++) if (!seen[j]) return set_err(ctx, NX_ERR_ARG, std::string(who) + ": a batch without fractions (finalize_logup_batched requires every batch 0 .. last)");
+    }
+    std::vector<LogupBatchFrac> h(n_fracs);
+    std::vector<const u32*> cols; std::vector<u32> ap;
+    for (u32 s = 0; s < n_fracs; s++) {
+        const nx_logup_frac& f = fracs[order[s]];
+        if (!f.alpha_powers || !f.z || !f.scale || (f.n_tuple_cols && !f.d_tuple_cols)) return set_err(ctx, NX_ERR_ARG, std::string(who) + ": incomplete fraction");
+        h[s].first_col = (u32)cols.size(); h[s].n_cols = f.n_tuple_cols; h[s].first_ap = (u32)(ap.size() / 4);
+        h[s].out_col = (s + 1 == n_fracs || batch[order[s + 1]] != batch[order[s]]) ? batch[order[s]] + 1 : 0;
+        for (u32 k = 0; k < f.n_tuple_cols; k++) { if (!f.d_tuple_cols[k]) return set_err(ctx, NX_ERR_ARG, std::string(who) + ": NULL tuple column"); cols.push_back(f.d_tuple_cols[k]); }
+        ap.insert(ap.end(), f.alpha_powers, f.alpha_powers + 4 * (size_t)f.n_tuple_cols);
+        h[s].mult = f.d_mult; h[s].z = q_load(f.z); h[s].scale = q_load(f.scale);
+    }
+    for (size_t k = 0; k < 4 * (size_t)n_cols; k++) if (!d_out[k]) return set_err(ctx, NX_ERR_ARG, std::string(who) + ": NULL output column");
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t b_fr = h.size() * sizeof(LogupBatchFrac), b_cols = cols.size() * 8, b_ap = ap.size() * 4, b_out = (size_t)n_cols * 32;
     const size_t o_cols = al(b_fr), o_ap = o_cols + al(b_cols), o_out = o_ap + al(b_ap), total = o_out + al(b_out) + 16;
@@ -439,13 +458,28 @@ int nx_logup_cols(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, ui
     }
     const u32 n = 1u << log_size;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(logup_cols_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const LogupBatchFrac*)blob, n_cols, (const u32* const*)(blob + o_cols),
+        hipLaunchKernelGGL(logup_cols_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const LogupBatchFrac*)blob, n_fracs, (const u32* const*)(blob + o_cols),
                            (const u32*)(blob + o_ap), (u32* const*)(blob + o_out), n);
         e = hipGetLastError();
     }
     dev_free(ctx, blob);   // stream-ordered: reused only by later work on this stream
-    if (e != hipSuccess) return hip_fail(ctx, e, "nx_logup_cols", __FILE__, __LINE__);
+    if (e != hipSuccess) return hip_fail(ctx, e, who, __FILE__, __LINE__);
     return NX_OK;
+}
+
+// n_cols logup columns of one component in one launch: column j = sum over i <= j of fraction i (what n_cols calls of nx_logup_col
+// with d_prev4 = the previous column produce).  d_out: 4 n_cols coordinate columns.
+int nx_logup_cols(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, uint32_t n_cols, uint32_t* const* d_out) {
+    NX_GUARD(ctx);
+    return logup_cols_launch(ctx, log_size, fracs, n_cols, nullptr, n_cols, d_out, "nx_logup_cols");
+}
+
+int nx_logup_cols_batched(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac* fracs, uint32_t n_fracs, const uint32_t* batching, uint32_t n_cols, uint32_t* const* d_out) {
+    NX_GUARD(ctx);
+    if (batching) return logup_cols_launch(ctx, log_size, fracs, n_fracs, batching, n_cols, d_out, "nx_logup_cols_batched");
+    std::vector<uint32_t> pairs(n_fracs);
+    for (uint32_t i = 0; i < n_fracs; i++) pairs[i] = i / 2;
+    return logup_cols_launch(ctx, log_size, fracs, n_fracs, pairs.data(), n_cols, d_out, "nx_logup_cols_batched");
 }
 
 // LogupTraceGenerator::finalize_last for n_cols secure columns of one size in three launches and ONE device-to-host copy (the

@@ -147,6 +147,7 @@ static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_c
                        size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st) {
     PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
     H_TRY(check_components(ctx, comps, n_comps, ucfg));
+    for (uint32_t i = 0; i < n_comps; i++) if (comps[i].logup_mode) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth: logup_mode is nx_prove_machine's (this machine's interaction trace is a synthetic fill)");
     H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
     uint32_t max_log = 0;
     std::vector<Loc> locs = locations(comps, n_comps, &max_log);
@@ -192,18 +193,37 @@ static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_c
 }
 
 // ================================================================ nx_prove_machine: real logup + recorded AIR ===========
-// Component (log_size, n_pre, n_main, n_inter = 4 L): L logup columns.  Fraction j of a row:
-//   den_j = main[a_j] - z                       (j even: a one-element tuple, like the reference's check_bytes limb, range256.rs:281-284)
-//         = main[a_j] + alpha main[b_j] - z     (j odd: a two-element tuple)
-//   num_j = 1,  or  -main[m_j] when j % 3 == 2  (the table side of a lookup: a negated multiplicity column)
-//   a_j = (3 + 7 j) % n_main, b_j = (5 + 11 j) % n_main, m_j = (2 + 13 j) % n_main
-// Logup column j holds sum_{i <= j} fraction_i(row) (LogupColGenerator::finalize_col); the last one is finalised by
-// LogupTraceGenerator::finalize_last (claimed sum; prefix sum over the rows of value - claimed / N).
+// Component (log_size, n_pre, n_main, n_inter = 4 L, bound, logup_mode): L logup columns holding F fractions — F = L (one per column),
+// 2 L (NX_LOGUP_PAIRS) or 2 L - 1 (PAIRS | ODD).  Fraction f of a row:
+//   den_f = t[a_f] - z                       (f even: a one-element tuple, like the reference's check_bytes limb, range256.rs:281-284)
+//         = t[a_f] + alpha t[b_f] - z        (f odd: a two-element tuple)
+//   num_f = 1,  or  -main[m_f] when f % 3 == 2  (the table side of a lookup: a negated multiplicity column)
+//   t = the MAIN trace, a_f = (3 + 7 f) % n_main, b_f = (5 + 11 f) % n_main, m_f = (2 + 13 f) % n_main
+//   NX_LOGUP_TABLE: t = the PREPROCESSED trace (get_preprocessed_column, reference extensions/multiplicity.rs:111-124),
+//   a_f = (2 + 3 f) % n_pre, b_f = (1 + 5 f) % n_pre, and EVERY numerator is -main[m_f]
+// Logup column j holds the sum of the fractions of batches <= j (LogupColGenerator::finalize_col; a batch is one fraction, or the pair
+// (2 j, 2 j + 1) merged as (a d + b c) / (b d) by LogupTraceBuilder::add_to_relation_with, prover2/machine/src/lookups/
+// logup_trace_builder.rs:86-101); the last one is finalised by LogupTraceGenerator::finalize_last (claimed sum; prefix sum over the rows
+// of value - claimed / N).
 // Constraints, in declaration order: the two transition constraints and the degree-2 constraints of the synthetic main trace (as
-// nx_prove_synth), then per logup column stwo-constraint-framework's finalize_logup_batched with one fraction per batch:
-//   (S_j - S_{j-1}) den_j - num_j                                             j < L - 1
-//   (S_j(row) - S_j(row - 1) - S_{j-1}(row) + claimed / N) den_j - num_j      j = L - 1 (mask [-1, 0] on the last column)
-static void logup_cols(uint32_t j, uint32_t n_main, uint32_t* a, uint32_t* b, uint32_t* m) { *a = (3 + 7 * j) % n_main; *b = (5 + 11 * j) % n_main; *m = (2 + 13 * j) % n_main; }
+// nx_prove_synth), then per logup column stwo-constraint-framework's finalize_logup_batched — with (N_j, D_j) the batch's fraction
+// num / den, or its pair sum (n0 d1 + n1 d0) / (d0 d1) (Fraction::add; finalize_logup_in_pairs, reference
+// extensions/keccak/round/constraints.rs:116: degree 3 under the bound +1):
+//   (S_j - S_{j-1}) D_j - N_j                                             j < L - 1
+//   (S_j(row) - S_j(row - 1) - S_{j-1}(row) + claimed / N) D_j - N_j      j = L - 1 (mask [-1, 0] on the last column)
+struct FracDef { bool table; uint32_t w, col[2]; bool has_mult; uint32_t mult; };
+static uint32_t n_logup_fracs(const nx_component_spec& c) {
+    const uint32_t L = c.n_inter / 4;
+    if (!(c.logup_mode & NX_LOGUP_PAIRS) || L == 0) return L;
+    return 2 * L - ((c.logup_mode & NX_LOGUP_ODD) ? 1 : 0);
+}
+static FracDef frac_def(const nx_component_spec& c, uint32_t f) {
+    FracDef d; d.table = (c.logup_mode & NX_LOGUP_TABLE) != 0; d.w = (f & 1) ? 2 : 1;
+    if (d.table) { d.col[0] = (2 + 3 * f) % c.n_pre; d.col[1] = (1 + 5 * f) % c.n_pre; d.has_mult = true; }
+    else { d.col[0] = (3 + 7 * f) % c.n_main; d.col[1] = (5 + 11 * f) % c.n_main; d.has_mult = f % 3 == 2; }
+    d.mult = (2 + 13 * f) % c.n_main;
+    return d;
+}
 
 struct ProgEmit {
     std::vector<nx_cinstr> p;
@@ -249,23 +269,25 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc, 
                 e.op(NX_C_CONSTRAINT_B, 0, T2); nc++;
             }
     }
-    if (L) {
+    const uint32_t TB = (c.logup_mode & NX_LOGUP_TABLE) ? (uint32_t)PRE : (uint32_t)MAIN;      // where the tuples are read
+    if (L && !(c.logup_mode & NX_LOGUP_PAIRS)) {
         e.op(NX_C_CONSTE, EZ, 0); e.op(NX_C_CONSTE, EAL, 1); e.op(NX_C_CONSTE, ESH, 2); e.op(NX_C_CONSTE, ENZ, 3); e.op(NX_C_SUBE, ENZ, ENZ, EZ);   // -z
         auto S = [&](uint32_t j) { return (uint32_t)ES + 4 * (j % 5); };       // S_j lives in slot j % 5: a chunk of 4 never overwrites S_{j0 - 1}
         for (uint32_t j0 = 0; j0 < L; j0 += 4) {
             const uint32_t j1 = std::min(L, j0 + 4);
             for (uint32_t j = j0; j < j1; j++) {                               // the chunk's loads
-                uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m);
+                const FracDef d = frac_def(c, j);
                 const uint32_t t = TUP + 3 * (j - j0);
-                e.op(NX_C_LOAD, t, MAIN + a, 0);
-                if (j & 1) e.op(NX_C_LOAD, t + 1, MAIN + b, 0);
-                if (j % 3 == 2) e.op(NX_C_LOAD, t + 2, MAIN + m, 0);
+                e.op(NX_C_LOAD, t, TB + d.col[0], 0);
+                if (d.w == 2) e.op(NX_C_LOAD, t + 1, TB + d.col[1], 0);
+                if (d.has_mult) e.op(NX_C_LOAD, t + 2, MAIN + d.mult, 0);
                 e.op(NX_C_LOADE, S(j), INT + 4 * j, 0);
                 if (j + 1 == L) e.op(NX_C_LOADE, EPR, INT + 4 * j, (uint32_t)-1);
             }
             for (uint32_t j = j0; j < j1; j++) {
+                const FracDef d = frac_def(c, j);
                 const uint32_t t = TUP + 3 * (j - j0), cur = S(j), prev = S(j + 4);   // (j - 1) % 5 == (j + 4) % 5
-                if (j & 1) { e.op(NX_C_MULEB, EDEN, EAL, t + 1); e.op(NX_C_ADDEB, EDEN, EDEN, t); e.op(NX_C_ADDE, EDEN, EDEN, ENZ); }
+                if (d.w == 2) { e.op(NX_C_MULEB, EDEN, EAL, t + 1); e.op(NX_C_ADDEB, EDEN, EDEN, t); e.op(NX_C_ADDE, EDEN, EDEN, ENZ); }
                 else e.op(NX_C_ADDEB, EDEN, ENZ, t);
                 if (j + 1 < L) {
                     if (j == 0) e.op(NX_C_MULE, ET, cur, EDEN);
@@ -276,9 +298,64 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc, 
                     e.op(NX_C_ADDE, ET, ET, ESH);
                     e.op(NX_C_MULE, ET, ET, EDEN);
                 }
-                if (j % 3 == 2) e.op(NX_C_ADDEB, ET, ET, t + 2);              // - num = + main[m]
+                if (d.has_mult) e.op(NX_C_ADDEB, ET, ET, t + 2);              // - num = + main[m]
                 else { e.op(NX_C_CONST, T2, P - 1); e.op(NX_C_ADDEB, ET, ET, T2); }   // - num = - 1
                 e.op(NX_C_CONSTRAINT_E, 0, ET); nc++;
+            }
+        }
+    } else if (L) {
+        // finalize_logup_in_pairs: column j sums fractions 2 j and 2 j + 1.  Registers of this form: B 14..37 the tuple / multiplicity
+        // values of a chunk of 4 columns (8 fractions x 3), E quads from 40.
+        enum { PT = 14, PE = 40, PZ = PE, PAL = PE + 4, PSH = PE + 8, PNZ = PE + 12, PD0 = PE + 16, PD1 = PE + 20, PDD = PE + 24, PTT = PE + 28, PN = PE + 32, PPR = PE + 36,
+               PS = PE + 40 /* 5 quads */, PREGS = PE + 60 };
+        g.n_regs = PREGS;
+        const uint32_t F = n_logup_fracs(c);
+        e.op(NX_C_CONSTE, PZ, 0); e.op(NX_C_CONSTE, PAL, 1); e.op(NX_C_CONSTE, PSH, 2); e.op(NX_C_CONSTE, PNZ, 3); e.op(NX_C_SUBE, PNZ, PNZ, PZ);   // -z
+        auto S = [&](uint32_t j) { return (uint32_t)PS + 4 * (j % 5); };
+        for (uint32_t j0 = 0; j0 < L; j0 += 4) {
+            const uint32_t j1 = std::min(L, j0 + 4);
+            for (uint32_t j = j0; j < j1; j++) {
+                for (uint32_t f = 2 * j; f < std::min(F, 2 * j + 2); f++) {
+                    const FracDef d = frac_def(c, f);
+                    const uint32_t t = PT + 3 * (f - 2 * j0);
+                    e.op(NX_C_LOAD, t, TB + d.col[0], 0);
+                    if (d.w == 2) e.op(NX_C_LOAD, t + 1, TB + d.col[1], 0);
+                    if (d.has_mult) e.op(NX_C_LOAD, t + 2, MAIN + d.mult, 0);
+                }
+                e.op(NX_C_LOADE, S(j), INT + 4 * j, 0);
+                if (j + 1 == L) e.op(NX_C_LOADE, PPR, INT + 4 * j, (uint32_t)-1);
+            }
+            for (uint32_t j = j0; j < j1; j++) {
+                const uint32_t cur = S(j), prev = S(j + 4);
+                const bool two = 2 * j + 1 < F;
+                const FracDef d0 = frac_def(c, 2 * j), d1 = frac_def(c, two ? 2 * j + 1 : 2 * j);
+                const uint32_t t0 = PT + 3 * (2 * j - 2 * j0), t1 = t0 + 3;
+                auto den = [&](uint32_t dst, const FracDef& d, uint32_t t) {
+                    if (d.w == 2) { e.op(NX_C_MULEB, dst, PAL, t + 1); e.op(NX_C_ADDEB, dst, dst, t); e.op(NX_C_ADDE, dst, dst, PNZ); }
+                    else e.op(NX_C_ADDEB, dst, PNZ, t);
+                };
+                den(PD0, d0, t0);
+                if (two) den(PD1, d1, t1);
+                uint32_t diff = PTT;
+                if (j + 1 < L) {
+                    if (j == 0) diff = cur;                                    // S_0 - 0
+                    else e.op(NX_C_SUBE, PTT, cur, prev);
+                } else {
+                    e.op(NX_C_SUBE, PTT, cur, PPR);
+                    if (j > 0) e.op(NX_C_SUBE, PTT, PTT, prev);
+                    e.op(NX_C_ADDE, PTT, PTT, PSH);
+                }
+                if (two) {
+                    e.op(NX_C_MULE, PDD, PD0, PD1); e.op(NX_C_MULE, PTT, diff, PDD);            // diff d0 d1
+                    // - (n0 d1 + n1 d0)
+                    if (d0.has_mult) { e.op(NX_C_MULEB, PN, PD1, t0 + 2); e.op(NX_C_ADDE, PTT, PTT, PN); } else e.op(NX_C_SUBE, PTT, PTT, PD1);
+                    if (d1.has_mult) { e.op(NX_C_MULEB, PN, PD0, t1 + 2); e.op(NX_C_ADDE, PTT, PTT, PN); } else e.op(NX_C_SUBE, PTT, PTT, PD0);
+                } else {
+                    e.op(NX_C_MULE, PTT, diff, PD0);
+                    if (d0.has_mult) e.op(NX_C_ADDEB, PTT, PTT, t0 + 2);
+                    else { e.op(NX_C_CONST, T2, P - 1); e.op(NX_C_ADDEB, PTT, PTT, T2); }
+                }
+                e.op(NX_C_CONSTRAINT_E, 0, PTT); nc++;
             }
         }
     }
@@ -288,30 +365,46 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc, 
     return g;
 }
 
-// The logup interaction trace of one component from the main-trace columns `mainv` (evaluations, bit-reversed circle-domain order;
-// whole columns, or this GPU's row block of n_rows = 2^log_rows rows): inter = 4 L coordinate columns of n_rows words.
-static int logup_columns(nx_ctx* ctx, const nx_component_spec& c, uint32_t log_rows, const std::map<uint32_t, const uint32_t*>& mainv, const uint32_t z[4], const uint32_t alpha[4],
+// The logup interaction trace of one component from the trace columns its fractions read — `mainv` / `prev`: main / preprocessed column
+// index -> evaluations (bit-reversed circle-domain order; whole columns, or this GPU's row block of n_rows = 2^log_rows rows): inter =
+// 4 L coordinate columns of n_rows words.
+typedef std::map<uint32_t, const uint32_t*> ColMap;
+static int logup_columns(nx_ctx* ctx, const nx_component_spec& c, uint32_t log_rows, const ColMap& mainv, const ColMap& prev, const uint32_t z[4], const uint32_t alpha[4],
                          uint32_t* const* inter) {
-    const uint32_t L = c.n_inter / 4;
+    const uint32_t L = c.n_inter / 4, F = n_logup_fracs(c);
+    const bool pairs = (c.logup_mode & NX_LOGUP_PAIRS) != 0;
     static const uint32_t one[4] = {1, 0, 0, 0}, minus_one[4] = {P - 1, 0, 0, 0};
     uint32_t ap[8] = {1, 0, 0, 0, alpha[0], alpha[1], alpha[2], alpha[3]};     // LookupElements alpha powers [1, alpha]
     const bool per_column = ctx->opt.logup_per_column != 0;   // A/B: one nx_logup_col launch per column
-    std::vector<nx_logup_frac> fr(L);
-    std::vector<const uint32_t*> tuples(2 * (size_t)L);
-    for (uint32_t j = 0; j < L; j++) {
-        uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m);
-        tuples[2 * j] = mainv.at(a); tuples[2 * j + 1] = (j & 1) ? mainv.at(b) : nullptr;
-        nx_logup_frac& f = fr[j];
-        f.d_tuple_cols = &tuples[2 * j]; f.n_tuple_cols = (j & 1) ? 2 : 1; f.alpha_powers = ap; f.z = z;
-        f.d_mult = j % 3 == 2 ? mainv.at(m) : nullptr; f.scale = j % 3 == 2 ? minus_one : one;
-        if (per_column) H_TRY(nx_logup_col(ctx, log_rows, &f, nullptr, j ? (const uint32_t* const*)(inter + 4 * (j - 1)) : nullptr, inter + 4 * j));
+    std::vector<nx_logup_frac> fr(F);
+    std::vector<const uint32_t*> tuples(2 * (size_t)F);
+    for (uint32_t f = 0; f < F; f++) {
+        const FracDef d = frac_def(c, f);
+        const ColMap& src = d.table ? prev : mainv;
+        tuples[2 * f] = src.at(d.col[0]); tuples[2 * f + 1] = d.w == 2 ? src.at(d.col[1]) : nullptr;
+        nx_logup_frac& q = fr[f];
+        q.d_tuple_cols = &tuples[2 * f]; q.n_tuple_cols = d.w; q.alpha_powers = ap; q.z = z;
+        q.d_mult = d.has_mult ? mainv.at(d.mult) : nullptr; q.scale = d.has_mult ? minus_one : one;
     }
-    if (!per_column) H_TRY(nx_logup_cols(ctx, log_rows, fr.data(), L, inter));
-    return NX_OK;
+    if (per_column) {
+        for (uint32_t j = 0; j < L; j++) {
+            const uint32_t f0 = pairs ? 2 * j : j;
+            const nx_logup_frac* fb = pairs && f0 + 1 < F ? &fr[f0 + 1] : nullptr;
+            H_TRY(nx_logup_col(ctx, log_rows, &fr[f0], fb, j ? (const uint32_t* const*)(inter + 4 * (j - 1)) : nullptr, inter + 4 * j));
+        }
+        return NX_OK;
+    }
+    if (pairs) return nx_logup_cols_batched(ctx, log_rows, fr.data(), F, nullptr, L, inter);
+    return nx_logup_cols(ctx, log_rows, fr.data(), L, inter);
 }
-static std::set<uint32_t> logup_main_columns(const nx_component_spec& c) {
+// the columns of tree 0 (preprocessed) / 1 (main) the component's fractions read: their evaluations are needed after the commit
+static std::set<uint32_t> logup_needed_columns(const nx_component_spec& c, uint32_t tree) {
     std::set<uint32_t> s;
-    for (uint32_t j = 0; j < c.n_inter / 4; j++) { uint32_t a, b, m; logup_cols(j, c.n_main, &a, &b, &m); s.insert(a); if (j & 1) s.insert(b); if (j % 3 == 2) s.insert(m); }
+    for (uint32_t f = 0; f < n_logup_fracs(c); f++) {
+        const FracDef d = frac_def(c, f);
+        if ((d.table ? 0u : 1u) == tree) { s.insert(d.col[0]); if (d.w == 2) s.insert(d.col[1]); }
+        if (tree == 1 && d.has_mult) s.insert(d.mult);
+    }
     return s;
 }
 
@@ -322,7 +415,12 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
                          size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st, const HostTrace* host = nullptr) {
     PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
     H_TRY(check_components(ctx, comps, n_comps, ucfg));
-    for (uint32_t i = 0; i < n_comps; i++) if (comps[i].n_inter % 4) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: n_inter = 4 x (number of logup columns)");
+    for (uint32_t i = 0; i < n_comps; i++) {
+        if (comps[i].n_inter % 4) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: n_inter = 4 x (number of logup columns)");
+        const uint32_t m = comps[i].logup_mode;
+        if (m > (NX_LOGUP_PAIRS | NX_LOGUP_ODD | NX_LOGUP_TABLE) || ((m & NX_LOGUP_ODD) && !(m & NX_LOGUP_PAIRS)))
+            return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: logup_mode is a set of NX_LOGUP_PAIRS / NX_LOGUP_ODD (with PAIRS only) / NX_LOGUP_TABLE");
+    }
     H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
     uint32_t max_log = 0;
     std::vector<Loc> locs = locations(comps, n_comps, &max_log);
@@ -349,62 +447,60 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     // assembling the components' programs, looking their kernels up, the vote of a row-sharded prove — runs while the GPU fills, and
     // only then the two commits (each ends in the synchronisation that fetches its root): the GPU does not idle through the set-up.
     TreeBuilder tb0 = cs.tree_builder(), tb1 = cs.tree_builder();
-    if (host) {
-        for (uint32_t i = 0; i < n_comps; i++) {
-            DevBuf slab; H_TRY(slab.alloc(ctx, (size_t)comps[i].n_pre << comps[i].log_size));
-            tb0.extend_evals_host(std::move(slab), comps[i].n_pre, comps[i].log_size, host->pre + locs[i].pre0, host->coset_order);
-        }
-    } else H_TRY(fill_and_extend(cs, tb0, comps, n_comps, 0, seed, 0));                // machine.rs:208-228
-
-    // The main trace is consumed by its commitment (the columns become coefficients), and the interaction trace needs its
-    // evaluations afterwards: the reference clones the whole finalized trace (machine.rs:232); here only the columns the logup
-    // fractions read are kept.  One GPU: clones of the filled columns (nx_copy).  Row-sharded: the logup is row-wise, so every GPU
-    // needs ITS ROWS of those columns — for this synthetic trace the generator fills that block directly.
-    std::vector<DevBuf> kept(n_comps);
-    std::vector<std::map<uint32_t, const uint32_t*>> kept_ptr(n_comps);
-    {
-        TreeBuilder& tb = tb1;
+    // A trace tree is consumed by its commitment (the columns become coefficients), and the interaction trace needs evaluations
+    // afterwards: the reference clones the whole finalized trace (machine.rs:232) and keeps the preprocessed one; here only the columns
+    // the logup fractions read are kept — main columns, and the preprocessed columns of a table component (NX_LOGUP_TABLE).  One GPU:
+    // clones of the filled columns (nx_copy).  Row-sharded: the logup is row-wise, so every GPU needs ITS ROWS of those columns — for
+    // this synthetic trace the generator fills that block directly.  Host hand-over: cloned as the columns arrive (keep list).
+    std::vector<DevBuf> kept[2]; kept[0].resize(n_comps); kept[1].resize(n_comps);
+    std::vector<ColMap> kept_ptr[2]; kept_ptr[0].resize(n_comps); kept_ptr[1].resize(n_comps);
+    auto stage_tree = [&](uint32_t tree, TreeBuilder& tb) -> int {              // machine.rs:208-228 (tree 0), :230-237 (tree 1)
         std::vector<std::pair<uint32_t, uint32_t>> groups, local;
-        for (uint32_t i = 0; i < n_comps; i++) groups.push_back({comps[i].n_main, comps[i].log_size});
+        for (uint32_t i = 0; i < n_comps; i++) groups.push_back({tree == 0 ? comps[i].n_pre : comps[i].n_main, comps[i].log_size});
         plan_local_columns(groups, D, &local);
         for (uint32_t i = 0; i < n_comps; i++) {
             const nx_component_spec& c = comps[i];
-            const uint32_t lo = local[i].first, hi = local[i].second, log = c.log_size;
+            const uint32_t lo = local[i].first, hi = local[i].second, log = c.log_size, n_tree = groups[i].first;
             DevBuf slab;
-            if (hi > lo) {
+            if (host) H_TRY(slab.alloc(ctx, (size_t)n_tree << log));
+            else if (hi > lo) {
                 H_TRY(slab.alloc(ctx, (size_t)(hi - lo) << log));
                 auto p = col_ptrs(slab.p, hi - lo, log);
-                if (!host) H_TRY(synth_fill_range(ctx, c, i, 1, seed, 0, lo, hi - lo, p.data(), 0, 1u << log));
+                H_TRY(synth_fill_range(ctx, c, i, tree, seed, 0, lo, hi - lo, p.data(), 0, 1u << log));
             }
-            const std::set<uint32_t> need = logup_main_columns(c);
+            const std::set<uint32_t> need = logup_needed_columns(c, tree);
+            DevBuf& kb = kept[tree][i]; ColMap& kp = kept_ptr[tree][i];
             if (host) {
                 // the columns the logup fractions read are cloned as they arrive (keep list); the slab is filled by the commit
                 std::vector<std::pair<uint32_t, uint32_t*>> keep;
                 if (!need.empty()) {
-                    H_TRY(kept[i].alloc(ctx, need.size() << log));
+                    H_TRY(kb.alloc(ctx, need.size() << log));
                     size_t q = 0;
-                    for (uint32_t k : need) { uint32_t* dst = kept[i].p + (q++ << log); keep.push_back({k, dst}); kept_ptr[i][k] = dst; }
+                    for (uint32_t k : need) { uint32_t* dst = kb.p + (q++ << log); keep.push_back({k, dst}); kp[k] = dst; }
                 }
-                tb.extend_evals_host(std::move(slab), c.n_main, log, host->main + locs[i].main0, host->coset_order, keep);
+                tb.extend_evals_host(std::move(slab), n_tree, log, (tree == 0 ? host->pre + locs[i].pre0 : host->main + locs[i].main0), host->coset_order, keep);
                 continue;
             }
             if (!need.empty()) {
                 if (D.on() && log < (uint32_t)D.log_w + 2) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: every trace column needs at least 4 rows per GPU");
                 const uint64_t nb = D.on() ? D.block(log) : ((uint64_t)1 << log);
-                H_TRY(kept[i].alloc(ctx, need.size() * (size_t)nb));
+                H_TRY(kb.alloc(ctx, need.size() * (size_t)nb));
                 size_t q = 0;
                 std::vector<uint32_t*> cd; std::vector<const uint32_t*> csrc;
                 for (uint32_t k : need) {
-                    uint32_t* dst = kept[i].p + q * (size_t)nb;
+                    uint32_t* dst = kb.p + q * (size_t)nb;
                     if (!D.on()) { cd.push_back(dst); csrc.push_back(slab.p + ((size_t)k << log)); }              // Column::clone (R4), batched below
-                    else { uint32_t* one[1] = {dst}; H_TRY(synth_fill_range(ctx, c, i, 1, seed, 0, k, 1, one, (uint32_t)D.begin(log), (uint32_t)nb)); }
-                    kept_ptr[i][k] = dst; q++;
+                    else { uint32_t* one[1] = {dst}; H_TRY(synth_fill_range(ctx, c, i, tree, seed, 0, k, 1, one, (uint32_t)D.begin(log), (uint32_t)nb)); }
+                    kp[k] = dst; q++;
                 }
                 H_TRY(copy_columns(ctx, cd.data(), csrc.data(), (uint32_t)cd.size(), (size_t)nb));
             }
-            tb.extend_evals_local(std::move(slab), c.n_main, log, lo, hi);
+            tb.extend_evals_local(std::move(slab), n_tree, log, lo, hi);
         }
-    }
+        return NX_OK;
+    };
+    H_TRY(stage_tree(0, tb0));
+    H_TRY(stage_tree(1, tb1));
     {
         // Everything that can fail on ONE rank only before the exchanges start — the hiprtc compilation of the components' kernels
         // (the text does not depend on the proof: lookup elements and claimed sums are run-time constants) — happens here, followed
@@ -441,7 +537,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
                 DevBuf rows; H_TRY(rows.alloc(ctx, (size_t)c.n_inter * nb));                  // every logup column, this GPU's rows
                 std::vector<uint32_t*> ip(c.n_inter);
                 for (uint32_t k = 0; k < c.n_inter; k++) ip[k] = rows.p + (size_t)k * nb;
-                H_TRY(logup_columns(ctx, c, log_rows, kept_ptr[i], z, alpha, ip.data()));
+                H_TRY(logup_columns(ctx, c, log_rows, kept_ptr[1][i], kept_ptr[0][i], z, alpha, ip.data()));
                 uint32_t cs4[4];
                 if (!D.on()) {
                     H_TRY(nx_logup_finalize_last(ctx, log, ip.data() + 4 * (L - 1), cs4));
@@ -480,7 +576,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
             tb2.extend_evals_local(std::move(slab), c.n_inter, log, lo, hi);
         }
     }
-    kept.clear();
+    kept[0].clear(); kept[1].clear();
     lap(&st->interaction);
     channel.mix_felts(claimed);                                                       // machine.rs:262
     H_TRY(tb2.commit_begin());                                                        // machine.rs:263, queued; its root is fetched below
@@ -552,6 +648,19 @@ int nx_machine_air_source(const nx_component_spec* comp, char** h_source) {
     nxhip::PcsConfig one = {0, 1, 1, 0, 0, 1};      // a bound of 0 means "the config's": taken as 1 here (no config in this entry)
     nxhip::GComponent g = nxhip::machine_component(*comp, nxhip::Loc{0, 0, 0}, one);
     return nx_air_compile(nullptr, g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, (uint32_t)g.cols.size(), (uint32_t)g.econsts.size() / 4, g.n_constraints, nullptr, h_source);
+}
+
+int nx_machine_air_program(const nx_component_spec* comp, uint32_t cfg_log_constraint_degree, nx_cinstr** h_program, uint32_t* n_instr, uint32_t* n_regs, uint32_t* n_constraints) {
+    if (!comp || !h_program || !n_instr || !n_regs || !n_constraints || comp->n_inter % 4 || comp->n_pre < 2 || comp->n_main < 2 || cfg_log_constraint_degree < 1 ||
+        cfg_log_constraint_degree > 2 || comp->logup_mode > 7 || ((comp->logup_mode & NX_LOGUP_ODD) && !(comp->logup_mode & NX_LOGUP_PAIRS)))
+        return set_err(nullptr, NX_ERR_ARG, "nx_machine_air_program: bad argument");
+    nxhip::PcsConfig cfg = {0, 1, 1, 0, 0, cfg_log_constraint_degree};
+    nxhip::GComponent g = nxhip::machine_component(*comp, nxhip::Loc{0, 0, 0}, cfg);
+    nx_cinstr* out = (nx_cinstr*)malloc(std::max<size_t>(g.prog.size(), 1) * sizeof(nx_cinstr));
+    if (!out) return set_err(nullptr, NX_ERR_OOM, "nx_machine_air_program: malloc failed");
+    memcpy(out, g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
+    *h_program = out; *n_instr = (uint32_t)g.prog.size(); *n_regs = g.n_regs; *n_constraints = g.n_constraints;
+    return NX_OK;
 }
 
 int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* cfg, uint64_t seed, const uint8_t* ad,

@@ -7,8 +7,13 @@ the trace and the logup interaction trace come from the oracle (oracle/air.h, or
 transcript follows reference prover/src/machine.rs:197-290 through the oracle's prover session (oracle/air_generic.h).  The
 proof must equal nx_prove_machine's word for word.
 
-Component (log_size, n_pre, n_main, 4 L[, log constraint-degree bound — 0 / absent = the config's]).  Fraction j of a row: den_j = main[a_j] - z (j even) or main[a_j] + alpha main[b_j] - z
-(j odd); num_j = 1, or -main[m_j] when j % 3 == 2; a_j = (3 + 7 j) % n_main, b_j = (5 + 11 j) % n_main, m_j = (2 + 13 j) % n_main.
+Component (log_size, n_pre, n_main, 4 L[, log constraint-degree bound — 0 / absent = the config's[, logup mode]]).  Fraction f of a
+row: den_f = main[a_f] - z (f even) or main[a_f] + alpha main[b_f] - z (f odd); num_f = 1, or -main[m_f] when f % 3 == 2;
+a_f = (3 + 7 f) % n_main, b_f = (5 + 11 f) % n_main, m_f = (2 + 13 f) % n_main.  Logup mode (include/nexus_hip.h NX_LOGUP_*):
+0 = one fraction per logup column (finalize_logup); PAIRS = two per column (finalize_logup_in_pairs over columns built pairwise like
+reference prover2/machine/src/lookups/logup_trace_builder.rs:86-101; | ODD: the last column holds the single left-over fraction);
+TABLE = the tuples read PREPROCESSED columns a_f = (2 + 3 f) % n_pre, b_f = (1 + 5 f) % n_pre and every numerator is -main[m_f]
+(reference prover/src/extensions/multiplicity.rs:111-124).
 """
 import os
 
@@ -19,8 +24,37 @@ import oracle_lib as O
 P = O.P
 
 
-def logup_cols(j, n_main):
-    return (3 + 7 * j) % n_main, (5 + 11 * j) % n_main, (2 + 13 * j) % n_main
+PAIRS, ODD, TABLE = 1, 2, 4
+
+
+def logup_mode(comp):
+    return comp[5] if len(comp) > 5 else 0
+
+
+def n_fracs(comp):
+    L, mode = comp[3] // 4, logup_mode(comp)
+    if not (mode & PAIRS) or L == 0:
+        return L
+    return 2 * L - (1 if mode & ODD else 0)
+
+
+def frac_def(comp, f):
+    """(tree of the tuple columns, tuple column indices, multiplicity main column or None) of fraction f"""
+    n_pre, n_main, mode = comp[1], comp[2], logup_mode(comp)
+    m = (2 + 13 * f) % n_main
+    if mode & TABLE:
+        tup = [(2 + 3 * f) % n_pre] + ([(1 + 5 * f) % n_pre] if f & 1 else [])
+        return 0, tup, m
+    tup = [(3 + 7 * f) % n_main] + ([(5 + 11 * f) % n_main] if f & 1 else [])
+    return 1, tup, (m if f % 3 == 2 else None)
+
+
+def batches(comp):
+    """the fractions of every logup column (finalize_logup_batched's batching: one per column, or in pairs)"""
+    F, L = n_fracs(comp), comp[3] // 4
+    if logup_mode(comp) & PAIRS:
+        return [list(range(2 * j, min(F, 2 * j + 2))) for j in range(L)]
+    return [[j] for j in range(L)]
 
 
 def machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd=1):
@@ -47,10 +81,27 @@ def machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd=1):
             pb.add_constraint(c2 * main[k - 1] * main[k - 2] if quartic else c2)
     if L:
         ze, al, sh = pb.econst(z), pb.econst(alpha), pb.econst(shift)
+        pre = {}                                                   # preprocessed columns a table component's tuples read (offset 0)
+
+        def tuple_col(tree, k):
+            if tree == 1:
+                return main[k]
+            if k not in pre:
+                pre[k] = pb.next_trace_mask(PRE + k)[0]
+            return pre[k]
+
         prev = None
-        for j in range(L):
-            a, b, m = logup_cols(j, n_main)
-            den = (al * main[b] + main[a] - ze) if j & 1 else (main[a] - ze)          # E arithmetic: B - E lowers to (-E) + B
+        for j, fs in enumerate(batches(comp)):
+            # Fraction sum of the batch (stwo-constraint-framework Fraction::add): (n0 d1 + n1 d0) / (d0 d1); a single fraction as it is
+            num_neg, den = None, None                              # - numerator, denominator
+            for f in fs:
+                tree, tup, m = frac_def(comp, f)
+                d = tuple_col(tree, tup[0]) - ze if len(tup) == 1 else al * tuple_col(tree, tup[1]) + tuple_col(tree, tup[0]) - ze   # E arithmetic: B - E lowers to (-E) + B
+                nn = main[m] if m is not None else pb.const(P - 1)                                   # - num
+                if den is None:
+                    num_neg, den = nn, d
+                else:
+                    num_neg, den = num_neg * d + nn * den, den * d
             if j + 1 < L:
                 (cur,) = pb.next_secure_mask(INT + 4 * j)
                 diff = cur if prev is None else cur - prev
@@ -60,7 +111,6 @@ def machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd=1):
                 if prev is not None:
                     diff = diff - prev
                 diff = diff + sh
-            num_neg = main[m] if j % 3 == 2 else pb.const(P - 1)                      # - num
             pb.add_constraint(diff * den + num_neg)
             prev = cur
     cols = [(0, pre0 + k) for k in range(n_pre)] + [(1, main0 + k) for k in range(n_main)] + [(2, inter0 + k) for k in range(n_inter)]
@@ -70,30 +120,37 @@ def machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd=1):
     return ap.Component(log, prog, cols, masks, log_constraint_degree_bound=comp[4] if len(comp) > 4 else 0)
 
 
-def interaction_trace(comp, main_cols, z, alpha):
-    """LogupTraceGenerator as the reference drives it (one fraction per column, finalize_col, finalize_last) on the oracle.
-    main_cols: the component's finalized main-trace columns.  Returns (4 L coordinate columns, claimed sum)."""
+def interaction_trace(comp, main_cols, z, alpha, pre_cols=None):
+    """LogupTraceGenerator as the reference drives it (one fraction per column or a merged pair, finalize_col, finalize_last) on the
+    oracle.  main_cols / pre_cols: the component's finalized main-trace / preprocessed columns.  Returns (4 L coordinate columns,
+    claimed sum)."""
     log, n_pre, n_main, n_inter = comp[:4]
     L = n_inter // 4
     if L == 0:
         return [], np.zeros(4, np.uint32)
     ap = np.array([[1, 0, 0, 0], list(alpha)], np.uint32)
     cols, prev = [], None
-    for j in range(L):
-        a, b, m = logup_cols(j, n_main)
-        tup = [main_cols[a], main_cols[b]] if j & 1 else [main_cols[a]]
-        den = O.logup_combine(tup, ap[:len(tup)], z)
-        if j % 3 == 2:
-            col = O.logup_finalize_col(den, scale_a=(P - 1, 0, 0, 0), mult_a=main_cols[m], prev=prev)
+    for fs in batches(comp):
+        args = []
+        for f in fs:
+            tree, tup, m = frac_def(comp, f)
+            src = main_cols if tree == 1 else pre_cols
+            den = O.logup_combine([src[k] for k in tup], ap[:len(tup)], z)
+            args.append((den, (P - 1, 0, 0, 0), main_cols[m]) if m is not None else (den, (1, 0, 0, 0), None))
+        if len(args) == 2:                                                # LogupTraceBuilder: (a d + b c) / (b d)
+            (da, sa, ma), (db, sb, mb) = args
+            col = O.logup_finalize_col(da, scale_a=sa, mult_a=ma, den_b=db, scale_b=sb, mult_b=mb, prev=prev)
         else:
-            col = O.logup_finalize_col(den, prev=prev)
+            (da, sa, ma), = args
+            col = O.logup_finalize_col(da, scale_a=sa, mult_a=ma, prev=prev)
         cols.append(col); prev = col
     cols[-1], claimed = O.logup_finalize_last(cols[-1])
     return [c for col in cols for c in col], claimed
 
 
-def prove_machine(comps, cfg, seed=1, ad=b"", threads=None):
-    """nexus_vm_prover::prove for the machine, on the CPU oracle: returns the NXP1 proof words."""
+def prove_machine(comps, cfg, seed=1, ad=b"", threads=None, component_fn=None):
+    """nexus_vm_prover::prove for the machine, on the CPU oracle: returns the NXP1 proof words.
+    component_fn(ap, comp, loc, z, alpha, shift, cfg_lcd) (default: machine_component, the checker's own emission) builds a component."""
     import ref_emitter as ap            # the checker's own emitter: the product's recorder is not imported
     threads = threads or max(4, os.cpu_count() or 4)
     O.lib().orc_logup_set_threads(threads)
@@ -103,14 +160,15 @@ def prove_machine(comps, cfg, seed=1, ad=b"", threads=None):
         s.mix_u64(byte)                                       # machine.rs:198-200
     for c in comps:
         s.mix_u64(c[0])                                       # machine.rs:204-206
-    s.commit(O.synth_tree_columns(comps, 0, seed, threads=threads))            # :208-228
+    pre = O.synth_tree_columns(comps, 0, seed, threads=threads)
+    s.commit(pre)                                             # :208-228
     main = O.synth_tree_columns(comps, 1, seed, threads=threads)
     s.commit(main)                                            # :230-237 (the session copies: `main` keeps the evaluations, like the reference's clone)
     z, alpha = s.draw_felts(2)                                # :239-240
-    inter, claimed, shifts, off = [], [], [], 0
+    inter, claimed, shifts, off, poff = [], [], [], 0, 0
     for c in comps:
-        cols, cs = interaction_trace(c, main[off:off + c[2]], z, alpha)
-        off += c[2]
+        cols, cs = interaction_trace(c, main[off:off + c[2]], z, alpha, pre[poff:poff + c[1]])
+        off += c[2]; poff += c[1]
         inter += cols; claimed.append(cs)
         n_inv = pow((1 << c[0]) % P, P - 2, P)
         shifts.append(np.array([(int(x) * n_inv) % P for x in cs], np.uint32))
@@ -119,7 +177,7 @@ def prove_machine(comps, cfg, seed=1, ad=b"", threads=None):
     locs, a, b, d = [], 0, 0, 0
     for c in comps:
         locs.append((a, b, d)); a += c[1]; b += c[2]; d += c[3]
-    components = [machine_component(ap, c, l, z, alpha, sh, int(cfg[6])) for c, l, sh in zip(comps, locs, shifts)]
+    components = [(component_fn or machine_component)(ap, c, l, z, alpha, sh, int(cfg[6])) for c, l, sh in zip(comps, locs, shifts)]
     return s.prove(components)                                # :286-290
 
 

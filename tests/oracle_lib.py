@@ -100,7 +100,7 @@ def default_cfg(pow_bits=10, log_blowup=1, n_queries=3, log_last=0, hash_mode=HA
 
 def comps_array(comps):
     """comps: list of (log_size, n_pre, n_main, n_inter[, log_constraint_degree_bound]) — the bound defaults to 0 = the config's."""
-    return np.array([tuple(c) + (0,) * (5 - len(c)) for c in comps], dtype=np.int32).reshape(-1, 5).copy()
+    return np.array([(tuple(c) + (0,) * 5)[:5] for c in comps], dtype=np.int32).reshape(-1, 5).copy()   # a 6th entry (the machine's logup mode) is the checker's (tests/machine_ref.py), not the oracle's
 
 
 class Twiddles:
@@ -218,6 +218,12 @@ def eval_constraint_program(program, cols, alpha_powers, denom_inv, log_size, lo
     den = u32(denom_inv)
     L.orc_eval_constraint_program(ptr(ins), len(ins) // 4, program.n_regs, ptr_array(cols), ptr(ec), ptr(pw), ptr(den), log_size, log_eval, ptr_array(acc))
     return acc
+
+
+def qm31_mul(a, b):
+    a, b, o = u32(a), u32(b), np.zeros(4, np.uint32)
+    lib().orc_qm31_mul(ptr(a), ptr(b), ptr(o))
+    return o
 
 
 def logup_combine(cols, alpha_powers, z):

@@ -58,9 +58,24 @@ MACHINE_CASES = [
     # ... and the v1 shape: the main component +2 (components/mod.rs:12), the extensions +1 (extensions/multiplicity.rs:108-110)
     ([(12, 27, 90, 32, 2)] + [(6 + k, 2, 4 + k, 4, 1) for k in range(4)], dict(pow_bits=6, log_constraint_degree=2)),
 ]
+# The logup forms the reference's other components use: finalize_logup_in_pairs — two fractions per column built pairwise
+# (prover2/machine/src/lookups/logup_trace_builder.rs:86-101), degree-3 constraints under the bound +1 (extensions/keccak/round/
+# constraints.rs:116, eval.rs:28-30) —, an odd number of fractions, and table components whose tuples read PREPROCESSED columns with
+# -multiplicity numerators (extensions/multiplicity.rs:111-124, keccak/bitwise_table/constraints.rs)
+PAIRS, ODD, TABLE = M.PAIRS, M.ODD, M.TABLE
+LOGUP_FORM_CASES = [
+    ([(9, 3, 20, 12, 0, PAIRS)], dict(pow_bits=5)),
+    ([(10, 5, 30, 20, 1, PAIRS | ODD), (8, 4, 3, 4, 1, TABLE), (7, 3, 16, 32, 1, TABLE | PAIRS)], dict(pow_bits=6)),
+    ([(8, 2, 9, 4, 0, PAIRS | ODD), (6, 3, 5, 4, 0, PAIRS)], dict(pow_bits=4, hash_mode=1, fri_alpha_mode=1)),        # one column: a single left-over fraction / one pair
+    # the v1 shape with its extensions as the reference declares them: main +2 finalize_logup (components/mod.rs:53), final_reg / keccak
+    # in pairs, a bitwise table in pairs over preprocessed columns, a multiplicity table (one fraction per column)
+    ([(12, 27, 90, 32, 2, 0), (8, 2, 10, 12, 1, PAIRS), (9, 3, 16, 32, 1, TABLE | PAIRS), (6, 4, 2, 4, 1, TABLE), (7, 2, 12, 12, 1, PAIRS | ODD)], dict(pow_bits=6, log_constraint_degree=2)),
+    ([(11, 5, 40, 24, 2, PAIRS), (11, 3, 17, 8, 1, TABLE | PAIRS | ODD)], dict(pow_bits=5, log_constraint_degree=2)),   # pairs under a +2 bound next to degree-4 constraints
+]
+MACHINE_CASES_ALL = MACHINE_CASES + LOGUP_FORM_CASES
 
 
-@pytest.mark.parametrize("comps,kw", MACHINE_CASES)
+@pytest.mark.parametrize("comps,kw", MACHINE_CASES_ALL)
 def test_machine_prove_bit_exact_vs_oracle(be, nz, oracle, comps, kw):
     words, stats = be.prove_machine(comps, nz.default_config(**kw), seed=0xBEEF, ad=b"\x01\x02", want_stats=True)
     ref = M.prove_machine(comps, O.default_cfg(**kw), seed=0xBEEF, ad=b"\x01\x02", threads=THREADS)
@@ -123,6 +138,20 @@ def test_machine_quarter_domain_composition_on_and_off(nz, oracle):
             b = nz.HipBackend()
             b.set_option("air.quarter_domain", quarter); b.set_option("air.half_domain", half); b.set_option("air.degree_split", split)
             _same(ref, b.prove_machine(comps, nz.default_config(**kw), seed=28, ad=b"q4"))
+            b.close()
+
+
+def test_logup_forms_under_every_composition_option(nz, oracle):
+    """The paired / table statements under every combination of the exact-algebra options: the degree-3 pair constraints are not
+    eligible for the half domain (they need all 2N rows) and must land on the committed domain whatever is switched on; the per-column
+    trace launches ("logup.per_column": nx_logup_col with two fractions) give the same columns as the batched launch."""
+    for comps, kw in (LOGUP_FORM_CASES[1], LOGUP_FORM_CASES[3], LOGUP_FORM_CASES[4]):
+        ref = M.prove_machine(comps, O.default_cfg(**kw), seed=61, ad=b"lf", threads=THREADS)
+        for quarter, half, split, per_col in ((1, 1, 1, 0), (0, 0, 0, 0), (1, 0, 1, 1), (0, 1, 0, 0)):
+            b = nz.HipBackend()
+            b.set_option("air.quarter_domain", quarter); b.set_option("air.half_domain", half); b.set_option("air.degree_split", split)
+            b.set_option("logup.per_column", per_col)
+            _same(ref, b.prove_machine(comps, nz.default_config(**kw), seed=61, ad=b"lf"))
             b.close()
 
 
@@ -214,6 +243,9 @@ def _run_ranks(nz, world, fn, transport="native"):
     (4, [(14, 5, 35, 16), (13, 3, 17, 8)], dict(pow_bits=7)),
     (8, [(13, 27, 347, 64)], dict(pow_bits=8)),
     (4, [(12, 5, 35, 16, 1), (9, 3, 17, 8, 2), (7, 2, 6, 4, 1)], dict(pow_bits=6, log_constraint_degree=2)),    # per-component bounds
+    (4, LOGUP_FORM_CASES[1][0], LOGUP_FORM_CASES[1][1]),                                                            # pairs, an odd count, tables over preprocessed columns
+    (2, LOGUP_FORM_CASES[3][0], LOGUP_FORM_CASES[3][1]),
+    (8, [(11, 5, 40, 24, 2, PAIRS), (11, 3, 17, 8, 1, TABLE | PAIRS | ODD)], dict(pow_bits=5, log_constraint_degree=2)),
 ])
 def test_machine_row_sharded_equals_single_gpu(be, nz, world, comps, kw):
     """ONE proof on 2 / 4 / 8 ranks (threads with one context each on this GPU): the logup interaction trace is computed on row
@@ -367,7 +399,8 @@ def test_machine_from_a_host_resident_trace_equals_the_device_generated_one(be, 
     transforms (TreeBuilder::extend_evals_host): same trace -> the same proof as nx_prove_machine generates on the device (which the
     tests above tie to the oracle), in both host orders — bit-reversed circle-domain evaluations, and the natural coset order of the
     reference's `Vec<Vec<M31>>` with R3's permutation on the device; several components, sizes below and above a 16-column chunk."""
-    for comps, kw in (([(12, 27, 90, 32), (9, 3, 20, 8), (6, 2, 5, 4)], dict(pow_bits=5)), ([(11, 3, 17, 8, 2), (11, 2, 33, 4, 1)], dict(pow_bits=4, log_constraint_degree=2))):
+    for comps, kw in (([(12, 27, 90, 32), (9, 3, 20, 8), (6, 2, 5, 4)], dict(pow_bits=5)), ([(11, 3, 17, 8, 2), (11, 2, 33, 4, 1)], dict(pow_bits=4, log_constraint_degree=2)),
+                      ([(10, 5, 30, 20, 1, PAIRS | ODD), (8, 4, 3, 4, 1, TABLE), (8, 20, 16, 32, 1, TABLE | PAIRS)], dict(pow_bits=4))):   # kept PREPROCESSED columns too
         cfg = nz.default_config(**kw)
         ref = be.prove_machine(comps, cfg, seed=41, ad=b"host")
         pre = [c for s in be.synth_fill_tree(comps, 0, 41) for c in s.to_cpu()]
@@ -439,7 +472,7 @@ def test_config5_keccak_shaped_machine(be, nz, oracle):
     """BASELINE config #5 shape (two keccak round components of 16 and 8 rows per instance, byte-lane main columns, 4
     logup columns per lane-level lookup, so the interaction tree is the widest one): real logup columns and the recorded AIR on the
     device, word for word against the oracle machine; then the same bytes as ONE proof on 8 ranks."""
-    comps = [(12, 8, 160, 256), (11, 8, 96, 160), (6, 2, 5, 4)]
+    comps = [(12, 8, 160, 256, 1, PAIRS), (11, 8, 96, 160, 1, PAIRS), (6, 3, 16, 32, 1, TABLE | PAIRS), (6, 4, 2, 4, 1, TABLE)]
     kw = dict(pow_bits=6)
     cfg = nz.default_config(**kw)
     words = be.prove_machine(comps, cfg, seed=0x5EED, ad=b"keccak-shaped")
@@ -528,6 +561,7 @@ def test_config5_keccak_shaped_at_full_width(be, nz, oracle):
     ks = importlib.util.module_from_spec(spec); spec.loader.exec_module(ks)
     comps = ks.keccak_shaped_components(shift=4)
     assert [c[0] for c in comps] == [14, 13, 8, 8, 7] and comps[0][2] == 1000 and comps[0][3] == 2000
+    assert all(c[5] & PAIRS for c in comps[:4]) and all(c[5] & TABLE for c in comps[2:])     # rounds and bitwise tables in pairs; tables over preprocessed columns
     kw = dict(pow_bits=6)
     words = be.prove_machine(comps, nz.default_config(**kw), seed=0xCEC, ad=b"k5")
     _same(M.prove_machine(comps, O.default_cfg(**kw), seed=0xCEC, ad=b"k5", threads=THREADS), words)
@@ -537,7 +571,9 @@ def _prover2_shaped(shift):
     """tools/many_components.py's statement (reference prover2/machine/src/lib.rs:9-65: ~55 components of different sizes, few columns
     each) with every size reduced by `shift` bits so that the CPU checker finishes in seconds"""
     base = [(20, 2, 60, 40)] * 2 + [(18, 2, 40, 24)] * 6 + [(16, 2, 30, 16)] * 10 + [(14, 2, 24, 12)] * 12 + [(12, 2, 20, 8)] * 14 + [(10, 2, 12, 8)] * 11
-    return [(lg - shift, a, b, c) for lg, a, b, c in base]
+    # every prover2 component declares its lookups through finalize_logup_in_pairs (prover2/machine/src/components/*/mod.rs) over columns
+    # built pairwise by LogupTraceBuilder (lookups/logup_trace_builder.rs:86-101); the range-check tables read preprocessed columns
+    return [(lg - shift, a, b, c, 0, PAIRS | (TABLE if i % 9 == 8 else 0) | (ODD if i % 5 == 4 else 0)) for i, (lg, a, b, c) in enumerate(base)]
 
 
 def test_prover2_shaped_55_components_bit_exact(be, nz, oracle):
@@ -548,8 +584,9 @@ def test_prover2_shaped_55_components_bit_exact(be, nz, oracle):
     assert len(comps) == 55
     kw = dict(pow_bits=6)
     cfg, ocfg = nz.default_config(**kw), O.default_cfg(**kw)
-    words = be.prove(comps, cfg, seed=55, ad=b"p2")
-    _same(oracle.prove_synth(comps, ocfg, seed=55, ad=b"p2", threads=THREADS), words)
+    plain = [c[:4] for c in comps]                  # nx_prove_synth: the hand-written path has no logup forms
+    words = be.prove(plain, cfg, seed=55, ad=b"p2")
+    _same(oracle.prove_synth(plain, ocfg, seed=55, ad=b"p2", threads=THREADS), words)
     mwords = be.prove_machine(comps, cfg, seed=55, ad=b"p2")
     _same(M.prove_machine(comps, ocfg, seed=55, ad=b"p2", threads=THREADS), mwords)
     comps4 = _prover2_shaped(5)                     # every column needs >= 4 rows per rank on 4 ranks: smallest component 2^5

@@ -1111,6 +1111,63 @@ def test_logup_pipeline_matches_oracle(be, oracle, log):
     assert np.array_equal(got, np.stack(ref_last)) and got.max() < P
 
 
+@pytest.mark.parametrize("log", [5, 12])
+def test_logup_cols_batched_matches_oracle(be, oracle, log):
+    """nx_logup_cols_batched = finalize_logup_batched on the trace side: relation tuples of 1 ... 8 columns with their alpha powers
+    (Relation::combine), fractions assigned to batches in pairs (NULL batching, odd count), by an explicit monotone batching with a
+    batch of three, and by a NON-monotone one (Stwo's batching is any assignment): column j = the sum of the fractions of batches
+    <= j.  The oracle merges a pair as LogupTraceBuilder does, (a d + b c) / (b d) (reference prover2/machine/src/lookups/
+    logup_trace_builder.rs:93-97), and chains single fractions through finalize_col's `prev`."""
+    rng = np.random.default_rng(700 + log)
+    n = 1 << log
+    widths = [1, 2, 3, 4, 5, 6, 7, 8, 2, 1, 3]
+    F = len(widths)
+    z = rng.integers(0, P, 4, dtype=np.uint32)
+    alpha = rng.integers(0, P, 4, dtype=np.uint32)
+    ap = [np.array([1, 0, 0, 0], np.uint32)]
+    for _ in range(7):
+        ap.append(oracle.qm31_mul(ap[-1], alpha))
+    ap = np.stack(ap)
+    tup = [rng.integers(0, P, (w, n), dtype=np.uint32) for w in widths]
+    mult = [rng.integers(0, 1 << 20, n, dtype=np.uint32) if f % 3 != 1 else None for f in range(F)]
+    scale = [(P - 1, 0, 0, 0) if f % 2 else (1, 0, 0, 0) for f in range(F)]
+    fracs, keep = [], []
+    for f in range(F):
+        d = dict(tuple=be.columns_from_host(tup[f]), alphas=ap[:widths[f]], z=z, scale=scale[f])
+        if mult[f] is not None:
+            d["mult"] = be.columns_from_host(mult[f])
+        fracs.append(d)
+    dens = [oracle.logup_combine(list(tup[f]), ap[:widths[f]], z) for f in range(F)]
+
+    def expected(batching):
+        n_cols = max(batching) + 1
+        cols, prev = [], None
+        for j in range(n_cols):
+            fs = [f for f in range(F) if batching[f] == j]
+            while fs:
+                if len(fs) >= 2:
+                    a, b = fs[0], fs[1]; fs = fs[2:]
+                    prev = oracle.logup_finalize_col(dens[a], scale_a=scale[a], mult_a=mult[a], den_b=dens[b], scale_b=scale[b], mult_b=mult[b], prev=prev)
+                else:
+                    a = fs[0]; fs = fs[1:]
+                    prev = oracle.logup_finalize_col(dens[a], scale_a=scale[a], mult_a=mult[a], prev=prev)
+            cols.append(prev)
+        return cols
+
+    for batching in (None, [0, 0, 1, 2, 2, 2, 3, 4, 4, 5, 5], [3, 0, 1, 1, 0, 2, 4, 4, 2, 3, 0]):
+        got = be.logup_cols_batched(fracs, batching)
+        want = expected(batching if batching is not None else [f // 2 for f in range(F)])
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.to_cpu(), np.stack(w))
+    # every batch 0 .. last must hold a fraction (finalize_logup_batched asserts it); a batch index outside the columns is refused
+    import nexus_zkvm_amd as nz
+    with pytest.raises(nz.NexusHipError):
+        be.logup_cols_batched(fracs, [0, 0, 2, 2, 2, 2, 3, 4, 4, 5, 5])
+    with pytest.raises(nz.NexusHipError):
+        be.logup_cols_batched(fracs, [0] * F, n_cols=0)
+
+
 def test_column_utilities(be):
     """nx_copy (Column::clone) and the building blocks of a modular all-reduce (nx_m31_add_into / widen / narrow)."""
     rng = np.random.default_rng(3)

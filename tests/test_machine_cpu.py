@@ -36,6 +36,11 @@ def _verify(comps, cfg, words, ad=b""):
     # per-component constraint-degree bounds (the reference's are per component): big +1 components, one small +2 component
     ([(7, 2, 20, 12, 1), (5, 2, 4, 4, 2), (4, 2, 3, 0, 1)], dict(pow_bits=3, log_constraint_degree=2)),
     ([(6, 2, 9, 8, 2), (6, 2, 4, 4, 1), (3, 2, 3, 0)], dict(pow_bits=3, log_constraint_degree=2)),     # the v1 shape: main +2, extensions +1, one defaulted
+    # the reference's other logup forms: finalize_logup_in_pairs (two fractions per column, degree 3 under the bound +1),
+    # an odd number of fractions, and table components whose tuples read preprocessed columns with -multiplicity numerators
+    ([(6, 3, 9, 12, 1, M.PAIRS)], dict(pow_bits=3)),
+    ([(6, 3, 9, 8, 0, M.PAIRS | M.ODD), (5, 4, 3, 4, 1, M.TABLE), (4, 5, 4, 8, 1, M.TABLE | M.PAIRS)], dict(pow_bits=3)),
+    ([(6, 2, 9, 8, 2, 0), (5, 2, 6, 4, 1, M.PAIRS | M.ODD), (5, 3, 4, 12, 1, M.PAIRS | M.TABLE | M.ODD)], dict(pow_bits=3, log_constraint_degree=2)),
 ])
 def test_oracle_machine_proves_and_verifies(oracle, comps, kw):
     import ref_emitter as ap
@@ -46,11 +51,11 @@ def test_oracle_machine_proves_and_verifies(oracle, comps, kw):
     assert np.array_equal(words, M.prove_machine(comps, cfg, seed=11, ad=ad, threads=2))
     # verify: rebuild the statement on the verifier side (claimed sums recomputed from the trace, as the reference ships them with the proof)
     v, z, alpha, roots = _verify(comps, cfg, words, ad)
-    main = O.synth_tree_columns(comps, 1, 11)
-    claimed, shifts, off = [], [], 0
+    main, pre = O.synth_tree_columns(comps, 1, 11), O.synth_tree_columns(comps, 0, 11)
+    claimed, shifts, off, poff = [], [], 0, 0
     for c in comps:
-        _, cs = M.interaction_trace(c, main[off:off + c[2]], z, alpha)
-        off += c[2]
+        _, cs = M.interaction_trace(c, main[off:off + c[2]], z, alpha, pre[poff:poff + c[1]])
+        off += c[2]; poff += c[1]
         claimed.append(cs)
         n_inv = pow((1 << c[0]) % P, P - 2, P)
         shifts.append(np.array([(int(x) * n_inv) % P for x in cs], np.uint32))
@@ -67,28 +72,34 @@ def test_oracle_machine_proves_and_verifies(oracle, comps, kw):
     assert v2.verify(components, bad) is not None
 
 
-def test_logup_constraints_catch_a_wrong_interaction_trace(oracle):
-    """A fraction with the wrong sign breaks the recorded logup constraints: the oracle prover's OODS check refuses."""
+@pytest.mark.parametrize("mode", [0, M.PAIRS, M.PAIRS | M.ODD, M.TABLE | M.PAIRS])
+def test_logup_constraints_catch_a_wrong_interaction_trace(oracle, mode):
+    """A trace built from other tuple columns than the AIR constrains breaks the recorded logup constraints — in every logup form: the
+    oracle prover's OODS check refuses."""
     import ref_emitter as ap
-    comps = [(5, 2, 6, 8)]
+    comps = [(5, 4, 6, 8, 1, mode)]
     cfg = O.default_cfg(pow_bits=2)
-    real = M.logup_cols
+    real = M.frac_def
+
+    def shifted(comp, f):
+        tree, tup, m = real(comp, f)
+        return tree, [(tup[0] + 1) % comp[1 + tree]] + tup[1:], m
     try:
-        M.logup_cols = lambda j, n: ((4 + 7 * j) % n, (5 + 11 * j) % n, (2 + 13 * j) % n)     # trace built for other tuple columns ...
-        main = O.synth_tree_columns(comps, 1, 3)
+        M.frac_def = shifted                                                                     # trace built for other tuple columns ...
+        main, pre = O.synth_tree_columns(comps, 1, 3), O.synth_tree_columns(comps, 0, 3)
         s = O.ProverSession(cfg, 5, 2)
         s.mix_u64(5)
-        s.commit(O.synth_tree_columns(comps, 0, 3)); s.commit(main)
+        s.commit(pre); s.commit(main)
         z, alpha = s.draw_felts(2)
-        cols, cs = M.interaction_trace(comps[0], main, z, alpha)
+        cols, cs = M.interaction_trace(comps[0], main, z, alpha, pre)
         s.mix_felts(np.array([cs], np.uint32)); s.commit(cols)
-        M.logup_cols = real                                                                      # ... than the AIR constrains
+        M.frac_def = real                                                                        # ... than the AIR constrains
         n_inv = pow(32, P - 2, P)
         comp = M.machine_component(ap, comps[0], (0, 0, 0), z, alpha, np.array([(int(x) * n_inv) % P for x in cs], np.uint32))
         with pytest.raises(RuntimeError):
             s.prove([comp])
     finally:
-        M.logup_cols = real
+        M.frac_def = real
 
 
 def test_per_component_degree_bound_sets_the_composition_size(oracle):
@@ -110,3 +121,35 @@ def test_per_component_degree_bound_sets_the_composition_size(oracle):
     sy_g = O.prove_synth([c for c in big], cfg2, seed=9)
     sy_p = O.prove_synth(per, cfg2, seed=9)
     assert len(sy_p) < len(sy_g) and O.verify_synth(per, cfg2, sy_p) is None and O.verify_synth(big, cfg2, sy_p) is not None
+
+
+@pytest.mark.parametrize("comps,kw", [
+    ([(6, 3, 9, 8)], dict(pow_bits=2)),
+    ([(6, 3, 9, 12, 1, M.PAIRS), (5, 2, 6, 8, 1, M.PAIRS | M.ODD)], dict(pow_bits=2)),
+    ([(6, 4, 9, 20, 0, M.PAIRS | M.ODD), (5, 4, 3, 4, 1, M.TABLE), (4, 5, 4, 8, 1, M.TABLE | M.PAIRS)], dict(pow_bits=2)),
+    ([(6, 2, 19, 36, 2, M.PAIRS), (5, 3, 4, 12, 1, M.PAIRS | M.TABLE | M.ODD), (5, 3, 4, 8, 2, M.TABLE)], dict(pow_bits=2, log_constraint_degree=2)),
+])
+def test_product_emission_equals_the_checkers_proof(oracle, comps, kw):
+    """The PRODUCT's recorded program for a machine component (csrc/machine.hip machine_component, handed out by the host-only export
+    nx_machine_air_program) run through the ORACLE's prover session gives the proof of the checker's own, independent emission
+    (tests/ref_emitter.py) — in every logup form.  No GPU: the -m gpu suite then compares the device prover with these bytes."""
+    import ctypes as C
+    import nexus_zkvm_amd as nz
+    import ref_emitter as RE
+    lib = nz.load_library()
+
+    def product_component(ap, comp, loc, z, alpha, shift, cfg_lcd):
+        chk = M.machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd)       # the column list and the declared masks are the statement's
+        spec = nz.ComponentSpec(*[int(x) for x in comp])
+        prog, n, regs, nc = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        assert lib.nx_machine_air_program(C.byref(spec), cfg_lcd, C.byref(prog), C.byref(n), C.byref(regs), C.byref(nc)) == 0
+        ins = np.ctypeslib.as_array(C.cast(prog, C.POINTER(C.c_uint32)), shape=(n.value, 4)).copy()
+        lib.nx_free_host(prog)
+        assert nc.value == chk.program.n_constraints
+        p = RE.Program([tuple(int(x) for x in row) for row in ins], [list(map(int, z)), list(map(int, alpha)), list(map(int, shift)), [0, 0, 0, 0]], regs.value, nc.value, {})
+        return RE.Component(chk.log_size, p, chk.cols, chk.masks, chk.log_constraint_degree_bound)
+
+    cfg = O.default_cfg(**kw)
+    ref = M.prove_machine(comps, cfg, seed=21, ad=b"e", threads=4)
+    got = M.prove_machine(comps, cfg, seed=21, ad=b"e", threads=4, component_fn=product_component)
+    assert np.array_equal(ref, got)
