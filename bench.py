@@ -8,8 +8,10 @@ decommit -> proof bytes on the host; everything resident in HBM (the trace is ge
 `value` = 2^log_n_rows * steps / seconds (max over ranks).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--log-rows 22] [--no-cpu-baseline] [--no-v1-shaped] [--one-proof]
-For N > 1 it is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
-RCCL).  Default for N > 1: one independent proof of the 2^22-row trace per GPU (batch throughput, "scaling": "weak") as `value`;
+For N > 1 it runs one rank per GPU over RCCL: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...`, or — started PLAINLY as `python bench.py --gpus N` (no WORLD_SIZE in the environment) — it starts those N ranks by
+itself (self_launch below: the same torch.distributed.run command on 127.0.0.1 and a free port; the line says so in "launcher").
+Default for N > 1: one independent proof of the 2^22-row trace per GPU (batch throughput, "scaling": "weak") as `value`;
 the same run then ALSO tries ONE row-sharded proof on the N GPUs and reports it in the "one_proof" block (strong scaling, bytes over
 xGMI, equality with the single-GPU proof) — guarded so that no failure or hang there can cost the headline line.
 --one-proof: the N GPUs prove ONE trace together (row-sharded prove, "strong" — DESIGN.md §7); that path is byte-exact on thread
@@ -90,6 +92,21 @@ def _disarm_guardian(guard):
         pass
 
 
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): run the same command line under torch.distributed.run — one
+    process per GPU, rendezvous on 127.0.0.1 and a free port — and hand its exit code back.  Rank 0's JSON line passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ)
+    env["NX_BENCH_LAUNCHER"] = "self (bench.py started torch.distributed.run: %d ranks, 127.0.0.1:%d)" % (n_gpus, port)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +136,10 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank on GPU 0 (RCCL refuses that; use with --backend gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (the form the driver uses for N = 1): this process becomes the launcher of the N ranks
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,6 +150,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: libnexus_hip has no CPU fallback")
     if args.same_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible; one process per GPU — --same-device only for tests over gloo)" % (rank, torch.cuda.device_count()))
+    launcher = os.environ.get("NX_BENCH_LAUNCHER") or ("torch.distributed.run (external)" if world > 1 else "none (one process, one GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -296,6 +320,7 @@ def main():
             "value": n_cycles / elapsed,
             "unit": "cycles/s",
             "n_gpus": world,
+            "launcher": launcher,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,

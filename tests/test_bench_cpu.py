@@ -13,3 +13,31 @@ def test_guardian_prints_the_line_when_the_process_dies_and_stays_silent_otherwi
                           cwd=root, capture_output=True, text=True, timeout=60)
     lines = [l for l in fine.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and json.loads(lines[0])["one_proof"] == {"ok": True}, (fine.stdout, fine.stderr)
+
+
+def test_plain_start_with_several_gpus_builds_the_launch_command(monkeypatch):
+    """bench.py --gpus N started without a launcher hands the same arguments to torch.distributed.run (one process per GPU, 127.0.0.1,
+    a free port) and returns its exit code; with WORLD_SIZE set (it IS a rank) nothing is launched.  (The launch itself runs in the
+    GPU suite: test_bench_started_plainly_with_gpus_2_launches_its_own_ranks.)"""
+    import subprocess, sys, os
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    assert bench.self_launch(8, ["--gpus", "8", "--steps", "2"]) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5:] == [os.path.abspath(bench.__file__), "--gpus", "8", "--steps", "2"]
+    assert seen["env"]["NX_BENCH_LAUNCHER"].startswith("self") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # main(): --gpus 2 without WORLD_SIZE -> self_launch; its code is the process's
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1"])
+    try:
+        bench.main()
+        assert False, "main() should have exited through the launcher"
+    except SystemExit as e:
+        assert e.code == 7 and seen["cmd"][-4:] == ["--gpus", "2", "--steps", "1"]

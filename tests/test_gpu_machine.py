@@ -712,6 +712,28 @@ def test_bench_two_processes_one_proof(tmp_path):
     assert out["value"] > 0 and out["scaling"] == "weak" and "error" in out["one_proof"]
 
 
+def test_bench_started_plainly_with_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses for N = 1) starts the 2 ranks by
+    itself — the JSON line says n_gpus 2 and names the launcher — instead of silently benchmarking one GPU; the N = 1 line is
+    unchanged apart from the new "launcher" key."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NX_FRI_DIST_MIN_LOG", "NX_BENCH_LAUNCHER")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--log-rows", "14", "--backend", "gloo", "--same-device"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["launcher"].startswith("self") and out["value"] > 0
+    assert "error" not in out["one_proof"] and out["one_proof"]["equals_single_gpu"] is True
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--log-rows", "14", "--no-cpu-baseline", "--no-v1-shaped", "--no-host-trace"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["launcher"].startswith("none") and out["scaling"] == "strong" and "one_proof" not in out
+
+
 def test_torch_transport_on_device_buffers_nccl_world1(be, nz):
     """The RCCL transport of the row-sharded prove (nexus_zkvm_amd.sharded.TorchDistComm) on REAL device buffers of the library:
     zero-copy torch views over nx_alloc memory, dist.all_to_all_single with split sizes and all_gather_into_tensor on the nccl (= RCCL)
