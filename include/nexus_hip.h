@@ -58,8 +58,8 @@ const char* nx_last_error(const nx_ctx* ctx); /* ctx may be NULL: last global er
 int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
 /* Per-context policy and tuning.  The NX_* environment variables only seed a new context's defaults; what a
  * context does is decided by its own options, so two contexts of one process may differ.  Names: "fft.batch_cols" (2^22-row columns per launch of the LDE),
- * "fft.streams" (1..4), "comm.timeout_ms" (native RCCL transport: the longest a rank waits for its peers in one collective before it aborts the communicator and fails
- * the prove, default 120000; 0 = wait for ever), "fri.dist_min_log", "dist.chunks" and "air.degree_split" (1: degree-aware composition, see
+ * "fft.streams" (1..4), "comm.timeout_ms" (both library transports — native RCCL and the in-process one: the longest a rank waits for its peers in one collective before it
+ * aborts the communicator / breaks the group and fails the prove, default 120000; 0 = wait for ever), "fri.dist_min_log", "dist.chunks" and "air.degree_split" (1: degree-aware composition, see
  * nx_air_constraint_degrees) — row-sharded prove: every GPU of a proof must use the same values of these three, they shape the
  * exchanges —, "air.segment" (instruction budget of one generated AIR kernel), "quotients.coeffs" (1: the DEEP quotients of a wide
  * size group are accumulated from the coefficient columns — half the bytes at blowup 2; one GPU only), "air.half_domain" (1: constraints
@@ -398,6 +398,16 @@ void nx_comm_rccl_destroy(nx_comm* comm);
 typedef struct nx_comm_group nx_comm_group;
 int nx_comm_group_create(int32_t world, nx_comm_group** out);
 void nx_comm_group_destroy(nx_comm_group* group);
+/* A group that a failure broke (abort, a timeout) stays broken until it is re-armed: call this when EVERY rank's thread has returned
+ * from its prove call (refused while a rank is still copying).  The prove entries abort only on failures that can leave peers waiting
+ * — a HIP / transport / allocation error on one rank —; a refusal every rank reaches by itself (an argument error, the vote before the
+ * first exchange, ProvingError::ConstraintsNotSatisfied from the all-gathered sampled values) leaves the group and an RCCL
+ * communicator usable for the next proof. */
+int nx_comm_group_reset(nx_comm_group* group);
+int nx_comm_group_broken(const nx_comm_group* group);
+/* 1: rank `from_rank` pulls from `to_rank`'s device peer to peer (xGMI) or they share a device; 0: the runtime stages those copies
+ * (peer access could not be enabled); -1: one of the two communicators does not exist yet. */
+int nx_comm_group_peer_access(nx_comm_group* group, int32_t from_rank, int32_t to_rank);
 int nx_comm_local_create(nx_comm_group* group, nx_ctx* ctx, int32_t rank, nx_comm** out);
 void nx_comm_local_destroy(nx_comm* comm);
 /* Which columns of a tree a GPU transforms: groups = (column count, log size) per component in commit order; consecutive groups

@@ -34,6 +34,20 @@ class LocalGroup:
         if rc != 0:
             raise NexusHipError(f"nx_comm_group_create failed ({rc}): {L.nx_last_error(None).decode()}")
 
+    def reset(self):
+        """Re-arm a group a failure broke (nx_comm_group_reset): only when every rank's thread has left its prove call."""
+        L = load_library()
+        rc = L.nx_comm_group_reset(self.h)
+        if rc != 0:
+            raise NexusHipError(f"nx_comm_group_reset failed ({rc}): {L.nx_last_error(None).decode()}")
+
+    def broken(self):
+        return bool(load_library().nx_comm_group_broken(self.h))
+
+    def peer_access(self, from_rank, to_rank):
+        """1 peer to peer / same device, 0 staged by the runtime, -1 a communicator does not exist yet (nx_comm_group_peer_access)"""
+        return int(load_library().nx_comm_group_peer_access(self.h, int(from_rank), int(to_rank)))
+
     def close(self):
         if self.h:
             load_library().nx_comm_group_destroy(self.h)

@@ -88,7 +88,10 @@ struct RcclComm {
 static void abort_comm(RcclComm* c) {
     if (!c->comm || c->aborted) return;
     c->aborted = true;
-    if (c->api->CommAbort) (void)c->api->CommAbort(c->comm); else (void)c->api->CommDestroy(c->comm);
+    // without ncclCommAbort the communicator is LEAKED: ncclCommDestroy on a communicator with a collective stuck on its stream can block
+    // for ever — the very situation wait_stream's timeout escapes
+    if (c->api->CommAbort) (void)c->api->CommAbort(c->comm);
+    else c->err += " [ncclCommAbort is not exported by this RCCL: the communicator was leaked, not destroyed]";
     c->comm = nullptr;
 }
 

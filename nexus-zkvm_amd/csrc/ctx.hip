@@ -285,6 +285,7 @@ int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
         if (!strcmp(e.name, name)) {
             if (value < e.lo || value > e.hi) return set_err(ctx, NX_ERR_ARG, std::string("nx_ctx_set_option: value out of range for ") + name);
             ctx->opt.*(e.field) = (int)value;
+            if (e.field == &nx_options::commit_pipe_cols) ctx->opt.commit_pipe_cols = value < 16 ? 0 : (int)(value / 16) * 16;   // whole 16-column hash blocks, like NX_PIPE_COLS
             return NX_OK;
         }
     return set_err(ctx, NX_ERR_ARG, std::string("nx_ctx_set_option: unknown option ") + name);

@@ -70,6 +70,11 @@ struct nx_ctx {
     double kind_ms[4];
     uint64_t kind_bytes[4];
     std::vector<uint32_t> last_claimed;   // nx_machine_claimed_sums: 4 words per component of the last nx_prove_machine
+    // The failure a sharded prove is returning was reached by EVERY rank on its own (the vote before the first exchange, an option
+    // mismatch, ConstraintsNotSatisfied from the all-gathered sampled values): nobody is left waiting in a collective, so the entry
+    // point must not abort the transport — an abort cannot be undone (ncclCommAbort; a broken thread-rank group) and an invalid trace
+    // is an input error, not a reason to re-bootstrap a prover farm's communicator.
+    bool symmetric_failure = false;
 };
 enum { NX_T_LDE = 0, NX_T_MERKLE = 1, NX_T_QUOT = 2, NX_T_OTHER = 3 };
 

@@ -607,8 +607,10 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
 using namespace nx;
 
 // A rank whose sharded prove failed leaves its peers waiting in the next collective: tell the transport (nx_comm.abort, optional)
-static void abort_peers(const nx_comm* comm, int rc) {
-    if (rc != NX_OK && comm && comm->world > 1 && comm->abort) comm->abort(comm->user);
+// — unless the failure is one every rank reached by itself (ctx->symmetric_failure: the vote, ConstraintsNotSatisfied) or an argument
+// error caught before the communicator was touched: an abort cannot be undone, and an invalid trace must not cost a prover farm its group
+static void abort_peers(nx_ctx* ctx, const nx_comm* comm, int rc) {
+    if (rc != NX_OK && rc != NX_ERR_ARG && !ctx->symmetric_failure && comm && comm->world > 1 && comm->abort) comm->abort(comm->user);
 }
 
 static int hand_out(nx_ctx* ctx, int rc, std::vector<uint32_t>& w, uint32_t** proof_words, size_t* n_words, const char* who) {
@@ -636,8 +638,9 @@ int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t
     NX_GUARD(ctx);
     if (!ctx || !comps || !cfg || !proof_words || !n_words || !comm) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth_sharded: NULL argument");
     std::vector<uint32_t> w;
+    ctx->symmetric_failure = false;
     const int rc = nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
-    abort_peers(comm, rc);
+    abort_peers(ctx, comm, rc);
     return hand_out(ctx, rc, w, proof_words, n_words, "nx_prove_synth_sharded");
 }
 
@@ -668,8 +671,9 @@ int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_com
     NX_GUARD(ctx);
     if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: NULL argument");
     std::vector<uint32_t> w;
+    ctx->symmetric_failure = false;
     const int rc = nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
-    abort_peers(comm, rc);
+    abort_peers(ctx, comm, rc);
     return hand_out(ctx, rc, w, proof_words, n_words, "nx_prove_machine");
 }
 

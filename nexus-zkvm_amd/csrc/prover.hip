@@ -26,15 +26,17 @@ int dist_init(nx_ctx* ctx, const nx_comm* comm, Dist* out) {
 }
 int vote_before_exchanges(nx_ctx* ctx, const Dist& D, int rc_local, const char* who) {
     if (!D.on()) return rc_local;
+    struct Symmetric { nx_ctx* c; bool armed = true; ~Symmetric() { if (armed) c->symmetric_failure = true; } } sym{ctx};   // every refusal below is every rank's (the all-gather itself failing is not)
     struct Ballot { int32_t rc; int32_t opt[5]; };
     const Ballot mine = {rc_local, {ctx->opt.air_degree_split, ctx->opt.air_half_domain, ctx->opt.air_quarter_domain, ctx->opt.fri_dist_min_log, ctx->opt.dist_chunks}};
     std::vector<Ballot> all((size_t)D.world);
-    H_TRY(D.allgather_host(ctx, &mine, sizeof mine, all.data()));
+    { const int rc = D.allgather_host(ctx, &mine, sizeof mine, all.data()); if (rc != NX_OK) { sym.armed = false; return rc; } }
     for (int r = 0; r < D.world; r++)
         if (all[r].rc != NX_OK) return rc_local != NX_OK ? rc_local : set_err(ctx, NX_ERR_HIP, std::string(who) + ": rank " + std::to_string(r) + " failed to prepare its kernels (code " + std::to_string(all[r].rc) + "); no rank proceeds");
     for (int r = 0; r < D.world; r++)
         if (memcmp(all[r].opt, all[0].opt, sizeof mine.opt) != 0)
             return set_err(ctx, NX_ERR_ARG, std::string(who) + ": the ranks of one proof run different context options (air.degree_split / air.half_domain / air.quarter_domain / fri.dist_min_log / dist.chunks: rank 0 vs rank " + std::to_string(r) + "); they shape the exchanges and must agree");
+    sym.armed = false;
     return NX_OK;
 }
 
@@ -1031,8 +1033,10 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         // what catches it.
         QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[T][k][0];
         QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
-        if (!q_eq(lhs, air.eval_composition_at_point(oods, proof.sampled_values, random_coeff)))
+        if (!q_eq(lhs, air.eval_composition_at_point(oods, proof.sampled_values, random_coeff))) {
+            ctx->symmetric_failure = true;       // every rank holds the same all-gathered sampled values and reaches this verdict by itself
             return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
+        }
     }
     lap(&st->oods);
     QM31 q_coeff = channel.draw_secure_felt();
@@ -1732,8 +1736,9 @@ int nx_prover_tree_commit(nx_prover* p, uint8_t root[32]) {
     for (auto& r : p->pending) tb.extend_evals_local(std::move(r.slab), r.n_cols, r.log, r.lo, r.hi);
     p->pending.clear(); p->open = false;
     {
+        p->ctx->symmetric_failure = false;
         const int rc = tb.commit(p->channel);
-        if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort) p->comm_copy.abort(p->comm_copy.user); return rc; }
+        if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort && !p->ctx->symmetric_failure) p->comm_copy.abort(p->comm_copy.user); return rc; }
     }
     if (root) memcpy(root, p->cs->trees.back().root.w, 32);
     return NX_OK;
@@ -1772,9 +1777,10 @@ int nx_prover_tree_commit_host(nx_prover* p, const uint32_t* const* h_cols, int 
         }
         return tb.commit(p->channel);
     };
+    p->ctx->symmetric_failure = false;
     const int rc = run();
     p->pending.clear(); p->open = false;
-    if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort) p->comm_copy.abort(p->comm_copy.user); return rc; }
+    if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort && !p->ctx->symmetric_failure) p->comm_copy.abort(p->comm_copy.user); return rc; }
     if (root) memcpy(root, p->cs->trees.back().root.w, 32);
     return NX_OK;
 }
@@ -1805,12 +1811,14 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
         air.comps.push_back(std::move(g));
     }
     if (p->proved) { while (p->cs->trees.size() > p->pre_trees) p->cs->trees.pop_back(); p->channel = p->pre_channel; }   // a second prove of the session
+    ctx->symmetric_failure = false;
     if (p->cs->dist.on()) {
         // everything that can fail on one rank only (argument checks, hiprtc) happens before the first exchange, then the ranks vote
         int rc_local = air.check(*p->cs);
         for (auto& c : air.comps) if (rc_local == NX_OK) rc_local = nxhip::prepare_component_kernels(ctx, p->cfg, c, true);
         const int rcv = nxhip::vote_before_exchanges(ctx, p->cs->dist, rc_local, "nx_prover_prove");
-        if (rcv != NX_OK) { if (p->has_comm && p->comm_copy.abort && rc_local == NX_OK && rcv != NX_ERR_ARG) p->comm_copy.abort(p->comm_copy.user); return rcv; }
+        // a no-go of the vote is every rank's: nobody entered an exchange, nothing to abort (only a vote whose own all-gather failed is one-sided)
+        if (rcv != NX_OK) { if (p->has_comm && p->comm_copy.abort && !ctx->symmetric_failure) p->comm_copy.abort(p->comm_copy.user); return rcv; }
     }
     NX_TRY(air.check(*p->cs));
     const bool timed = stats != nullptr;
@@ -1829,7 +1837,7 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     if (!p->proved) { p->pre_trees = p->cs->trees.size(); p->pre_channel = p->channel; p->proved = true; }
     int rc = nxhip::prove_core(ctx, *p->cs, p->channel, p->cfg, p->tw, air, &w, st, lap);
     if (rc != NX_OK) { while (p->cs->trees.size() > p->pre_trees) p->cs->trees.pop_back(); p->channel = p->pre_channel; p->proved = false; }
-    if (rc != NX_OK && p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort) p->comm_copy.abort(p->comm_copy.user);   // the peers wait in a collective this rank will not enter
+    if (rc != NX_OK && p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort && !ctx->symmetric_failure) p->comm_copy.abort(p->comm_copy.user);   // the peers wait in a collective this rank will not enter
     if (timed) nxhip::finish_stats(ctx, st, t_start);
     ctx->timing = false;
     p->cs->dist.comm_ms = nullptr; p->cs->dist.comm_bytes = nullptr;

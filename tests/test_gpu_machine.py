@@ -354,6 +354,92 @@ def test_native_transport_abort_and_timeout(nz):
     b1.free_local_comm(c1); b1.close(); group.close()
 
 
+def test_symmetric_refusals_leave_the_group_usable_and_reset_rearms_a_broken_one(be, nz, oracle):
+    """an abort cannot be undone (a thread-rank group stays broken, ncclCommAbort kills an RCCL communicator), so the prove
+    entries abort only on failures that can leave a peer waiting.  Refusals every rank reaches by itself — the option vote before the
+    first exchange, ProvingError::ConstraintsNotSatisfied from the all-gathered sampled values — leave the SAME group and communicators
+    usable for the next proof; a group broken by a real abort is re-armed by nx_comm_group_reset once every rank has left."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    world = 2
+    comps = [(10, 3, 20, 8, 2)]
+    cfg = nz.default_config(pow_bits=4, log_constraint_degree=2)
+    ref = be.prove_machine(comps, cfg, seed=5)
+    group = nz.LocalGroup(world)
+    bes = [nz.HipBackend(0) for _ in range(world)]
+    comms = [bes[r].local_comm(group, r) for r in range(world)]
+    assert group.peer_access(0, 1) == 1 and group.peer_access(1, 0) == 1          # both ranks on this box's GPU
+
+    def on_ranks(fn):
+        out = [None] * world
+
+        def run(r):
+            try:
+                out[r] = ("ok", fn(bes[r], comms[r], r))
+            except nz.NexusHipError as e:
+                out[r] = ("err", str(e))
+        th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(timeout=120)
+        assert not any(x.is_alive() for x in th)
+        return out
+
+    try:
+        # 1. the option vote: NX_ERR_ARG on every rank, nothing aborted
+        def mismatched(b, comm, r):
+            b.set_option("air.degree_split", r)
+            try:
+                return b.prove_machine(comps, cfg, seed=5, comm=comm)
+            finally:
+                b.set_option("air.degree_split", 1)
+        res = on_ranks(mismatched)
+        assert all(k == "err" and "different context options" in v for k, v in res), res
+        assert not group.broken()
+        for k, v in on_ranks(lambda b, comm, r: b.prove_machine(comps, cfg, seed=5, comm=comm)):
+            assert k == "ok"; _same(ref, v)
+        # 2. an invalid trace through the session: ConstraintsNotSatisfied on every rank, the group survives
+        log = 9
+        scfg = nz.default_config(pow_bits=4)
+        nat, fin = AE.logup_main_trace(log, 42)
+
+        def session(bad):
+            def fn(b, comm, r):
+                ss = b.prover_session(scfg, log)
+                ss.set_comm(comm)
+                try:
+                    ss.mix_u64(log); ss.commit([])
+                    cols = [c.copy() for c in fin]
+                    if bad:
+                        cols[0][5] ^= 1
+                    ss.commit(cols)
+                    z, alpha = ss.draw_felt(), ss.draw_felt()
+                    inter, shift = AE.logup_interaction_trace(log, nat, z, alpha)
+                    ss.mix_felts(np.zeros(4, np.uint32)); ss.commit(inter)
+                    return ss.prove([AE.logup_component(ap, log, z, alpha, shift)])
+                finally:
+                    ss.close()
+            return fn
+        res = on_ranks(session(True))
+        assert all(k == "err" and "ConstraintsNotSatisfied" in v for k, v in res), res
+        assert not group.broken()
+        good = on_ranks(session(False))
+        assert all(k == "ok" for k, _ in good) and np.array_equal(good[0][1], good[1][1])
+        # 3. a real abort breaks the group for good ... until it is re-armed
+        comms[1].abort(comms[1].user)
+        assert group.broken()
+        assert all(k == "err" for k, _ in on_ranks(lambda b, comm, r: b.prove_machine(comps, cfg, seed=5, comm=comm)))
+        group.reset()
+        assert not group.broken()
+        for k, v in on_ranks(lambda b, comm, r: b.prove_machine(comps, cfg, seed=5, comm=comm)):
+            assert k == "ok"; _same(ref, v)
+    finally:
+        for r in range(world):
+            bes[r].free_local_comm(comms[r]); bes[r].close()
+        group.close()
+
+
 def test_ranks_with_different_plan_options_are_refused_before_the_first_exchange(nz):
     """"air.degree_split" & co. decide which domains a row-sharded prove evaluates and exchanges on; a rank configured
     differently would meet its peers in mismatched collectives.  The pre-exchange vote carries the options: every rank gets NX_ERR_ARG."""
