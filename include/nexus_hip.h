@@ -63,9 +63,11 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
  * nx_air_constraint_degrees) — row-sharded prove: every GPU of a proof must use the same values of these three, they shape the
  * exchanges —, "air.segment" (instruction budget of one generated AIR kernel), "quotients.coeffs" (1: the DEEP quotients of a wide
  * size group are accumulated from the coefficient columns — half the bytes at blowup 2; one GPU only), "air.half_domain" (1: constraints
- * of degree <= 2 are evaluated on the first half of the committed 2N-point domain; one GPU, blowup 2), "air.quarter_domain" (1: constraints
- * of degree 4 / 5 that read no neighbour row are evaluated on the committed 2N rows plus the first quarter of the 4N-point domain — 3N + 1
- * samples instead of 4N; one GPU, blowup 2, component bound 2).  Kernel-shape switches kept for A/B measurement (defaults are the
+ * of degree <= 2 are evaluated on the first half of the committed 2N-point domain; one GPU, blowup 2), "air.quarter_domain" (constraints
+ * of degree 4 / 5 are evaluated on the committed 2N rows plus the first quarter of the 4N-point domain — 3N + 1 samples instead of 4N;
+ * 1: only those that read no neighbour row, 2 (default): all of them, the columns read at a neighbour row — the reference's Pc /
+ * IsPadding, prover/src/column.rs:13-20 — evaluated on the first HALF of that domain, which holds the neighbours of its first quarter;
+ * one GPU, blowup 2, component bound 2).  Kernel-shape switches kept for A/B measurement (defaults are the
  * measured best): "fft.kmax" (most layers of a non-first FFT pass, 1..11), "fft.fused" (fused middle launch of the LDE), "merkle.subtree"
  * (highest level built by the fused sub-tree launch; 0 = one launch per level), "merkle.pair_levels" (two node-only levels per launch
  * above it), "commit.pipe_cols" (leaf hashing beside the LDE in

@@ -244,7 +244,7 @@ static nx_options options_from_env() {
     o.air_degree_split = env_int("NX_AIR_DEGREE_SPLIT", 1) != 0;
     o.quotients_coeffs = env_int("NX_QUOTIENTS_COEFFS", 1) != 0;
     o.air_half_domain = env_int("NX_AIR_HALF_DOMAIN", 1) != 0;
-    o.air_quarter_domain = env_int("NX_AIR_QUARTER_DOMAIN", 1) != 0;
+    o.air_quarter_domain = std::max(0, std::min(2, env_int("NX_AIR_QUARTER_DOMAIN", 2)));   // 2: also constraints that read a neighbour row
     o.comm_timeout_ms = std::max(0, env_int("NX_COMM_TIMEOUT_MS", 120000));
     o.fft_kmax = clampi(env_int("NX_FFT_KMAX", 9), 1, 11);
     o.fft_fused = env_int("NX_FFT_FUSED", 1) != 0;
@@ -267,7 +267,7 @@ static const OptEntry k_options[] = {
     {"air.degree_split", &nx_options::air_degree_split, 0, 1},
     {"quotients.coeffs", &nx_options::quotients_coeffs, 0, 1},
     {"air.half_domain", &nx_options::air_half_domain, 0, 1},
-    {"air.quarter_domain", &nx_options::air_quarter_domain, 0, 1},
+    {"air.quarter_domain", &nx_options::air_quarter_domain, 0, 2},
     {"comm.timeout_ms", &nx_options::comm_timeout_ms, 0, 1 << 30},
     {"fft.kmax", &nx_options::fft_kmax, 1, 11},
     {"fft.fused", &nx_options::fft_fused, 0, 1},

@@ -19,7 +19,7 @@ struct nx_options {
     int air_segment;              // "air.segment": estimated-instruction budget of one generated AIR kernel
     int quotients_coeffs;         // "quotients.coeffs": DEEP quotients of wide size groups from the coefficient columns (single GPU)
     int air_half_domain;          // "air.half_domain": constraints of degree <= 2 are evaluated on HALF of the committed 2N-point domain (single GPU, blowup 2)
-    int air_quarter_domain;       // "air.quarter_domain": degree-4/5 constraints that read no neighbour row are evaluated on the committed 2N rows + the first QUARTER of the 4N-point domain (3N + 1 samples; single GPU, blowup 2, bound 2)
+    int air_quarter_domain;       // "air.quarter_domain": degree-4/5 constraints are evaluated on the committed 2N rows + the first QUARTER of the 4N-point domain (3N + 1 samples; single GPU, blowup 2, bound 2); 1: only those that read no neighbour row, 2: all (neighbour-read columns on the first half)
     int comm_timeout_ms;          // "comm.timeout_ms": native RCCL transport, longest wait for the peers in one collective (0 = for ever)
     // schedule choices that were A/B'd and settled (DESIGN.md section 6.1 lists the measurements); kept as options — not as getenv calls spread over
     // the kernels' launchers — so that a tool can still flip one on ONE context

@@ -233,8 +233,9 @@ struct ProgEmit {
 // econsts of a component: [z, alpha, claimed / N, 0]
 // A component whose constraint-degree bound is 2 HAS constraints that need it (degree 4 or 5; v1's shift chips, reference
 // prover/src/chips/instructions/i/sra.rs:267-307): every degree-2 main-trace constraint of such a component is multiplied by the two
-// columns it squares — degree 4, satisfied by the same trace — so that all its main columns are needed on the 4x domain.  The logup
-// constraints keep degree 2, as the reference's one-fraction-per-column finalize_logup (components/mod.rs:53) makes them.
+// columns it squares, and each of the two transition constraints by main0 main1 — degree 4, satisfied by the same trace — so that all its
+// main columns are needed on the 4x domain and two of them at a neighbour row there.  The logup constraints keep degree 2 (one fraction per
+// column, the reference's finalize_logup, components/mod.rs:53) or 3 (pairs).
 static GComponent machine_component(const nx_component_spec& c, const Loc& loc, const PcsConfig& cfg) {
     GComponent g;
     g.log_size = c.log_size;
@@ -257,8 +258,14 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc, 
     e.op(NX_C_LOAD, ring(0), MAIN + 0, 0); e.op(NX_C_LOAD, ring(1), MAIN + 1, 0);
     e.op(NX_C_LOAD, T0, MAIN + 0, 1); e.op(NX_C_LOAD, T1, MAIN + 1, 1); e.op(NX_C_LOAD, T3, PRE + 1, 0);
     e.op(NX_C_CONST, T2, 1); e.op(NX_C_SUB, T3, T2, T3);
-    e.op(NX_C_SUB, T0, T0, ring(0)); e.op(NX_C_SUB, T0, T0, T2); e.op(NX_C_MUL, T0, T0, T3); e.op(NX_C_CONSTRAINT_B, 0, T0); nc++;
-    e.op(NX_C_SUB, T1, T1, ring(1)); e.op(NX_C_SUB, T1, T1, ring(0)); e.op(NX_C_MUL, T1, T1, T3); e.op(NX_C_CONSTRAINT_B, 0, T1); nc++;
+    // quartic: the two transition constraints times main0 main1 too — degree 4 AND a neighbour row, like the reference's constraints over
+    // its masked columns Pc / IsPadding (prover/src/column.rs:13-20, trace/eval.rs:22-50): what the quarter domain's neighbour rows are for
+    e.op(NX_C_SUB, T0, T0, ring(0)); e.op(NX_C_SUB, T0, T0, T2); e.op(NX_C_MUL, T0, T0, T3);
+    if (quartic) { e.op(NX_C_MUL, T0, T0, ring(0)); e.op(NX_C_MUL, T0, T0, ring(1)); }
+    e.op(NX_C_CONSTRAINT_B, 0, T0); nc++;
+    e.op(NX_C_SUB, T1, T1, ring(1)); e.op(NX_C_SUB, T1, T1, ring(0)); e.op(NX_C_MUL, T1, T1, T3);
+    if (quartic) { e.op(NX_C_MUL, T1, T1, ring(0)); e.op(NX_C_MUL, T1, T1, ring(1)); }
+    e.op(NX_C_CONSTRAINT_B, 0, T1); nc++;
     for (uint32_t k0 = 2; k0 < c.n_main; k0 += 8) {
         const uint32_t k1 = std::min(c.n_main, k0 + 8);
         for (uint32_t k = k0; k < k1; k++) e.op(NX_C_LOAD, ring(k), MAIN + k, 0);

@@ -1224,7 +1224,7 @@ int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g, 
         return NX_OK;
     }
     std::string key((const char*)g.prog.data(), g.prog.size() * sizeof(nx_cinstr));
-    key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs) + "|" + std::to_string(g.econsts.size() / 4) + "|" + std::to_string(bound) + (can_half ? "|h" : "|-") + (can_low ? "l" : "-") + (can_quarter ? "q" : "-");
+    key += "|" + std::to_string(g.cols.size()) + "|" + std::to_string(g.n_regs) + "|" + std::to_string(g.econsts.size() / 4) + "|" + std::to_string(bound) + (can_half ? "|h" : "|-") + (can_low ? "l" : "-") + (can_quarter ? (ctx->opt.air_quarter_domain >= 2 ? "Q" : "q") : "-");
     SplitCache& sc = split_cache();
     {
         std::lock_guard<std::mutex> lk(sc.mu);
@@ -1242,10 +1242,12 @@ int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g, 
     std::vector<int> where_c(g.n_constraints);
     for (uint32_t j = 0; j < g.n_constraints; j++) where_c[j] = where_of[deg[j] <= 2 ? 0 : deg[j] == 3 ? 1 : 2];
     if (can_quarter) {
-        // degree 4 / 5 (d <= 2^2 + 1: the quotient has 3N + 1 coefficients) that read the current row only: the sub-domain holds no neighbour rows
+        // degree 4 / 5 (d <= 2^2 + 1: the quotient has 3N + 1 coefficients)
         std::vector<char> nb;
         air_constraint_neighbours(g.prog.data(), (uint32_t)g.prog.size(), g.n_regs, &nb);
-        for (uint32_t j = 0; j < g.n_constraints; j++) if (where_c[j] == GComponent::ON_FULL && deg[j] >= 4 && deg[j] <= 5 && !nb[j]) where_c[j] = GComponent::ON_QUARTER;
+        // "air.quarter_domain" = 2 (the default): neighbour-reading constraints too — their columns get a 2N-point transform (compute_composition)
+        const bool with_neighbours = ctx->opt.air_quarter_domain >= 2;
+        for (uint32_t j = 0; j < g.n_constraints; j++) if (where_c[j] == GComponent::ON_FULL && deg[j] >= 4 && deg[j] <= 5 && (with_neighbours || !nb[j])) where_c[j] = GComponent::ON_QUARTER;
     }
     std::vector<GComponent::Part> parts;
     for (int where : {GComponent::ON_HALF, GComponent::ON_LOW, GComponent::ON_QUARTER, GComponent::ON_FULL}) {
@@ -1444,31 +1446,51 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
                     H_TRY(columns_on_eval_domain(cs, c.cols, n, n + 1, masked, &cols, used));
                     H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 1, qg.acc2n.c, 0, 2 * N));
                 }
-                // 2. the columns the part reads, on the first quarter of the 4N-point domain (an N-point transform each) and at row N
-                std::vector<size_t> sel;
-                for (size_t k = 0; k < c.cols.size(); k++) if (!used || (k < used->size() && (*used)[k])) sel.push_back(k);
-                const size_t ns = sel.size();
-                std::vector<const uint32_t*> src(ns);
+                // 2. the columns the part reads, on the first quarter of the 4N-point domain (an N-point transform each) and at row N.
+                // A column that is read at a neighbour row (`masked`: the reference's Pc / IsPadding, prover/src/column.rs:13-20) is
+                // evaluated on the first HALF of the 4N-point domain instead — a 2N-point transform: the trace step maps the first quarter
+                // +-(g + <g_{N/2}>) onto the second and back (tests/test_exact_algebra_cpu.py::test_neighbour_rows_of_the_first_quarter_
+                // are_the_second_quarter), so the neighbour of every quarter row, and of row N, lies in rows [0, 2N) and the kernel's own
+                // row arithmetic on the 4N-point domain indexes that buffer unchanged.
+                std::vector<size_t> sel, selm;
+                for (size_t k = 0; k < c.cols.size(); k++) if (!used || (k < used->size() && (*used)[k])) (masked[k] ? selm : sel).push_back(k);
+                const size_t ns = sel.size(), nm = selm.size();
+                std::vector<const uint32_t*> src(ns), srcm(nm);
                 for (size_t i = 0; i < ns; i++) src[i] = cs.trees[c.cols[sel[i]].first].polys[c.cols[sel[i]].second].ptr;
-                DevBuf ext, wv; H_TRY(ext.alloc(ctx, std::max<size_t>(ns, 1) << n)); H_TRY(wv.alloc(ctx, std::max<size_t>(ns, 4)));
+                for (size_t i = 0; i < nm; i++) srcm[i] = cs.trees[c.cols[selm[i]].first].polys[c.cols[selm[i]].second].ptr;
+                DevBuf ext, extm, wv; H_TRY(ext.alloc(ctx, std::max<size_t>(ns, 1) << n)); H_TRY(wv.alloc(ctx, std::max<size_t>(ns, 4)));
                 auto dst = col_ptrs(ext.p, (uint32_t)ns, n);
                 if (ns) H_TRY(nx_evaluate_batch(ctx, qtw[n], src.data(), (uint32_t)ns, n, 0, dst.data()));
+                std::vector<uint32_t*> dstm;
+                if (nm) {
+                    nx_twiddles* htw = nullptr;                      // the first half of the 4N-point domain as a 2N-point circle domain
+                    H_TRY(twiddles_first_part(ctx, cs.tw, n + 1, 1, &htw));
+                    struct Guard { nx_twiddles* t; ~Guard() { nx_twiddles_destroy(t); } } guard{htw};
+                    H_TRY(extm.alloc(ctx, nm << (n + 1)));
+                    dstm = col_ptrs(extm.p, (uint32_t)nm, n + 1);
+                    H_TRY(nx_evaluate_batch(ctx, htw, srcm.data(), (uint32_t)nm, n, 1, dstm.data()));
+                    H_TRY(nx_sync(ctx));                             // the sub-tree is released here
+                }
                 const std::vector<uint32_t> den = vanishing_denominators(n, n + 2);
                 std::vector<const uint32_t*> ptrs(c.cols.size(), nullptr);
                 for (size_t i = 0; i < ns; i++) ptrs[sel[i]] = dst[i];
+                for (size_t i = 0; i < nm; i++) ptrs[selm[i]] = dstm[i];
                 uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = qg.accq.c[k];
                 H_TRY(air_eval_rows(ctx, part.kernel, ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 2, a4, 0, N));
-                if (ns) {
-                    const Pt w = pt_from_index(circle_domain_index((int)n + 2, bitrev(N, (int)n + 2)));
-                    std::vector<uint32_t> pidx(ns), pts(8 * ns), ev(4 * ns), wh(ns);
-                    uint32_t pw8[8]; { QPt qp; qp.x = q_from_m(w.x); qp.y = q_from_m(w.y); q_store(pw8, qp.x); q_store(pw8 + 4, qp.y); }
-                    for (size_t i = 0; i < ns; i++) { pidx[i] = (uint32_t)i; memcpy(&pts[8 * i], pw8, 32); }
-                    H_TRY(nx_eval_at_points(ctx, src.data(), n, pidx.data(), pts.data(), (uint32_t)ns, ev.data()));
-                    for (size_t i = 0; i < ns; i++) wh[i] = ev[4 * i];                       // a base-field polynomial at a base-field point
-                    H_TRY(nx_upload(ctx, wv.p, wh.data(), ns));
-                    for (size_t i = 0; i < ns; i++) ptrs[sel[i]] = bias_rows((const uint32_t*)(wv.p + i), N);      // one-row "columns", indexed with the global row N
+                if (ns + nm) {
+                    if (ns) {
+                        const Pt w = pt_from_index(circle_domain_index((int)n + 2, bitrev(N, (int)n + 2)));
+                        std::vector<uint32_t> pidx(ns), pts(8 * ns), ev(4 * ns), wh(ns);
+                        uint32_t pw8[8]; { QPt qp; qp.x = q_from_m(w.x); qp.y = q_from_m(w.y); q_store(pw8, qp.x); q_store(pw8 + 4, qp.y); }
+                        for (size_t i = 0; i < ns; i++) { pidx[i] = (uint32_t)i; memcpy(&pts[8 * i], pw8, 32); }
+                        H_TRY(nx_eval_at_points(ctx, src.data(), n, pidx.data(), pts.data(), (uint32_t)ns, ev.data()));
+                        for (size_t i = 0; i < ns; i++) wh[i] = ev[4 * i];                       // a base-field polynomial at a base-field point
+                        H_TRY(nx_upload(ctx, wv.p, wh.data(), ns));
+                        for (size_t i = 0; i < ns; i++) ptrs[sel[i]] = bias_rows((const uint32_t*)(wv.p + i), N);      // one-row "columns", indexed with the global row N
+                    }
+                    // the neighbour-read columns keep their 2N-row buffers: row N and its neighbours (first quarter) are both in them
                     H_TRY(air_eval_rows(ctx, part.kernel, ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 2, a4, N, 1));
-                    H_TRY(nx_sync(ctx));                                                   // ext / wv are released at the end of this block
+                    H_TRY(nx_sync(ctx));                                                   // ext / extm / wv are released at the end of this block
                 }
                 continue;
             }

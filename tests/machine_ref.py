@@ -60,7 +60,8 @@ def batches(comp):
 def machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd=1):
     """The component's AIR through the recording evaluator: what `add_constraints` of a FrameworkEval would declare.
     A component whose degree bound (its own, or the config's `cfg_lcd` when 0 / absent) is 2 has degree-4 constraints: each degree-2
-    main-trace constraint times the two columns it squares (the logup constraints stay degree 2, like finalize_logup's)."""
+    main-trace constraint times the two columns it squares, each transition constraint times main0 main1 (degree 4 over a neighbour
+    row); the logup constraints stay degree 2 (finalize_logup) or 3 (in pairs)."""
     log, n_pre, n_main, n_inter = comp[:4]
     bound = comp[4] if len(comp) > 4 and comp[4] else cfg_lcd
     quartic = bound >= 2
@@ -72,8 +73,9 @@ def machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd=1):
     m1, m1n = pb.next_trace_mask(MAIN + 1, (0, 1))
     (is_last,) = pb.next_trace_mask(PRE + 1)
     not_last = 1 - is_last
-    pb.add_constraint((m0n - m0 - 1) * not_last)
-    pb.add_constraint((m1n - m1 - m0) * not_last)
+    t0, t1 = (m0n - m0 - 1) * not_last, (m1n - m1 - m0) * not_last
+    pb.add_constraint(t0 * m0 * m1 if quartic else t0)          # +2 components: degree 4 over a neighbour row (the reference's Pc / IsPadding constraints)
+    pb.add_constraint(t1 * m0 * m1 if quartic else t1)
     main = [m0, m1] + [pb.next_trace_mask(MAIN + k)[0] for k in range(2, n_main)]
     for k in range(2, n_main):
         if k % 16 >= 2:

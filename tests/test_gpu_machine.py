@@ -134,7 +134,9 @@ def test_machine_quarter_domain_composition_on_and_off(nz, oracle):
              ([(9, 3, 20, 8, 2), (9, 2, 9, 4, 2), (10, 3, 12, 8, 1), (6, 2, 5, 4, 2)], dict(pow_bits=4, log_constraint_degree=2))]
     for comps, kw in cases:
         ref = M.prove_machine(comps, O.default_cfg(**kw), seed=28, ad=b"q4", threads=THREADS)
-        for quarter, half, split in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0)):
+        # quarter = 2 (default): the degree-4 transition constraints — they read main0 / main1 at the next row — go to the quarter domain too,
+        # those two columns evaluated on the first HALF of the 4N-point domain; 1: they stay on the 4N-point domain; 0: off
+        for quarter, half, split in ((2, 1, 1), (1, 1, 1), (0, 1, 1), (2, 0, 1), (2, 1, 0), (2, 0, 0), (1, 0, 0)):
             b = nz.HipBackend()
             b.set_option("air.quarter_domain", quarter); b.set_option("air.half_domain", half); b.set_option("air.degree_split", split)
             _same(ref, b.prove_machine(comps, nz.default_config(**kw), seed=28, ad=b"q4"))
