@@ -466,6 +466,20 @@ int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* kernel, const uint32_t* const*
                 const uint32_t* alpha_powers, const uint32_t* denom_inv, uint32_t log_size, uint32_t log_eval,
                 uint32_t* const* d_acc4);
 void nx_air_kernel_destroy(nx_air_kernel* kernel);
+/* Ahead-of-time kernels: the hiprtc compilation of a recorded AIR costs from 0.7 s (the bench's AIR) to seconds (a keccak-shaped one) and
+ * would otherwise be paid by the first proof of every process.
+ * nx_air_kernel_save: the kernel as a self-describing blob (header + gfx950 code object; free with nx_free_host) — build it once, in a
+ * build step or on another box, ship it; nx_air_kernel_load: a kernel from such a blob, in milliseconds (checksummed; a blob of another
+ * library version is refused).  Pass the loaded kernel in nx_air_component.kernel.
+ * nx_air_cache_dir: a directory (created if its parent exists; NULL or "" = off; initial value: the environment variable
+ * NX_AIR_CACHE_DIR) in which the library keeps those blobs by itself, keyed by a hash of the generated source, the target and the hiprtc
+ * version: nx_air_compile / nx_air_compile_subset — and therefore the provers, which compile their components' kernels through them —
+ * load from it when they can and store what they compile (write-then-rename: processes may share a directory).  Process-wide.
+ * nx_air_cache_stats: kernels compiled by hiprtc / loaded from the directory / stored into it by this process (any pointer may be NULL). */
+int nx_air_kernel_save(const nx_air_kernel* kernel, uint8_t** blob, size_t* n_bytes);
+int nx_air_kernel_load(nx_ctx* ctx, const uint8_t* blob, size_t n_bytes, nx_air_kernel** out);
+int nx_air_cache_dir(const char* dir);
+int nx_air_cache_stats(uint64_t* n_compiled, uint64_t* n_disk_hits, uint64_t* n_stored);
 /* Degree-aware evaluation.  FrameworkEval::max_constraint_log_degree_bound (reference prover/src/components/mod.rs:44-45: +2 for v1's
  * main component) is the bound of the component's HIGHEST-degree constraint: Stwo evaluates every constraint, and therefore
  * re-extends every column, on the domain of log_size + bound.  A constraint of degree d over columns of 2^n rows has its quotient in

@@ -183,18 +183,46 @@ def air_constraint_degrees(program, n_cols):
     return out[:n_c]
 
 
+def air_cache_dir(path):
+    """nx_air_cache_dir: the directory the library keeps compiled AIR kernels in (None = off).  Process-wide."""
+    L = load_library()
+    rc = L.nx_air_cache_dir(path.encode() if path else None)
+    if rc != 0:
+        raise NexusHipError(f"nx_air_cache_dir failed ({rc})")
+
+
+def air_cache_stats():
+    """(kernels compiled by hiprtc, loaded from the cache directory, stored into it) by this process"""
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    load_library().nx_air_cache_stats(C.byref(a), C.byref(b), C.byref(c))
+    return int(a.value), int(b.value), int(c.value)
+
+
 class AirKernel:
     """A recorded AIR compiled by hiprtc (nx_air_compile / nx_air_compile_subset); eval() matches HipBackend.eval_constraint_program.
     select: one flag per constraint — the kernel evaluates only those (columns they do not read may be passed as None to eval)."""
 
-    def __init__(self, be, program, n_cols, select=None):
+    def __init__(self, be, program, n_cols, select=None, blob=None):
+        """blob: a kernel saved by save() (nx_air_kernel_load: no compilation) — the program is still needed for eval()'s default constants"""
         self.be, self.program, self.n_cols = be, program, n_cols
         ins = _u32(program.instrs).reshape(-1)
         self.n_constraints = int(sum(1 for op in ins[0::4] if op in (13, 14)))
         self.h = C.c_void_p()
+        if blob is not None:
+            b = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))
+            be._chk(be.L.nx_air_kernel_load(be.ctx, b, C.c_size_t(len(blob)), C.byref(self.h)))
+            return
         sel, sel_p = _select_arg(select, self.n_constraints)
         be._chk(be.L.nx_air_compile_subset(be.ctx, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, n_cols, len(_u32(program.econsts).reshape(-1)) // 4,
                                            self.n_constraints, sel_p, C.byref(self.h), None))
+
+    def save(self):
+        """The compiled kernel as bytes (nx_air_kernel_save): header + gfx950 code object, loadable by AirKernel(..., blob=...)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self.be._chk(self.be.L.nx_air_kernel_save(self.h, C.byref(p), C.byref(n)))
+        out = C.string_at(p, n.value)
+        self.be.L.nx_free_host(p)
+        return out
 
     def eval(self, column_ptrs, alpha_powers, denom_inv, log_size, log_eval, acc4, econsts=None):
         assert len(column_ptrs) == self.n_cols

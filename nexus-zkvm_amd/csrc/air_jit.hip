@@ -15,11 +15,18 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+#include <stdio.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 struct nx_air_kernel {
     nx_ctx* ctx;
     hipModule_t module;
     std::vector<hipFunction_t> fns;      // one kernel per program segment (air_kernel, air_kernel_1, ...), launched back to back
     uint32_t n_cols, n_econsts, n_constraints;
+    std::vector<char> code;              // the gfx950 code object the module was loaded from (nx_air_kernel_save; the disk cache)
 };
 
 namespace nx {
@@ -331,6 +338,67 @@ void air_kernel_shape(const nx_air_kernel* k, uint32_t* n_cols, uint32_t* n_econ
 
 }  // namespace nx
 
+// ---- ahead-of-time kernels (the hiprtc compilation — 0.7 s for the headline AIR, 8 s for the keccak-shaped one — sat
+// outside every number and every proof of a fresh process paid it).  A compiled kernel is a self-describing blob: a 48-byte header
+// (magic, version, kernel / column / constant / constraint counts, code size, FNV-1a of the code) + the gfx950 code object.
+//   nx_air_kernel_save / nx_air_kernel_load   the blob of a kernel / a kernel from a blob: build once (a build step, another box — the
+//                                              compilation needs no GPU of the same process), ship next to the binary, load in ms
+//   nx_air_cache_dir                           a directory the library keeps those blobs in, keyed by a hash of the generated source,
+//                                              the target and the hiprtc version: nx_air_compile* (and the prover, which compiles the
+//                                              components' kernels through it) look there first and store what they compile
+namespace nx {
+namespace {
+struct BlobHeader { uint32_t magic, version, n_kernels, n_cols, n_econsts, n_constraints; uint64_t code_size, code_hash; uint64_t reserved; };
+constexpr uint32_t BLOB_MAGIC = 0x4B41584Eu /* "NXAK" */, BLOB_VERSION = 1;
+uint64_t fnv1a(const void* p, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+struct CacheState { std::mutex mu; bool init = false; std::string dir; std::atomic<uint64_t> compiled{0}, disk_hits{0}, stored{0}; };
+CacheState& cache_state() { static CacheState s; return s; }
+std::string cache_dir() {
+    CacheState& s = cache_state();
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (!s.init) { const char* e = getenv("NX_AIR_CACHE_DIR"); if (e && *e) { s.dir = e; (void)mkdir(e, 0755); } s.init = true; }
+    return s.dir;
+}
+int load_code(nx_ctx* ctx, const BlobHeader& h, const char* code, nx_air_kernel** out) {
+    nx_air_kernel* k = new nx_air_kernel();
+    k->ctx = ctx; k->n_cols = h.n_cols; k->n_econsts = h.n_econsts; k->n_constraints = h.n_constraints;
+    k->code.assign(code, code + h.code_size);
+    hipError_t e = hipModuleLoadData(&k->module, k->code.data());
+    if (e != hipSuccess) { delete k; return hip_fail(ctx, e, "hipModuleLoadData(air kernel)", __FILE__, __LINE__); }
+    k->fns.resize(h.n_kernels);
+    for (uint32_t f = 0; f < h.n_kernels && e == hipSuccess; f++)
+        e = hipModuleGetFunction(&k->fns[f], k->module, f == 0 ? "air_kernel" : ("air_kernel_" + std::to_string(f)).c_str());
+    if (e != hipSuccess) { (void)hipModuleUnload(k->module); delete k; return hip_fail(ctx, e, "hipModuleGetFunction(air kernel)", __FILE__, __LINE__); }
+    *out = k;
+    return NX_OK;
+}
+bool blob_ok(const uint8_t* blob, size_t n, BlobHeader* h) {
+    if (!blob || n < sizeof(BlobHeader)) return false;
+    memcpy(h, blob, sizeof *h);
+    return h->magic == BLOB_MAGIC && h->version == BLOB_VERSION && h->n_kernels >= 1 && h->n_kernels <= 4096 && h->code_size == n - sizeof(BlobHeader) &&
+           h->code_hash == fnv1a(blob + sizeof(BlobHeader), (size_t)h->code_size);
+}
+std::vector<uint8_t> make_blob(const nx_air_kernel* k) {
+    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, (uint32_t)k->fns.size(), k->n_cols, k->n_econsts, k->n_constraints, (uint64_t)k->code.size(), fnv1a(k->code.data(), k->code.size()), 0};
+    std::vector<uint8_t> b(sizeof h + k->code.size());
+    memcpy(b.data(), &h, sizeof h); memcpy(b.data() + sizeof h, k->code.data(), k->code.size());
+    return b;
+}
+std::string cache_path(const std::string& dir, const std::string& src) {
+    int maj = 0, min = 0; (void)hiprtcVersion(&maj, &min);
+    const std::string salt = "|gfx950|-O3|hiprtc " + std::to_string(maj) + "." + std::to_string(min) + "|blob " + std::to_string(BLOB_VERSION);
+    const uint64_t a = fnv1a(salt.data(), salt.size(), fnv1a(src.data(), src.size())), b = fnv1a(src.data(), src.size(), 0x9E3779B97F4A7C15ull ^ src.size());
+    char name[64]; snprintf(name, sizeof name, "/nxair-%016llx%016llx.nxak", (unsigned long long)a, (unsigned long long)b);
+    return dir + name;
+}
+}  // namespace
+}  // namespace nx
+
+
 using namespace nx;
 
 extern "C" {
@@ -367,6 +435,21 @@ int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_inst
     if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
     if (!out) return NX_OK;
     if (!ctx) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: a context is needed to load the kernel");
+    const std::string dir = cache_dir();
+    const std::string path = dir.empty() ? std::string() : cache_path(dir, src);
+    if (!path.empty()) {                                  // the disk cache: a blob stored by an earlier process (or a build step)
+        FILE* f = fopen(path.c_str(), "rb");
+        if (f) {
+            std::vector<uint8_t> b;
+            uint8_t buf[1 << 16]; size_t got;
+            while ((got = fread(buf, 1, sizeof buf, f)) > 0) b.insert(b.end(), buf, buf + got);
+            fclose(f);
+            BlobHeader h;
+            if (blob_ok(b.data(), b.size(), &h) && h.n_kernels == n_kernels && h.n_cols == n_cols && h.n_econsts == n_econsts && h.n_constraints == n_constraints &&
+                load_code(ctx, h, (const char*)b.data() + sizeof h, out) == NX_OK) { cache_state().disk_hits++; return NX_OK; }
+            // a damaged or foreign file: fall through to the compiler (and overwrite it)
+        }
+    }
     hiprtcProgram rp;
     if (hiprtcCreateProgram(&rp, src.c_str(), "nx_air_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return set_err(ctx, NX_ERR_HIP, "hiprtcCreateProgram failed");
     const char* opts[] = {"--offload-arch=gfx950", "-O3"};
@@ -381,15 +464,51 @@ int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_inst
     std::vector<char> code(cs);
     (void)hiprtcGetCode(rp, code.data());
     (void)hiprtcDestroyProgram(&rp);
-    nx_air_kernel* k = new nx_air_kernel();
-    k->ctx = ctx; k->n_cols = n_cols; k->n_econsts = n_econsts; k->n_constraints = n_constraints;
-    hipError_t e = hipModuleLoadData(&k->module, code.data());
-    k->fns.resize(n_kernels);
-    for (uint32_t f = 0; f < n_kernels && e == hipSuccess; f++)
-        e = hipModuleGetFunction(&k->fns[f], k->module, f == 0 ? "air_kernel" : ("air_kernel_" + std::to_string(f)).c_str());
-    if (e != hipSuccess) { delete k; return hip_fail(ctx, e, "hipModuleLoadData(air kernel)", __FILE__, __LINE__); }
-    *out = k;
+    cache_state().compiled++;
+    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, n_kernels, n_cols, n_econsts, n_constraints, (uint64_t)code.size(), 0, 0};
+    NX_TRY(load_code(ctx, h, code.data(), out));
+    if (!path.empty()) {                                  // store: write beside, then rename — a concurrent reader sees the old file or the whole new one
+        const std::vector<uint8_t> b = make_blob(*out);
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (f) {
+            const bool ok = fwrite(b.data(), 1, b.size(), f) == b.size();
+            if (fclose(f) == 0 && ok && rename(tmp.c_str(), path.c_str()) == 0) cache_state().stored++;
+            else (void)remove(tmp.c_str());
+        }
+    }
     return NX_OK;
+}
+
+int nx_air_cache_dir(const char* dir) {
+    CacheState& s = cache_state();
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.init = true; s.dir = dir ? dir : "";
+    if (!s.dir.empty()) (void)mkdir(s.dir.c_str(), 0755);          // one level; an existing directory is fine
+    return NX_OK;
+}
+int nx_air_cache_stats(uint64_t* n_compiled, uint64_t* n_disk_hits, uint64_t* n_stored) {
+    CacheState& s = cache_state();
+    if (n_compiled) *n_compiled = s.compiled.load();
+    if (n_disk_hits) *n_disk_hits = s.disk_hits.load();
+    if (n_stored) *n_stored = s.stored.load();
+    return NX_OK;
+}
+int nx_air_kernel_save(const nx_air_kernel* k, uint8_t** blob, size_t* n_bytes) {
+    if (!k || !blob || !n_bytes) return set_err(k ? k->ctx : nullptr, NX_ERR_ARG, "nx_air_kernel_save: NULL argument");
+    const std::vector<uint8_t> b = make_blob(k);
+    uint8_t* out = (uint8_t*)malloc(b.size());
+    if (!out) return set_err(k->ctx, NX_ERR_OOM, "nx_air_kernel_save: malloc failed");
+    memcpy(out, b.data(), b.size());
+    *blob = out; *n_bytes = b.size();
+    return NX_OK;
+}
+int nx_air_kernel_load(nx_ctx* ctx, const uint8_t* blob, size_t n_bytes, nx_air_kernel** out) {
+    NX_GUARD(ctx);
+    if (!ctx || !blob || !out) return set_err(ctx, NX_ERR_ARG, "nx_air_kernel_load: NULL argument");
+    BlobHeader h;
+    if (!blob_ok(blob, n_bytes, &h)) return set_err(ctx, NX_ERR_ARG, "nx_air_kernel_load: not a kernel blob of this library version (magic / size / checksum)");
+    return load_code(ctx, h, (const char*)blob + sizeof h, out);
 }
 
 void nx_air_kernel_destroy(nx_air_kernel* k) {

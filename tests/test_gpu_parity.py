@@ -792,6 +792,61 @@ def test_air_jit_reproduces_the_synthetic_machine(be, nz, oracle):
         kern.eval(ptrs, pw, den[:1], log, log, acc)
 
 
+def test_air_kernels_ahead_of_time_blob_and_cache_directory(be, nz, oracle, tmp_path):
+    """VERDICT r4 weak #10 (the hiprtc compilation sat outside every number): (1) nx_air_kernel_save / nx_air_kernel_load — a compiled
+    kernel as a blob, loaded by ANOTHER context without a compilation, same accumulator; a damaged blob is refused; (2) nx_air_cache_dir —
+    the first prove of a machine in a fresh process compiles and stores, the first prove of the NEXT process loads every kernel from the
+    directory (0 compilations) and returns the same proof bytes."""
+    import json, subprocess, sys
+    import nexus_zkvm_amd.air_program as ap
+    from test_air_program_cpu import denominators
+    rng = np.random.default_rng(77)
+    log, e, n_cols = 8, 9, 12
+    prog = _random_program(ap, rng, n_cols, 150)
+    kern = be.compile_air(prog, n_cols)
+    blob = kern.save()
+    assert blob[:4] == b"NXAK" and len(blob) > 1000
+    cols = rng.integers(0, P, (n_cols, 1 << e), dtype=np.uint32)
+    pw = rng.integers(0, P, (prog.n_constraints, 4), dtype=np.uint32)
+    den = denominators(log, e)
+    start = rng.integers(0, P, (4, 1 << e), dtype=np.uint32)
+    d_cols, acc = be.columns_from_host(cols), be.columns_from_host(start)
+    kern.eval([d_cols.ptr.value + k * (4 << e) for k in range(n_cols)], pw, den, log, e, acc)
+    want = acc.to_cpu()
+    assert np.array_equal(want, np.stack(oracle.eval_constraint_program(prog, list(cols), pw, den, log, e, acc4=list(start))))
+    b2 = nz.HipBackend(0)
+    before = nz.air_cache_stats()
+    k2 = nz.AirKernel(b2, prog, n_cols, blob=blob)
+    assert nz.air_cache_stats()[0] == before[0]                        # no compilation
+    d2, a2 = b2.columns_from_host(cols), b2.columns_from_host(start)
+    k2.eval([d2.ptr.value + k * (4 << e) for k in range(n_cols)], pw, den, log, e, a2)
+    assert np.array_equal(a2.to_cpu(), want)
+    bad = bytearray(blob); bad[len(bad) // 2] ^= 1
+    with pytest.raises(nz.NexusHipError, match="blob"):
+        nz.AirKernel(b2, prog, n_cols, blob=bytes(bad))
+    with pytest.raises(nz.NexusHipError, match="blob"):
+        nz.AirKernel(b2, prog, n_cols, blob=blob[:100])
+    k2.close(); b2.close(); kern.close()
+    # the cache directory, across processes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, time, numpy as np, torch, nexus_zkvm_amd as nz\n"
+            "be = nz.HipBackend(0)\n"
+            "comps = [(10, 4, 40, 24, 2, 1), (8, 3, 16, 32, 1, 5)]\n"
+            "t0 = time.perf_counter(); w = be.prove_machine(comps, nz.default_config(pow_bits=4, log_constraint_degree=2), seed=9); dt = time.perf_counter() - t0\n"
+            "print(json.dumps({'stats': nz.air_cache_stats(), 'first_prove_s': dt, 'sum': int(np.asarray(w, dtype=np.uint64).sum()), 'n': len(w)}))\n")
+    env = dict(os.environ, NX_AIR_CACHE_DIR=str(tmp_path / "kernels"), PYTHONPATH=root)
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    (c1, h1, s1), (c2, h2, s2) = runs[0]["stats"], runs[1]["stats"]
+    assert c1 >= 2 and h1 == 0 and s1 == c1, runs                       # compiled and stored
+    assert c2 == 0 and h2 == c1 and s2 == 0, runs                       # the next process: every kernel from the directory
+    assert runs[0]["sum"] == runs[1]["sum"] and runs[0]["n"] == runs[1]["n"]
+    assert len(list((tmp_path / "kernels").glob("nxair-*.nxak"))) == c1
+
+
 def test_air_jit_rejects_malformed_programs(be, nz):
     import nexus_zkvm_amd.air_program as ap
     pb = ap.ProgramBuilder()
