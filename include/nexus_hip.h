@@ -445,7 +445,11 @@ enum {
     NX_C_ADDEB = 11,        /* E[dst] = E[a] + B[b]                                                  */
     NX_C_LOADE = 12,        /* E[dst] = (cols[a], cols[a+1], cols[a+2], cols[a+3])[row + (int32)b steps]  (a secure column) */
     NX_C_CONSTRAINT_B = 13, /* add_constraint(B[a])                                                  */
-    NX_C_CONSTRAINT_E = 14  /* add_constraint(E[a])                                                  */
+    NX_C_CONSTRAINT_E = 14, /* add_constraint(E[a])                                                  */
+    /* logup FRACTION programs only (nx_logup_program): a relation entry of the AIR, add_to_relation(RelationEntry { relation,
+     * multiplicity, values }) — numerator = the multiplicity expression, denominator = relation.combine(values) */
+    NX_C_FRAC = 15,         /* fraction E[a] / E[b] of logup column (batch) dst                       */
+    NX_C_FRACB = 16         /* fraction B[a] / E[b] of logup column (batch) dst (a base-field numerator) */
 };
 typedef struct nx_cinstr { uint32_t op, dst, a, b; } nx_cinstr;
 int nx_eval_constraint_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs,
@@ -599,6 +603,24 @@ int nx_logup_finalize_last(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_co
  * launches and one device-to-host copy: the form for AIRs with many components / logup columns (BASELINE config #5). */
 int nx_logup_finalize_last_batch(nx_ctx* ctx, uint32_t log_size, uint32_t* const* d_cols4, uint32_t n_cols,
                                  uint32_t* claimed_sums);
+
+/* The interaction trace of a component FROM ITS RECORDED AIR.  A recording EvalAtRow sees every relation entry the AIR declares —
+ * eval.add_to_relation(RelationEntry::new(relation, multiplicity, &values)), e.g. reference prover/src/components/mod.rs:48-56,
+ * prover/src/extensions/keccak/round/constraints.rs:95-116, prover2's components — as two expressions over the trace columns: the
+ * multiplicity and relation.combine(values) = sum_i alpha^i values_i - z.  Those expressions, lowered like constraints (same opcodes,
+ * loads of the component's preprocessed / main columns, any row offset) with one NX_C_FRAC / NX_C_FRACB per entry, ARE the
+ * interaction trace: logup column j (batch j of finalize_logup / finalize_logup_in_pairs / finalize_logup_batched) holds the sum over
+ * the entries of batches <= j of multiplicity / denominator — what the reference's hand-written generators (prover/src/traits.rs:
+ * 124-145 -> every chip's fill_interaction_trace; prover2/machine/src/lookups/logup_trace_builder.rs:22-121) must compute too, or
+ * their own constraints fail.  So the generator of EVERY chip and component moves to the device without touching one of them.
+ * program: the fractions in non-decreasing batch order, every batch 0 .. n_logup_cols - 1 present; d_cols: the component's columns
+ * as EVALUATIONS on the trace domain (bit-reversed circle-domain order, 2^log_size words; columns the program does not load may be
+ * NULL — the interaction columns themselves always are); d_out: 4 n_logup_cols coordinate columns.  Follow with
+ * nx_logup_finalize_last on the last column.  Compiled by hiprtc (cached per context; nx_air_cache_dir applies).
+ * h_source_out (optional; then ctx / d_cols / d_out may be NULL and no GPU is needed): the generated HIP source. */
+int nx_logup_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, const uint32_t* const* d_cols,
+                     uint32_t n_cols, const uint32_t* econsts, uint32_t n_econsts, uint32_t log_size, uint32_t n_logup_cols,
+                     uint32_t* const* d_out, char** h_source_out);
 
 /* Config #2: LDE + Blake2s commit of n_cols random columns of 2^log_size rows (already resident,
  * bit-reversed evaluations, overwritten by their coefficients); d_lde receives the LDE columns. */

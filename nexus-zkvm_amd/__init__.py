@@ -170,6 +170,21 @@ def air_source(program, n_cols, select=None):
         L.nx_free_host(src)
 
 
+def logup_program_source(program, n_cols, n_logup_cols):
+    """The HIP source nx_logup_program generates for a fraction program (needs no GPU and no context)."""
+    L = load_library()
+    ins = _u32(program.instrs).reshape(-1)
+    ec = _u32(program.econsts).reshape(-1)
+    src = C.c_char_p()
+    rc = L.nx_logup_program(None, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, None, n_cols, ec.ctypes.data_as(C.c_void_p) if len(ec) else None, len(ec) // 4,
+                            4, n_logup_cols, None, C.byref(src))
+    if rc != 0:
+        raise NexusHipError(f"nx_logup_program failed ({rc}): {L.nx_last_error(None).decode()}")
+    out = src.value.decode()
+    L.nx_free_host(src)
+    return out
+
+
 def air_constraint_degrees(program, n_cols):
     """nx_air_constraint_degrees: an upper bound of every constraint's degree in the trace columns (host only)."""
     L = load_library()
@@ -885,6 +900,20 @@ class HipBackend:
         ptrs = (C.c_void_p * (4 * n_cols))(*[o.ptr.value + k * (4 << log) for o in outs for k in range(4)])
         b = None if batching is None else _u32(batching)
         self._chk(self.L.nx_logup_cols_batched(self.ctx, log, arr, len(fracs), b.ctypes.data_as(C.c_void_p) if b is not None else None, n_cols, ptrs))
+        return outs
+
+    def logup_program(self, program, column_ptrs, log_size, n_logup_cols=None, econsts=None):
+        """The interaction trace of a component from the relation entries its recorded AIR declares (nx_logup_program): program =
+        ProgramBuilder.build_logup(); column_ptrs: one device pointer per component column (None where the program loads nothing).
+        Returns one 4-column DeviceColumns per logup column (follow with logup_finalize_last on the last one)."""
+        n_logup_cols = program.n_logup_cols if n_logup_cols is None else n_logup_cols
+        ins = _u32(program.instrs).reshape(-1)
+        ec = _u32(program.econsts if econsts is None else econsts).reshape(-1)
+        ptrs = (C.c_void_p * max(1, len(column_ptrs)))(*column_ptrs)
+        outs = [DeviceColumns(self, 4, log_size) for _ in range(n_logup_cols)]
+        optr = (C.c_void_p * max(1, 4 * n_logup_cols))(*[o.ptr.value + k * (4 << log_size) for o in outs for k in range(4)])
+        self._chk(self.L.nx_logup_program(self.ctx, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, ptrs, len(column_ptrs),
+                                          ec.ctypes.data_as(C.c_void_p) if len(ec) else None, len(ec) // 4, log_size, n_logup_cols, optr, None))
         return outs
 
     def logup_finalize_last(self, col4):

@@ -12,11 +12,20 @@ common subexpressions, allocates the per-row registers (a secure-field value = 4
     (b,) = pb.next_trace_mask(col=1)
     pb.add_constraint((a_next - a - pb.const(1)) * b)           # EvalAtRow::add_constraint
     prog = pb.build()
+
+Lookups are recorded the way the reference declares them (prover/src/components/mod.rs:48-56, extensions/keccak/round/constraints.rs:95-116):
+    rel = pb.relation(z, alpha, 3)                               # LookupElements<3>: z, alpha (run-time secure constants)
+    pb.add_to_relation(rel, 1, [a, b, c])                        # RelationEntry::new(relation, multiplicity, &values)
+    pb.add_to_relation(rel, -m, [x, y, w])
+    pb.finalize_logup_in_pairs(first_interaction_col, claimed_sum / N)   # or finalize_logup / finalize_logup_batched
+and yield BOTH the logup constraints (in `build()`, exactly stwo-constraint-framework's finalize_logup_batched) and the fraction
+program `build_logup()` that nx_logup_program turns into the interaction trace on the device — the same relation entries, so the
+trace satisfies the constraints by construction.
 """
 import numpy as np
 
 P = (1 << 31) - 1
-(LOAD, CONST, ADD, SUB, MUL, NEG, CONSTE, ADDE, SUBE, MULE, MULEB, ADDEB, LOADE, CONSTRAINT_B, CONSTRAINT_E) = range(15)
+(LOAD, CONST, ADD, SUB, MUL, NEG, CONSTE, ADDE, SUBE, MULE, MULEB, ADDEB, LOADE, CONSTRAINT_B, CONSTRAINT_E, FRAC, FRACB) = range(17)
 
 
 class Expr:
@@ -67,6 +76,22 @@ class Component:
         self.masks = [list(masks[k]) if masks is not None else list(program.masks.get(k, (0,))) for k in range(len(self.cols))]
 
 
+class Relation:
+    """LookupElements<N> as the recorder sees them: z and the alpha powers are secure constants of the program (run-time values)."""
+
+    def __init__(self, z, alpha_powers):
+        self.z, self.alpha_powers = z, alpha_powers
+
+    def combine(self, values):
+        """Relation::combine: sum_i alpha^i values_i - z"""
+        assert 1 <= len(values) <= len(self.alpha_powers)
+        acc = None
+        for a, v in zip(self.alpha_powers, values):
+            term = a * v
+            acc = term if acc is None else acc + term
+        return acc - self.z
+
+
 class ProgramBuilder:
     def __init__(self):
         self.nodes = []          # (op, kind, args...)
@@ -74,6 +99,9 @@ class ProgramBuilder:
         self.constraints = []    # node ids in declaration order
         self.econsts = []
         self.masks = {}
+        self.entries = []        # relation entries since the last finalize_logup*: (numerator Expr, denominator Expr)
+        self.fractions = []      # finalized: (numerator id, denominator id, logup column)
+        self.n_logup_cols = 0
 
     def _node(self, key, kind):
         if key in self.cse:
@@ -138,12 +166,81 @@ class ProgramBuilder:
     def add_constraint(self, expr):
         self.constraints.append(expr.id)
 
+    # ---- lookups (stwo-constraint-framework: RelationEntry, EvalAtRow::add_to_relation, finalize_logup*)
+    def relation(self, z, alpha, n):
+        """LookupElements<n> with the drawn z and alpha (4 words each): alpha powers 1, alpha, ..., alpha^(n-1) as secure constants"""
+        from_q = lambda q: tuple(int(x) % P for x in q)
+        pw, cur = [], (1, 0, 0, 0)
+        for _ in range(n):
+            pw.append(self.econst(cur))
+            cur = _qm31_mul(cur, from_q(alpha))
+        return Relation(self.econst(from_q(z)), pw)
+
+    def add_to_relation(self, relation, multiplicity, values):
+        """eval.add_to_relation(RelationEntry::new(relation, multiplicity, &values)): one fraction multiplicity / relation.combine(values)"""
+        num = multiplicity if isinstance(multiplicity, Expr) else self.const(int(multiplicity))
+        self.entries.append((num, relation.combine([v if isinstance(v, Expr) else self.const(int(v)) for v in values])))
+
+    def finalize_logup(self, first_interaction_col, cumsum_shift):
+        self.finalize_logup_batched(first_interaction_col, cumsum_shift, list(range(len(self.entries))))
+
+    def finalize_logup_in_pairs(self, first_interaction_col, cumsum_shift):
+        self.finalize_logup_batched(first_interaction_col, cumsum_shift, [i // 2 for i in range(len(self.entries))])
+
+    def finalize_logup_batched(self, first_interaction_col, cumsum_shift, batching):
+        """stwo-constraint-framework's finalize_logup_batched: entry i belongs to batch batching[i]; batch j owns the secure interaction
+        column first_interaction_col + 4 j; per batch the constraint (S_j - S_{j-1}) D - N with N / D the batch's fraction sum, the
+        last one over the [-1, 0] mask with the claimed-sum shift.  cumsum_shift: claimed_sum / N (4 words, a run-time constant)."""
+        assert len(batching) == len(self.entries) and self.entries
+        last = max(batching)
+        assert sorted(set(batching)) == list(range(last + 1)), "every batch 0 .. last must hold an entry"
+        shift = self.econst(tuple(int(x) % P for x in cumsum_shift))
+        base = self.n_logup_cols
+        prev = None
+        for j in range(last + 1):
+            num = den = None
+            for (n, d), b in zip(self.entries, batching):
+                if b != j:
+                    continue
+                if den is None:
+                    num, den = n, d
+                else:
+                    num, den = num * d + n * den, den * d            # Fraction::add
+            col = int(first_interaction_col) + 4 * j
+            if j < last:
+                (cur,) = self.next_secure_mask(col)
+                diff = cur if prev is None else cur - prev
+            else:
+                prow, cur = self.next_secure_mask(col, (-1, 0))
+                diff = cur - prow
+                if prev is not None:
+                    diff = diff - prev
+                diff = diff + shift
+            self.add_constraint(diff * den - num)
+            prev = cur
+            for (n, d), b in zip(self.entries, batching):
+                if b == j:
+                    self.fractions.append((n.id, d.id, base + j))
+        self.n_logup_cols = base + last + 1
+        self.entries = []
+
+    def build_logup(self):
+        """The fraction program of the finalized relation entries (nx_logup_program / oracle logup_program): the interaction trace."""
+        assert not self.entries, "relation entries without a finalize_logup*"
+        prog = self._lower([("frac", f) for f in self.fractions])
+        prog.n_logup_cols = self.n_logup_cols
+        return prog
+
     # ---- lowering
     def build(self):
+        return self._lower([("cons", c) for c in self.constraints])
+
+    def _lower(self, roots):
         nodes = self.nodes
-        # liveness: only nodes reachable from a constraint are emitted
+        root_ids = lambda r: [r[1]] if r[0] == "cons" else [r[1][0], r[1][1]]
+        # liveness: only nodes reachable from a root are emitted
         needed = [False] * len(nodes)
-        stack = list(self.constraints)
+        stack = [i for r in roots for i in root_ids(r)]
         while stack:
             i = stack.pop()
             if needed[i]:
@@ -184,17 +281,21 @@ class ProgramBuilder:
                     stack.append((c, False))
 
         CHUNK = 8
-        for j, nid in enumerate(self.constraints):
+        for j, root in enumerate(roots):
             if j % CHUNK == 0:
-                for nxt in self.constraints[j:j + CHUNK]:
-                    emit(nxt, loads_only=True)
-            emit(nid)
-            order.append(("cons", nid))
+                for nxt in roots[j:j + CHUNK]:
+                    for nid in root_ids(nxt):
+                        emit(nid, loads_only=True)
+            for nid in root_ids(root):
+                emit(nid)
+            order.append(root)
         # last use of every node (position in `order`)
         last = {}
         for pos, (what, i) in enumerate(order):
             if what == "cons":
                 last[i] = pos
+            elif what == "frac":
+                last[i[0]] = pos; last[i[1]] = pos
             else:
                 key = nodes[i][0]
                 for a in ([key[1], key[2]] if key[0] in ("add", "sub", "mul", "adde", "sube", "mule", "muleb", "addeb") else [key[1]] if key[0] == "neg" else []):
@@ -220,6 +321,8 @@ class ProgramBuilder:
             touched = []
             if what == "cons":
                 touched = [i]
+            elif what == "frac":
+                touched = [i[0], i[1]]
             else:
                 key = nodes[i][0]
                 touched = [key[1], key[2]] if key[0] in ("add", "sub", "mul", "adde", "sube", "mule", "muleb", "addeb") else [key[1]] if key[0] == "neg" else []
@@ -242,6 +345,10 @@ class ProgramBuilder:
             if what == "cons":
                 out.append((CONSTRAINT_B if nodes[i][1] == "B" else CONSTRAINT_E, 0, reg(i), 0))
                 continue
+            if what == "frac":
+                assert nodes[i[1]][1] == "E", "a relation's denominator is a secure-field value"
+                out.append((FRACB if nodes[i[0]][1] == "B" else FRAC, i[2], reg(i[0]), reg(i[1])))
+                continue
             key = nodes[i][0]
             if key[0] == "load":
                 out.append((LOAD, reg(i), key[1], key[2] & 0xFFFFFFFF))
@@ -257,4 +364,15 @@ class ProgramBuilder:
                 out.append((opmap[key[0]], reg(i), reg(key[1]), reg(key[2])))
         instrs = np.array(out, dtype=np.uint32).reshape(-1, 4)
         econsts = np.array(self.econsts, dtype=np.uint32).reshape(-1, 4) if self.econsts else np.zeros((0, 4), np.uint32)
-        return Program(instrs, n_regs, econsts, len(self.constraints), {k: list(v) for k, v in self.masks.items()})
+        n_cons = sum(1 for r in roots if r[0] == "cons")
+        return Program(instrs, n_regs, econsts, n_cons, {k: list(v) for k, v in self.masks.items()})
+
+
+def _qm31_mul(x, y):
+    """(a + b u)(c + d u) over CM31 = M31[i] / (i^2 + 1), u^2 = 2 + i — host arithmetic for the alpha powers of a relation"""
+    def cmul(p, q):
+        return ((p[0] * q[0] - p[1] * q[1]) % P, (p[0] * q[1] + p[1] * q[0]) % P)
+    a, b, c, d = (x[0], x[1]), (x[2], x[3]), (y[0], y[1]), (y[2], y[3])
+    ac, bd, ad, bc = cmul(a, c), cmul(b, d), cmul(a, d), cmul(b, c)
+    r = ((2 * bd[0] - bd[1]) % P, (2 * bd[1] + bd[0]) % P)
+    return ((ac[0] + r[0]) % P, (ac[1] + r[1]) % P, (ad[0] + bc[0]) % P, (ad[1] + bc[1]) % P)

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <stdio.h>
 #include <sys/stat.h>
@@ -175,6 +176,8 @@ static ProgDeps program_deps(const nx_cinstr* prog, uint32_t n_instr, uint32_t n
         case NX_C_MULEB: case NX_C_ADDEB: use(i, in.a, 4); use(i, in.b, 1); def(i, in.dst, 4); break;
         case NX_C_CONSTRAINT_B: use(i, in.a, 1); cons_index[i] = n_c++; break;
         case NX_C_CONSTRAINT_E: use(i, in.a, 4); cons_index[i] = n_c++; break;
+        case NX_C_FRAC: use(i, in.a, 4); use(i, in.b, 4); break;
+        case NX_C_FRACB: use(i, in.a, 1); use(i, in.b, 4); break;
         default: break;
         }
     }
@@ -399,6 +402,7 @@ std::string cache_path(const std::string& dir, const std::string& src) {
 }  // namespace nx
 
 
+namespace nx { int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out); }
 using namespace nx;
 
 extern "C" {
@@ -435,6 +439,14 @@ int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_inst
     if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
     if (!out) return NX_OK;
     if (!ctx) return set_err(ctx, NX_ERR_ARG, "nx_air_compile: a context is needed to load the kernel");
+    return compile_source(ctx, src, n_kernels, n_cols, n_econsts, n_constraints, out);
+}
+
+}  // extern "C"
+
+namespace nx {
+// generated source -> loaded kernels: the cache directory first, else hiprtc (and the directory is fed)
+int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out) {
     const std::string dir = cache_dir();
     const std::string path = dir.empty() ? std::string() : cache_path(dir, src);
     if (!path.empty()) {                                  // the disk cache: a blob stored by an earlier process (or a build step)
@@ -479,6 +491,9 @@ int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_inst
     }
     return NX_OK;
 }
+}  // namespace nx
+
+extern "C" {
 
 int nx_air_cache_dir(const char* dir) {
     CacheState& s = cache_state();
@@ -567,3 +582,258 @@ int nx_air_eval(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_co
 }
 
 }  // extern "C"
+
+// ================================================================ logup fraction programs (nx_logup_program) ================
+// The interaction trace of a component from the relation entries its recorded AIR declares (include/nexus_hip.h).  Same lowering
+// as the constraint kernels — straight-line code per row, cut into segments at BATCH boundaries so that no kernel outgrows the
+// instruction cache; a segment starts from the running sum the previous one left in its last column.  Inside a segment the
+// denominators are inverted in groups of up to 8 with ONE M31 inverse per group (Montgomery's trick on the QM31 norms, as
+// logup_cols_kernel does: logup.hip).  Rows are the trace domain's own (2^log_size evaluations, bit-reversed circle-domain
+// order); a row offset is taken in natural coset order, where the trace step is +1.
+namespace nx {
+
+static const char* LOGUP_PRELUDE = R"SRC(
+FI u32 m_sqr(u32 a) { return m_mul(a, a); }
+FI u32 m_sqn(u32 a, int n) { for (int i = 0; i < n; i++) a = m_sqr(a); return a; }
+FI u32 m_inv(u32 a) {
+    const u32 t2 = m_mul(m_sqr(a), a), t4 = m_mul(m_sqn(t2, 2), t2), t8 = m_mul(m_sqn(t4, 4), t4), t16 = m_mul(m_sqn(t8, 8), t8);
+    const u32 t24 = m_mul(m_sqn(t16, 8), t8), t28 = m_mul(m_sqn(t24, 4), t4), t29 = m_mul(m_sqr(t28), a);
+    return m_mul(m_sqn(t29, 2), a);
+}
+// natural coset row <-> position in bit-reversed circle-domain order (reference prover/src/trace/utils_external.rs:24-39)
+FI u32 pos_of_coset_row(u32 c, int log) { const u32 N = 1u << log; const u32 d = (c & 1) ? N - 1 - (c >> 1) : (c >> 1); return bitrev(d, log); }
+FI u32 coset_row_of_pos(u32 p, int log) { const u32 N = 1u << log, d = bitrev(p, log); return d < N / 2 ? 2 * d : 2 * (N - 1 - d) + 1; }
+FI u32 trace_row_offset(u32 r, int log, int off) { if (off == 0) return r; return pos_of_coset_row((coset_row_of_pos(r, log) + (u32)off) & ((1u << log) - 1), log); }
+// the norm part of a QM31 inverse: x^-1 = (a, -b) D^-1, D = a^2 - (2 + i) b^2 in CM31, D^-1 = conj(D) / (D.a^2 + D.b^2)
+FI void q_norm(Q x, u32& da, u32& db, u32& nrm) {
+    u32 a0, a1, b0, b1; c_mul(x.a, x.b, x.a, x.b, a0, a1); c_mul(x.c, x.d, x.c, x.d, b0, b1);
+    da = m_sub(a0, m_sub(m_add(b0, b0), b1)); db = m_sub(a1, m_add(m_add(b1, b1), b0));
+    nrm = m_add(m_sqr(da), m_sqr(db));
+}
+FI Q q_inv_from(Q x, u32 da, u32 db, u32 ninv) {       // ninv = 1 / nrm
+    const u32 ia = m_mul(da, ninv), ib = m_mul(m_neg(db), ninv);
+    Q r; c_mul(x.a, x.b, ia, ib, r.a, r.b); c_mul(m_neg(x.c), m_neg(x.d), ia, ib, r.c, r.d);
+    return r;
+}
+)SRC";
+
+constexpr uint32_t LOGUP_PROG_GROUP = 8;
+
+static std::string generate_logup_kernel(const nx_cinstr* prog, const std::vector<uint32_t>& keep, uint32_t n_regs, uint32_t first_col, const std::vector<char>& batch_end, const std::string& name) {
+    std::string s;
+    s += "extern \"C\" __attribute__((global)) __attribute__((amdgpu_flat_work_group_size(256, 256))) void " + name +
+         "(const u32* const* __restrict__ cols, const u32* __restrict__ econst, u32* const* __restrict__ out, int log_size, u32 n) {\n"
+         "  const u32 r = __builtin_amdgcn_workgroup_id_x() * 256 + __builtin_amdgcn_workitem_id_x();\n  if (r >= n) return;\n";
+    std::vector<int> offs;
+    for (uint32_t i : keep)
+        if (prog[i].op == NX_C_LOAD || prog[i].op == NX_C_LOADE) { int o = (int)prog[i].b; if (std::find(offs.begin(), offs.end(), o) == offs.end()) offs.push_back(o); }
+    auto off_name = [](int o) { return std::string("row_") + (o < 0 ? "m" : "p") + std::to_string(o < 0 ? -o : o); };
+    for (int o : offs) s += "  const u32 " + off_name(o) + " = trace_row_offset(r, log_size, " + std::to_string(o) + ");\n";
+    for (uint32_t k = 0; k < n_regs; k++) s += (k % 16 == 0 ? std::string("  u32 ") : std::string(", ")) + "r" + std::to_string(k) + ((k % 16 == 15 || k + 1 == n_regs) ? " = 0;\n" : " = 0");
+    auto R = [](uint32_t i) { return "r" + std::to_string(i); };
+    auto E = [&](uint32_t i) { return "Q{" + R(i) + ", " + R(i + 1) + ", " + R(i + 2) + ", " + R(i + 3) + "}"; };
+    auto setE = [&](uint32_t d, const std::string& expr) {
+        return "  { const Q t_ = " + expr + "; " + R(d) + " = t_.a; " + R(d + 1) + " = t_.b; " + R(d + 2) + " = t_.c; " + R(d + 3) + " = t_.d; }\n";
+    };
+    if (first_col == 0) s += "  Q run = {0, 0, 0, 0};\n";
+    else {
+        const std::string b = std::to_string(4 * (first_col - 1));
+        s += "  Q run = {out[" + b + "][r], out[" + b + " + 1][r], out[" + b + " + 2][r], out[" + b + " + 3][r]};\n";
+    }
+    struct Pending { uint32_t instr; bool base; };
+    std::vector<Pending> group;
+    uint32_t uid = 0;
+    auto resolve = [&]() {            // invert the group's denominators together, add the fractions in order, store finished columns
+        if (group.empty()) return;
+        const size_t G = group.size();
+        auto v = [&](const char* p, size_t k) { return std::string(p) + std::to_string(uid) + "_" + std::to_string(k); };
+        s += "  {\n";
+        for (size_t k = 0; k < G; k++) {
+            s += "    u32 " + v("da", k) + ", " + v("db", k) + ", " + v("nr", k) + "; q_norm(" + v("fd", k) + ", " + v("da", k) + ", " + v("db", k) + ", " + v("nr", k) + ");\n";
+            s += "    const u32 " + v("nz", k) + " = " + v("nr", k) + " ? " + v("nr", k) + " : 1u, " + v("pp", k) + " = " + (k ? "m_mul(" + v("pp", k - 1) + ", " + v("nz", k) + ")" : v("nz", k)) + ";\n";
+        }
+        s += "    u32 inv = m_inv(" + v("pp", G - 1) + ");\n";
+        for (size_t k = G; k-- > 0;) {
+            s += "    const u32 " + v("ni", k) + " = " + v("nr", k) + " ? " + (k ? "m_mul(inv, " + v("pp", k - 1) + ")" : std::string("inv")) + " : 0u;" + (k ? " inv = m_mul(inv, " + v("nz", k) + ");" : "") + "\n";
+        }
+        for (size_t k = 0; k < G; k++) {
+            const nx_cinstr& in = prog[group[k].instr];
+            s += "    { const Q qi = q_inv_from(" + v("fd", k) + ", " + v("da", k) + ", " + v("db", k) + ", " + v("ni", k) + "); ";
+            if (group[k].base) s += "run = q_add(run, Q{m_mul(qi.a, " + v("fn", k) + "), m_mul(qi.b, " + v("fn", k) + "), m_mul(qi.c, " + v("fn", k) + "), m_mul(qi.d, " + v("fn", k) + ")}); }\n";
+            else s += "run = q_add(run, q_mul(" + v("fn", k) + ", qi)); }\n";
+            if (batch_end[group[k].instr]) {
+                const std::string b = std::to_string(4 * in.dst);
+                s += "    out[" + b + "][r] = run.a; out[" + b + " + 1][r] = run.b; out[" + b + " + 2][r] = run.c; out[" + b + " + 3][r] = run.d;\n";
+            }
+        }
+        s += "  }\n";
+        group.clear(); uid++;
+    };
+    for (uint32_t i : keep) {
+        const nx_cinstr& in = prog[i];
+        switch (in.op) {
+        case NX_C_LOAD: s += "  " + R(in.dst) + " = G(cols[" + std::to_string(in.a) + "])[" + off_name((int)in.b) + "];\n"; break;
+        case NX_C_CONST: s += "  " + R(in.dst) + " = " + std::to_string(in.a) + "u;\n"; break;
+        case NX_C_ADD: s += "  " + R(in.dst) + " = m_add(" + R(in.a) + ", " + R(in.b) + ");\n"; break;
+        case NX_C_SUB: s += "  " + R(in.dst) + " = m_sub(" + R(in.a) + ", " + R(in.b) + ");\n"; break;
+        case NX_C_MUL: s += "  " + R(in.dst) + " = m_mul(" + R(in.a) + ", " + R(in.b) + ");\n"; break;
+        case NX_C_NEG: s += "  " + R(in.dst) + " = m_neg(" + R(in.a) + ");\n"; break;
+        case NX_C_CONSTE: { std::string b = std::to_string(4 * in.a); s += setE(in.dst, "Q{econst[" + b + "], econst[" + b + " + 1], econst[" + b + " + 2], econst[" + b + " + 3]}"); break; }
+        case NX_C_ADDE: s += setE(in.dst, "q_add(" + E(in.a) + ", " + E(in.b) + ")"); break;
+        case NX_C_SUBE: s += setE(in.dst, "q_sub(" + E(in.a) + ", " + E(in.b) + ")"); break;
+        case NX_C_MULE: s += setE(in.dst, "q_mul(" + E(in.a) + ", " + E(in.b) + ")"); break;
+        case NX_C_MULEB: s += setE(in.dst, "Q{m_mul(" + R(in.a) + ", " + R(in.b) + "), m_mul(" + R(in.a + 1) + ", " + R(in.b) + "), m_mul(" + R(in.a + 2) + ", " + R(in.b) + "), m_mul(" + R(in.a + 3) + ", " + R(in.b) + ")}"); break;
+        case NX_C_ADDEB: s += setE(in.dst, "Q{m_add(" + R(in.a) + ", " + R(in.b) + "), " + R(in.a + 1) + ", " + R(in.a + 2) + ", " + R(in.a + 3) + "}"); break;
+        case NX_C_LOADE: {
+            std::string o = off_name((int)in.b);
+            s += setE(in.dst, "Q{G(cols[" + std::to_string(in.a) + "])[" + o + "], G(cols[" + std::to_string(in.a + 1) + "])[" + o + "], G(cols[" + std::to_string(in.a + 2) + "])[" + o + "], G(cols[" +
+                                  std::to_string(in.a + 3) + "])[" + o + "]}");
+            break;
+        }
+        case NX_C_FRAC: case NX_C_FRACB: {
+            // the registers may be reused by later instructions: the fraction is copied out until its group is resolved
+            const std::string k = std::to_string(uid) + "_" + std::to_string(group.size());
+            s += "  const Q fd" + k + " = " + E(in.b) + "; ";
+            s += in.op == NX_C_FRACB ? "const u32 fn" + k + " = " + R(in.a) + ";\n" : "const Q fn" + k + " = " + E(in.a) + ";\n";
+            group.push_back({i, in.op == NX_C_FRACB});
+            if (group.size() == LOGUP_PROG_GROUP) resolve();
+            break;
+        }
+        default: break;
+        }
+    }
+    resolve();
+    s += "}\n";
+    return s;
+}
+
+int validate_logup_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, uint32_t n_cols, uint32_t n_econsts, uint32_t n_logup_cols) {
+    if (n_instr && !program) return set_err(ctx, NX_ERR_ARG, "logup program: NULL program");
+    if (n_regs == 0 || n_regs > 4096) return set_err(ctx, NX_ERR_ARG, "logup program: register count out of range");
+    std::vector<nx_cinstr> compute;
+    uint32_t next_batch = 0; bool any = false;
+    for (uint32_t i = 0; i < n_instr; i++) {
+        const nx_cinstr& in = program[i];
+        if (in.op == NX_C_CONSTRAINT_B || in.op == NX_C_CONSTRAINT_E) return set_err(ctx, NX_ERR_ARG, "logup program: a constraint instruction (the fractions are the roots of this program)");
+        if (in.op == NX_C_FRAC || in.op == NX_C_FRACB) {
+            const uint32_t wa = in.op == NX_C_FRAC ? 4 : 1;
+            if (!(in.a <= n_regs && wa <= n_regs - in.a && in.b <= n_regs && 4 <= n_regs - in.b)) return set_err(ctx, NX_ERR_ARG, "logup program: malformed instruction " + std::to_string(i));
+            if (in.dst >= n_logup_cols) return set_err(ctx, NX_ERR_ARG, "logup program: fraction of a logup column the component does not have");
+            if (any ? (in.dst != next_batch && in.dst != next_batch + 1) : in.dst != 0)
+                return set_err(ctx, NX_ERR_ARG, "logup program: fractions must come in non-decreasing batch order and every batch 0 .. last must hold one (finalize_logup_batched)");
+            next_batch = in.dst; any = true;
+            continue;
+        }
+        compute.push_back(in);
+    }
+    if (n_logup_cols && (!any || next_batch + 1 != n_logup_cols)) return set_err(ctx, NX_ERR_ARG, "logup program: a logup column without fractions");
+    uint32_t n_c = 0;
+    return validate_air_program(ctx, compute.data(), (uint32_t)compute.size(), n_regs, n_cols, n_econsts, &n_c);
+}
+
+static std::string generate_logup_source(const nx_ctx* ctx, const nx_cinstr* prog, uint32_t n_instr, uint32_t n_regs, uint32_t* n_kernels) {
+    const ProgDeps pd = program_deps(prog, n_instr, n_regs);
+    std::string s = std::string(AIR_PRELUDE) + LOGUP_PRELUDE;
+    std::vector<char> batch_end(n_instr, 0);
+    { int last = -1; for (uint32_t i = 0; i < n_instr; i++) if (prog[i].op == NX_C_FRAC || prog[i].op == NX_C_FRACB) { if (last >= 0 && prog[last].dst != prog[i].dst) batch_end[last] = 1; last = (int)i; } if (last >= 0) batch_end[last] = 1; }
+    uint32_t n_seg = 0, cost = 0, first_col = 0;
+    std::vector<char> in_seg(n_instr, 0);
+    auto add_slice = [&](uint32_t root) {
+        uint32_t added = 0;
+        std::vector<uint32_t> st{root};
+        while (!st.empty()) {
+            uint32_t i = st.back(); st.pop_back();
+            if (in_seg[i]) continue;
+            in_seg[i] = 1; added += prog[i].op == NX_C_FRAC || prog[i].op == NX_C_FRACB ? 120 : instr_cost(prog[i].op);
+            for (uint32_t d : pd.deps[i]) if (!in_seg[d]) st.push_back(d);
+        }
+        return added;
+    };
+    bool any = false;
+    auto flush = [&]() {
+        std::vector<uint32_t> keep;
+        for (uint32_t i = 0; i < n_instr; i++) if (in_seg[i]) keep.push_back(i);
+        s += generate_logup_kernel(prog, keep, n_regs, first_col, batch_end, n_seg == 0 ? std::string("air_kernel") : "air_kernel_" + std::to_string(n_seg));
+        n_seg++;
+        std::fill(in_seg.begin(), in_seg.end(), 0); cost = 0; any = false;
+    };
+    const uint32_t budget = segment_budget(ctx);
+    for (uint32_t i = 0; i < n_instr; i++) {
+        if (prog[i].op != NX_C_FRAC && prog[i].op != NX_C_FRACB) continue;
+        if (!any) first_col = prog[i].dst;
+        cost += add_slice(i); any = true;
+        if (batch_end[i] && cost >= budget) flush();            // cut only where a column is complete: the next segment reads it back
+    }
+    if (any || n_seg == 0) flush();
+    *n_kernels = n_seg;
+    return s;
+}
+
+struct LogupKernelCache { std::mutex mu; std::map<std::pair<nx_ctx*, std::string>, nx_air_kernel*> map; };
+static LogupKernelCache& logup_kernel_cache() { static LogupKernelCache c; return c; }
+void logup_kernels_release(nx_ctx* ctx) {
+    LogupKernelCache& kc = logup_kernel_cache();
+    std::lock_guard<std::mutex> lk(kc.mu);
+    for (auto it = kc.map.begin(); it != kc.map.end();) { if (it->first.first == ctx) { nx_air_kernel_destroy(it->second); it = kc.map.erase(it); } else ++it; }
+}
+
+}  // namespace nx
+
+extern "C" int nx_logup_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_instr, uint32_t n_regs, const uint32_t* const* d_cols, uint32_t n_cols, const uint32_t* econsts,
+                                uint32_t n_econsts, uint32_t log_size, uint32_t n_logup_cols, uint32_t* const* d_out, char** h_source_out) {
+    NX_GUARD(ctx);
+    if (!program || (n_econsts && !econsts)) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: NULL argument");
+    if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: log_size out of range");
+    NX_TRY(validate_logup_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, n_logup_cols));
+    uint32_t n_kernels = 1;
+    const std::string src = generate_logup_source(ctx, program, n_instr, n_regs, &n_kernels);
+    if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
+    if (!ctx || !d_out) { if (h_source_out) return NX_OK; return set_err(ctx, NX_ERR_ARG, "nx_logup_program: a context and output columns are needed to run"); }
+    if (n_logup_cols == 0) return NX_OK;
+    if (n_cols && !d_cols) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: NULL column table");
+    for (uint32_t i = 0; i < n_instr; i++) {                  // a loaded column must be there
+        const nx_cinstr& in = program[i];
+        if (in.op == NX_C_LOAD && !d_cols[in.a]) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: the program loads a column that was passed as NULL");
+        if (in.op == NX_C_LOADE) for (uint32_t k = 0; k < 4; k++) if (!d_cols[in.a + k]) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: the program loads a column that was passed as NULL");
+    }
+    for (size_t k = 0; k < 4 * (size_t)n_logup_cols; k++) if (!d_out[k]) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: NULL output column");
+    const nx_air_kernel* k = nullptr;
+    {
+        LogupKernelCache& kc = logup_kernel_cache();
+        { std::lock_guard<std::mutex> lk(kc.mu); auto it = kc.map.find({ctx, src}); if (it != kc.map.end()) k = it->second; }
+        if (!k) {
+            nx_air_kernel* nk = nullptr;
+            NX_TRY(compile_source(ctx, src, n_kernels, n_cols, n_econsts, n_logup_cols, &nk));      // outside the lock: entries are per context
+            std::lock_guard<std::mutex> lk(kc.mu);
+            kc.map.insert({{ctx, src}, nk});
+            k = nk;
+        }
+    }
+    const size_t b_cols = (size_t)n_cols * 8, b_ec = (size_t)n_econsts * 16, b_out = (size_t)n_logup_cols * 32;
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_ec = al(b_cols), o_out = o_ec + al(b_ec), total = o_out + al(b_out) + 16;
+    std::vector<uint8_t> host(total, 0);
+    if (b_cols) memcpy(host.data(), d_cols, b_cols);
+    if (b_ec) memcpy(host.data() + o_ec, econsts, b_ec);
+    memcpy(host.data() + o_out, d_out, b_out);
+    uint8_t* blob = nullptr;
+    NX_TRY(dev_alloc(ctx, total, (void**)&blob));
+    hipError_t e = hipSuccess;
+    for (size_t off = 0; off < total && e == hipSuccess; off += (size_t)4 << 20) {
+        const size_t nb = std::min(total - off, (size_t)4 << 20);
+        void* st = nullptr;
+        int rc = stage(ctx, host.data() + off, nb, &st);
+        if (rc != NX_OK) { dev_free(ctx, blob); return rc; }
+        e = hipMemcpyAsync(blob + off, st, nb, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    const void* p_cols = blob; const void* p_ec = blob + o_ec; const void* p_out = blob + o_out;
+    int ls = (int)log_size; uint32_t n = 1u << log_size;
+    void* args[] = {&p_cols, &p_ec, &p_out, &ls, &n};
+    for (hipFunction_t fn : k->fns) {
+        if (e != hipSuccess) break;
+        e = hipModuleLaunchKernel(fn, (n + 255) / 256, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr);
+    }
+    dev_free(ctx, blob);
+    if (e != hipSuccess) return hip_fail(ctx, e, "nx_logup_program", __FILE__, __LINE__);
+    return NX_OK;
+}

@@ -337,6 +337,7 @@ void nx_ctx_destroy(nx_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     nxhip::machine_kernels_release(ctx);
+    nx::logup_kernels_release(ctx);
     timing_flush(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     dev_cache_release(ctx);

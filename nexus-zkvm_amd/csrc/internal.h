@@ -92,6 +92,7 @@ struct nx_tree {
     std::vector<uint32_t*> layers;  // layers[k]: 2^k nodes x 8 words, device
 };
 
+namespace nx { void logup_kernels_release(nx_ctx* ctx); }       // air_jit.hip: compiled logup fraction programs cached per context
 namespace nxhip { void machine_kernels_release(nx_ctx* ctx); }   // machine.hip: compiled AIR kernels cached per context
 
 namespace nx {

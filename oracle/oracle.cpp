@@ -241,6 +241,10 @@ void orc_eval_constraint_program(const uint32_t* prog, uint32_t n_instr, uint32_
     eval_constraint_program((const CInstr*)prog, n_instr, n_regs, cols, econsts, pw, denom_inv, log_size, log_eval, acc4);
 }
 
+void orc_logup_program(const uint32_t* prog, uint32_t n_instr, uint32_t n_regs, const uint32_t** cols, const uint32_t* econsts, int log_size, uint32_t n_logup_cols, uint32_t** out) {
+    logup_program((const CInstr*)prog, n_instr, n_regs, cols, econsts, log_size, n_logup_cols, out);
+}
+
 void orc_logup_combine(const uint32_t** cols, uint32_t n_cols, const uint32_t* alpha_powers, const uint32_t* z, int log, uint32_t** out4) {
     logup_combine(cols, n_cols, alpha_powers, z, log, out4);
 }

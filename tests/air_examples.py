@@ -110,3 +110,55 @@ def tree_count_statement(ap, n_trees, log=6, seed=11):
     split = n_main - 6
     cols = [(3, i - split) if (t == 1 and i >= split) else (t, i) for t, i in comp.cols]
     return [pre, main[:split], inter, main[split:]], ap.Component(log, comp.program, cols, comp.masks)
+
+
+# ---- a lookup-heavy component declared through the recorder's relation API (the reference's way: add_to_relation + finalize_logup*) ----
+RELATION_COLS = 7        # main columns a, b, c, d, m, p, q
+
+
+def relation_main_trace(log, seed):
+    """a, b, d, m free; c = a*b + 3; p = a + d (so that a constraint ties it); q free.  Natural order + finalized."""
+    rng = np.random.default_rng(seed)
+    n = 1 << log
+    a, b, d, q = (rng.integers(0, P, n, dtype=np.uint64) for _ in range(4))
+    m = rng.integers(0, 1 << 12, n, dtype=np.uint64)
+    c = (a * b + 3) % P
+    p = (a + d) % P
+    nat = [x.astype(np.uint32) for x in (a, b, c, d, m, p, q)]
+    return nat, [O.finalize_column(x) for x in nat]
+
+
+def relation_program(ap, z, alpha, shift, batching="pairs", main0=0, inter0=RELATION_COLS):
+    """The recorder run over a component with 5 relation entries of 2 relations: tuples of 1, 2 and 3 values built from EXPRESSIONS
+    (a + 5, a value at the NEXT row), multiplicities 1, -m and the expression (q - 1) — what the reference's chips declare
+    (prover/src/extensions/keccak/round/constraints.rs:95-116: (is_padding - 1); bitwise_table/constraints.rs:50-71: al + const).
+    Returns the ProgramBuilder (build() = constraints, build_logup() = the fraction program)."""
+    pb = ap.ProgramBuilder()
+    a, a_next = pb.next_trace_mask(main0 + 0, (0, 1))
+    (b,) = pb.next_trace_mask(main0 + 1)
+    (c,) = pb.next_trace_mask(main0 + 2)
+    (d,) = pb.next_trace_mask(main0 + 3)
+    (m,) = pb.next_trace_mask(main0 + 4)
+    (p,) = pb.next_trace_mask(main0 + 5)
+    (q,) = pb.next_trace_mask(main0 + 6)
+    pb.add_constraint(c - a * b - 3)
+    pb.add_constraint(p - a - d)
+    r3 = pb.relation(z, alpha, 3)
+    r2 = pb.relation([int(x) ^ 1 for x in z], alpha, 2)         # a second relation: its own z
+    pb.add_to_relation(r3, 1, [a, b, c])
+    pb.add_to_relation(r3, -m, [a + 5, d, a_next])
+    pb.add_to_relation(r2, q - 1, [p, b])
+    pb.add_to_relation(r2, 1, [d])
+    pb.add_to_relation(r3, -m, [b, 7])
+    if batching == "pairs":
+        pb.finalize_logup_in_pairs(inter0, shift)
+    elif batching == "single":
+        pb.finalize_logup(inter0, shift)
+    else:
+        pb.finalize_logup_batched(inter0, shift, batching)
+    return pb
+
+
+def relation_component(ap, log, pb, n_logup_cols):
+    cols = [(1, k) for k in range(RELATION_COLS)] + [(2, k) for k in range(4 * n_logup_cols)]
+    return ap.Component(log, pb.build(), cols)

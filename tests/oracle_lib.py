@@ -220,6 +220,18 @@ def eval_constraint_program(program, cols, alpha_powers, denom_inv, log_size, lo
     return acc
 
 
+def logup_program(program, cols, log_size, n_logup_cols):
+    """The interaction trace from a fraction program (oracle/constraints.h logup_program): cols = the component's columns (None for
+    columns the program does not load); returns n_logup_cols lists of 4 coordinate columns."""
+    ins = np.asarray(program.instrs, dtype=np.uint32).reshape(-1).copy()
+    ec = np.asarray(program.econsts, dtype=np.uint32).reshape(-1).copy() if len(program.econsts) else np.zeros(4, np.uint32)
+    keep = [u32(c) if c is not None else None for c in cols]
+    arr = (C.c_void_p * max(1, len(keep)))(*[c.ctypes.data if c is not None else None for c in keep])
+    out = [np.zeros(1 << log_size, np.uint32) for _ in range(4 * n_logup_cols)]
+    lib().orc_logup_program(ptr(ins), len(ins) // 4, program.n_regs, arr, ptr(ec), log_size, n_logup_cols, ptr_array(out))
+    return [out[4 * j:4 * j + 4] for j in range(n_logup_cols)]
+
+
 def qm31_mul(a, b):
     a, b, o = u32(a), u32(b), np.zeros(4, np.uint32)
     lib().orc_qm31_mul(ptr(a), ptr(b), ptr(o))

@@ -1223,6 +1223,79 @@ def test_logup_cols_batched_matches_oracle(be, oracle, log):
         be.logup_cols_batched(fracs, [0] * F, n_cols=0)
 
 
+@pytest.mark.parametrize("log,batching,segment", [(6, "pairs", 9000), (12, "single", 9000), (12, [2, 0, 1, 1, 0], 200), (15, "pairs", 300)])
+def test_logup_program_matches_oracle(be, nz, oracle, log, batching, segment):
+    """nx_logup_program: the interaction trace of a component from the relation entries its recorded AIR declares —
+    tuples of 1 ... 3 values that are columns, expressions (a + 5) or next-row reads, multiplicities 1, -m and (q - 1), two relations —
+    compiled by hiprtc, against the oracle's literal interpreter; with a small "air.segment" budget the program is several kernels,
+    each continuing from the running sum its predecessor stored; then finalize_last."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    rng = np.random.default_rng(log)
+    z, alpha = rng.integers(0, P, 4, dtype=np.uint32), rng.integers(0, P, 4, dtype=np.uint32)
+    nat, fin = AE.relation_main_trace(log, 500 + log)
+    frac = AE.relation_program(ap, z, alpha, (0, 0, 0, 0), batching).build_logup()
+    want = oracle.logup_program(frac, fin + [None] * (4 * frac.n_logup_cols), log, frac.n_logup_cols)
+    b = nz.HipBackend(0)
+    b.set_option("air.segment", segment)
+    d = b.columns_from_host(np.stack(fin))
+    ptrs = [d.ptr.value + k * (4 << log) for k in range(len(fin))] + [None] * (4 * frac.n_logup_cols)
+    got = b.logup_program(frac, ptrs, log)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.to_cpu(), np.stack(w))
+    claimed = b.logup_finalize_last(got[-1])
+    last, ref_claimed = oracle.logup_finalize_last(want[-1])
+    assert np.array_equal(claimed, ref_claimed) and np.array_equal(got[-1].to_cpu(), np.stack(last))
+    # a second call reuses the compiled kernels (other lookup elements: they are run-time constants)
+    frac2 = AE.relation_program(ap, alpha, z, (0, 0, 0, 0), batching).build_logup()
+    assert np.array_equal(np.asarray(frac2.instrs), np.asarray(frac.instrs))
+    c0 = nz.air_cache_stats()[0]
+    got2 = b.logup_program(frac2, ptrs, log)
+    assert nz.air_cache_stats()[0] == c0
+    want2 = oracle.logup_program(frac2, fin + [None] * (4 * frac.n_logup_cols), log, frac.n_logup_cols)
+    assert all(np.array_equal(g.to_cpu(), np.stack(w)) for g, w in zip(got2, want2))
+    with pytest.raises(nz.NexusHipError, match="NULL"):
+        b.logup_program(frac, [None] * len(ptrs), log)
+    b.close()
+
+
+def test_session_with_the_interaction_trace_generated_from_the_recorded_air(be, nz, oracle):
+    """The whole flow a Rust-side prove takes once the chips' generators are gone (reference_patch/machine_hip.rs): the main tree
+    goes up from host memory with its evaluations KEPT on the device, the lookup elements are drawn, nx_logup_program + finalize_last
+    build the interaction tree on the device from the recorded relation entries, the claimed sum is mixed, the tree committed from
+    DEVICE columns, and the proof equals the oracle session's, word for word."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    from test_logup_cpu import _relation_statement
+    log = 10
+    for batching in ("pairs", "single"):
+        ref, frac, (z0, a0), fin = _relation_statement(log, batching, seed=77)
+        cfg = nz.default_config(pow_bits=3)
+        s = be.prover_session(cfg, log)
+        s.mix_u64(log)
+        s.commit([])
+        _, kept = s.commit_host(fin, keep=range(len(fin)))
+        z, alpha = s.draw_felts(2)
+        assert np.array_equal(z, z0) and np.array_equal(alpha, a0)
+        prog = AE.relation_program(ap, z, alpha, (0, 0, 0, 0), batching).build_logup()
+        ptrs = [kept[k].ptr.value for k in range(len(fin))] + [None] * (4 * prog.n_logup_cols)
+        cols = be.logup_program(prog, ptrs, log)
+        claimed = be.logup_finalize_last(cols[-1])
+        n_inv = pow((1 << log) % P, P - 2, P)
+        shift = [(int(x) * n_inv) % P for x in claimed]
+        s.mix_felts(np.array([claimed], np.uint32))
+        dev = s.tree_begin([log] * (4 * prog.n_logup_cols))
+        for j, col in enumerate(cols):
+            for q in range(4):
+                be._chk(be.L.nx_copy(be.ctx, C.c_void_p(dev[4 * j + q]), C.c_void_p(col.ptr.value + q * (4 << log)), C.c_size_t(1 << log)))
+        s.tree_commit()
+        pb = AE.relation_program(ap, z, alpha, shift, batching)
+        words = s.prove([AE.relation_component(ap, log, pb, prog.n_logup_cols)])
+        s.close()
+        assert np.array_equal(words, ref)
+
+
 def test_column_utilities(be):
     """nx_copy (Column::clone) and the building blocks of a modular all-reduce (nx_m31_add_into / widen / narrow)."""
     rng = np.random.default_rng(3)

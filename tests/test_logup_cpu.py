@@ -2,6 +2,8 @@
 rests on (no Stwo here to compare with): the fractions really are num/den, merged pairs are sums of fractions, the running
 column is a sum over columns, the claimed sum is the sum of all fractions, and after finalize_last the column is a prefix
 sum in natural coset order whose last row is zero (sum of (x - mean) over all rows)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -81,3 +83,98 @@ def test_logup_identities(oracle, log):
         run = q_add_py(run, tuple((a - b) % P for a, b in zip(c1[p], mean)))
         assert lr[p] == run
     assert lr[coset_row_position(n - 1, log)] == (0, 0, 0, 0)
+
+
+# ---------------- the interaction trace FROM THE RECORDED AIR (nx_logup_program / oracle logup_program) ----------------
+
+def _relation_statement(log, batching, seed=77):
+    """Drive the oracle session: main tree, lookup elements, interaction trace from the fraction program, prove.  Returns (proof, pb)."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    # a batch of three fractions makes a degree-4 constraint (diff d0 d1 d2): the bound +2; pairs are degree 3 under +1 like the reference's
+    lcd = 1 if isinstance(batching, str) else 2
+    cfg = O.default_cfg(pow_bits=3, log_constraint_degree=lcd)
+    nat, fin = AE.relation_main_trace(log, seed)
+    s = O.ProverSession(cfg, log, 2)
+    s.mix_u64(log)
+    s.commit([])
+    s.commit(fin)
+    z, alpha = s.draw_felts(2)
+    # the fraction program does not depend on the claimed sum: record once with a zero shift, generate the trace, then record the
+    # constraints with the real shift (the reference builds its components after the interaction trace too, machine.rs:264-285)
+    pb0 = AE.relation_program(ap, z, alpha, (0, 0, 0, 0), batching)
+    frac = pb0.build_logup()
+    cols = O.logup_program(frac, fin + [None] * (4 * frac.n_logup_cols), log, frac.n_logup_cols)
+    cols[-1], claimed = O.logup_finalize_last(cols[-1])
+    n_inv = pow((1 << log) % P, P - 2, P)
+    shift = [(int(x) * n_inv) % P for x in claimed]
+    s.mix_felts(np.array([claimed], np.uint32))
+    s.commit([c for col in cols for c in col])
+    pb = AE.relation_program(ap, z, alpha, shift, batching)
+    return s.prove([AE.relation_component(ap, log, pb, frac.n_logup_cols)]), frac, (z, alpha), fin
+
+
+@pytest.mark.parametrize("batching", ["pairs", "single", [0, 0, 0, 1, 2], [2, 0, 1, 1, 0]])
+def test_interaction_trace_from_the_recorded_relation_entries_satisfies_its_constraints(oracle, batching):
+    """the reference fills its interaction trace with hand-written per-chip generators that mirror the relation entries
+    of the AIR.  Here the entries themselves — recorded by the same evaluator that records the constraints — are lowered to a fraction
+    program and THAT is the generator: expression multiplicities ((q - 1), -m), tuple values that are expressions or next-row reads,
+    two relations, any batching.  The oracle prover's constraint check (ProvingError::ConstraintsNotSatisfied) accepts the trace."""
+    proof, frac, _, _ = _relation_statement(6, batching)
+    assert len(proof) > 100
+    n_cols = {"pairs": 3, "single": 5}.get(batching if isinstance(batching, str) else "", 3)
+    assert frac.n_logup_cols == n_cols
+
+
+def test_fraction_program_equals_the_hand_written_generator(oracle):
+    """The same columns as LogupTraceGenerator driven by hand (combine + finalize_col, tests/oracle_lib.py): one fraction per column,
+    tuples of raw columns, numerators 1 and -m."""
+    import nexus_zkvm_amd.air_program as ap
+    rng = np.random.default_rng(9)
+    log, n = 7, 128
+    cols = [rng.integers(0, P, n, dtype=np.uint32) for _ in range(4)]
+    z, alpha = rng.integers(0, P, 4, dtype=np.uint32), rng.integers(0, P, 4, dtype=np.uint32)
+    pb = ap.ProgramBuilder()
+    v = [pb.next_trace_mask(k)[0] for k in range(4)]
+    rel = pb.relation(z, alpha, 3)
+    pb.add_to_relation(rel, 1, [v[0], v[1], v[2]])
+    pb.add_to_relation(rel, -v[3], [v[1]])
+    pb.finalize_logup(4, (0, 0, 0, 0))
+    frac = pb.build_logup()
+    got = O.logup_program(frac, cols + [None] * 8, log, 2)
+    apw = np.stack([np.array([1, 0, 0, 0], np.uint32), alpha, O.qm31_mul(alpha, alpha)])
+    c0 = O.logup_finalize_col(O.logup_combine(cols[:3], apw, z))
+    c1 = O.logup_finalize_col(O.logup_combine([cols[1]], apw[:1], z), scale_a=(P - 1, 0, 0, 0), mult_a=cols[3], prev=c0)
+    assert all(np.array_equal(a, b) for a, b in zip(got[0], c0)) and all(np.array_equal(a, b) for a, b in zip(got[1], c1))
+
+
+def test_generated_logup_kernel_source_compiles_for_gfx950(oracle, tmp_path):
+    """nx_logup_program's generated HIP (no GPU needed for the text) through an offline hipcc for gfx950; a small "air.segment" budget
+    forces several kernels: each later one starts from the running sum its predecessor stored.  Malformed programs are refused."""
+    import shutil, subprocess
+    import nexus_zkvm_amd as nz
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    pb = AE.relation_program(ap, (1, 2, 3, 4), (5, 6, 7, 8), (0, 0, 0, 0), "pairs")
+    frac = pb.build_logup()
+    src = nz.logup_program_source(frac, AE.RELATION_COLS + 12, 3)
+    assert src.count("__attribute__((global))") == 1 and "trace_row_offset" in src and "m_inv(" in src
+    f = tmp_path / "logup.hip"
+    f.write_text(src)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-c", str(f), "-o", str(tmp_path / "l.o")], check=True, timeout=300)
+    os.environ["NX_AIR_SEGMENT"] = "200"
+    try:
+        many = nz.logup_program_source(frac, AE.RELATION_COLS + 12, 3)
+    finally:
+        del os.environ["NX_AIR_SEGMENT"]
+    assert many.count("__attribute__((global))") == 3 and "Q run = {out[" in many
+    (tmp_path / "logup3.hip").write_text(many)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-O3", "-c", str(tmp_path / "logup3.hip"), "-o", str(tmp_path / "l3.o")], check=True, timeout=300)
+    with pytest.raises(nz.NexusHipError, match="logup column"):
+        nz.logup_program_source(frac, AE.RELATION_COLS + 12, 2)
+    bad = ap.Program(np.concatenate([frac.instrs[-1:], frac.instrs[:-1]]), frac.n_regs, frac.econsts, 0)     # the last fraction first: batches out of order
+    with pytest.raises(nz.NexusHipError, match="batch order"):
+        nz.logup_program_source(bad, AE.RELATION_COLS + 12, 3)
+    with pytest.raises(nz.NexusHipError, match="constraint instruction"):
+        nz.logup_program_source(pb.build(), AE.RELATION_COLS + 12, 3)
