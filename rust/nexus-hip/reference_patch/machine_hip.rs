@@ -8,16 +8,20 @@
 //!   :197-206  Blake2sChannel, mix_u64 per AD byte / per log size       `Session::mix_u64`
 //!   :208-237  tree_builder.extend_evals(..) / .commit(channel) x2      `Session::tree_begin` + `tree_commit_host` (upload under the transforms)
 //!   :239-240  C::draw_lookup_elements(&mut lookup_elements, channel)   a host `Blake2sChannel` set to the session's digest (`host_channel_at`)
-//!   :242-263  generate_interaction_trace, mix_felts, commit            the reference's CPU generator, then `tree_commit_host`
+//!   :242-263  generate_interaction_trace, mix_felts, commit            ON THE DEVICE: every component's relation entries, recorded by the same
+//!                                                                      evaluator that records its constraints, run as a fraction program
+//!                                                                      (`Session::logup_trace` = nx_logup_program + finalize_last) over the
+//!                                                                      kept evaluations of the preprocessed / main columns, straight into the
+//!                                                                      interaction tree's columns; `mix_felts`; `tree_commit` — no chip's
+//!                                                                      `fill_interaction_trace` is called, nothing of tree 2 crosses PCIe
 //!   :264-285  FrameworkComponent::new(..) / to_component_prover(..)    `record_component(..)` over the same `MachineEval` / extension evals
 //!   :286-290  stwo::prover::prove(..)                                  `Session::prove` (composition, OODS, DEEP quotients, FRI, PoW, decommit)
 //!   :292-296  Proof { stark_proof, claimed_sum, log_size }             `proof_bytes` (postcard) -> `Proof`
 //!
 //! NOT COMPILED in the build image (no Rust toolchain); the `use` block below is machine.rs:1-47's (its `super::` is this file's `crate::`) — the
-//! structural test holds every `crate::` path here to the ones machine.rs itself imports.  The interaction trace stays on the CPU in this first cut
-//! (LogupTraceGenerator is written against SimdBackend); `sys::nx_logup_cols` + `sys::nx_logup_finalize_last` take over once the
-//! chips' `fill_interaction_trace` hand their tuples over as column lists (the device kernels and their parity tests exist:
-//! csrc/logup.hip, tests/test_gpu_machine.py).
+//! structural test holds every `crate::` path here to the ones machine.rs itself imports.  The uploads are the preprocessed and the main tree only
+//! (with the CPU generator the ~1000 interaction columns of a 2^22-row proof were 16.8 GB over PCIe); the reference's own
+//! `generate_interaction_trace` (traits.rs:124-145) stays the cross-check of a debug build (`NEXUS_HIP_CHECK_LOGUP=1`).
 use num_traits::Zero;
 use stwo::{
     core::{
@@ -77,13 +81,40 @@ fn host_columns(evals: &[SimdEval]) -> (Vec<*const u32>, Vec<u32>) {
     (ptrs, logs)
 }
 
-/// TreeBuilder::extend_evals(..) + commit(channel) for one trace tree (machine.rs:208-228, :230-237, :249-263): the columns stay in the
-/// SimdBackend evaluations' memory and go up in chunks under the commit's own transforms (nx_prover_tree_commit_host)
-fn commit_tree(session: &mut Session, evals: &[SimdEval]) -> Result<(), HipError> {
+/// TreeBuilder::extend_evals(..) + commit(channel) for one trace tree (machine.rs:208-228, :230-237): the columns stay in the
+/// SimdBackend evaluations' memory and go up in chunks under the commit's own transforms (nx_prover_tree_commit_host).  Every column's
+/// EVALUATIONS are also kept on the device (cloned as the chunks arrive: the reference's `finalized_trace.clone()`, machine.rs:232) —
+/// the fraction programs read them after the commit has turned the tree's own columns into coefficients.  Returns the kept columns.
+fn commit_tree_keeping_evaluations(session: &mut Session, evals: &[SimdEval]) -> Result<Vec<*const u32>, HipError> {
     let (host, logs) = host_columns(evals);
     session.tree_begin(&logs)?;
-    session.tree_commit_host(&host, false, &[])?;
-    Ok(())
+    let mut keep: Vec<(u32, *mut u32)> = Vec::with_capacity(logs.len());
+    let mut i = 0;
+    while i < logs.len() {                                   // one allocation per run of equally sized columns
+        let mut j = i;
+        while j < logs.len() && logs[j] == logs[i] { j += 1; }
+        for (k, p) in session.alloc_columns(j - i, logs[i])?.into_iter().enumerate() { keep.push(((i + k) as u32, p)); }
+        i = j;
+    }
+    session.tree_commit_host(&host, false, &keep)?;
+    Ok(keep.iter().map(|k| k.1 as *const u32).collect())
+}
+
+/// The interaction tree (machine.rs:242-263) from the components' recorded relation entries: `recorded[c]` is component c recorded with a
+/// ZERO claimed sum (the fractions do not depend on it); its columns of trees 0 / 1 are looked up in the kept evaluations, its columns of
+/// tree 2 are the session's own (tree_begin), filled in place.  Returns the claimed sums in component order.
+fn interaction_tree_on_device(session: &mut Session, recorded: &[RecordedComponent], kept: [&[*const u32]; 2]) -> Result<Vec<[u32; 4]>, HipError> {
+    let mut logs: Vec<u32> = Vec::new();
+    for c in recorded { logs.extend(std::iter::repeat(c.log_size).take(4 * c.n_logup_cols as usize)); }
+    let tree2 = session.tree_begin(&logs)?;
+    let mut claimed = Vec::with_capacity(recorded.len());
+    for c in recorded {
+        let cols: Vec<*const u32> = c.col_tree.iter().zip(&c.col_index).map(|(&t, &i)| if t < 2 { kept[t as usize][i as usize] } else { std::ptr::null() }).collect();
+        // the component's interaction columns, in the order it declared them (TraceLocations hands them out consecutively)
+        let out: Vec<*mut u32> = c.col_tree.iter().zip(&c.col_index).filter(|(&t, _)| t == 2).map(|(_, &i)| tree2[i as usize]).collect();
+        claimed.push(session.logup_trace(c, &cols, &out)?);
+    }
+    Ok(claimed)
 }
 
 fn to_proving_error(e: HipError) -> ProvingError {
@@ -160,7 +191,7 @@ impl<C: MachineChip + Sync> Machine<C> {
         for extension_trace in &extension_traces {
             tree0.extend(extension_trace.to_circle_evaluation(PREPROCESSED_TRACE_IDX));
         }
-        commit_tree(&mut session, &tree0).map_err(to_proving_error)?;
+        let kept0 = commit_tree_keeping_evaluations(&mut session, &tree0).map_err(to_proving_error)?;
         drop(tree0);
 
         // ---- machine.rs:230-237: main tree
@@ -168,30 +199,40 @@ impl<C: MachineChip + Sync> Machine<C> {
         for extension_trace in &extension_traces {
             tree1.extend(extension_trace.to_circle_evaluation(ORIGINAL_TRACE_IDX));
         }
-        commit_tree(&mut session, &tree1).map_err(to_proving_error)?;
+        let kept1 = commit_tree_keeping_evaluations(&mut session, &tree1).map_err(to_proving_error)?;
         drop(tree1);
 
-        // ---- machine.rs:239-263: lookup elements from the session's channel, interaction trace (CPU), claimed sums, interaction tree
+        // ---- machine.rs:239-263: lookup elements from the session's channel; the interaction trace from the components' own relation
+        // entries on the device; claimed sums; interaction tree.  The components are recorded a first time with zero claimed sums: their
+        // fraction programs are what generates the trace (the constraints are recorded again below, once the sums are known — the
+        // reference, too, builds its components after the interaction trace: machine.rs:264-285).
         let mut lookup_elements = AllLookupElements::default();
         C::draw_lookup_elements(&mut lookup_elements, &mut host_channel_at(&session), &extensions_config);
-        let (interaction_trace, claimed_sum) = generate_interaction_trace::<C>(
-            &finalized_trace,
-            &preprocessed_trace,
-            &finalized_program_trace,
-            &lookup_elements,
-        );
-        let mut tree2: Vec<SimdEval> = interaction_trace;
-        let mut all_claimed_sums = vec![claimed_sum];
-        for (ext, extension_trace) in extensions_iter.clone().zip(extension_traces) {
-            let (interaction_trace, claimed_sum) =
-                ext.generate_interaction_trace(extension_trace, &prover_side_note, &lookup_elements);
-            all_claimed_sums.push(claimed_sum);
-            tree2.extend(interaction_trace);
+        let mut first_pass = TraceLocations::default();
+        let mut generators: Vec<RecordedComponent> = vec![record_component(
+            &MachineEval::<C>::new(log_size, lookup_elements.clone(), extensions_config.clone()),
+            &mut first_pass,
+            SecureField::zero(),
+        )];
+        for (ext, log_size) in extensions_iter.clone().zip(all_log_sizes.get(1..).unwrap_or_default()) {
+            generators.push(ext.to_recorded_component(&mut first_pass, &lookup_elements, *log_size, SecureField::zero()));
         }
-        let claimed_words: Vec<u32> = all_claimed_sums.iter().flat_map(|s| q4(*s)).collect();
+        let claimed = interaction_tree_on_device(&mut session, &generators, [&kept0, &kept1]).map_err(to_proving_error)?;
+        drop(generators);
+        let all_claimed_sums: Vec<SecureField> = claimed
+            .iter()
+            .map(|w| SecureField::from_m31_array([BaseField::from(w[0]), BaseField::from(w[1]), BaseField::from(w[2]), BaseField::from(w[3])]))
+            .collect();
+        let claimed_sum = all_claimed_sums[0];
+        if std::env::var("NEXUS_HIP_CHECK_LOGUP").is_ok() {
+            // the reference's CPU generator as a cross-check of the device trace (debug only: it is the 16.8 GB this route avoids)
+            let (_, cpu_sum) = generate_interaction_trace::<C>(&finalized_trace, &preprocessed_trace, &finalized_program_trace, &lookup_elements);
+            assert_eq!(cpu_sum, claimed_sum, "device logup trace and fill_interaction_trace disagree on the main component's claimed sum");
+        }
+        drop(extension_traces);
+        let claimed_words: Vec<u32> = claimed.iter().flatten().copied().collect();
         session.mix_felts(&claimed_words);
-        commit_tree(&mut session, &tree2).map_err(to_proving_error)?;
-        drop(tree2);
+        session.tree_commit().map_err(to_proving_error)?;
 
         // ---- machine.rs:264-285: the components, recorded instead of instantiated (same evals, same order, same claimed sums)
         let mut locations = TraceLocations::default();

@@ -268,12 +268,16 @@ pub struct RecordedComponent {
     pub mask_count: Vec<u32>, pub mask_offsets: Vec<i32>,
     /// the reference's bound is per component: main +2 (components/mod.rs:12,44-45), extensions +1 (extensions/multiplicity.rs:108-110)
     pub log_constraint_degree_bound: u32,
+    /// the component's relation entries as a fraction program (`NX_C_FRAC` / `NX_C_FRACB`): `Session::logup_trace` runs it on the device
+    /// to produce the component's `n_logup_cols` secure interaction columns — the reference's `generate_interaction_trace`
+    /// (traits.rs:124-145) / `LogupTraceBuilder` (prover2 lookups/logup_trace_builder.rs:22-121) without any chip-side code
+    pub logup_program: Vec<sys::nx_cinstr>, pub logup_n_regs: u32, pub logup_econsts: Vec<u32>, pub n_logup_cols: u32,
 }
 
 /// machine.rs:184-296 on the device, on a context of the session's own (several sessions may prove concurrently, one per thread).
 /// Order of calls = the reference's transcript: `mix_u64` (:198-206), `tree_begin` / fill / `tree_commit` per trace tree (:208-263)
 /// with `draw_felts` (:239-240) and `mix_felts` (:262) in between, `prove` (:286-290).
-pub struct Session { ctx: *mut sys::nx_ctx, p: *mut sys::nx_prover, comm: *mut sys::nx_comm, comm_is_local: bool }
+pub struct Session { ctx: *mut sys::nx_ctx, p: *mut sys::nx_prover, comm: *mut sys::nx_comm, comm_is_local: bool, owned: Vec<*mut u32> }
 
 /// The shared board of the in-process transport (csrc/comm_local.hip): one per proof, shared (`Arc`) by the threads that prove it — one
 /// thread per GPU, each with its own `Session` and `Session::set_local_comm(&group, rank)`.  No RCCL, no second process.
@@ -287,6 +291,11 @@ impl LocalGroup {
         Ok(Self(g, world))
     }
 }
+impl LocalGroup {
+    /// re-arm a group that an abort or a timeout broke — when every rank's thread has returned from its prove (`nx_comm_group_reset`)
+    pub fn reset(&self) -> Result<(), HipError> { try_check(std::ptr::null(), unsafe { sys::nx_comm_group_reset(self.0) }) }
+    pub fn is_broken(&self) -> bool { unsafe { sys::nx_comm_group_broken(self.0) != 0 } }
+}
 impl Drop for LocalGroup { fn drop(&mut self) { unsafe { sys::nx_comm_group_destroy(self.0) } } }
 impl Session {
     pub fn new(cfg: &sys::nx_pcs_config, max_log_size: u32, device: i32) -> Result<Self, HipError> {
@@ -297,7 +306,7 @@ impl Session {
             unsafe { sys::nx_ctx_destroy(c) };
             return Err(e);
         }
-        Ok(Self { ctx: c, p, comm: std::ptr::null_mut(), comm_is_local: false })
+        Ok(Self { ctx: c, p, comm: std::ptr::null_mut(), comm_is_local: false, owned: Vec::new() })
     }
     /// one proof on the GPUs of a node: the native RCCL transport (csrc/comm_rccl.hip); `unique_id` from rank 0's `rccl_unique_id()`.
     /// The communicator belongs to the session and is destroyed with it (after the prover, which refers to it).
@@ -359,6 +368,35 @@ impl Session {
         try_check(self.ctx, unsafe { sys::nx_prover_tree_commit_host(self.p, host_cols.as_ptr(), coset_order as i32, idx.as_ptr(), idx.len() as u32, dst.as_ptr(), r.as_mut_ptr()) })?;
         Ok(r)
     }
+    /// `n_cols` device columns of 2^log_size words that live as long as the session (the kept evaluations of the trace columns the
+    /// logup fractions read: `tree_commit_host`'s `keep` targets)
+    pub fn alloc_columns(&mut self, n_cols: usize, log_size: u32) -> Result<Vec<*mut u32>, HipError> {
+        let mut base = std::ptr::null_mut();
+        let words = n_cols.max(1) << log_size;
+        try_check(self.ctx, unsafe { sys::nx_alloc(self.ctx, words, &mut base) })?;
+        self.owned.push(base);
+        Ok((0..n_cols).map(|k| unsafe { base.add(k << log_size) }).collect())
+    }
+    /// The component's interaction trace from its recorded relation entries, on the device (`nx_logup_program`), finalised
+    /// (`LogupTraceGenerator::finalize_last`: `nx_logup_finalize_last`).  `cols[k]`: the evaluations (bit-reversed circle-domain order)
+    /// of component column k, null where the fraction program loads nothing (the interaction columns themselves); `out`: the
+    /// component's 4 x n_logup_cols coordinate columns — typically the session's own, from `tree_begin` of the interaction tree, so
+    /// nothing is copied.  Returns the claimed sum (machine.rs:249-262).
+    pub fn logup_trace(&mut self, comp: &RecordedComponent, cols: &[*const u32], out: &[*mut u32]) -> Result<[u32; 4], HipError> {
+        if comp.n_logup_cols == 0 { return Ok([0; 4]); }
+        if out.len() != 4 * comp.n_logup_cols as usize || cols.len() != comp.col_tree.len() { return Err(HipError::Argument("logup_trace: column table of the wrong length".into())); }
+        try_check(self.ctx, unsafe { sys::nx_logup_program(self.ctx, comp.logup_program.as_ptr(), comp.logup_program.len() as u32, comp.logup_n_regs, cols.as_ptr(), cols.len() as u32,
+                                                           comp.logup_econsts.as_ptr(), (comp.logup_econsts.len() / 4) as u32, comp.log_size, comp.n_logup_cols, out.as_ptr(), std::ptr::null_mut()) })?;
+        let mut claimed = [0u32; 4];
+        try_check(self.ctx, unsafe { sys::nx_logup_finalize_last(self.ctx, comp.log_size, out[out.len() - 4..].as_ptr(), claimed.as_mut_ptr()) })?;
+        Ok(claimed)
+    }
+    /// Compiled AIR / fraction kernels are kept in `dir` across processes (`nx_air_cache_dir`): the first proof of a process loads
+    /// them in milliseconds instead of paying hiprtc (seconds for an AIR of the reference's size).  Process-wide.
+    pub fn kernel_cache_dir(dir: &str) -> Result<(), HipError> {
+        let c = std::ffi::CString::new(dir).map_err(|_| HipError::Argument("path holds a NUL byte".into()))?;
+        try_check(std::ptr::null(), unsafe { sys::nx_air_cache_dir(c.as_ptr()) })
+    }
     /// stwo::prover::prove (machine.rs:286-290): NXP1 proof words
     pub fn prove(&mut self, comps: &[RecordedComponent]) -> Result<Vec<u32>, HipError> {
         let raw: Vec<sys::nx_air_component> = comps.iter().map(|c| sys::nx_air_component {
@@ -397,6 +435,7 @@ impl Drop for Session {
     fn drop(&mut self) {
         unsafe {
             sys::nx_prover_destroy(self.p);
+            for p in self.owned.drain(..) { sys::nx_free(self.ctx, p); }
             if !self.comm.is_null() { if self.comm_is_local { sys::nx_comm_local_destroy(self.comm) } else { sys::nx_comm_rccl_destroy(self.comm) } }
             sys::nx_ctx_destroy(self.ctx);
         }

@@ -11,6 +11,13 @@
 //! `nx_cinstr` words.  The result is a `RecordedComponent`: program + the component's columns in the three trace trees + the mask
 //! offsets each column is sampled at — what `FrameworkComponent<E>` is to Stwo, as data.
 //!
+//! The relation entries are recorded too: `add_to_relation(RelationEntry::new(relation, multiplicity, &values))` (components/mod.rs:48-56,
+//! extensions/keccak/round/constraints.rs:95-116, every prover2 component) leaves the pair (multiplicity, relation.combine(values)) —
+//! two more DAG roots — and `finish()` lowers them to the FRACTION program (`NX_C_FRAC` / `NX_C_FRACB`, include/nexus_hip.h) that
+//! `nx_logup_program` turns into the component's interaction trace on the device: the reference's hand-written generators
+//! (traits.rs:124-145 -> every chip's `fill_interaction_trace`; prover2 `LogupTraceBuilder`) compute exactly these fractions, so none
+//! of them has to be touched or ported (air_program.py `add_to_relation` / `build_logup` is the Python twin; tests/test_logup_cpu.py).
+//!
 //! NOT COMPILED here (no Rust toolchain in the build image).  The trait surface implemented below — `EvalAtRow`'s associated-type
 //! bounds, `logup_proxy!`, `LogupAtRow::new` — is [upstream-recollection] of stwo-constraint-framework @ 0790eba; the reference shows
 //! its USE (`eval.next_interaction_mask(ORIGINAL_TRACE_IDX, [0, 1])`, `eval.get_preprocessed_column(PreProcessedColumnId { id })`:
@@ -85,7 +92,8 @@ mod stwo_glue {
     use stwo::core::fields::qm31::SecureField;
     use stwo::core::fields::FieldExpOps;
     use stwo_constraint_framework::preprocessed_columns::PreProcessedColumnId;
-    use stwo_constraint_framework::{EvalAtRow, FrameworkEval, LogupAtRow, INTERACTION_TRACE_IDX, PREPROCESSED_TRACE_IDX};
+    use stwo::prover::lookups::utils::Fraction;
+    use stwo_constraint_framework::{EvalAtRow, FrameworkEval, LogupAtRow, Relation, RelationEntry, INTERACTION_TRACE_IDX, PREPROCESSED_TRACE_IDX};
 
     fn q4(s: SecureField) -> [u32; 4] { let a = s.to_m31_array(); [a[0].0, a[1].0, a[2].0, a[3].0] }
 
@@ -140,6 +148,16 @@ mod stwo_glue {
             self.rec.constraints.push(EF::from(constraint));
         }
         fn combine_ef(values: [F; 4]) -> EF { e(ENode::Combine(values)) }
+        /// `EvalAtRow::add_to_relation` — the trait's default body (Fraction::new(multiplicity, relation.combine(values)) ->
+        /// write_logup_frac) with the fraction ALSO kept as two roots of the recorder: the interaction trace is generated from them
+        /// [upstream-recollection: `RelationEntry { relation, multiplicity, values }`, `Fraction::new`, `Relation::combine`]
+        fn add_to_relation<R: Relation<F, EF>>(&mut self, entry: RelationEntry<'_, F, EF, R>) {
+            let frac = Fraction::new(entry.multiplicity.clone(), entry.relation.combine(entry.values));
+            self.rec.fracs.push((frac.numerator.clone(), frac.denominator.clone()));
+            self.write_logup_frac(frac);
+        }
+        // write_logup_frac / finalize_logup / finalize_logup_in_pairs / finalize_logup_batched: Stwo's own (the logup CONSTRAINTS are
+        // its statements, not a restatement); they end in next_extension_interaction_mask + add_constraint calls on this evaluator
         stwo_constraint_framework::logup_proxy!();
     }
 
@@ -182,6 +200,8 @@ pub struct Recorder {
     pub col_index: Vec<u32>,
     pub masks: Vec<Vec<i32>>,
     pub constraints: Vec<EF>,
+    /// the relation entries in declaration order: (multiplicity, relation.combine(values))
+    pub fracs: Vec<(EF, EF)>,
     preprocessed: HashMap<u32, u32>,        // preprocessed tree index -> component column
 }
 impl Recorder {
@@ -199,15 +219,30 @@ impl Recorder {
     /// Lower the recorded DAG (air_program.py ProgramBuilder.build, rule for rule).
     pub fn finish(self, log_size: u32, log_constraint_degree_bound: u32) -> RecordedComponent {
         let mut lo = Lowering::default();
-        let roots: Vec<(usize, bool)> = self.constraints.iter().map(|c| lo.constraint_root(c)).collect();
+        let roots: Vec<Root> = self.constraints.iter().map(|c| { let (i, secure) = lo.constraint_root(c); Root::Cons(i, secure) }).collect();
         let (program, n_regs) = lo.emit(&roots);
         let mut mask_count = Vec::new();
         let mut mask_offsets = Vec::new();
         for m in &self.masks { mask_count.push(m.len() as u32); mask_offsets.extend_from_slice(m); }
+        // The fraction program.  Which batch an entry belongs to is read off what finalize_logup* did: it took one secure interaction
+        // column per batch, so (interaction columns) / 4 batches — one entry each (finalize_logup) or two (finalize_logup_in_pairs, the
+        // last batch one when the count is odd); the reference uses no other batching (a custom `Batching` would have to be passed in).
+        let n_logup_cols = (self.col_tree.iter().filter(|&&t| t == 2).count() / 4) as u32;
+        let f = self.fracs.len() as u32;
+        let per_batch = if f == n_logup_cols { 1 } else if f.div_ceil(2) == n_logup_cols { 2 } else {
+            panic!("{f} relation entries in {n_logup_cols} logup columns: neither finalize_logup nor finalize_logup_in_pairs")
+        };
+        let mut fl = Lowering::default();
+        let froots: Vec<Root> = self.fracs.iter().enumerate().map(|(i, (num, den))| {
+            let (n, secure) = fl.constraint_root(num);           // a lifted base multiplicity (1, -m) stays a base numerator: NX_C_FRACB
+            Root::Frac { num: n, num_secure: secure, den: fl.ext(den), batch: i as u32 / per_batch }
+        }).collect();
+        let (logup_program, logup_n_regs) = if froots.is_empty() { (Vec::new(), 1) } else { fl.emit(&froots) };
         RecordedComponent {
             log_size, program, n_regs, n_constraints: roots.len() as u32,
             econsts: lo.econsts.iter().flat_map(|q| q.iter().copied()).collect(),
             col_tree: self.col_tree, col_index: self.col_index, mask_count, mask_offsets, log_constraint_degree_bound,
+            logup_program, logup_n_regs, logup_econsts: fl.econsts.iter().flat_map(|q| q.iter().copied()).collect(), n_logup_cols,
         }
     }
 }
@@ -229,6 +264,13 @@ impl Key {
     }
     fn is_load(&self) -> bool { matches!(self, Key::Load(..) | Key::LoadE(..)) }
     fn is_secure(&self) -> bool { matches!(self, Key::LoadE(..) | Key::ConstE(..) | Key::AddE(..) | Key::SubE(..) | Key::MulE(..) | Key::MulEB(..) | Key::AddEB(..)) }
+}
+
+/// What a lowered program ends in: a constraint (node, secure?) or a relation entry's fraction (include/nexus_hip.h NX_C_FRAC / NX_C_FRACB)
+#[derive(Clone, Copy, Debug)]
+enum Root { Cons(usize, bool), Frac { num: usize, num_secure: bool, den: usize, batch: u32 } }
+impl Root {
+    fn nodes(&self) -> Vec<usize> { match *self { Root::Cons(i, _) => vec![i], Root::Frac { num, den, .. } => vec![num, den] } }
 }
 
 #[derive(Default)]
@@ -304,9 +346,9 @@ impl Lowering {
         (self.ext(c), true)
     }
 
-    fn emit(&mut self, roots: &[(usize, bool)]) -> (Vec<sys::nx_cinstr>, u32) {
+    fn emit(&mut self, roots: &[Root]) -> (Vec<sys::nx_cinstr>, u32) {
         #[derive(Clone, Copy)]
-        enum Item { Node(usize), Cons(usize, bool) }
+        enum Item { Node(usize), Root(Root) }
         const CHUNK: usize = 8;
         let nodes = self.nodes.clone();
         let mut order: Vec<Item> = Vec::new();
@@ -326,15 +368,15 @@ impl Lowering {
                 for &k in kids.iter().rev() { stack.push((k, false)); }
             }
         };
-        for (j, &(root, secure)) in roots.iter().enumerate() {
-            if j % CHUNK == 0 { for &(r, _) in &roots[j..(j + CHUNK).min(roots.len())] { emit_root(r, true, &mut order, &mut emitted); } }
-            emit_root(root, false, &mut order, &mut emitted);
-            order.push(Item::Cons(root, secure));
+        for (j, root) in roots.iter().enumerate() {
+            if j % CHUNK == 0 { for r in &roots[j..(j + CHUNK).min(roots.len())] { for n in r.nodes() { emit_root(n, true, &mut order, &mut emitted); } } }
+            for n in root.nodes() { emit_root(n, false, &mut order, &mut emitted); }
+            order.push(Item::Root(*root));
         }
         // last use of every node
         let mut last: HashMap<usize, usize> = HashMap::new();
         for (pos, it) in order.iter().enumerate() {
-            match *it { Item::Cons(i, _) => { last.insert(i, pos); } Item::Node(i) => { for k in nodes[i].children() { last.insert(k, pos); } } }
+            match *it { Item::Root(r) => { for n in r.nodes() { last.insert(n, pos); } } Item::Node(i) => { for k in nodes[i].children() { last.insert(k, pos); } } }
         }
         // linear scan: base registers and secure quads from separate pools
         let (mut free_b, mut free_e, mut n_b, mut n_e): (Vec<u32>, Vec<u32>, u32, u32) = (vec![], vec![], 0, 0);
@@ -344,7 +386,7 @@ impl Lowering {
                 let s = if nodes[i].is_secure() { (true, free_e.pop().unwrap_or_else(|| { n_e += 1; n_e - 1 })) } else { (false, free_b.pop().unwrap_or_else(|| { n_b += 1; n_b - 1 })) };
                 slot.insert(i, s);
             }
-            let mut touched: Vec<usize> = match *it { Item::Cons(i, _) => vec![i], Item::Node(i) => nodes[i].children() };
+            let mut touched: Vec<usize> = match *it { Item::Root(r) => r.nodes(), Item::Node(i) => nodes[i].children() };
             touched.sort_unstable(); touched.dedup();
             for a in touched {
                 if last.get(&a) == Some(&pos) { if let Some(&(sec, idx)) = slot.get(&a) { if sec { free_e.push(idx) } else { free_b.push(idx) } } }
@@ -357,7 +399,8 @@ impl Lowering {
         let mut out = Vec::with_capacity(order.len());
         for it in &order {
             match *it {
-                Item::Cons(i, secure) => out.push(ins(if secure { sys::NX_C_CONSTRAINT_E } else { sys::NX_C_CONSTRAINT_B }, 0, reg(i), 0)),
+                Item::Root(Root::Cons(i, secure)) => out.push(ins(if secure { sys::NX_C_CONSTRAINT_E } else { sys::NX_C_CONSTRAINT_B }, 0, reg(i), 0)),
+                Item::Root(Root::Frac { num, num_secure, den, batch }) => out.push(ins(if num_secure { sys::NX_C_FRAC } else { sys::NX_C_FRACB }, batch, reg(num), reg(den))),
                 Item::Node(i) => out.push(match nodes[i] {
                     Key::Load(c, o) => ins(sys::NX_C_LOAD, reg(i), c, o as u32),
                     Key::LoadE(c, o) => ins(sys::NX_C_LOADE, reg(i), c, o as u32),

@@ -252,13 +252,21 @@ def test_recording_evaluator_lowers_to_the_abi_opcodes():
                    "fn add_constraint<G>", "fn combine_ef", "logup_proxy!()", "pub fn record_component<E: FrameworkEval>", "const CHUNK: usize = 8;", "a.min(c), a.max(c)"):
         assert needle in src, needle
     header_ops = re.findall(r"#define (NX_C_\w+)", open(HEADER).read()) or re.findall(r"\b(NX_C_[A-Z_]+)\b\s*=", open(HEADER).read())
-    assert len(set(header_ops)) == 15
+    assert len(set(header_ops)) == 17            # 15 constraint-program opcodes + NX_C_FRAC / NX_C_FRACB (the relation entries' fraction program)
     for op in set(header_ops):
         assert "sys::" + op in src, op
     patch = open(os.path.join(HIP_DIR, "reference_patch", "machine_hip.rs")).read()
     for needle in ("pub fn prove_hip(trace: &impl Trace, view: &View) -> Result<Proof, ProvingError>", "record_component(", "session.prove(&components)", "proof_bytes(",
-                   "generate_interaction_trace::<C>(", "C::draw_lookup_elements("):
+                   "generate_interaction_trace::<C>(", "C::draw_lookup_elements(",
+                   # the interaction tree is generated on the device from the recorded relation entries; tree 2 is never uploaded
+                   "interaction_tree_on_device(&mut session, &generators, [&kept0, &kept1])", "session.logup_trace(c, &cols, &out)", "session.tree_commit()"):
         assert needle in patch, needle
+    assert patch.count("tree_commit_host(") == 1 and "commit_tree(&mut session, &tree2)" not in patch      # only trees 0 and 1 go over PCIe
+    for needle in ("fn add_to_relation<R: Relation<F, EF>>", "self.rec.fracs.push(", "Root::Frac {", "sys::NX_C_FRAC", "sys::NX_C_FRACB", "logup_program, logup_n_regs"):
+        assert needle in src, needle
+    lib = open(os.path.join(HIP_DIR, "src", "lib.rs")).read()
+    for needle in ("pub fn logup_trace(&mut self, comp: &RecordedComponent", "sys::nx_logup_program(", "sys::nx_logup_finalize_last(", "pub fn alloc_columns(", "sys::nx_comm_group_reset("):
+        assert needle in lib, needle
 
 
 def test_rust_sources_are_lexically_balanced():
