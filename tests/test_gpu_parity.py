@@ -99,7 +99,7 @@ def test_context_options_are_per_context_and_validated(nz):
         a.set_option("dist.chunks", 2)
         assert a.get_option("fft.streams") == 1 and b.get_option("fft.streams") == 3
         assert a.get_option("dist.chunks") == 2 and b.get_option("dist.chunks") == 0
-        for name, v in (("fft.streams", 9), ("air.quarter_domain", 2), ("fft.pipe", 1), ("no.such.option", 1), ("air.segment", 1)):
+        for name, v in (("fft.streams", 9), ("air.quarter_domain", 3), ("fft.pipe", 1), ("no.such.option", 1), ("air.segment", 1)):
             with pytest.raises(nz.NexusHipError):
                 a.set_option(name, v)
     finally:
