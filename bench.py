@@ -304,6 +304,27 @@ def main():
         except Exception as e:   # noqa: BLE001 — the headline line must still be printed
             host_trace = {"error": repr(e)[:300]}
 
+    # A program that is proved again and again commits the SAME preprocessed tree every time (reference machine.rs:208-228): with
+    # "machine.reuse_preprocessed" the tree of the first proof is adopted by the later ones (nx_prover_tree_adopt's rule; same proof bytes).
+    # Informational — `value` always commits every tree afresh, as the reference does.
+    pre_reuse = None
+    if world == 1 and not args.legacy_synth:
+        try:
+            import numpy as np
+            be.set_option("machine.reuse_preprocessed", 1)
+            rsteps = max(1, min(3, args.steps))
+            r_el = timed(comps, cfg, rsteps, 1)
+            same = bool(np.array_equal(be.prove_machine(comps, cfg, seed=4242), words))
+            pre_reuse = {"ms_per_step": 1e3 * r_el / rsteps, "value": (1 << args.log_rows) * rsteps / r_el, "unit": "cycles/s", "steps": rsteps, "equals_fresh_commit_proof": same,
+                         "what": "the %d preprocessed columns' tree committed once and adopted by the following proofs (seeds differ: main and interaction trees are new every time)" % args.n_pre}
+        except Exception as e:   # noqa: BLE001 — informational
+            pre_reuse = {"error": repr(e)[:300]}
+        finally:
+            try:
+                be.set_option("machine.reuse_preprocessed", 0)
+            except Exception:   # noqa: BLE001
+                pass
+
     prover_options = {}
     for name in ("air.degree_split", "air.half_domain", "air.quarter_domain", "quotients.coeffs"):
         try:
@@ -358,6 +379,8 @@ def main():
                            "collectives": "one all-to-all per trace tree (LDE columns -> row blocks), all-gather of W subtree roots per tree, of the columns read at a non-zero mask offset, of the composition accumulator and of the FRI tail; sampled / queried values (KBs)"}
         if host_trace is not None:
             out["host_trace"] = host_trace
+        if pre_reuse is not None:
+            out["preprocessed_reuse"] = pre_reuse
         if v1 is not None:
             out["config_v1_shaped"] = v1
     # N > 1, default mode: `value` above is N independent proofs.  The SAME run then also tries ONE row-sharded proof on the N GPUs

@@ -541,6 +541,19 @@ int nx_prover_tree_commit(nx_prover* prover, uint8_t root[32]);
  * A row-sharded session uploads its own columns first (no overlap) and commits as usual. */
 int nx_prover_tree_commit_host(nx_prover* prover, const uint32_t* const* h_cols, int coset_order, const uint32_t* keep_idx,
                                uint32_t n_keep, uint32_t* const* d_keep, uint8_t root[32]);
+/* A committed tree that is proved over and over — the preprocessed tree: the reference commits the same preprocessed + program columns
+ * in every proof of a program (prover/src/machine.rs:208-228) and once more in every verification (machine.rs:363-417, verify.rs:103-143,
+ * which needs only the root) — need not be transformed and hashed again.  nx_prover_tree_share turns committed tree `tree_index` of a
+ * session into a reference-counted handle (the session keeps proving with it); nx_prover_tree_adopt makes it the NEXT tree of another
+ * session of the SAME context and mixes its root, exactly as nx_prover_tree_commit would after a fresh commit of the same columns: the
+ * proof bytes are those of the fresh commit.  After a commit a tree's buffers are read-only, so any number of sessions may hold one.
+ * One GPU; same blowup factor and node hash.  nx_committed_tree_release drops the handle (the buffers go when the last session that
+ * adopted it is destroyed); nx_committed_tree_root: the root and the column count (a verifier's preprocessed-root check). */
+typedef struct nx_committed_tree nx_committed_tree;
+int nx_prover_tree_share(nx_prover* prover, uint32_t tree_index, nx_committed_tree** out);
+int nx_prover_tree_adopt(nx_prover* prover, const nx_committed_tree* tree, uint8_t root[32]);
+int nx_committed_tree_root(const nx_committed_tree* tree, uint8_t root[32], uint32_t* n_cols);
+void nx_committed_tree_release(nx_committed_tree* tree);
 /* A component: what FrameworkComponent<E> is to Stwo (reference prover/src/components/mod.rs:15-57).  Column k of the program is
  * column col_index[k] of tree col_tree[k] (TraceLocationAllocator); it is sampled at the mask_count[k] row offsets listed next in
  * mask_offsets (InfoEvaluator, components/mod.rs:59-67) — every LOAD offset must be listed, every committed column must be

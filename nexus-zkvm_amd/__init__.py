@@ -342,6 +342,18 @@ class ProverSession:
                                                          kd if len(kept) else None, root.ctypes.data_as(C.c_void_p)))
         return root, kept
 
+    def share_tree(self, tree_index):
+        """nx_prover_tree_share: committed tree `tree_index` of this session as a handle other sessions of the same backend can adopt."""
+        h = C.c_void_p()
+        self.be._chk(self.be.L.nx_prover_tree_share(self.h, int(tree_index), C.byref(h)))
+        return SharedTree(self.be, h)
+
+    def adopt_tree(self, shared):
+        """nx_prover_tree_adopt: the shared tree becomes this session's next tree (no upload, no transform, no hashing); returns the root."""
+        root = np.zeros(8, np.uint32)
+        self.be._chk(self.be.L.nx_prover_tree_adopt(self.h, shared.h, root.ctypes.data_as(C.c_void_p)))
+        return root
+
     def prove(self, components, kernels=None, want_stats=False):
         """components: air_program.Component list; kernels: optional AirKernel per component (compiled once, reused)."""
         arr = (AirComponentC * len(components))()
@@ -375,6 +387,29 @@ class ProverSession:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class SharedTree:
+    """A committed tree shared between sessions (nx_committed_tree): release() when no further session will adopt it."""
+
+    def __init__(self, be, h):
+        self.be, self.h = be, h
+
+    def root(self):
+        r, n = np.zeros(8, np.uint32), C.c_uint32()
+        self.be._chk(self.be.L.nx_committed_tree_root(self.h, r.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return r, int(n.value)
+
+    def release(self):
+        if self.h and self.be.ctx:
+            self.be.L.nx_committed_tree_release(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
         except Exception:
             pass
 
@@ -417,6 +452,8 @@ def load_library():
     L.nx_prover_destroy.argtypes = [C.c_void_p]
     L.nx_comm_group_destroy.argtypes = [C.c_void_p]
     L.nx_comm_local_destroy.argtypes = [C.c_void_p]
+    L.nx_committed_tree_release.argtypes = [C.c_void_p]
+    L.nx_committed_tree_release.restype = None
     for name in ("nx_ctx_destroy", "nx_twiddles_destroy", "nx_tree_destroy", "nx_free_host", "nx_air_kernel_destroy", "nx_prover_destroy", "nx_comm_group_destroy",
                  "nx_comm_local_destroy", "nx_comm_rccl_destroy"):
         getattr(L, name).restype = None

@@ -255,6 +255,7 @@ static nx_options options_from_env() {
     o.fri_tail = env_int("NX_FRI_TAIL", 1) != 0;
     o.logup_scan_tiled = env_int("NX_LOGUP_SCAN_TILED", 1) != 0;
     o.logup_per_column = env_int("NX_LOGUP_PER_COLUMN", 0) != 0;
+    o.machine_reuse_pre = env_int("NX_MACHINE_REUSE_PREPROCESSED", 0) != 0;
     return o;
 }
 struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
@@ -278,6 +279,7 @@ static const OptEntry k_options[] = {
     {"fri.tail", &nx_options::fri_tail, 0, 1},
     {"logup.scan_tiled", &nx_options::logup_scan_tiled, 0, 1},
     {"logup.per_column", &nx_options::logup_per_column, 0, 1},
+    {"machine.reuse_preprocessed", &nx_options::machine_reuse_pre, 0, 1},
 };
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return set_err(ctx, NX_ERR_ARG, "nx_ctx_set_option: NULL argument");

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <memory>
 #include "../../include/nexus_hip.h"
 #include "field.cuh"
 
@@ -31,6 +32,7 @@ struct nx_options {
     int fri_tail;                 // "fri.tail": last FRI layers in one launch
     int logup_scan_tiled;         // "logup.scan_tiled": finalize_last as coalesced tiles
     int logup_per_column;         // "logup.per_column": one nx_logup_col launch per column instead of nx_logup_cols
+    int machine_reuse_pre;        // "machine.reuse_preprocessed": nx_prove_machine keeps the committed preprocessed tree of a statement shape in the context and adopts it in later proofs (nx_prover_tree_adopt's rule; default 0: every proof commits it afresh, as the reference does)
     int air_degree_split;         // "air.degree_split": constraints of degree <= 3 of a component with a bound > 1 are evaluated on the log_size + 1 domain
 };
 
@@ -75,6 +77,8 @@ struct nx_ctx {
     // point must not abort the transport — an abort cannot be undone (ncclCommAbort; a broken thread-rank group) and an invalid trace
     // is an input error, not a reason to re-bootstrap a prover farm's communicator.
     bool symmetric_failure = false;
+    // "machine.reuse_preprocessed": committed preprocessed trees by statement shape (nxhip::CommitmentTreeProver, type-erased here)
+    std::map<std::string, std::shared_ptr<void>> machine_pre_cache;
 };
 enum { NX_T_LDE = 0, NX_T_MERKLE = 1, NX_T_QUOT = 2, NX_T_OTHER = 3 };
 

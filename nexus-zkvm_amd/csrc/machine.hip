@@ -506,7 +506,22 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         }
         return NX_OK;
     };
-    H_TRY(stage_tree(0, tb0));
+    // "machine.reuse_preprocessed": the preprocessed tree of this statement shape was committed by an earlier proof on this context — the
+    // columns do not depend on the seed (a program's preprocessed + program trace, reference machine.rs:208-228) — and is adopted instead
+    // of being filled, transformed and hashed again (nx_prover_tree_adopt's rule: same root into the transcript, same proof bytes)
+    std::string pre_key;
+    std::shared_ptr<CommitmentTreeProver> pre_shared;
+    if (ctx->opt.machine_reuse_pre && !host && !D.on()) {
+        bool table = false;
+        for (uint32_t i = 0; i < n_comps; i++) table = table || (comps[i].logup_mode & NX_LOGUP_TABLE);     // a table's fractions read preprocessed EVALUATIONS: those proofs fill the tree
+        if (!table) {
+            pre_key = "b" + std::to_string(cfg.log_blowup) + "h" + std::to_string(ctx->hash_mode);
+            for (uint32_t i = 0; i < n_comps; i++) pre_key += "|" + std::to_string(comps[i].log_size) + ":" + std::to_string(comps[i].n_pre);
+            auto it = ctx->machine_pre_cache.find(pre_key);
+            if (it != ctx->machine_pre_cache.end()) pre_shared = std::static_pointer_cast<CommitmentTreeProver>(it->second);
+        }
+    }
+    if (!pre_shared) H_TRY(stage_tree(0, tb0));
     H_TRY(stage_tree(1, tb1));
     {
         // Everything that can fail on ONE rank only before the exchanges start — the hiprtc compilation of the components' kernels
@@ -521,7 +536,15 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         H_TRY(vote_before_exchanges(ctx, D, rc_local, "nx_prove_machine"));
     }
     lap(&st->trace_gen);
-    H_TRY(tb0.commit(channel));                                                       // machine.rs:208-228
+    if (pre_shared) { cs.trees.push_back(borrow_tree(pre_shared)); channel.mix_root(pre_shared->root); }
+    else {
+        H_TRY(tb0.commit(channel));                                                   // machine.rs:208-228
+        if (!pre_key.empty()) {                                                       // keep it for the next proof of this shape
+            auto sp = std::make_shared<CommitmentTreeProver>(std::move(cs.trees[0]));
+            cs.trees[0] = borrow_tree(sp);
+            ctx->machine_pre_cache[pre_key] = sp;
+        }
+    }
     H_TRY(tb1.commit(channel));                                                       // machine.rs:230-237
     lap(&st->commit);
 

@@ -85,6 +85,7 @@ struct MerkleDecommitment { std::vector<Blake2sHash> hash_witness; std::vector<u
 // the layers above the W subtree roots (identical on every GPU).
 struct TreeRef {
     nx_tree* local = nullptr;
+    bool borrowed = false;                               // the nodes belong to a shared tree (CommitmentTreeProver::backing keeps it alive)
     int log_w = 0;
     uint32_t n_layers = 0;                               // global layer count
     std::vector<std::vector<Blake2sHash>> top;           // top[k], k <= log_w
@@ -92,9 +93,9 @@ struct TreeRef {
     TreeRef() { memset(root.w, 0, 32); }
     TreeRef(const TreeRef&) = delete;
     TreeRef& operator=(const TreeRef&) = delete;
-    TreeRef(TreeRef&& o) noexcept : local(o.local), log_w(o.log_w), n_layers(o.n_layers), top(std::move(o.top)), root(o.root) { o.local = nullptr; }
-    TreeRef& operator=(TreeRef&& o) noexcept { if (local) nx_tree_destroy(local); local = o.local; log_w = o.log_w; n_layers = o.n_layers; top = std::move(o.top); root = o.root; o.local = nullptr; return *this; }
-    ~TreeRef() { if (local) nx_tree_destroy(local); }
+    TreeRef(TreeRef&& o) noexcept : local(o.local), borrowed(o.borrowed), log_w(o.log_w), n_layers(o.n_layers), top(std::move(o.top)), root(o.root) { o.local = nullptr; }
+    TreeRef& operator=(TreeRef&& o) noexcept { if (local && !borrowed) nx_tree_destroy(local); local = o.local; borrowed = o.borrowed; log_w = o.log_w; n_layers = o.n_layers; top = std::move(o.top); root = o.root; o.local = nullptr; return *this; }
+    ~TreeRef() { if (local && !borrowed) nx_tree_destroy(local); }
 };
 // MerkleProver::commit over columns of global log sizes `logs` (whole columns, or row blocks when dist is on): the tree, its root
 // downloaded.  Row-sharded: local subtree + all-gather of the W subtree roots + the top log2 W levels on the host.
@@ -141,8 +142,13 @@ struct CommitmentTreeProver {
     std::vector<DevBuf> bufs;
     TreeRef merkle;
     Blake2sHash root;
+    // A tree ADOPTED from a shared one (nx_prover_tree_adopt: the preprocessed tree of a program that is proved again and again): the
+    // column references and the Merkle layers point into `backing`, which owns the buffers; this entry owns nothing.  After a commit
+    // every buffer of a tree is read-only (coefficients, extensions, nodes), so any number of sessions may read one backing tree.
+    std::shared_ptr<CommitmentTreeProver> backing;
     CommitmentTreeProver() {}
     CommitmentTreeProver(CommitmentTreeProver&&) = default;
+    CommitmentTreeProver& operator=(CommitmentTreeProver&&) = default;
     CommitmentTreeProver(const CommitmentTreeProver&) = delete;
 };
 
@@ -205,6 +211,8 @@ class CommitmentSchemeProver {
     TreeBuilder tree_builder() { return TreeBuilder(*this); }
 };
 
+// a non-owning view of a committed tree (same columns, same nodes, same root) that keeps `src` alive
+CommitmentTreeProver borrow_tree(const std::shared_ptr<CommitmentTreeProver>& src);
 std::vector<uint32_t*> col_ptrs(uint32_t* base, uint32_t n, uint32_t log);
 int upload_owned(nx_ctx* ctx, const uint32_t* h, size_t n_words, DevBuf* out);
 
@@ -295,6 +303,9 @@ struct GenericAir : AirProver {
 void machine_kernels_release(nx_ctx* ctx);
 
 }  // namespace nxhip
+
+// A committed tree shared between sessions of one context (nx_prover_tree_share / nx_prover_tree_adopt)
+struct nx_committed_tree { nx_ctx* ctx; uint32_t log_blowup; int hash_mode; std::shared_ptr<nxhip::CommitmentTreeProver> tree; };
 
 struct nx_prover {
     nx_ctx* ctx; nx_pcs_config ucfg; nxhip::PcsConfig cfg; nx_twiddles* tw = nullptr; uint32_t max_log;

@@ -182,6 +182,16 @@ void merkle_decommit_fill(const DecommitPlan& plan, const GatherBatch& gb, std::
 }
 
 // ---------------------------------------------------------------- commitment scheme ----------
+CommitmentTreeProver borrow_tree(const std::shared_ptr<CommitmentTreeProver>& src) {
+    CommitmentTreeProver t;
+    t.polys = src->polys; t.owner = src->owner; t.evals = src->evals;
+    t.merkle.local = src->merkle.local; t.merkle.borrowed = true; t.merkle.log_w = src->merkle.log_w; t.merkle.n_layers = src->merkle.n_layers;
+    t.merkle.top = src->merkle.top; t.merkle.root = src->merkle.root;
+    t.root = src->root;
+    t.backing = src;
+    return t;
+}
+
 std::vector<uint32_t*> col_ptrs(uint32_t* base, uint32_t n, uint32_t log) {
     std::vector<uint32_t*> v(n);
     for (uint32_t i = 0; i < n; i++) v[i] = base + ((size_t)i << log);
@@ -1191,6 +1201,8 @@ void machine_kernels_release(nx_ctx* ctx) {   // nx_ctx_destroy: the modules bel
     std::lock_guard<std::mutex> lk(kc.mu);
     for (auto it = kc.map.begin(); it != kc.map.end();) { if (it->first.first == ctx) { nx_air_kernel_destroy(it->second); it = kc.map.erase(it); } else ++it; }
     release_split_cache(ctx);
+    (void)nx_sync(ctx);
+    ctx->machine_pre_cache.clear();          // the kept preprocessed trees: their buffers go back to the context's allocator, which is still alive here
 }
 
 // A constraint of degree d <= 3 over columns of 2^n rows has its quotient in the FFT space of the 2^(n+1)-point domain (d <= 2^e + 1
@@ -1763,6 +1775,49 @@ int nx_prover_tree_commit(nx_prover* p, uint8_t root[32]) {
         if (rc != NX_OK) { if (p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort && !p->ctx->symmetric_failure) p->comm_copy.abort(p->comm_copy.user); return rc; }
     }
     if (root) memcpy(root, p->cs->trees.back().root.w, 32);
+    return NX_OK;
+}
+
+// A committed tree as a handle other sessions of the same context can adopt: the session's entry becomes a view of the shared tree.
+int nx_prover_tree_share(nx_prover* p, uint32_t tree_index, nx_committed_tree** out) {
+    NX_GUARD(p ? p->ctx : nullptr);
+    if (!p || !out) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_tree_share: NULL argument");
+    if (p->cs->dist.on()) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_share: one GPU (a row-sharded tree is spread over the ranks)");
+    const size_t limit = p->proved ? p->pre_trees : p->cs->trees.size();
+    if (tree_index >= limit) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_share: no such committed trace tree");
+    nxhip::CommitmentTreeProver& cur = p->cs->trees[tree_index];
+    std::shared_ptr<nxhip::CommitmentTreeProver> sp = cur.backing ? cur.backing : std::make_shared<nxhip::CommitmentTreeProver>(std::move(cur));
+    if (!cur.backing) p->cs->trees[tree_index] = nxhip::borrow_tree(sp);
+    *out = new nx_committed_tree{p->ctx, p->cfg.log_blowup, p->ctx->hash_mode, sp};
+    return NX_OK;
+}
+// TreeBuilder::commit for a tree that was committed before: no upload, no transform, no hashing — the root enters the transcript as it
+// would after a fresh commit, the prove reads the shared coefficients / extensions / nodes.
+int nx_prover_tree_adopt(nx_prover* p, const nx_committed_tree* shared, uint8_t root[32]) {
+    NX_GUARD(p ? p->ctx : nullptr);
+    if (!p || !shared || !shared->tree) return set_err(p ? p->ctx : nullptr, NX_ERR_ARG, "nx_prover_tree_adopt: NULL argument");
+    if (p->open) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_adopt: a tree is begun but not committed");
+    if (p->proved) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_adopt: the session has proved; its trace trees are fixed");
+    if (p->cs->dist.on()) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_adopt: one GPU");
+    if (shared->ctx != p->ctx) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_adopt: the tree lives in another context (its buffers belong to that context's device and allocator)");
+    if (shared->log_blowup != p->cfg.log_blowup || shared->hash_mode != p->ctx->hash_mode) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_adopt: the tree was committed under another blowup factor or node hash");
+    if (p->cs->trees.size() >= 16) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_adopt: at most 16 trace trees");
+    for (auto& c : shared->tree->polys) if (c.log > p->max_log) return set_err(p->ctx, NX_ERR_ARG, "nx_prover_tree_adopt: a column is larger than the session's max_log_size");
+    p->cs->trees.push_back(nxhip::borrow_tree(shared->tree));
+    p->channel.mix_root(shared->tree->root);
+    if (root) memcpy(root, shared->tree->root.w, 32);
+    return NX_OK;
+}
+void nx_committed_tree_release(nx_committed_tree* t) {
+    if (!t) return;
+    NX_GUARD(t->ctx);
+    (void)nx_sync(t->ctx);                      // a prove that read the tree may still be queued
+    delete t;
+}
+int nx_committed_tree_root(const nx_committed_tree* t, uint8_t root[32], uint32_t* n_cols) {
+    if (!t || !t->tree || !root) return set_err(nullptr, NX_ERR_ARG, "nx_committed_tree_root: NULL argument");
+    memcpy(root, t->tree->root.w, 32);
+    if (n_cols) *n_cols = (uint32_t)t->tree->polys.size();
     return NX_OK;
 }
 

@@ -1296,6 +1296,69 @@ def test_session_with_the_interaction_trace_generated_from_the_recorded_air(be, 
         assert np.array_equal(words, ref)
 
 
+def test_preprocessed_tree_shared_between_sessions_and_proofs(be, nz, oracle):
+    """the preprocessed tree of a program is the same in every proof of that program (reference machine.rs:208-228)
+    and in every verification (machine.rs:363-417).  nx_prover_tree_share / nx_prover_tree_adopt: a second session adopts the tree the
+    first one committed — no upload, transform or hashing — and its proof equals the oracle's for the same statement, word for word;
+    the first session still proves; a tree of another blowup is refused.  And nx_prove_machine's "machine.reuse_preprocessed" keeps the
+    tree per statement shape: later proofs (other seeds) equal the ones a fresh context produces."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    log, n_pre, n_main, n_inter = 9, 3, 12, 6
+    kw = dict(pow_bits=4)
+    cfg, ocfg = nz.default_config(**kw), O.default_cfg(**kw)
+    comps = [(log, n_pre, n_main, n_inter)]
+    comp = AE.synthetic_component(ap, log, n_pre, n_main, n_inter)
+    pre = [c for s in be.synth_fill_tree(comps, 0, 1) for c in s.to_cpu()]
+
+    def statement(session, seed, first_tree):
+        session.mix_u64(log)
+        first_tree(session)
+        main = oracle.synth_tree_columns(comps, 1, seed)
+        session.commit(main)
+        session.mix_felts(np.zeros(4, np.uint32))
+        session.commit(oracle.synth_tree_columns(comps, 2, seed, inter_seed=5))
+        return session.prove([comp])
+
+    refs = {}
+    for seed in (11, 12):
+        o = O.ProverSession(ocfg, log)
+        refs[seed] = statement(o, seed, lambda s: s.commit(pre))
+    s1 = be.prover_session(cfg, log)
+    w1 = statement(s1, 11, lambda s: s.commit(pre))
+    assert np.array_equal(w1, refs[11])
+    shared = s1.share_tree(0)
+    root, n = shared.root()
+    assert n == n_pre and np.array_equal(root, w1[6:14])
+    s2 = be.prover_session(cfg, log)
+    w2 = statement(s2, 12, lambda s: s.adopt_tree(shared))
+    assert np.array_equal(w2, refs[12])
+    assert np.array_equal(s1.prove([comp]), refs[11])                       # the sharing session still proves (its entry is a view now)
+    s1.close()                                                            # ... and may go: the handle and s2 keep the tree alive
+    s3 = be.prover_session(cfg, log)
+    assert np.array_equal(statement(s3, 11, lambda s: s.adopt_tree(shared)), refs[11])
+    s4 = be.prover_session(nz.default_config(pow_bits=4, log_blowup=2), log)
+    s4.mix_u64(log)
+    with pytest.raises(nz.NexusHipError, match="blowup"):
+        s4.adopt_tree(shared)
+    other = nz.HipBackend(0)
+    s5 = other.prover_session(cfg, log)
+    with pytest.raises(nz.NexusHipError, match="another context"):
+        s5.adopt_tree(shared)
+    s5.close(); other.close()
+    shared.release(); s2.close(); s3.close(); s4.close()
+    # nx_prove_machine
+    mcomps = [(11, 27, 60, 16), (8, 3, 9, 4, 1, 1)]
+    mcfg = nz.default_config(pow_bits=5)
+    fresh = [be.prove_machine(mcomps, mcfg, seed=s, ad=b"r") for s in (1, 2, 3)]
+    b = nz.HipBackend(0)
+    b.set_option("machine.reuse_preprocessed", 1)
+    for s, want in zip((1, 2, 3, 1), fresh + fresh[:1]):
+        assert np.array_equal(b.prove_machine(mcomps, mcfg, seed=s, ad=b"r"), want)
+    assert np.array_equal(b.prove_machine([(10, 27, 60, 16)], mcfg, seed=1), be.prove_machine([(10, 27, 60, 16)], mcfg, seed=1))   # another shape: its own tree
+    b.close()
+
+
 def test_column_utilities(be):
     """nx_copy (Column::clone) and the building blocks of a modular all-reduce (nx_m31_add_into / widen / narrow)."""
     rng = np.random.default_rng(3)
