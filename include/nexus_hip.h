@@ -290,6 +290,10 @@ typedef struct nx_prove_stats { /* milliseconds, device-synchronised stage bound
     double interaction;          /* logup interaction-trace generation (nx_prove_machine)         */
     double comm_ms;              /* wall time inside nx_comm callbacks (one proof on several GPUs) */
     uint64_t comm_bytes;         /* bytes this GPU sent to its peers                               */
+    /* collectives this GPU entered during the prove, by kind — each is also a host synchronisation of the stream (one proof on several
+     * GPUs): all-to-all of column shards into row blocks, all-gathers of device buffers, all-gathers of host words (roots, sampled
+     * values, votes).  DESIGN.md section 7 bounds them by the statement's shape; tests/test_gpu_machine.py holds the bound. */
+    uint32_t n_alltoallv, n_allgather_dev, n_allgather_host, n_comm_reserved;
 } nx_prove_stats;
 
 /* Fill tree `tree` (0 preprocessed / 1 main / 2 interaction) of the synthetic trace directly in

@@ -423,7 +423,8 @@ class LogupFrac(C.Structure):
 class ProveStats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("trace_gen", "commit", "composition", "oods", "quotients", "fri", "pow", "decommit", "total")] + \
                [("lde_kernel_ms", C.c_double), ("lde_algorithmic_bytes", C.c_uint64), ("merkle_kernel_ms", C.c_double),
-                ("merkle_algorithmic_bytes", C.c_uint64), ("interaction", C.c_double), ("comm_ms", C.c_double), ("comm_bytes", C.c_uint64)]
+                ("merkle_algorithmic_bytes", C.c_uint64), ("interaction", C.c_double), ("comm_ms", C.c_double), ("comm_bytes", C.c_uint64),
+                ("n_alltoallv", C.c_uint32), ("n_allgather_dev", C.c_uint32), ("n_allgather_host", C.c_uint32), ("n_comm_reserved", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -167,7 +167,7 @@ static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_c
     Blake2sChannel channel;
     for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
     CommitmentSchemeProver cs(ctx, tw, cfg);                                          // machine.rs:202-203
-    if (comm) { H_TRY(dist_init(ctx, comm, &cs.dist)); cs.dist.comm_ms = &st->comm_ms; cs.dist.comm_bytes = &st->comm_bytes; }
+    if (comm) { H_TRY(dist_init(ctx, comm, &cs.dist)); cs.dist.comm_ms = &st->comm_ms; cs.dist.comm_bytes = &st->comm_bytes; cs.dist.comm_calls = &st->n_alltoallv; }
     for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
     lap(&st->commit);
 
@@ -446,7 +446,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     Blake2sChannel channel;
     for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
     CommitmentSchemeProver cs(ctx, tw, cfg);                                          // machine.rs:202-203
-    if (comm) { H_TRY(dist_init(ctx, comm, &cs.dist)); cs.dist.comm_ms = &st->comm_ms; cs.dist.comm_bytes = &st->comm_bytes; }
+    if (comm) { H_TRY(dist_init(ctx, comm, &cs.dist)); cs.dist.comm_ms = &st->comm_ms; cs.dist.comm_bytes = &st->comm_bytes; cs.dist.comm_calls = &st->n_alltoallv; }
     const Dist& D = cs.dist;
     for (uint32_t i = 0; i < n_comps; i++) channel.mix_u64(comps[i].log_size);        // machine.rs:204-206
     if (host && D.on()) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine_host: one GPU (a row-sharded session takes host columns through nx_prover_tree_commit_host)");

@@ -46,6 +46,7 @@ double now_ms();
 struct Dist {
     const nx_comm* comm = nullptr; int rank = 0, world = 1, log_w = 0;
     double* comm_ms = nullptr; uint64_t* comm_bytes = nullptr;      // accounting sinks (nx_prove_stats), may be null
+    uint32_t* comm_calls = nullptr;                                  // [alltoallv, allgather_dev, allgather_host] counters of nx_prove_stats, may be null
     bool on() const { return world > 1; }
     uint64_t block(uint32_t log) const { return ((uint64_t)1 << log) >> log_w; }        // rows per GPU of a column of 2^log rows
     uint64_t begin(uint32_t log) const { return block(log) * (uint64_t)rank; }            // first row of this GPU's block

@@ -45,6 +45,7 @@ int Dist::allgather_host(nx_ctx* ctx, const void* send, size_t bytes, void* recv
     CommClock clk(*this);
     C_TRY(comm->allgather(comm->user, send, bytes, recv));
     if (comm_bytes) *comm_bytes += bytes * (size_t)(world - 1);
+    if (comm_calls) comm_calls[2]++;
     return NX_OK;
 }
 int Dist::allgather_dev(nx_ctx* ctx, const uint32_t* d_send, size_t words, uint32_t* d_recv) const {
@@ -52,6 +53,7 @@ int Dist::allgather_dev(nx_ctx* ctx, const uint32_t* d_send, size_t words, uint3
     CommClock clk(*this);
     C_TRY(comm->allgather_dev(comm->user, d_send, words, d_recv));
     if (comm_bytes) *comm_bytes += words * 4 * (size_t)(world - 1);
+    if (comm_calls) comm_calls[1]++;
     return NX_OK;
 }
 int Dist::allgather_cols(nx_ctx* ctx, const std::vector<const uint32_t*>& blk, size_t rb, uint32_t* whole_base, uint64_t whole_stride) const {
@@ -79,6 +81,7 @@ int Dist::alltoallv(nx_ctx* ctx, const uint32_t* d_send, const size_t* soff, con
     CommClock clk(*this);
     C_TRY(comm->alltoallv(comm->user, d_send, soff, scnt, d_recv, roff, rcnt));
     if (comm_bytes) for (int r = 0; r < world; r++) if (r != rank) *comm_bytes += scnt[r] * 4;
+    if (comm_calls) comm_calls[0]++;
     return NX_OK;
 }
 
@@ -1903,7 +1906,7 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     nx_prove_stats* st = stats ? stats : &local;
     memset(st, 0, sizeof *st);
     if (timed) { ctx->timing = true; timing_reset(ctx); }
-    p->cs->dist.comm_ms = &st->comm_ms; p->cs->dist.comm_bytes = &st->comm_bytes;
+    p->cs->dist.comm_ms = &st->comm_ms; p->cs->dist.comm_bytes = &st->comm_bytes; p->cs->dist.comm_calls = &st->n_alltoallv;
     nxhip::Lap lap{ctx, timed, 0};
     double t_start = 0;
     if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = nxhip::now_ms(); }
@@ -1917,7 +1920,7 @@ int nx_prover_prove(nx_prover* p, const nx_air_component* comps, uint32_t n_comp
     if (rc != NX_OK && p->has_comm && p->comm_copy.world > 1 && p->comm_copy.abort && !ctx->symmetric_failure) p->comm_copy.abort(p->comm_copy.user);   // the peers wait in a collective this rank will not enter
     if (timed) nxhip::finish_stats(ctx, st, t_start);
     ctx->timing = false;
-    p->cs->dist.comm_ms = nullptr; p->cs->dist.comm_bytes = nullptr;
+    p->cs->dist.comm_ms = nullptr; p->cs->dist.comm_bytes = nullptr; p->cs->dist.comm_calls = nullptr;
     if (rc != NX_OK) return rc;
     uint32_t* out = (uint32_t*)malloc(w.size() * 4);
     if (!out) return set_err(ctx, NX_ERR_OOM, "nx_prover_prove: malloc failed");

@@ -455,6 +455,41 @@ def test_ranks_with_different_plan_options_are_refused_before_the_first_exchange
     assert all_back and all(e is not None and "different context options" in e for e in errs), errs
 
 
+@pytest.mark.parametrize("comps,kw", [
+    ([(13, 27, 347, 64)], dict(pow_bits=6)),
+    ([(13, 5, 35, 16, 1), (12, 3, 17, 8, 2), (12, 4, 9, 12, 1, 1), (9, 2, 6, 4, 1)], dict(pow_bits=6, log_constraint_degree=2)),
+])
+def test_collectives_of_one_proof_on_8_ranks_are_bounded_by_the_statement_shape(be, nz, comps, kw):
+    """what ONE proof on W GPUs costs besides bytes is the NUMBER of collectives — each is a host synchronisation of
+    every rank's stream.  nx_prove_stats counts them by kind; the count depends on the statement's SHAPE (trees, distinct column sizes,
+    components, FRI layers), not on rows or columns: DESIGN.md section 7 states the bound, this test holds it at W = 8, and the same
+    statement with 4x the rows enters exactly the same collectives plus one per additional sharded FRI layer."""
+    cfg = nz.default_config(**kw)
+
+    def counts(cs):
+        res = _run_ranks(nz, 8, lambda b, comm, rank: b.prove_machine(cs, cfg, seed=3, ad=b"c", comm=comm, want_stats=True))
+        st = res[0][1]
+        for r in range(1, 8):
+            assert all(res[r][1][k] == st[k] for k in ("n_alltoallv", "n_allgather_dev", "n_allgather_host")), (r, res[r][1], st)    # every rank enters the same collectives
+        return st["n_alltoallv"], st["n_allgather_dev"], st["n_allgather_host"]
+    a2a, dev, host = counts(comps)
+    C_ = len(comps)
+    sizes = len({c[0] for c in comps})
+    logup = sum(1 for c in comps if c[3])
+    re_ext = sum(1 for c in comps if (c[4] if len(c) > 4 and c[4] else kw.get("log_constraint_degree", 1)) != 1)       # bound != blowup: re-evaluated columns cross the links
+    fri_layers = max(c[0] for c in comps) + 2 + kw.get("log_constraint_degree", 1)
+    # all-to-all: one per tree and size run (LDE columns -> row blocks), one per logup component (its columns back to column shards), at most
+    # two per re-evaluated component (its low / high parts); device all-gathers: the last logup column and the neighbour-row columns of a
+    # part per component, the accumulators per evaluation-domain size, the FRI switch; host all-gathers: vote, 4 x W subtree roots,
+    # sampled values, queried words, one per sharded FRI layer
+    bound = (3 * sizes + logup + 2 * re_ext, 4 * C_ + 3 * sizes + 2, 8 + fri_layers)
+    assert a2a <= bound[0] and dev <= bound[1] and host <= bound[2], ((a2a, dev, host), bound)
+    assert a2a >= 3 and host >= 6                                                                                # ... and the counters count
+    big = [(c[0] + 2,) + tuple(c[1:]) for c in comps]
+    a2, d2, h2 = counts(big)
+    assert (a2, d2) == (a2a, dev) and 0 <= h2 - host <= 2, ((a2a, dev, host), (a2, d2, h2))
+
+
 @pytest.mark.parametrize("world,chunks", [(2, 3), (4, 2), (8, 4)])
 def test_machine_row_sharded_with_chunked_exchange(be, nz, monkeypatch, world, chunks):
     """The column chunks of the row-sharded commit (chunk q+1's LDE enqueued before chunk q's all-to-all; the receive slab is
