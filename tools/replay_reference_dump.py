@@ -41,6 +41,28 @@ def col(seed, c, log):
     return v.astype(np.uint32)
 
 
+def logup_pairs_columns(z, alpha, be=None):
+    """The "logup_pairs" known answer of tools/dump_reference.rs restated: LogupTraceGenerator driven in PAIRS like prover2's
+    LogupTraceBuilder (reference prover2/machine/src/lookups/logup_trace_builder.rs:86-101) over seeded columns t0..t3 of 2^6 rows —
+    column 0 = 1 / (t0 - z)  merged with  -t3 / (t1 + alpha t2 - z)  as (a d + b c) / (b d); column 1 = the left-over fraction
+    1 / (t2 + alpha t0 + alpha^2 t1 - z) on top; finalize_last.  Returns (8 coordinate columns, claimed sum); with `be`, the device's."""
+    import oracle_lib as O
+    t = [col(3, c, 6) for c in range(4)]
+    ap = np.stack([np.array([1, 0, 0, 0], np.uint32), np.asarray(alpha, np.uint32), O.qm31_mul(alpha, alpha)])
+    minus_one = (P - 1, 0, 0, 0)
+    if be is None:
+        c0 = O.logup_finalize_col(O.logup_combine([t[0]], ap[:1], z), den_b=O.logup_combine([t[1], t[2]], ap[:2], z), scale_b=minus_one, mult_b=t[3])
+        c1 = O.logup_finalize_col(O.logup_combine([t[2], t[0], t[1]], ap, z), prev=c0)
+        c1, claimed = O.logup_finalize_last(c1)
+        return [np.asarray(x) for x in c0 + c1], np.asarray(claimed)
+    d = be.columns_from_host(np.stack(t))
+    one = lambda ks: be.columns_from_host(np.stack([t[k] for k in ks]))
+    cols = be.logup_cols_batched([dict(tuple=one([0]), alphas=ap[:1], z=z), dict(tuple=one([1, 2]), alphas=ap[:2], z=z, mult=be.columns_from_host(t[3]), scale=minus_one),
+                                  dict(tuple=one([2, 0, 1]), alphas=ap, z=z)])
+    claimed = be.logup_finalize_last(cols[1])
+    return [x for c in cols for x in c.to_cpu()], np.asarray(claimed)
+
+
 def synth_dump(hash_mode):
     """The "kat" section of tools/dump_reference.rs, produced by the oracle instead of Stwo (self-test input)."""
     import ctypes as C
@@ -62,8 +84,12 @@ def synth_dump(hash_mode):
     L.orc_channel_mix_felts(ch, O.ptr(np.concatenate([f, fs[0]])), C.c_size_t(2)); L.orc_channel_digest(ch, O.ptr(dig)); steps.append({"digest": dig.tobytes().hex()})
     L.orc_channel_mix_root(ch, O.ptr(np.frombuffer(root, np.uint32).copy())); L.orc_channel_digest(ch, O.ptr(dig)); steps.append({"digest": dig.tobytes().hex()})
     w8 = np.zeros(8, np.uint32); L.orc_channel_draw_u32s(ch, O.ptr(w8)); steps.append({"draw_random_bytes": w8.tobytes().hex()})
+    zl, al = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
+    L.orc_channel_draw_secure_felt(ch, O.ptr(zl)); L.orc_channel_draw_secure_felt(ch, O.ptr(al))
+    lc, lclaimed = logup_pairs_columns(zl, al)
     L.orc_channel_free(ch)
-    return {"kat": {"twiddles_log5": {"twiddles": [int(x) for x in tw], "itwiddles": [int(x) for x in itw]},
+    logup = {"z": [int(x) for x in zl], "alpha": [int(x) for x in al], "columns": [[int(v) for v in c] for c in lc], "claimed_sum": [int(x) for x in lclaimed]}
+    return {"kat": {"logup_pairs": logup, "twiddles_log5": {"twiddles": [int(x) for x in tw], "itwiddles": [int(x) for x in itw]},
                     "lde_log6": {"coeffs": [int(x) for x in co], "lde": [int(x) for x in otw.evaluate(co, 7)]},
                     "eval_at_point": {"point": [[int(x) for x in pt[:4]], [int(x) for x in pt[4:]]], "value": [int(x) for x in O.eval_at_point(co, pt)]},
                     "merkle": {"root": root.hex()}, "channel": steps},
@@ -155,6 +181,14 @@ def replay(d, be, found_modes):
     check("channel.mix_root", dig.tobytes().hex() == steps[4]["digest"])
     w8 = np.zeros(8, np.uint32); L.orc_channel_draw_u32s(ch, O.ptr(w8))
     check("channel.draw_random_bytes", w8.tobytes().hex() == steps[5]["draw_random_bytes"])
+    # R8: the paired logup columns and finalize_last (the dump draws z and alpha from the channel right after the steps above)
+    if "logup_pairs" in k:
+        lp = k["logup_pairs"]
+        lc, lclaimed = logup_pairs_columns(np.array(lp["z"], np.uint32), np.array(lp["alpha"], np.uint32))
+        check("logup in pairs + finalize_last (oracle)", all(np.array_equal(a, b) for a, b in zip(lc, lp["columns"])) and list(lclaimed) == lp["claimed_sum"])
+        if be:
+            gc, gclaimed = logup_pairs_columns(np.array(lp["z"], np.uint32), np.array(lp["alpha"], np.uint32), be)
+            check("logup in pairs + finalize_last (GPU)", all(np.array_equal(a, b) for a, b in zip(gc, lp["columns"])) and list(gclaimed) == lp["claimed_sum"])
     print("     (grind / quotient / fold known answers: compare `channel[6:]`, `quotients`, `folds`, `decompose` with orc_channel_grind, orc_accumulate_quotients,")
     print("      orc_fold_circle_into_line, orc_fold_line_dom, orc_fri_decompose on the same seeded columns — see tests/test_gpu_parity.py for the call shapes)")
     # proofs: structure and the serializer's field order
