@@ -13,7 +13,15 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 sets = sys.argv[4:] or [""]
 be = nz.HipBackend(0)
 tw = be.precompute_twiddles(log)
-cols = be.synth_fill_tree([(log, 2, ncols, 0)], 1, seed=3)[0]
+if os.environ.get("FFT_TUNE_BYTE_LIMBS") == "1":   # config #2's byte-limb variant: values in [0, 256) like the reference's limb columns (prover/src/trace/utils.rs:57-62)
+    cols = be.columns(ncols, log)
+    _rng = np.random.default_rng(3)
+    for _c0 in range(0, ncols, 32):
+        _n = min(32, ncols - _c0)
+        _blk = _rng.integers(0, 256, (_n, 1 << log), dtype=np.uint32)
+        be._chk(be.L.nx_upload(be.ctx, __import__("ctypes").c_void_p(cols.ptr.value + _c0 * (4 << log)), _blk.ctypes.data_as(__import__("ctypes").c_void_p), __import__("ctypes").c_size_t(_blk.size)))
+else:
+    cols = be.synth_fill_tree([(log, 2, ncols, 0)], 1, seed=3)[0]
 out = be.columns(ncols, log + 1)
 import ctypes as _C
 if os.environ.get("FFT_TUNE_ZEROS") == "1":      # DVFS probe: all-zero data toggles far fewer bits (MI355X_MICROARCH.md: the chip clocks to its power budget)

@@ -79,7 +79,9 @@ def run_world(world):
     s = stats[0]
     return {"transport": "native (csrc/comm_local.hip)" if NATIVE else "python (sharded.ThreadGroup)", "ms": max(times) * 1e3, "same_proof_bytes": all(same), "rank0_stages_ms": {k: round(v, 3) for k, v in s.items() if isinstance(v, float) and k not in ("comm_ms",)},
             "rank0_comm_ms": s.get("comm_ms"), "rank0_comm_bytes": s.get("comm_bytes"),
-            "rank0_collectives": counts, "rank0_collective_calls": sum(counts.values())}
+            "rank0_collectives": counts, "rank0_collective_calls": sum(counts.values()),
+            # counted by the library itself (nx_prove_stats, any transport): each is also a host synchronisation of the rank's stream
+            "rank0_n_alltoallv": s.get("n_alltoallv"), "rank0_n_allgather_dev": s.get("n_allgather_dev"), "rank0_n_allgather_host": s.get("n_allgather_host")}
 
 
 for w in worlds:
