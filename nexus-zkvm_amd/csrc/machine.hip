@@ -537,15 +537,21 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     }
     lap(&st->trace_gen);
     if (pre_shared) { cs.trees.push_back(borrow_tree(pre_shared)); channel.mix_root(pre_shared->root); }
+    else if (host || D.on()) H_TRY(tb0.commit(channel));                              // machine.rs:208-228
     else {
-        H_TRY(tb0.commit(channel));                                                   // machine.rs:208-228
+        // both tree builds are queued before the first root is fetched: the main tree's transforms do not depend on the preprocessed
+        // root, so the GPU does not idle through that download (the roots still enter the transcript in order)
+        H_TRY(tb0.commit_begin());
+        H_TRY(tb1.commit_begin());
+        H_TRY(tb0.commit_end(channel));
         if (!pre_key.empty()) {                                                       // keep it for the next proof of this shape
             auto sp = std::make_shared<CommitmentTreeProver>(std::move(cs.trees[0]));
             cs.trees[0] = borrow_tree(sp);
             ctx->machine_pre_cache[pre_key] = sp;
         }
+        H_TRY(tb1.commit_end(channel));
     }
-    H_TRY(tb1.commit(channel));                                                       // machine.rs:230-237
+    if (pre_shared || host || D.on()) H_TRY(tb1.commit(channel));                     // machine.rs:230-237
     lap(&st->commit);
 
     // machine.rs:239-247: draw_lookup_elements, generate_interaction_trace
