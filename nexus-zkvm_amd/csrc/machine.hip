@@ -536,22 +536,21 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         H_TRY(vote_before_exchanges(ctx, D, rc_local, "nx_prove_machine"));
     }
     lap(&st->trace_gen);
+    bool main_queued = false;
     if (pre_shared) { cs.trees.push_back(borrow_tree(pre_shared)); channel.mix_root(pre_shared->root); }
-    else if (host || D.on()) H_TRY(tb0.commit(channel));                              // machine.rs:208-228
     else {
-        // both tree builds are queued before the first root is fetched: the main tree's transforms do not depend on the preprocessed
-        // root, so the GPU does not idle through that download (the roots still enter the transcript in order)
-        H_TRY(tb0.commit_begin());
-        H_TRY(tb1.commit_begin());
-        H_TRY(tb0.commit_end(channel));
+        // "machine.queue_trees": both tree builds are queued before the first root is fetched — the main tree's transforms do not depend
+        // on the preprocessed root, so the GPU does not idle through that download (the roots still enter the transcript in order)
+        main_queued = !host && !D.on() && ctx->opt.machine_queue_trees;
+        if (main_queued) { H_TRY(tb0.commit_begin()); H_TRY(tb1.commit_begin()); H_TRY(tb0.commit_end(channel)); }
+        else H_TRY(tb0.commit(channel));                                              // machine.rs:208-228
         if (!pre_key.empty()) {                                                       // keep it for the next proof of this shape
             auto sp = std::make_shared<CommitmentTreeProver>(std::move(cs.trees[0]));
             cs.trees[0] = borrow_tree(sp);
             ctx->machine_pre_cache[pre_key] = sp;
         }
-        H_TRY(tb1.commit_end(channel));
     }
-    if (pre_shared || host || D.on()) H_TRY(tb1.commit(channel));                     // machine.rs:230-237
+    if (main_queued) H_TRY(tb1.commit_end(channel)); else H_TRY(tb1.commit(channel));   // machine.rs:230-237
     lap(&st->commit);
 
     // machine.rs:239-247: draw_lookup_elements, generate_interaction_trace
