@@ -256,7 +256,7 @@ static nx_options options_from_env() {
     o.logup_scan_tiled = env_int("NX_LOGUP_SCAN_TILED", 1) != 0;
     o.logup_per_column = env_int("NX_LOGUP_PER_COLUMN", 0) != 0;
     o.machine_reuse_pre = env_int("NX_MACHINE_REUSE_PREPROCESSED", 0) != 0;
-    o.machine_queue_trees = env_int("NX_MACHINE_QUEUE_TREES", 1) != 0;
+    o.machine_queue_trees = env_int("NX_MACHINE_QUEUE_TREES", 0) != 0;   // measured: no gain (profiles/r05_queue_trees_ab.txt)
     return o;
 }
 struct OptEntry { const char* name; int nx_options::*field; int lo, hi; };
