@@ -136,8 +136,12 @@ extern "C" int nx_eval_constraint_program(nx_ctx* ctx, const nx_cinstr* program,
     uint8_t* blob = nullptr;
     NX_TRY(dev_alloc(ctx, total, (void**)&blob));
     hipError_t er = hipSuccess;
-    auto up = [&](size_t off, const void* src, size_t bytes) { if (er == hipSuccess && bytes) er = hipMemcpyAsync(blob + off, src, bytes, hipMemcpyHostToDevice, ctx->stream); };
+    // through the staging ring: the caller's arrays may be freed as soon as this (stream-ordered) entry returns, and a large program
+    // copied straight from pageable memory would have its pages pinned in place by the runtime (internal.h, h_bounce)
+    int up_rc = NX_OK;
+    auto up = [&](size_t off, const void* src, size_t bytes) { if (er == hipSuccess && up_rc == NX_OK && bytes) up_rc = upload_async_staged(ctx, blob + off, src, bytes); };
     up(0, program, b_prog); up(o_cols, d_cols, b_cols); up(o_ec, econsts, b_ec); up(o_pw, alpha_powers, b_pw); up(o_den, denom_inv, b_den);
+    if (up_rc != NX_OK) { dev_free(ctx, blob); return up_rc; }
     if (er == hipSuccess) {
         static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
         if (!(attr_set.load() & (1ull << (ctx->device & 63)))) {

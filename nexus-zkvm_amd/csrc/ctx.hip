@@ -1,5 +1,8 @@
 // Context, device memory, staging ring, gather, timing.  Part of libnexus_hip.so (gfx950 only).
 #include "internal.h"
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -34,6 +37,71 @@ int stage(nx_ctx* ctx, const void* h_src, size_t bytes, void** d_out) {
                                hipMemcpyHostToDevice, ctx->stream));
     *d_out = ctx->d_scratch + ctx->scratch_off;
     ctx->scratch_off += need;
+    return NX_OK;
+}
+
+constexpr size_t BOUNCE_HALF = (size_t)4 << 20, BOUNCE_MIN = (size_t)32 << 10;
+static int bounce_ready(nx_ctx* ctx) {
+    if (ctx->h_bounce) return NX_OK;
+    NX_HIP(ctx, hipHostMalloc((void**)&ctx->h_bounce, 2 * BOUNCE_HALF, hipHostMallocDefault));
+    for (int k = 0; k < 2; k++) NX_HIP(ctx, hipEventCreateWithFlags(&ctx->bounce_ev[k], hipEventDisableTiming));
+    return NX_OK;
+}
+int copy_h2d_blocking(nx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t stream) {
+    if (!bytes) return NX_OK;
+    if (!stream) stream = ctx->stream;
+    if (bytes < BOUNCE_MIN || host_pinned_by_owner(h_src, bytes)) {      // small: the runtime stages it by itself; pinned by its owner: DMA straight from it
+        NX_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, stream));
+        NX_HIP(ctx, hipStreamSynchronize(stream));
+        return NX_OK;
+    }
+    NX_TRY(bounce_ready(ctx));
+    size_t i = 0;
+    for (size_t off = 0; off < bytes; off += BOUNCE_HALF, i++) {
+        const int k = (int)(i & 1);
+        const size_t n = std::min(BOUNCE_HALF, bytes - off);
+        if (i >= 2) NX_HIP(ctx, hipEventSynchronize(ctx->bounce_ev[k]));          // the copy that read this half two chunks ago is done
+        memcpy(ctx->h_bounce + k * BOUNCE_HALF, (const uint8_t*)h_src + off, n);
+        NX_HIP(ctx, hipMemcpyAsync((uint8_t*)d_dst + off, ctx->h_bounce + k * BOUNCE_HALF, n, hipMemcpyHostToDevice, stream));
+        NX_HIP(ctx, hipEventRecord(ctx->bounce_ev[k], stream));
+    }
+    NX_HIP(ctx, hipStreamSynchronize(stream));
+    return NX_OK;
+}
+int copy_d2h_blocking(nx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!bytes) return NX_OK;
+    if (bytes < BOUNCE_MIN || host_pinned_by_owner(h_dst, bytes)) {
+        NX_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return NX_OK;
+    }
+    NX_TRY(bounce_ready(ctx));
+    // chunk i lands in half i & 1 while chunk i - 1 is copied out to the caller
+    const size_t n_chunks = (bytes + BOUNCE_HALF - 1) / BOUNCE_HALF;
+    for (size_t i = 0; i <= n_chunks; i++) {
+        if (i < n_chunks) {
+            const int k = (int)(i & 1);
+            const size_t off = i * BOUNCE_HALF, n = std::min(BOUNCE_HALF, bytes - off);
+            NX_HIP(ctx, hipMemcpyAsync(ctx->h_bounce + k * BOUNCE_HALF, (const uint8_t*)d_src + off, n, hipMemcpyDeviceToHost, ctx->stream));
+            NX_HIP(ctx, hipEventRecord(ctx->bounce_ev[k], ctx->stream));
+        }
+        if (i >= 1) {
+            const int k = (int)((i - 1) & 1);
+            const size_t off = (i - 1) * BOUNCE_HALF, n = std::min(BOUNCE_HALF, bytes - off);
+            NX_HIP(ctx, hipEventSynchronize(ctx->bounce_ev[k]));
+            memcpy((uint8_t*)h_dst + off, ctx->h_bounce + k * BOUNCE_HALF, n);
+        }
+    }
+    return NX_OK;
+}
+int upload_async_staged(nx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    const size_t chunk = (size_t)4 << 20;
+    for (size_t off = 0; off < bytes; off += chunk) {
+        const size_t n = std::min(chunk, bytes - off);
+        void* st = nullptr;
+        NX_TRY(stage(ctx, (const uint8_t*)h_src + off, n, &st));
+        NX_HIP(ctx, hipMemcpyAsync((uint8_t*)d_dst + off, st, n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     return NX_OK;
 }
 
@@ -301,8 +369,19 @@ int nx_ctx_get_option(const nx_ctx* ctx, const char* name, int64_t* value) {
     return set_err(const_cast<nx_ctx*>(ctx), NX_ERR_ARG, std::string("nx_ctx_get_option: unknown option ") + name);
 }
 
+// NX_ABORT_BACKTRACE=1: the native stack of whoever calls abort() (a runtime assertion, a GPU fault handler, glibc's heap checks) on stderr
+static void abort_backtrace(int sig) {
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    static const char msg[] = "\n[nexus_hip] SIGABRT — native stack of the aborting thread:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
 int nx_ctx_create(int device, nx_ctx** out) {
     if (!out) return set_err(nullptr, NX_ERR_ARG, "nx_ctx_create: out is NULL");
+    { static bool once = false; if (!once) { once = true; const char* e = getenv("NX_ABORT_BACKTRACE"); if (e && *e == '1') signal(SIGABRT, abort_backtrace); } }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -348,6 +427,7 @@ void nx_ctx_destroy(nx_ctx* ctx) {
     for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_scratch) (void)hipHostFree(ctx->h_scratch);
+    if (ctx->h_bounce) { (void)hipHostFree(ctx->h_bounce); for (int k = 0; k < 2; k++) (void)hipEventDestroy(ctx->bounce_ev[k]); }
     for (auto& kv : ctx->free_pinned) (void)hipHostFree(kv.second);
     for (auto& kv : ctx->live_pinned) (void)hipHostFree(kv.first);
     for (int i = 0; i < 3; i++) { (void)hipStreamDestroy(ctx->side[i]); (void)hipEventDestroy(ctx->join_ev[i]); }
@@ -392,17 +472,13 @@ int nx_upload(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* h_src, size_t n_word
     NX_GUARD(ctx);
     if (!ctx || ((!d_dst || !h_src) && n_words)) return set_err(ctx, NX_ERR_ARG, "nx_upload: NULL argument");
     if (!n_words) return NX_OK;
-    NX_HIP(ctx, hipMemcpyAsync(d_dst, h_src, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
-    NX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_src may be pageable and reused by the caller
-    return NX_OK;
+    return copy_h2d_blocking(ctx, d_dst, h_src, n_words * 4);   // complete on return; the caller's (possibly pageable) pages are never pinned in place
 }
 int nx_download(nx_ctx* ctx, uint32_t* h_dst, const uint32_t* d_src, size_t n_words) {
     NX_GUARD(ctx);
     if (!ctx || ((!h_dst || !d_src) && n_words)) return set_err(ctx, NX_ERR_ARG, "nx_download: NULL argument");
     if (!n_words) return NX_OK;
-    NX_HIP(ctx, hipMemcpyAsync(h_dst, d_src, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-    NX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NX_OK;
+    return copy_d2h_blocking(ctx, h_dst, d_src, n_words * 4);
 }
 
 int nx_copy(nx_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, size_t n_words) {
@@ -453,17 +529,18 @@ int nx_gather(nx_ctx* ctx, const uint32_t* const* d_ptrs, const uint64_t* index,
     const uint32_t** dp = (const uint32_t**)d;
     uint64_t* di = (uint64_t*)(d + n * 8);
     uint32_t* dout = (uint32_t*)(d + n * 16);
-    hipError_t e = hipMemcpyAsync(dp, d_ptrs, n * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(di, index, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (upload_async_staged(ctx, dp, d_ptrs, n * 8) != NX_OK || upload_async_staged(ctx, di, index, n * 8) != NX_OK) e = hipErrorUnknown;   // the caller's arrays are never pinned in place (internal.h, h_bounce)
     if (e == hipSuccess) {
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dp, di, n, dout);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(h_out, dout, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    int rc = NX_OK;
+    if (e == hipSuccess) rc = copy_d2h_blocking(ctx, h_out, dout, n * 4);
+    else (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx, d);
     if (e != hipSuccess) return hip_fail(ctx, e, "nx_gather", __FILE__, __LINE__);
-    return NX_OK;
+    return rc;
 }
 
 void nx_free_host(void* p) { free(p); }

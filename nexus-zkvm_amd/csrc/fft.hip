@@ -612,7 +612,12 @@ int nx_upload_columns(nx_ctx* ctx, const uint32_t* const* h_cols, uint32_t n_col
         if (!registered[c]) (void)hipGetLastError();
         uint32_t* dst = coset_order ? d_tmp[k] : d_cols[c];
         if (coset_order && c >= 2) e = hipStreamWaitEvent(copy_stream, consumed[k], 0);      // the permute kernel of column c-2 has read d_tmp[k]
-        if (e == hipSuccess) e = hipMemcpyAsync(dst, h_cols[c], bytes, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) {
+            // a column that could not be pinned (already registered by someone else, ...) goes through the context's bounce buffer: a
+            // straight copy from pageable memory would be pinned in place by the runtime and released lazily (internal.h, h_bounce)
+            if (registered[c] || host_pinned_by_owner(h_cols[c], bytes)) e = hipMemcpyAsync(dst, h_cols[c], bytes, hipMemcpyHostToDevice, copy_stream);
+            else if (copy_h2d_blocking(ctx, dst, h_cols[c], bytes, copy_stream) != NX_OK) e = hipErrorUnknown;
+        }
         if (e == hipSuccess) e = hipEventRecord(copied[k], copy_stream);
         if (e == hipSuccess && coset_order) {
             e = hipStreamWaitEvent(ctx->stream, copied[k], 0);
@@ -660,17 +665,22 @@ int HostFeed::chunk(const uint32_t* const* h_cols, uint32_t* const* d_cols, uint
     const size_t n = (size_t)1 << log, bytes = n * 4;
     for (uint32_t c = 0; c < n_cols; c++) {
         if (!h_cols[c] || !d_cols[c]) return set_err(ctx, NX_ERR_ARG, "host feed: NULL column");
+        bool dma_ok = true;
         if (host_pinned_by_owner(h_cols[c], bytes)) {}                      // pinned once by its owner (nx_host_pin)
         else if (hipHostRegister((void*)h_cols[c], bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back(h_cols[c]);
-        else (void)hipGetLastError();                                            // falls back to a pageable copy
+        else { (void)hipGetLastError(); dma_ok = false; }                         // not pinnable: through the bounce buffer (never a pin-in-place copy: internal.h, h_bounce)
         const int k = (int)(n_done & 1);
+        auto h2d = [&](uint32_t* dst, hipStream_t st) -> int {
+            if (dma_ok) { NX_HIP(ctx, hipMemcpyAsync(dst, h_cols[c], bytes, hipMemcpyHostToDevice, st)); return NX_OK; }
+            return copy_h2d_blocking(ctx, dst, h_cols[c], bytes, st);
+        };
         if (!coset_order) {
             // no permutation to run: the second stream carries every other column's copy (two DMA queues in flight: 136.6 -> 132.7 ms
             // for the 374-column headline trace, bench.py host_trace)
-            NX_HIP(ctx, hipMemcpyAsync(d_cols[c], h_cols[c], bytes, hipMemcpyHostToDevice, (n_done & 1) ? ctx->perm_stream : ctx->copy_stream));
+            NX_TRY(h2d(d_cols[c], (n_done & 1) ? ctx->perm_stream : ctx->copy_stream));
         } else {
             if (n_done >= 2) NX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, consumed[k], 0));      // the permutation of column n_done - 2 has read d_tmp[k]
-            NX_HIP(ctx, hipMemcpyAsync(d_tmp[k], h_cols[c], bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+            NX_TRY(h2d(d_tmp[k], ctx->copy_stream));
             NX_HIP(ctx, hipEventRecord(copied[k], ctx->copy_stream));
             NX_HIP(ctx, hipStreamWaitEvent(ctx->perm_stream, copied[k], 0));
             ColSet s1, d1; s1.base = d_tmp[k]; s1.stride = 0; s1.table = nullptr; d1.base = d_cols[c]; d1.stride = 0; d1.table = nullptr;
@@ -766,9 +776,7 @@ int nx_upload_coset_order(nx_ctx* ctx, const uint32_t* h_natural, uint32_t log_s
     uint32_t* d_tmp = nullptr;
     size_t n = (size_t)1 << log_size;
     NX_TRY(dev_alloc(ctx, n * 4, (void**)&d_tmp));
-    hipError_t e = hipMemcpyAsync(d_tmp, h_natural, n * 4, hipMemcpyHostToDevice, ctx->stream);
-    int rc = NX_OK;
-    if (e != hipSuccess) rc = hip_fail(ctx, e, "hipMemcpyAsync", __FILE__, __LINE__);
+    int rc = copy_h2d_blocking(ctx, d_tmp, h_natural, n * 4);
     if (rc == NX_OK) { const uint32_t* sp = d_tmp; uint32_t* dp = d_dst; rc = nx_finalize_columns(ctx, &sp, &dp, 1, log_size); }
     (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx, d_tmp);

@@ -56,6 +56,12 @@ struct nx_ctx {
     uint8_t* d_scratch;
     size_t scratch_size, scratch_off;
     uint8_t* h_scratch;  // pinned mirror of the ring
+    // Bounce buffer of the blocking host <-> device copies (copy_h2d_blocking / copy_d2h_blocking): two pinned halves, allocated on first
+    // use.  A copy of >= 1 MiB from / to PAGEABLE memory makes the HIP runtime pin the caller's pages in place and release them lazily;
+    // when the caller's allocator hands the same heap pages out again (numpy arrays of one test after the other) the late release tears
+    // the mapping down under the next copy: "Memory access fault by GPU ... on address <host heap>" (reproduced 1 run in 4, round 5).
+    // Through the bounce buffer no caller page is ever pinned implicitly.
+    uint8_t* h_bounce = nullptr; hipEvent_t bounce_ev[2] = {nullptr, nullptr};
     // caching allocator: freed device blocks are kept by exact size and handed back to later nx_alloc calls
     // (a prove repeats the same slab sizes); reuse is safe because all work is ordered on ctx->stream.
     std::multimap<size_t, void*> free_blocks;
@@ -190,6 +196,11 @@ int copy_columns(nx_ctx* ctx, uint32_t* const* h_dst, const uint32_t* const* h_s
 // host ranges their owner pinned (nx_host_pin; process-wide like the driver's registration): the host-column entry points neither pin nor
 // unpin inside them
 bool host_pinned_by_owner(const void* p, size_t bytes);
+// blocking copies between caller (possibly pageable) host memory and the device: complete on return, never pin the caller's pages
+int copy_h2d_blocking(nx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes, hipStream_t stream = nullptr);   // stream: null = the context's
+int copy_d2h_blocking(nx_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+// stream-ordered upload of caller host memory that may be freed as soon as this returns (through the staging ring, in chunks)
+int upload_async_staged(nx_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 struct HostFeed {
     nx_ctx* ctx = nullptr; int coset_order = 0; uint32_t log = 0;
     uint32_t* d_tmp[2] = {nullptr, nullptr}; hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
