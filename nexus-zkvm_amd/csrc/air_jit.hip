@@ -16,7 +16,6 @@
 #include <stdlib.h>
 
 #include <atomic>
-#include <thread>
 #include <map>
 #include <mutex>
 #include <stdio.h>
@@ -25,12 +24,10 @@
 
 struct nx_air_kernel {
     nx_ctx* ctx;
-    std::vector<hipModule_t> modules;    // one per compilation unit (the segments of a large program are compiled in parallel, several per unit)
+    hipModule_t module;
     std::vector<hipFunction_t> fns;      // one kernel per program segment (air_kernel, air_kernel_1, ...), launched back to back
     uint32_t n_cols, n_econsts, n_constraints;
-    uint32_t n_units = 1;
-    std::vector<char> code;              // what the modules were loaded from (nx_air_kernel_save; the disk cache): one gfx950 code object, or
-                                         // n_units of them behind a table [u64 size] x n_units
+    std::vector<char> code;              // the gfx950 code object the module was loaded from (nx_air_kernel_save; the disk cache)
 };
 
 namespace nx {
@@ -373,33 +370,12 @@ int load_code(nx_ctx* ctx, const BlobHeader& h, const char* code, nx_air_kernel*
     nx_air_kernel* k = new nx_air_kernel();
     k->ctx = ctx; k->n_cols = h.n_cols; k->n_econsts = h.n_econsts; k->n_constraints = h.n_constraints;
     k->code.assign(code, code + h.code_size);
-    k->n_units = h.reserved > 1 ? (uint32_t)h.reserved : 1;
-    auto fail = [&](hipError_t e, const char* what) { for (hipModule_t m : k->modules) (void)hipModuleUnload(m); delete k; return hip_fail(ctx, e, what, __FILE__, __LINE__); };
-    std::vector<std::pair<size_t, size_t>> units;          // (offset, size) of every code object inside k->code
-    if (k->n_units == 1) units.push_back({0, k->code.size()});
-    else {
-        const size_t table = (size_t)k->n_units * 8;
-        if (k->n_units > 4096 || table > k->code.size()) { delete k; return set_err(ctx, NX_ERR_ARG, "kernel blob: bad unit table"); }
-        size_t off = table;
-        for (uint32_t u = 0; u < k->n_units; u++) {
-            uint64_t sz; memcpy(&sz, k->code.data() + 8 * (size_t)u, 8);
-            if (sz > k->code.size() - off) { delete k; return set_err(ctx, NX_ERR_ARG, "kernel blob: unit sizes exceed the payload"); }
-            units.push_back({off, (size_t)sz}); off += (size_t)sz;
-        }
-    }
-    for (auto& u : units) {
-        hipModule_t m;
-        hipError_t e = hipModuleLoadData(&m, k->code.data() + u.first);
-        if (e != hipSuccess) return fail(e, "hipModuleLoadData(air kernel)");
-        k->modules.push_back(m);
-    }
+    hipError_t e = hipModuleLoadData(&k->module, k->code.data());
+    if (e != hipSuccess) { delete k; return hip_fail(ctx, e, "hipModuleLoadData(air kernel)", __FILE__, __LINE__); }
     k->fns.resize(h.n_kernels);
-    for (uint32_t f = 0; f < h.n_kernels; f++) {
-        const std::string name = f == 0 ? std::string("air_kernel") : "air_kernel_" + std::to_string(f);
-        hipError_t e = hipErrorNotFound;
-        for (size_t m = 0; m < k->modules.size() && e != hipSuccess; m++) { e = hipModuleGetFunction(&k->fns[f], k->modules[m], name.c_str()); if (e != hipSuccess) (void)hipGetLastError(); }
-        if (e != hipSuccess) return fail(e, "hipModuleGetFunction(air kernel)");
-    }
+    for (uint32_t f = 0; f < h.n_kernels && e == hipSuccess; f++)
+        e = hipModuleGetFunction(&k->fns[f], k->module, f == 0 ? "air_kernel" : ("air_kernel_" + std::to_string(f)).c_str());
+    if (e != hipSuccess) { (void)hipModuleUnload(k->module); delete k; return hip_fail(ctx, e, "hipModuleGetFunction(air kernel)", __FILE__, __LINE__); }
     *out = k;
     return NX_OK;
 }
@@ -410,7 +386,7 @@ bool blob_ok(const uint8_t* blob, size_t n, BlobHeader* h) {
            h->code_hash == fnv1a(blob + sizeof(BlobHeader), (size_t)h->code_size);
 }
 std::vector<uint8_t> make_blob(const nx_air_kernel* k) {
-    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, (uint32_t)k->fns.size(), k->n_cols, k->n_econsts, k->n_constraints, (uint64_t)k->code.size(), fnv1a(k->code.data(), k->code.size()), k->n_units > 1 ? k->n_units : 0};
+    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, (uint32_t)k->fns.size(), k->n_cols, k->n_econsts, k->n_constraints, (uint64_t)k->code.size(), fnv1a(k->code.data(), k->code.size()), 0};
     std::vector<uint8_t> b(sizeof h + k->code.size());
     memcpy(b.data(), &h, sizeof h); memcpy(b.data() + sizeof h, k->code.data(), k->code.size());
     return b;
@@ -486,55 +462,22 @@ int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint
             // a damaged or foreign file: fall through to the compiler (and overwrite it)
         }
     }
-    // The kernels of a segmented program are independent translation units (prelude + kernel): a large AIR is dozens of them, and hiprtc
-    // spends seconds per unit.  They are compiled on up to "NX_AIR_COMPILE_THREADS" (default 8) host threads, several kernels per unit,
-    // and loaded as one module per unit; a program of one kernel is one unit as before.
-    const std::string marker = "extern \"C\" __attribute__((global))";
-    std::vector<size_t> starts;
-    for (size_t pos = src.find(marker); pos != std::string::npos; pos = src.find(marker, pos + 1)) starts.push_back(pos);
-    int n_threads = 8;
-    { const char* e = getenv("NX_AIR_COMPILE_THREADS"); if (e && *e) n_threads = std::max(1, atoi(e)); }
-    const uint32_t n_units = (starts.size() != n_kernels || n_kernels < 2 || n_threads < 2) ? 1u : std::min<uint32_t>(n_kernels, (uint32_t)n_threads);
-    std::vector<std::string> unit_src(n_units);
-    if (n_units == 1) unit_src[0] = src;
-    else {
-        const std::string prelude = src.substr(0, starts[0]);
-        for (uint32_t u = 0; u < n_units; u++) unit_src[u] = prelude;
-        for (uint32_t kx = 0; kx < n_kernels; kx++) unit_src[kx % n_units] += src.substr(starts[kx], (kx + 1 < n_kernels ? starts[kx + 1] : src.size()) - starts[kx]);
-    }
-    std::vector<std::vector<char>> unit_code(n_units);
-    std::vector<std::string> unit_err(n_units);
-    auto compile_unit = [&](uint32_t u) {
-        hiprtcProgram rp;
-        if (hiprtcCreateProgram(&rp, unit_src[u].c_str(), "nx_air_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { unit_err[u] = "hiprtcCreateProgram failed"; return; }
-        const char* opts[] = {"--offload-arch=gfx950", "-O3"};
-        if (hiprtcCompileProgram(rp, 2, opts) != HIPRTC_SUCCESS) {
-            size_t ls = 0; (void)hiprtcGetProgramLogSize(rp, &ls);
-            std::string log(ls, '\0'); if (ls) (void)hiprtcGetProgramLog(rp, &log[0]);
-            unit_err[u] = "hiprtc compilation of the recorded AIR failed: " + log.substr(0, 400);
-        } else {
-            size_t cs = 0; (void)hiprtcGetCodeSize(rp, &cs);
-            unit_code[u].resize(cs);
-            (void)hiprtcGetCode(rp, unit_code[u].data());
-        }
+    hiprtcProgram rp;
+    if (hiprtcCreateProgram(&rp, src.c_str(), "nx_air_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return set_err(ctx, NX_ERR_HIP, "hiprtcCreateProgram failed");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3"};
+    hiprtcResult cr = hiprtcCompileProgram(rp, 2, opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t ls = 0; (void)hiprtcGetProgramLogSize(rp, &ls);
+        std::string log(ls, '\0'); if (ls) (void)hiprtcGetProgramLog(rp, &log[0]);
         (void)hiprtcDestroyProgram(&rp);
-    };
-    if (n_units == 1) compile_unit(0);
-    else {
-        std::vector<std::thread> th;
-        for (uint32_t u = 0; u < n_units; u++) th.emplace_back(compile_unit, u);
-        for (auto& x : th) x.join();
+        return set_err(ctx, NX_ERR_HIP, "hiprtc compilation of the recorded AIR failed: " + log.substr(0, 400));
     }
-    for (uint32_t u = 0; u < n_units; u++) if (!unit_err[u].empty()) return set_err(ctx, NX_ERR_HIP, unit_err[u]);
+    size_t cs = 0; (void)hiprtcGetCodeSize(rp, &cs);
+    std::vector<char> code(cs);
+    (void)hiprtcGetCode(rp, code.data());
+    (void)hiprtcDestroyProgram(&rp);
     cache_state().compiled++;
-    std::vector<char> code;
-    if (n_units == 1) code = std::move(unit_code[0]);
-    else {
-        code.resize((size_t)n_units * 8);
-        for (uint32_t u = 0; u < n_units; u++) { const uint64_t sz = unit_code[u].size(); memcpy(code.data() + 8 * (size_t)u, &sz, 8); }
-        for (uint32_t u = 0; u < n_units; u++) code.insert(code.end(), unit_code[u].begin(), unit_code[u].end());
-    }
-    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, n_kernels, n_cols, n_econsts, n_constraints, (uint64_t)code.size(), 0, n_units > 1 ? n_units : 0};
+    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, n_kernels, n_cols, n_econsts, n_constraints, (uint64_t)code.size(), 0, 0};
     NX_TRY(load_code(ctx, h, code.data(), out));
     if (!path.empty()) {                                  // store: write beside, then rename — a concurrent reader sees the old file or the whole new one
         const std::vector<uint8_t> b = make_blob(*out);
@@ -587,7 +530,7 @@ void nx_air_kernel_destroy(nx_air_kernel* k) {
     if (!k) return;
     NX_GUARD(k->ctx);
     (void)hipStreamSynchronize(k->ctx->stream);
-    for (hipModule_t m : k->modules) (void)hipModuleUnload(m);
+    (void)hipModuleUnload(k->module);
     delete k;
 }
 

@@ -834,8 +834,7 @@ def test_air_kernels_ahead_of_time_blob_and_cache_directory(be, nz, oracle, tmp_
             "comps = [(10, 4, 40, 24, 2, 1), (8, 3, 16, 32, 1, 5)]\n"
             "t0 = time.perf_counter(); w = be.prove_machine(comps, nz.default_config(pow_bits=4, log_constraint_degree=2), seed=9); dt = time.perf_counter() - t0\n"
             "print(json.dumps({'stats': nz.air_cache_stats(), 'first_prove_s': dt, 'sum': int(np.asarray(w, dtype=np.uint64).sum()), 'n': len(w)}))\n")
-    # a small segment budget: every program is several kernels, compiled as parallel units and stored as multi-unit blobs
-    env = dict(os.environ, NX_AIR_CACHE_DIR=str(tmp_path / "kernels"), PYTHONPATH=root, NX_AIR_SEGMENT="400")
+    env = dict(os.environ, NX_AIR_CACHE_DIR=str(tmp_path / "kernels"), PYTHONPATH=root)
     runs = []
     for _ in range(2):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
