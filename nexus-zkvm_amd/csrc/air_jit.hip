@@ -27,6 +27,7 @@ struct nx_air_kernel {
     hipModule_t module;
     std::vector<hipFunction_t> fns;      // one kernel per program segment (air_kernel, air_kernel_1, ...), launched back to back
     uint32_t n_cols, n_econsts, n_constraints;
+    uint32_t kind = 0;                    // 0: constraint kernels (nx_air_eval's argument list); 1: fraction kernels of nx_logup_program (another argument list)
     std::vector<char> code;              // the gfx950 code object the module was loaded from (nx_air_kernel_save; the disk cache)
 };
 
@@ -368,7 +369,7 @@ std::string cache_dir() {
 }
 int load_code(nx_ctx* ctx, const BlobHeader& h, const char* code, nx_air_kernel** out) {
     nx_air_kernel* k = new nx_air_kernel();
-    k->ctx = ctx; k->n_cols = h.n_cols; k->n_econsts = h.n_econsts; k->n_constraints = h.n_constraints;
+    k->ctx = ctx; k->n_cols = h.n_cols; k->n_econsts = h.n_econsts; k->n_constraints = h.n_constraints; k->kind = (uint32_t)h.reserved;
     k->code.assign(code, code + h.code_size);
     hipError_t e = hipModuleLoadData(&k->module, k->code.data());
     if (e != hipSuccess) { delete k; return hip_fail(ctx, e, "hipModuleLoadData(air kernel)", __FILE__, __LINE__); }
@@ -386,7 +387,7 @@ bool blob_ok(const uint8_t* blob, size_t n, BlobHeader* h) {
            h->code_hash == fnv1a(blob + sizeof(BlobHeader), (size_t)h->code_size);
 }
 std::vector<uint8_t> make_blob(const nx_air_kernel* k) {
-    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, (uint32_t)k->fns.size(), k->n_cols, k->n_econsts, k->n_constraints, (uint64_t)k->code.size(), fnv1a(k->code.data(), k->code.size()), 0};
+    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, (uint32_t)k->fns.size(), k->n_cols, k->n_econsts, k->n_constraints, (uint64_t)k->code.size(), fnv1a(k->code.data(), k->code.size()), k->kind};
     std::vector<uint8_t> b(sizeof h + k->code.size());
     memcpy(b.data(), &h, sizeof h); memcpy(b.data() + sizeof h, k->code.data(), k->code.size());
     return b;
@@ -406,7 +407,7 @@ std::string cache_path(const std::string& dir, const std::string& src) {
 }  // namespace nx
 
 
-namespace nx { int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out); }
+namespace nx { int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out, uint32_t kind = 0); }
 using namespace nx;
 
 extern "C" {
@@ -450,7 +451,7 @@ int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_inst
 
 namespace nx {
 // generated source -> loaded kernels: the cache directory first, else hiprtc (and the directory is fed)
-int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out) {
+int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out, uint32_t kind) {
     const std::string dir = cache_dir();
     const std::string path = dir.empty() ? std::string() : cache_path(dir, src);
     if (!path.empty()) {                                  // the disk cache: a blob stored by an earlier process (or a build step)
@@ -461,7 +462,7 @@ int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint
             while ((got = fread(buf, 1, sizeof buf, f)) > 0) b.insert(b.end(), buf, buf + got);
             fclose(f);
             BlobHeader h;
-            if (blob_ok(b.data(), b.size(), &h) && h.n_kernels == n_kernels && h.n_cols == n_cols && h.n_econsts == n_econsts && h.n_constraints == n_constraints &&
+            if (blob_ok(b.data(), b.size(), &h) && h.n_kernels == n_kernels && h.n_cols == n_cols && h.n_econsts == n_econsts && h.n_constraints == n_constraints && h.reserved == kind &&
                 load_code(ctx, h, (const char*)b.data() + sizeof h, out) == NX_OK) { cache_state().disk_hits++; return NX_OK; }
             // a damaged or foreign file: fall through to the compiler (and overwrite it)
         }
@@ -481,7 +482,7 @@ int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint
     (void)hiprtcGetCode(rp, code.data());
     (void)hiprtcDestroyProgram(&rp);
     cache_state().compiled++;
-    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, n_kernels, n_cols, n_econsts, n_constraints, (uint64_t)code.size(), 0, 0};
+    BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, n_kernels, n_cols, n_econsts, n_constraints, (uint64_t)code.size(), 0, kind};
     NX_TRY(load_code(ctx, h, code.data(), out));
     if (!path.empty()) {                                  // store: write beside, then rename — a concurrent reader sees the old file or the whole new one
         const std::vector<uint8_t> b = make_blob(*out);
@@ -527,6 +528,7 @@ int nx_air_kernel_load(nx_ctx* ctx, const uint8_t* blob, size_t n_bytes, nx_air_
     if (!ctx || !blob || !out) return set_err(ctx, NX_ERR_ARG, "nx_air_kernel_load: NULL argument");
     BlobHeader h;
     if (!blob_ok(blob, n_bytes, &h)) return set_err(ctx, NX_ERR_ARG, "nx_air_kernel_load: not a kernel blob of this library version (magic / size / checksum)");
+    if (h.reserved != 0) return set_err(ctx, NX_ERR_ARG, "nx_air_kernel_load: the blob holds the fraction kernels of nx_logup_program (a cache-directory file), not constraint kernels");
     return load_code(ctx, h, (const char*)blob + sizeof h, out);
 }
 
@@ -547,6 +549,7 @@ namespace nx {
 int air_eval_rows(nx_ctx* ctx, const nx_air_kernel* k, const uint32_t* const* d_cols, const uint32_t* econsts, const uint32_t* alpha_powers, const uint32_t* denom_inv,
                   uint32_t log_size, uint32_t log_eval, uint32_t* const* d_acc4, uint32_t row_begin, uint32_t n_rows) {
     if (!ctx || !k || !d_acc4 || (k->n_cols && !d_cols)) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: NULL argument");
+    if (k->kind != 0) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: not a constraint kernel");
     if (log_size < 1 || log_eval <= log_size || log_eval > 30) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: need 1 <= log_size < log_eval <= 30");
     if ((uint64_t)row_begin + n_rows > ((uint64_t)1 << log_eval)) return set_err(ctx, NX_ERR_ARG, "nx_air_eval: row block outside the evaluation domain");
     if (!n_rows) return NX_OK;
@@ -807,7 +810,7 @@ extern "C" int nx_logup_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t 
         { std::lock_guard<std::mutex> lk(kc.mu); auto it = kc.map.find({ctx, src}); if (it != kc.map.end()) k = it->second; }
         if (!k) {
             nx_air_kernel* nk = nullptr;
-            NX_TRY(compile_source(ctx, src, n_kernels, n_cols, n_econsts, n_logup_cols, &nk));      // outside the lock: entries are per context
+            NX_TRY(compile_source(ctx, src, n_kernels, n_cols, n_econsts, n_logup_cols, &nk, 1));      // outside the lock: entries are per context
             std::lock_guard<std::mutex> lk(kc.mu);
             kc.map.insert({{ctx, src}, nk});
             k = nk;
