@@ -24,17 +24,8 @@
 //! `generate_interaction_trace` (traits.rs:124-145) stays the cross-check of a debug build (`NEXUS_HIP_CHECK_LOGUP=1`).
 use num_traits::Zero;
 use stwo::{
-    core::{
-        channel::Blake2sChannel,
-        fields::{m31::BaseField, qm31::SecureField},
-        pcs::PcsConfig,
-        vcs::blake2_hash::Blake2sHash,
-    },
-    prover::{
-        backend::simd::SimdBackend,
-        poly::{circle::CircleEvaluation, BitReversedOrder},
-        ProvingError,
-    },
+    core::{fields::qm31::SecureField, pcs::PcsConfig},
+    prover::ProvingError,
 };
 
 // a CHILD module of `machine` (`#[path = "machine_hip.rs"] mod hip;` inside machine.rs): `BASE_EXTENSIONS` and `Machine::max_log_size`
@@ -52,70 +43,9 @@ use crate::{
 };
 
 use nexus_hip::record::{record_component, TraceLocations};
+// the steps both reference patches share (this one and prove2_hip.rs): rust/nexus-hip/src/simd_host.rs
+use nexus_hip::simd_host::{commit_tree_keeping_evaluations, host_channel_at, interaction_tree_on_device, pcs_config, secure_from_words, SimdEval};
 use nexus_hip::{proof_bytes, HipError, RecordedComponent, Session};
-use nexus_hip_sys as sys;
-
-type SimdEval = CircleEvaluation<SimdBackend, BaseField, BitReversedOrder>;
-
-fn q4(s: SecureField) -> [u32; 4] {
-    let a = s.to_m31_array();
-    [a[0].0, a[1].0, a[2].0, a[3].0]
-}
-/// `C::draw_lookup_elements(&mut lookup_elements, prover_channel, ..)` (machine.rs:239-240) takes `&mut impl Channel`, and `Channel`
-/// is `Default + Clone`: it has to be a real channel.  A host `Blake2sChannel` standing where the session's transcript stands does it:
-/// the lookup elements are DRAWN (draws hash the digest with a counter and leave the digest alone), and what follows — `mix_felts` of
-/// the claimed sums, machine.rs:262 — replaces the digest by H(digest ‖ felts) and resets the counter, so the session's transcript
-/// needs no replay of the draws.  [upstream-recollection: `Blake2sChannel::update_digest` is public; the oracle's channel
-/// (oracle/blake2s.h, csrc/host/channel.h) restates the same rule and the parity suite runs the draw-then-mix sequence through it]
-fn host_channel_at(session: &Session) -> Blake2sChannel {
-    let mut ch = Blake2sChannel::default();
-    ch.update_digest(Blake2sHash(session.channel_digest()));
-    ch
-}
-
-/// host pointers of a batch of SimdBackend evaluations (bit-reversed circle-domain order already: `finalize_columns` ran on the CPU,
-/// trace/utils.rs:94-106) and their log sizes, in commit order
-fn host_columns(evals: &[SimdEval]) -> (Vec<*const u32>, Vec<u32>) {
-    let ptrs = evals.iter().map(|e| e.values.as_slice().as_ptr() as *const u32).collect();
-    let logs = evals.iter().map(|e| e.domain.log_size()).collect();
-    (ptrs, logs)
-}
-
-/// TreeBuilder::extend_evals(..) + commit(channel) for one trace tree (machine.rs:208-228, :230-237): the columns stay in the
-/// SimdBackend evaluations' memory and go up in chunks under the commit's own transforms (nx_prover_tree_commit_host).  Every column's
-/// EVALUATIONS are also kept on the device (cloned as the chunks arrive: the reference's `finalized_trace.clone()`, machine.rs:232) —
-/// the fraction programs read them after the commit has turned the tree's own columns into coefficients.  Returns the kept columns.
-fn commit_tree_keeping_evaluations(session: &mut Session, evals: &[SimdEval]) -> Result<Vec<*const u32>, HipError> {
-    let (host, logs) = host_columns(evals);
-    session.tree_begin(&logs)?;
-    let mut keep: Vec<(u32, *mut u32)> = Vec::with_capacity(logs.len());
-    let mut i = 0;
-    while i < logs.len() {                                   // one allocation per run of equally sized columns
-        let mut j = i;
-        while j < logs.len() && logs[j] == logs[i] { j += 1; }
-        for (k, p) in session.alloc_columns(j - i, logs[i])?.into_iter().enumerate() { keep.push(((i + k) as u32, p)); }
-        i = j;
-    }
-    session.tree_commit_host(&host, false, &keep)?;
-    Ok(keep.iter().map(|k| k.1 as *const u32).collect())
-}
-
-/// The interaction tree (machine.rs:242-263) from the components' recorded relation entries: `recorded[c]` is component c recorded with a
-/// ZERO claimed sum (the fractions do not depend on it); its columns of trees 0 / 1 are looked up in the kept evaluations, its columns of
-/// tree 2 are the session's own (tree_begin), filled in place.  Returns the claimed sums in component order.
-fn interaction_tree_on_device(session: &mut Session, recorded: &[RecordedComponent], kept: [&[*const u32]; 2]) -> Result<Vec<[u32; 4]>, HipError> {
-    let mut logs: Vec<u32> = Vec::new();
-    for c in recorded { logs.extend(std::iter::repeat(c.log_size).take(4 * c.n_logup_cols as usize)); }
-    let tree2 = session.tree_begin(&logs)?;
-    let mut claimed = Vec::with_capacity(recorded.len());
-    for c in recorded {
-        let cols: Vec<*const u32> = c.col_tree.iter().zip(&c.col_index).map(|(&t, &i)| if t < 2 { kept[t as usize][i as usize] } else { std::ptr::null() }).collect();
-        // the component's interaction columns, in the order it declared them (TraceLocations hands them out consecutively)
-        let out: Vec<*mut u32> = c.col_tree.iter().zip(&c.col_index).filter(|(&t, _)| t == 2).map(|(_, &i)| tree2[i as usize]).collect();
-        claimed.push(session.logup_trace(c, &cols, &out)?);
-    }
-    Ok(claimed)
-}
 
 fn to_proving_error(e: HipError) -> ProvingError {
     match e {
@@ -158,15 +88,7 @@ impl<C: MachineChip + Sync> Machine<C> {
         // ---- machine.rs:184-206: config, twiddles (inside the session), channel seeding
         let config = PcsConfig::default();
         let max_log = log_size.max(all_log_sizes.iter().copied().max().unwrap_or(0));
-        let cfg = sys::nx_pcs_config {
-            pow_bits: config.pow_bits,
-            log_blowup: config.fri_config.log_blowup_factor,
-            n_queries: config.fri_config.n_queries as u32,
-            log_last_layer_degree_bound: config.fri_config.log_last_layer_degree_bound,
-            hash_mode: sys::NX_HASH_BLAKE2S as u32,
-            fri_alpha_mode: sys::NX_FRI_ALPHA_PREV as u32,
-            log_constraint_degree: LOG_CONSTRAINT_DEGREE,
-        };
+        let cfg = pcs_config(&config, LOG_CONSTRAINT_DEGREE);
         let device: i32 = std::env::var("NEXUS_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
         let mut session = Session::new(&cfg, max_log, device).map_err(to_proving_error)?;
         for byte in view.view_associated_data().unwrap_or_default() {
@@ -221,7 +143,7 @@ impl<C: MachineChip + Sync> Machine<C> {
         drop(generators);
         let all_claimed_sums: Vec<SecureField> = claimed
             .iter()
-            .map(|w| SecureField::from_m31_array([BaseField::from(w[0]), BaseField::from(w[1]), BaseField::from(w[2]), BaseField::from(w[3])]))
+            .map(secure_from_words)
             .collect();
         let claimed_sum = all_claimed_sums[0];
         if std::env::var("NEXUS_HIP_CHECK_LOGUP").is_ok() {

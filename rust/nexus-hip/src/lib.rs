@@ -24,6 +24,8 @@ use std::sync::{Mutex, MutexGuard, OnceLock};
 pub mod record;
 #[cfg(stwo_traits)]
 pub mod backend;
+#[cfg(stwo_traits)]
+pub mod simd_host;
 
 // ------------------------------------------------------------------------------------------------ context ----
 /// Stwo's `Backend` is a zero-sized type whose methods are called from whatever (rayon) thread Stwo likes, while an `nx_ctx` is

@@ -1,0 +1,105 @@
+//! What the two reference patches (`reference_patch/machine_hip.rs` for `prover/src/machine.rs`, `reference_patch/prove2_hip.rs` for
+//! `prover2/machine/src/prove.rs`) share: the handful of steps that take the reference's `SimdBackend` evaluations — the trace columns
+//! its chips filled on the CPU — onto a `Session`.  Compiled only with `RUSTFLAGS="--cfg stwo_traits"` (it names Stwo types).
+//!
+//!   reference                                                                here
+//!   tree_builder.extend_evals(..) + .commit(channel)                         `commit_tree_keeping_evaluations`
+//!       (machine.rs:208-237, prove.rs:70-84)
+//!   draw_lookup_elements(.., channel)  (machine.rs:239-240, prove.rs:86-89)  a host `Blake2sChannel` at the session's digest: `host_channel_at`
+//!   generate_interaction_trace + extend_evals                                `interaction_tree_on_device`: the recorded relation entries run as
+//!       (machine.rs:242-263, prove.rs:91-105)                                fraction programs straight into the interaction tree's columns
+//!   PcsConfig::default() -> CommitmentSchemeProver::new (machine.rs:184-203) `pcs_config`
+use crate::{HipError, RecordedComponent, Session};
+use nexus_hip_sys as sys;
+
+use stwo::core::channel::Blake2sChannel;
+use stwo::core::fields::m31::BaseField;
+use stwo::core::fields::qm31::SecureField;
+use stwo::core::pcs::PcsConfig;
+use stwo::core::vcs::blake2_hash::Blake2sHash;
+use stwo::prover::backend::simd::SimdBackend;
+use stwo::prover::poly::circle::CircleEvaluation;
+use stwo::prover::poly::BitReversedOrder;
+
+pub type SimdEval = CircleEvaluation<SimdBackend, BaseField, BitReversedOrder>;
+
+/// the reference's `PcsConfig` as the C ABI's; `log_constraint_degree`: the largest `max_constraint_log_degree_bound - log_size` of the
+/// statement's components (v1: `LOG_CONSTRAINT_DEGREE`, components/mod.rs:12; v2: the largest `C::LOG_CONSTRAINT_DEGREE_BOUND`,
+/// framework/eval.rs:14-16) — it sizes the session's twiddles the way machine.rs:186-194 / prove.rs:53-58 size Stwo's
+pub fn pcs_config(config: &PcsConfig, log_constraint_degree: u32) -> sys::nx_pcs_config {
+    sys::nx_pcs_config {
+        pow_bits: config.pow_bits,
+        log_blowup: config.fri_config.log_blowup_factor,
+        n_queries: config.fri_config.n_queries as u32,
+        log_last_layer_degree_bound: config.fri_config.log_last_layer_degree_bound,
+        hash_mode: sys::NX_HASH_BLAKE2S as u32,
+        fri_alpha_mode: sys::NX_FRI_ALPHA_PREV as u32,
+        log_constraint_degree,
+    }
+}
+
+pub fn secure_words(s: SecureField) -> [u32; 4] {
+    let a = s.to_m31_array();
+    [a[0].0, a[1].0, a[2].0, a[3].0]
+}
+pub fn secure_from_words(w: &[u32; 4]) -> SecureField {
+    SecureField::from_m31_array([BaseField::from(w[0]), BaseField::from(w[1]), BaseField::from(w[2]), BaseField::from(w[3])])
+}
+
+/// `draw_lookup_elements(&mut lookup_elements, prover_channel, ..)` (machine.rs:239-240; prove.rs:86-89 — there `&mut Blake2sChannel`
+/// by name) takes a real channel.  A host `Blake2sChannel` standing where the session's transcript stands does it: the lookup elements
+/// are DRAWN (draws hash the digest with a counter and leave the digest alone), and what follows — `mix_felts` of the claimed sums,
+/// machine.rs:262 / prove.rs:104 — replaces the digest by H(digest ‖ felts) and resets the counter, so the session's transcript needs
+/// no replay of the draws.  [upstream-recollection: `Blake2sChannel::update_digest` is public; the oracle's channel (oracle/blake2s.h,
+/// csrc/host/channel.h) restates the same rule and the parity suite runs the draw-then-mix sequence through it]
+pub fn host_channel_at(session: &Session) -> Blake2sChannel {
+    let mut ch = Blake2sChannel::default();
+    ch.update_digest(Blake2sHash(session.channel_digest()));
+    ch
+}
+
+/// host pointers of a batch of SimdBackend evaluations (bit-reversed circle-domain order already: `finalize_columns` ran on the CPU,
+/// trace/utils.rs:94-106, prover2/trace/src/utils.rs:102-114) and their log sizes, in commit order
+pub fn host_columns(evals: &[SimdEval]) -> (Vec<*const u32>, Vec<u32>) {
+    let ptrs = evals.iter().map(|e| e.values.as_slice().as_ptr() as *const u32).collect();
+    let logs = evals.iter().map(|e| e.domain.log_size()).collect();
+    (ptrs, logs)
+}
+
+/// TreeBuilder::extend_evals(..) + commit(channel) for one trace tree: the columns stay in the SimdBackend evaluations' memory and go up
+/// in chunks under the commit's own transforms (nx_prover_tree_commit_host).  Every column's EVALUATIONS are also kept on the device
+/// (cloned as the chunks arrive: the reference's `finalized_trace.clone()`, machine.rs:232; `to_circle_evaluation`'s clone,
+/// prover2/trace/src/component.rs:63-79) — the fraction programs read them after the commit has turned the tree's own columns into
+/// coefficients.  Returns the kept columns, in commit order.
+pub fn commit_tree_keeping_evaluations(session: &mut Session, evals: &[SimdEval]) -> Result<Vec<*const u32>, HipError> {
+    let (host, logs) = host_columns(evals);
+    session.tree_begin(&logs)?;
+    let mut keep: Vec<(u32, *mut u32)> = Vec::with_capacity(logs.len());
+    let mut i = 0;
+    while i < logs.len() {                                   // one allocation per run of equally sized columns
+        let mut j = i;
+        while j < logs.len() && logs[j] == logs[i] { j += 1; }
+        for (k, p) in session.alloc_columns(j - i, logs[i])?.into_iter().enumerate() { keep.push(((i + k) as u32, p)); }
+        i = j;
+    }
+    session.tree_commit_host(&host, false, &keep)?;
+    Ok(keep.iter().map(|k| k.1 as *const u32).collect())
+}
+
+/// The interaction tree from the components' recorded relation entries: `recorded[c]` is component c recorded with a ZERO claimed sum
+/// (the fractions do not depend on it); its columns of trees 0 / 1 are looked up in the kept evaluations, its columns of tree 2 are
+/// the session's own (tree_begin), filled in place.  Returns the claimed sums in component order; the caller mixes them and commits
+/// (`mix_felts`, `tree_commit`: machine.rs:262-263, prove.rs:104-105).  Nothing of tree 2 crosses PCIe.
+pub fn interaction_tree_on_device(session: &mut Session, recorded: &[RecordedComponent], kept: [&[*const u32]; 2]) -> Result<Vec<[u32; 4]>, HipError> {
+    let mut logs: Vec<u32> = Vec::new();
+    for c in recorded { logs.extend(std::iter::repeat(c.log_size).take(4 * c.n_logup_cols as usize)); }
+    let tree2 = session.tree_begin(&logs)?;
+    let mut claimed = Vec::with_capacity(recorded.len());
+    for c in recorded {
+        let cols: Vec<*const u32> = c.col_tree.iter().zip(&c.col_index).map(|(&t, &i)| if t < 2 { kept[t as usize][i as usize] } else { std::ptr::null() }).collect();
+        // the component's interaction columns, in the order it declared them (TraceLocations hands them out consecutively)
+        let out: Vec<*mut u32> = c.col_tree.iter().zip(&c.col_index).filter(|(&t, _)| t == 2).map(|(_, &i)| tree2[i as usize]).collect();
+        claimed.push(session.logup_trace(c, &cols, &out)?);
+    }
+    Ok(claimed)
+}

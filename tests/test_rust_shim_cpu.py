@@ -152,26 +152,27 @@ def test_every_stwo_and_nexus_path_in_our_rust_is_observed_in_the_reference_or_l
     assert not any(p.startswith("stwo_prover") for p in mine)
 
 
+def _crate_paths(R, src, parent):
+    out = set()
+    for m in re.finditer(r"\buse\s+([^;]+);", R.strip_comments(src), flags=re.S):
+        for p in R.expand(re.sub(r"\s+", " ", m.group(1))):
+            p = p.replace(" ", "")
+            if p.startswith("super::"):
+                p = parent + p[len("super::"):]
+            if p.startswith("crate::"):
+                out.add(p)
+    return out
+
+
 def test_reference_patch_imports_what_machine_rs_imports():
     """rust/nexus-hip/reference_patch/machine_hip.rs is a child module of the reference's `machine`: every `crate::` item it imports is one
     machine.rs itself imports (there as `super::` / `crate::`), and what it takes from its parent exists there."""
     R = _load_scanner()
     patch = open(os.path.join(HIP_DIR, "reference_patch", "machine_hip.rs")).read()
-
-    def crate_paths(src, parent):
-        out = set()
-        for m in re.finditer(r"\buse\s+([^;]+);", R.strip_comments(src), flags=re.S):
-            for p in R.expand(re.sub(r"\s+", " ", m.group(1))):
-                p = p.replace(" ", "")
-                if p.startswith("super::"):
-                    p = parent + p[len("super::"):]
-                if p.startswith("crate::"):
-                    out.add(p)
-        return out
-    mine = crate_paths(patch, "crate::machine::")
+    mine = _crate_paths(R, patch, "crate::machine::")
     fixture = os.path.join(ROOT, "tests", "golden", "reference_machine_rs_use_paths.txt")
     if os.path.isdir("/root/reference"):
-        ref = crate_paths(open("/root/reference/prover/src/machine.rs").read(), "crate::")
+        ref = _crate_paths(R, open("/root/reference/prover/src/machine.rs").read(), "crate::")
         assert sorted(ref) == open(fixture).read().split(), "regenerate tests/golden/reference_machine_rs_use_paths.txt"
     ref = set(open(fixture).read().split())
     own = {p for p in mine if p.startswith("crate::machine::")}
@@ -181,6 +182,65 @@ def test_reference_patch_imports_what_machine_rs_imports():
     if os.path.isdir("/root/reference"):
         msrc = open("/root/reference/prover/src/machine.rs").read()
         assert "const BASE_EXTENSIONS" in msrc and "pub struct Machine" in msrc and "pub struct Proof" in msrc and "fn max_log_size" in msrc
+
+
+def test_prover2_patch_imports_what_prove_rs_imports():
+    """rust/nexus-hip/reference_patch/prove2_hip.rs is a sibling of the reference's `prove` module in prover2/machine/src/lib.rs (SURVEY.md
+    section 8(a) R2): every `crate::` / `super::` item it imports is one prove.rs itself imports, plus prove.rs's own `Proof`; the statements
+    it shares with prove.rs (trace generation, channel seeding, component order) are there; what README.md edit 6 adds to
+    `MachineComponent` sits next to the method it twins."""
+    R = _load_scanner()
+    patch = open(os.path.join(HIP_DIR, "reference_patch", "prove2_hip.rs")).read()
+    mine = _crate_paths(R, patch, "crate::")
+    fixture = os.path.join(ROOT, "tests", "golden", "reference_prove2_rs_use_paths.txt")
+    if os.path.isdir("/root/reference"):
+        ref = _crate_paths(R, open("/root/reference/prover2/machine/src/prove.rs").read(), "crate::")
+        assert sorted(ref) == open(fixture).read().split(), "regenerate tests/golden/reference_prove2_rs_use_paths.txt"
+    ref = set(open(fixture).read().split())
+    own = {"crate::prove::Proof", "crate::prove", "crate::verify"}          # prove.rs's own items (its test module names `crate::verify` too)
+    missing = sorted(p for p in mine - own if p not in ref)
+    assert missing == [], missing
+    assert "crate::BASE_COMPONENTS" in mine and "crate::side_note::SideNote" in mine and "crate::lookups::AllLookupElements" in mine
+    for needle in ("pub fn prove_hip(trace: &impl Trace, view: &View) -> Result<Proof, ProvingError>", "c.generate_component_trace(&mut prover_side_note)",
+                   "c.max_constraint_log_degree_bound(log_size) - log_size", "c.draw_lookup_elements(&mut lookup_elements, &mut host_channel)",
+                   "t.to_circle_evaluation(PREPROCESSED_TRACE_IDX)", "t.to_circle_evaluation(ORIGINAL_TRACE_IDX)",
+                   "interaction_tree_on_device(&mut session, &generators, [&kept0, &kept1])", "c.to_recorded_component(&mut locations, &lookup_elements, *log_size, *claimed_sum)",
+                   "session.mix_felts(&claimed_words)", "session.tree_commit()", "session.prove(&recorded)", "proof_bytes(&words, &claimed_words, &log_sizes)"):
+        assert needle in patch, needle
+    assert "tree_commit_host(" not in patch and "generate_interaction_trace(" not in R.strip_comments(patch)   # tree 2 is generated on the device
+    readme = open(os.path.join(HIP_DIR, "reference_patch", "README.md")).read()
+    for needle in ("fn to_recorded_component(&self, locations: &mut nexus_hip::record::TraceLocations", "BuiltInComponentEval::<C> { component: self, log_size, lookup_elements }",
+                   "mod prove_hip;", "pub use prove_hip::prove_hip;"):
+        assert needle in readme, needle
+    if os.path.isdir("/root/reference"):
+        er = open("/root/reference/prover2/machine/src/framework/traits/erased.rs").read()
+        assert "pub trait MachineComponent" in er and "fn to_component_prover<'a>(" in er and "BuiltInComponentEval::<C> {" in er and "C::LookupElements::get(lookup_elements)" in er
+        ev = open("/root/reference/prover2/machine/src/framework/eval.rs").read()
+        assert "pub(crate) component: &'a C" in ev and "pub(crate) log_size: u32" in ev and "pub(crate) lookup_elements: C::LookupElements" in ev
+        lib2 = open("/root/reference/prover2/machine/src/lib.rs").read()
+        assert "const BASE_COMPONENTS: &[&dyn framework::MachineComponent]" in lib2 and "\nmod prove;" in lib2
+        pr = R.strip_comments(open("/root/reference/prover2/machine/src/prove.rs").read())
+        for stmt in ("let mut prover_side_note = SideNote::new(trace, view);", "let components = BASE_COMPONENTS;", ".map(|c| c.generate_component_trace(&mut prover_side_note))",
+                     "let log_sizes: Vec<u32> = traces.iter().map(ComponentTrace::log_size).collect();", "for byte in view.view_associated_data().unwrap_or_default() {"):
+            assert stmt in pr and stmt in patch, stmt
+
+
+def test_the_two_reference_patches_share_their_device_steps():
+    """rust/nexus-hip/src/simd_host.rs holds what machine_hip.rs and prove2_hip.rs both do with the reference's SimdBackend evaluations
+    (commit while keeping the evaluations, the host channel the lookup elements are drawn from, the interaction tree from the recorded
+    relation entries); neither patch carries a private copy."""
+    host = open(os.path.join(HIP_DIR, "src", "simd_host.rs")).read()
+    for needle in ("pub fn commit_tree_keeping_evaluations(session: &mut Session, evals: &[SimdEval])", "pub fn host_channel_at(session: &Session) -> Blake2sChannel",
+                   "pub fn interaction_tree_on_device(session: &mut Session, recorded: &[RecordedComponent], kept: [&[*const u32]; 2])", "pub fn pcs_config(config: &PcsConfig, log_constraint_degree: u32)",
+                   "session.tree_commit_host(&host, false, &keep)", "session.logup_trace(c, &cols, &out)", "ch.update_digest(Blake2sHash(session.channel_digest()))"):
+        assert needle in host, needle
+    assert host.count("tree_commit_host(") == 1                   # only what the chips filled (trees 0 and 1) goes over PCIe
+    assert "#[cfg(stwo_traits)]\npub mod simd_host;" in open(HIP).read()
+    for f in ("machine_hip.rs", "prove2_hip.rs"):
+        patch = open(os.path.join(HIP_DIR, "reference_patch", f)).read()
+        assert "use nexus_hip::simd_host::{commit_tree_keeping_evaluations, host_channel_at, interaction_tree_on_device, pcs_config, secure_from_words, SimdEval};" in patch, f
+        for private in ("fn commit_tree_keeping_evaluations", "fn interaction_tree_on_device", "fn host_channel_at", "sys::nx_pcs_config {"):
+            assert private not in patch, (f, private)
 
 
 BACKEND_TRAITS = ["Backend", "BackendForChannel<Blake2sMerkleChannel>", "ColumnOps<BaseField>", "ColumnOps<SecureField>", "ColumnOps<Blake2sHash>",
@@ -259,9 +319,9 @@ def test_recording_evaluator_lowers_to_the_abi_opcodes():
     for needle in ("pub fn prove_hip(trace: &impl Trace, view: &View) -> Result<Proof, ProvingError>", "record_component(", "session.prove(&components)", "proof_bytes(",
                    "generate_interaction_trace::<C>(", "C::draw_lookup_elements(",
                    # the interaction tree is generated on the device from the recorded relation entries; tree 2 is never uploaded
-                   "interaction_tree_on_device(&mut session, &generators, [&kept0, &kept1])", "session.logup_trace(c, &cols, &out)", "session.tree_commit()"):
+                   "interaction_tree_on_device(&mut session, &generators, [&kept0, &kept1])", "session.tree_commit()"):
         assert needle in patch, needle
-    assert patch.count("tree_commit_host(") == 1 and "commit_tree(&mut session, &tree2)" not in patch      # only trees 0 and 1 go over PCIe
+    assert patch.count("commit_tree_keeping_evaluations(&mut session, &tree") == 2 and "&tree2" not in patch      # only trees 0 and 1 go over PCIe
     for needle in ("fn add_to_relation<R: Relation<F, EF>>", "self.rec.fracs.push(", "Root::Frac {", "sys::NX_C_FRAC", "sys::NX_C_FRACB", "logup_program, logup_n_regs"):
         assert needle in src, needle
     lib = open(os.path.join(HIP_DIR, "src", "lib.rs")).read()
