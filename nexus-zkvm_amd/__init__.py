@@ -940,24 +940,37 @@ class HipBackend:
         self._chk(self.L.nx_logup_cols_batched(self.ctx, log, arr, len(fracs), b.ctypes.data_as(C.c_void_p) if b is not None else None, n_cols, ptrs))
         return outs
 
-    def logup_program(self, program, column_ptrs, log_size, n_logup_cols=None, econsts=None):
+    def logup_program(self, program, column_ptrs, log_size, n_logup_cols=None, econsts=None, out_ptrs=None):
         """The interaction trace of a component from the relation entries its recorded AIR declares (nx_logup_program): program =
         ProgramBuilder.build_logup(); column_ptrs: one device pointer per component column (None where the program loads nothing).
-        Returns one 4-column DeviceColumns per logup column (follow with logup_finalize_last on the last one)."""
+        Returns one 4-column DeviceColumns per logup column (follow with logup_finalize_last on the last one) — or, with out_ptrs
+        (4 device pointers per logup column, e.g. a session's own interaction-tree columns from tree_begin), writes there and returns
+        out_ptrs: nothing is copied afterwards (rust/nexus-hip/src/simd_host.rs interaction_tree_on_device)."""
         n_logup_cols = program.n_logup_cols if n_logup_cols is None else n_logup_cols
         ins = _u32(program.instrs).reshape(-1)
         ec = _u32(program.econsts if econsts is None else econsts).reshape(-1)
         ptrs = (C.c_void_p * max(1, len(column_ptrs)))(*column_ptrs)
-        outs = [DeviceColumns(self, 4, log_size) for _ in range(n_logup_cols)]
-        optr = (C.c_void_p * max(1, 4 * n_logup_cols))(*[o.ptr.value + k * (4 << log_size) for o in outs for k in range(4)])
+        if out_ptrs is None:
+            outs = [DeviceColumns(self, 4, log_size) for _ in range(n_logup_cols)]
+            flat = [o.ptr.value + k * (4 << log_size) for o in outs for k in range(4)]
+        else:
+            outs, flat = out_ptrs, [int(x) for x in out_ptrs]
+            if len(flat) != 4 * n_logup_cols:
+                raise NexusHipError(f"logup_program: {len(flat)} output columns for {n_logup_cols} logup columns")
+        optr = (C.c_void_p * max(1, 4 * n_logup_cols))(*flat)
         self._chk(self.L.nx_logup_program(self.ctx, ins.ctypes.data_as(C.c_void_p), len(ins) // 4, program.n_regs, ptrs, len(column_ptrs),
                                           ec.ctypes.data_as(C.c_void_p) if len(ec) else None, len(ec) // 4, log_size, n_logup_cols, optr, None))
         return outs
 
-    def logup_finalize_last(self, col4):
-        """LogupTraceGenerator::finalize_last in place; returns the claimed sum (4 words)."""
+    def logup_finalize_last(self, col4, log_size=None):
+        """LogupTraceGenerator::finalize_last in place; returns the claimed sum (4 words).  col4: a 4-column DeviceColumns, or (with
+        log_size) the 4 device pointers of the coordinate columns."""
         cs = np.zeros(4, np.uint32)
-        self._chk(self.L.nx_logup_finalize_last(self.ctx, col4.log_size, col4.col_ptrs(), cs.ctypes.data_as(C.c_void_p)))
+        if log_size is None:
+            log_size, ptrs = col4.log_size, col4.col_ptrs()
+        else:
+            ptrs = (C.c_void_p * 4)(*[int(x) for x in col4])
+        self._chk(self.L.nx_logup_finalize_last(self.ctx, log_size, ptrs, cs.ctypes.data_as(C.c_void_p)))
         return cs
 
     def logup_finalize_last_batch(self, cols4_list):

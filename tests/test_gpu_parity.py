@@ -1296,6 +1296,51 @@ def test_session_with_the_interaction_trace_generated_from_the_recorded_air(be, 
         assert np.array_equal(words, ref)
 
 
+def test_prover2_shaped_session_builds_every_interaction_trace_in_place(be, nz, oracle):
+    """The Python twin of rust/nexus-hip/reference_patch/prove2_hip.rs (reference prover2/machine/src/prove.rs:34-135) and of
+    simd_host.rs interaction_tree_on_device: components of their own log sizes; the preprocessed and the main tree go up from HOST
+    memory, mixed sizes in one tree, every column's evaluations kept; the lookup elements are drawn; every component's fraction program
+    writes its logup columns STRAIGHT into the session's interaction-tree columns (tree_begin) — pairs and single-fraction columns side by
+    side, nothing copied —, finalize_last in place, the claimed sums mixed, the tree committed; the proof is the oracle session's."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    from test_logup_cpu import _v2_statement, _v2_trees, _v2_component_cols, V2_MAIN_POS
+    logs, batchings = (9, 11, 10), ("pairs", "single", "pairs")
+    ref, _, oroots, tree_logs, _, oclaimed = _v2_statement(logs, batchings)
+    cfg = nz.default_config(pow_bits=3)
+    fins, tree0, tree1 = _v2_trees(logs, 31)
+    s = be.prover_session(cfg, max(logs))
+    for log in logs:
+        s.mix_u64(log)
+    r0, kept0 = s.commit_host(tree0, keep=range(len(tree0)))
+    r1, kept1 = s.commit_host(tree1, keep=range(len(tree1)))
+    assert np.array_equal(r0, oroots[0]) and np.array_equal(r1, oroots[1])
+    z, alpha = s.draw_felts(2)
+    fracs = [AE.relation_program(ap, z, alpha, (0, 0, 0, 0), b).build_logup() for b in batchings]
+    dev = s.tree_begin(tree_logs[2])
+    claimed, shifts, base = [], [], 0
+    for c, (log, frac) in enumerate(zip(logs, fracs)):
+        ptrs = [kept0[c].ptr.value if k == 1 else kept1[6 * c + V2_MAIN_POS[k]].ptr.value for k in range(7)] + [None] * (4 * frac.n_logup_cols)
+        out = dev[base:base + 4 * frac.n_logup_cols]
+        assert be.logup_program(frac, ptrs, log, out_ptrs=out) is out
+        claimed.append(be.logup_finalize_last(out[-4:], log_size=log))
+        n_inv = pow((1 << log) % P, P - 2, P)
+        shifts.append([(int(x) * n_inv) % P for x in claimed[-1]])
+        base += 4 * frac.n_logup_cols
+    assert np.array_equal(np.array(claimed, np.uint32), oclaimed)
+    s.mix_felts(np.array(claimed, np.uint32))
+    assert np.array_equal(s.tree_commit(), oroots[2])
+    comps, base = [], 0
+    for c, (log, b, frac) in enumerate(zip(logs, batchings, fracs)):
+        comps.append(ap.Component(log, AE.relation_program(ap, z, alpha, shifts[c], b).build(), _v2_component_cols(c, frac.n_logup_cols, base)))
+        base += 4 * frac.n_logup_cols
+    words = s.prove(comps)
+    s.close()
+    assert np.array_equal(words, ref)
+    with pytest.raises(nz.NexusHipError, match="output columns"):
+        be.logup_program(fracs[0], [None] * 19, logs[0], out_ptrs=[1, 2, 3])
+
+
 def test_preprocessed_tree_shared_between_sessions_and_proofs(be, nz, oracle):
     """the preprocessed tree of a program is the same in every proof of that program (reference machine.rs:208-228)
     and in every verification (machine.rs:363-417).  nx_prover_tree_share / nx_prover_tree_adopt: a second session adopts the tree the

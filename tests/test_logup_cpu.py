@@ -114,6 +114,77 @@ def _relation_statement(log, batching, seed=77):
     return s.prove([AE.relation_component(ap, log, pb, frac.n_logup_cols)]), frac, (z, alpha), fin
 
 
+V2_MAIN_POS = {0: 0, 2: 1, 3: 2, 4: 3, 5: 4, 6: 5}          # component-local column -> place among the component's six main-tree columns
+
+
+def _v2_trees(logs, seed):
+    """A prover2-shaped statement (reference prover2/machine/src/prove.rs:70-84): every component brings its own log size, ONE column of
+    the preprocessed tree (the relation example's column b) and six of the main tree; trees are the components' columns, component after
+    component.  Returns (finalized columns per component, tree 0, tree 1)."""
+    import air_examples as AE
+    fins = [AE.relation_main_trace(log, seed + c)[1] for c, log in enumerate(logs)]
+    return fins, [f[1] for f in fins], [f[k] for f in fins for k in sorted(V2_MAIN_POS)]
+
+
+def _v2_component_cols(c, n_logup_cols, inter_base):
+    return [(0, c) if k == 1 else (1, 6 * c + V2_MAIN_POS[k]) for k in range(7)] + [(2, inter_base + j) for j in range(4 * n_logup_cols)]
+
+
+def _v2_statement(logs, batchings, seed=31):
+    """prove.rs:34-135 on the oracle session with the interaction trace generated from the recorded relation entries, per component
+    (what rust/nexus-hip/reference_patch/prove2_hip.rs does on the device).  Returns (proof, cfg, roots, tree log sizes, components)."""
+    import nexus_zkvm_amd.air_program as ap
+    import air_examples as AE
+    cfg = O.default_cfg(pow_bits=3, log_constraint_degree=1)
+    fins, tree0, tree1 = _v2_trees(logs, seed)
+    s = O.ProverSession(cfg, max(logs), 2)
+    for log in logs:
+        s.mix_u64(log)
+    roots = [s.commit(tree0), s.commit(tree1)]
+    z, alpha = s.draw_felts(2)
+    tree2, claimed_all, shifts, n_cols = [], [], [], []
+    for log, fin, batching in zip(logs, fins, batchings):
+        frac = AE.relation_program(ap, z, alpha, (0, 0, 0, 0), batching).build_logup()
+        cols = O.logup_program(frac, fin + [None] * (4 * frac.n_logup_cols), log, frac.n_logup_cols)
+        cols[-1], claimed = O.logup_finalize_last(cols[-1])
+        n_inv = pow((1 << log) % P, P - 2, P)
+        shifts.append([(int(x) * n_inv) % P for x in claimed])
+        claimed_all.append(claimed); n_cols.append(frac.n_logup_cols)
+        tree2 += [x for col in cols for x in col]
+    s.mix_felts(np.array(claimed_all, np.uint32))
+    roots.append(s.commit(tree2))
+    comps, base = [], 0
+    for c, (log, batching) in enumerate(zip(logs, batchings)):
+        comps.append(ap.Component(log, AE.relation_program(ap, z, alpha, shifts[c], batching).build(), _v2_component_cols(c, n_cols[c], base)))
+        base += 4 * n_cols[c]
+    tree_logs = [list(logs), [log for log in logs for _ in range(6)], [log for log, n in zip(logs, n_cols) for _ in range(4 * n)]]
+    return s.prove(comps), cfg, roots, tree_logs, comps, np.array(claimed_all, np.uint32)
+
+
+def test_prover2_shaped_statement_with_generated_interaction_traces_verifies(oracle):
+    """Three components of their own sizes, each with a preprocessed column, pairs and single-fraction columns side by side, every
+    interaction trace generated from the component's own recorded relation entries: the oracle prover accepts the traces (its
+    constraint check) and the oracle VERIFIER accepts the proof from the roots and the claimed sums alone."""
+    logs, batchings = (7, 9, 8), ("pairs", "single", "pairs")
+    proof, cfg, roots, tree_logs, comps, claimed = _v2_statement(logs, batchings)
+    assert _v2_verify(cfg, logs, roots, tree_logs, claimed, comps, proof) is None
+    bad = proof.copy(); bad[len(bad) // 2] ^= 1
+    assert _v2_verify(cfg, logs, roots, tree_logs, claimed, comps, bad) is not None
+    wrong = claimed.copy(); wrong[1, 0] ^= 1                     # a claimed sum the transcript does not hold
+    assert _v2_verify(cfg, logs, roots, tree_logs, wrong, comps, proof) is not None
+
+
+def _v2_verify(cfg, logs, roots, tree_logs, claimed, comps, words):
+    v = O.VerifierSession(cfg)
+    for log in logs:
+        v.mix_u64(log)
+    v.commit(roots[0], tree_logs[0]); v.commit(roots[1], tree_logs[1])
+    v.draw_felt(); v.draw_felt()
+    v.mix_felts(claimed)
+    v.commit(roots[2], tree_logs[2])
+    return v.verify(comps, words)
+
+
 @pytest.mark.parametrize("batching", ["pairs", "single", [0, 0, 0, 1, 2], [2, 0, 1, 1, 0]])
 def test_interaction_trace_from_the_recorded_relation_entries_satisfies_its_constraints(oracle, batching):
     """the reference fills its interaction trace with hand-written per-chip generators that mirror the relation entries
