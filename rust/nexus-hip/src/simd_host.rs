@@ -9,6 +9,8 @@
 //!   generate_interaction_trace + extend_evals                                `interaction_tree_on_device`: the recorded relation entries run as
 //!       (machine.rs:242-263, prove.rs:91-105)                                fraction programs straight into the interaction tree's columns
 //!   PcsConfig::default() -> CommitmentSchemeProver::new (machine.rs:184-203) `pcs_config`
+//!   the verifier's re-commitment of the preprocessed tree (R10:               `preprocessed_root_on_device`
+//!       machine.rs:363-411, prover2 verify.rs:118-135)
 use crate::{HipError, RecordedComponent, Session};
 use nexus_hip_sys as sys;
 
@@ -102,4 +104,18 @@ pub fn interaction_tree_on_device(session: &mut Session, recorded: &[RecordedCom
         claimed.push(session.logup_trace(c, &cols, &out)?);
     }
     Ok(claimed)
+}
+
+/// The verifier's "simulate the prover and compute expected commitment to preprocessed trace" (machine.rs:363-411; prover2
+/// verify.rs:118-135): a `CommitmentSchemeProver::<SimdBackend, _>` built only to interpolate, extend and hash the preprocessed columns
+/// and read `roots()[PREPROCESSED_TRACE_IDX]` — on the CPU the dominant cost of `verify`.  Here: the same
+/// columns through a session's first tree; the root is the 32 bytes the reference compares with `proof.commitments[0]`.
+/// `max_log_size` / `log_constraint_degree`: what the reference passes to `precompute_twiddles` there (largest log size; v1
+/// `LOG_CONSTRAINT_DEGREE`, v2 the largest per-component bound over its log size) — the tower only has to be tall enough.
+pub fn preprocessed_root_on_device(config: &PcsConfig, evals: &[SimdEval], max_log_size: u32, log_constraint_degree: u32, device: i32) -> Result<Blake2sHash, HipError> {
+    let cfg = pcs_config(config, log_constraint_degree);
+    let mut session = Session::new(&cfg, max_log_size, device)?;
+    let (host, logs) = host_columns(evals);
+    session.tree_begin(&logs)?;
+    Ok(Blake2sHash(session.tree_commit_host(&host, false, &[])?))
 }

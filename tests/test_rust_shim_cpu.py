@@ -234,7 +234,9 @@ def test_the_two_reference_patches_share_their_device_steps():
                    "pub fn interaction_tree_on_device(session: &mut Session, recorded: &[RecordedComponent], kept: [&[*const u32]; 2])", "pub fn pcs_config(config: &PcsConfig, log_constraint_degree: u32)",
                    "session.tree_commit_host(&host, false, &keep)", "session.logup_trace(c, &cols, &out)", "ch.update_digest(Blake2sHash(session.channel_digest()))"):
         assert needle in host, needle
-    assert host.count("tree_commit_host(") == 1                   # only what the chips filled (trees 0 and 1) goes over PCIe
+    # only what the chips filled goes over PCIe: the provers' trees 0 and 1 (one helper), and the verifier's re-commit of tree 0 (R10)
+    assert host.count("tree_commit_host(") == 2 and "pub fn preprocessed_root_on_device(config: &PcsConfig, evals: &[SimdEval]" in host
+    assert "preprocessed_root_on_device(&PcsConfig::default(), &evals, max_log, LOG_CONSTRAINT_DEGREE, 0)" in open(os.path.join(HIP_DIR, "reference_patch", "README.md")).read()
     assert "#[cfg(stwo_traits)]\npub mod simd_host;" in open(HIP).read()
     for f in ("machine_hip.rs", "prove2_hip.rs"):
         patch = open(os.path.join(HIP_DIR, "reference_patch", f)).read()
