@@ -322,6 +322,7 @@ static nx_options options_from_env() {
     o.fri_device_channel = env_int("NX_FRI_DEVICE_CHANNEL", 1) != 0;
     o.fri_tail = env_int("NX_FRI_TAIL", 1) != 0;
     o.logup_scan_tiled = env_int("NX_LOGUP_SCAN_TILED", 1) != 0;
+    o.logup_staged = env_int("NX_LOGUP_STAGED", 1) != 0;
     o.logup_per_column = env_int("NX_LOGUP_PER_COLUMN", 0) != 0;
     o.machine_reuse_pre = env_int("NX_MACHINE_REUSE_PREPROCESSED", 0) != 0;
     o.machine_queue_trees = env_int("NX_MACHINE_QUEUE_TREES", 0) != 0;   // measured: no gain (profiles/r05_queue_trees_ab.txt)
@@ -347,6 +348,7 @@ static const OptEntry k_options[] = {
     {"fri.device_channel", &nx_options::fri_device_channel, 0, 1},
     {"fri.tail", &nx_options::fri_tail, 0, 1},
     {"logup.scan_tiled", &nx_options::logup_scan_tiled, 0, 1},
+    {"logup.staged", &nx_options::logup_staged, 0, 1},
     {"logup.per_column", &nx_options::logup_per_column, 0, 1},
     {"machine.reuse_preprocessed", &nx_options::machine_reuse_pre, 0, 1},
     {"machine.queue_trees", &nx_options::machine_queue_trees, 0, 1},

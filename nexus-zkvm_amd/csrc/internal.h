@@ -31,6 +31,7 @@ struct nx_options {
     int fri_device_channel;       // "fri.device_channel": FRI commit phase with the channel on the device
     int fri_tail;                 // "fri.tail": last FRI layers in one launch
     int logup_scan_tiled;         // "logup.scan_tiled": finalize_last as coalesced tiles
+    int logup_staged;             // "logup.staged": nx_logup_cols requests every read of a group of fractions up front (values parked in LDS)
     int logup_per_column;         // "logup.per_column": one nx_logup_col launch per column instead of nx_logup_cols
     int machine_queue_trees;      // "machine.queue_trees": nx_prove_machine queues the preprocessed and the main tree builds before fetching the first root (1) or commits them one after the other (0; A/B)
     int machine_reuse_pre;        // "machine.reuse_preprocessed": nx_prove_machine keeps the committed preprocessed tree of a statement shape in the context and adopts it in later proofs (nx_prover_tree_adopt's rule; default 0: every proof commits it afresh, as the reference does)

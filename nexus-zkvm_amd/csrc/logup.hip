@@ -98,31 +98,66 @@ struct LogupBatchFrac { u32 first_col, n_cols, first_ap, out_col; const u32* mul
 // 3 multiplications per element): 57 -> 20 + 3 + 37/8 multiplications per fraction.  Same values: an inverse is unique; a zero
 // denominator (norm 0) still gives 0 like m_inv(0), and does not poison its group.
 constexpr int LOGUP_GROUP = 8;
+// STAGED: every memory read of a group — the tuple columns of its 8 fractions (up to LOGUP_TMAX of them) and their multiplicities — is
+// requested before the first value is used.  The fractions' tuple widths are run-time values, so the values cannot sit in (statically
+// indexed) registers: each lane parks its own row's values in LDS (stage[column][lane], read back by the same lane: no barrier) and the
+// combine loop indexes that.  Without it every column read of every fraction is a dependent scalar load (the pointer) + vector load with
+// a full wait in between: the kernel ran at the latency of ~500 serial round trips per lane (1.3 TB/s written at 250 fractions).
+constexpr int LOGUP_TMAX = 32;            // 32 KB of LDS per 256-lane block: 5 blocks per CU, what the 88 VGPRs allow anyway
+template <bool STAGED>
 __global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* __restrict__ fr, u32 n_fracs, const u32* const* __restrict__ tuple_cols,
                                                          const u32* __restrict__ ap /*4 words each*/, u32* const* __restrict__ out /*4 per logup column*/, u32 n) {
+    __shared__ u32 stage[STAGED ? LOGUP_TMAX * 256 : 1];
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+    if (r >= n) return;                                               // no barrier below: a lane only reads back what it staged itself
     QM31 run = q_zero();
     for (u32 j0 = 0; j0 < n_fracs; j0 += LOGUP_GROUP) {
-        QM31 den[LOGUP_GROUP]; CM31 dd[LOGUP_GROUP]; u32 nrm[LOGUP_GROUP], pre[LOGUP_GROUP];
+        QM31 den[LOGUP_GROUP]; CM31 dd[LOGUP_GROUP]; u32 nrm[LOGUP_GROUP], pre[LOGUP_GROUP], mv[LOGUP_GROUP];
+        bool staged = false; u32 c0 = 0;
+        if (STAGED) {
 #pragma unroll
-        for (int g = 0; g < LOGUP_GROUP; g++) {
-            if (j0 + g < n_fracs) {                                   // uniform
-                const LogupBatchFrac f = fr[j0 + g];
-                u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-                for (u32 k = 0; k < f.n_cols; k++) {
-                    const u32 v = gld(tuple_cols[f.first_col + k] + r);
-                    const u32* a = ap + 4 * (size_t)(f.first_ap + k);
-                    s0 = acc_mad(s0, a[0], v); s1 = acc_mad(s1, a[1], v); s2 = acc_mad(s2, a[2], v); s3 = acc_mad(s3, a[3], v);
-                    if ((k & 3) == 3) { s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3); }
+            for (int g = 0; g < LOGUP_GROUP; g++) {                   // the multiplicities first: in flight with everything below.  Branch-free
+                const u32 jg = j0 + g < n_fracs ? j0 + g : n_fracs - 1;   // (a select, not a jump: a join would wait for the load): a fraction
+                const u32* mp = fr[jg].mult;                          // without one reads a word of the first output column and drops it
+                mv[g] = gld((mp ? mp : (const u32*)out[0]) + r);
+            }
+            const u32 jl = (j0 + LOGUP_GROUP < n_fracs ? j0 + LOGUP_GROUP : n_fracs) - 1;
+            c0 = fr[j0].first_col;
+            const u32 T = fr[jl].first_col + fr[jl].n_cols - c0;      // the group's tuple columns are consecutive in the table (logup_cols_launch)
+            staged = T <= (u32)LOGUP_TMAX;                            // uniform; a wider group reads its columns where it uses them
+            if (staged) {
+                for (u32 t0 = 0; t0 < T; t0 += 8) {
+                    u32 v[8];
+#pragma unroll
+                    for (u32 i = 0; i < 8; i++) { const u32 t = t0 + i < T ? t0 + i : T - 1; v[i] = gld(tuple_cols[c0 + t] + r); }
+#pragma unroll
+                    for (u32 i = 0; i < 8; i++) { const u32 t = t0 + i < T ? t0 + i : T - 1; stage[t * 256 + threadIdx.x] = v[i]; }
                 }
-                den[g] = q_sub(qm(acc_final(s0), acc_final(s1), acc_final(s2), acc_final(s3)), f.z);
-                dd[g] = c_sub(c_mul(den[g].a, den[g].a), c_mul_R(c_mul(den[g].b, den[g].b)));
-                nrm[g] = m_add(m_sqr(dd[g].a), m_sqr(dd[g].b));
-            } else { den[g] = q_zero(); dd[g] = cm(0, 0); nrm[g] = 1; }
-            const u32 nz = nrm[g] ? nrm[g] : 1u;
-            pre[g] = g ? m_mul(pre[g - 1], nz) : nz;
+            }
         }
+        // phase 1, once per source of the values (the branch is taken per group, not per column read)
+        auto denominators = [&](auto value_of) {
+#pragma unroll
+            for (int g = 0; g < LOGUP_GROUP; g++) {
+                if (j0 + g < n_fracs) {                               // uniform
+                    const LogupBatchFrac f = fr[j0 + g];
+                    u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                    for (u32 k = 0; k < f.n_cols; k++) {
+                        const u32 v = value_of(f.first_col + k);
+                        const u32* a = ap + 4 * (size_t)(f.first_ap + k);
+                        s0 = acc_mad(s0, a[0], v); s1 = acc_mad(s1, a[1], v); s2 = acc_mad(s2, a[2], v); s3 = acc_mad(s3, a[3], v);
+                        if ((k & 3) == 3) { s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3); }
+                    }
+                    den[g] = q_sub(qm(acc_final(s0), acc_final(s1), acc_final(s2), acc_final(s3)), f.z);
+                    dd[g] = c_sub(c_mul(den[g].a, den[g].a), c_mul_R(c_mul(den[g].b, den[g].b)));
+                    nrm[g] = m_add(m_sqr(dd[g].a), m_sqr(dd[g].b));
+                } else { den[g] = q_zero(); dd[g] = cm(0, 0); nrm[g] = 1; }
+                const u32 nz = nrm[g] ? nrm[g] : 1u;
+                pre[g] = g ? m_mul(pre[g - 1], nz) : nz;
+            }
+        };
+        if (STAGED && staged) denominators([&](u32 col) { return stage[(col - c0) * 256 + threadIdx.x]; });
+        else denominators([&](u32 col) { return gld(tuple_cols[col] + r); });
         u32 inv = m_inv(pre[LOGUP_GROUP - 1]);
 #pragma unroll
         for (int g = LOGUP_GROUP - 1; g >= 0; g--) {
@@ -138,11 +173,12 @@ __global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* _
                 const LogupBatchFrac f = fr[j];
                 const CM31 di = cm(m_mul(dd[g].a, pre[g]), m_mul(m_neg(dd[g].b), pre[g]));
                 QM31 qi; qi.a = c_mul(den[g].a, di); qi.b = c_mul(c_neg(den[g].b), di);
+                const u32 mval = f.mult ? (STAGED ? mv[g] : gld(f.mult + r)) : 0u;
                 if ((f.scale.a.b | f.scale.b.a | f.scale.b.b) == 0) {          // uniform: a base-field numerator (+-1, a multiplicity): 4 products, not 16
-                    const u32 nm = f.mult ? m_mul(f.scale.a.a, gld(f.mult + r)) : f.scale.a.a;
+                    const u32 nm = f.mult ? m_mul(f.scale.a.a, mval) : f.scale.a.a;
                     run = q_add(run, q_mul_m(qi, nm));
                 } else {
-                    const QM31 num = f.mult ? q_mul_m(f.scale, gld(f.mult + r)) : f.scale;
+                    const QM31 num = f.mult ? q_mul_m(f.scale, mval) : f.scale;
                     run = q_add(run, q_mul(num, qi));
                 }
                 if (f.out_col) {                                               // uniform: the batch is complete (finalize_logup_batched: one column per batch)
@@ -458,8 +494,12 @@ static int logup_cols_launch(nx_ctx* ctx, uint32_t log_size, const nx_logup_frac
     }
     const u32 n = 1u << log_size;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(logup_cols_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const LogupBatchFrac*)blob, n_fracs, (const u32* const*)(blob + o_cols),
-                           (const u32*)(blob + o_ap), (u32* const*)(blob + o_out), n);
+        if (ctx->opt.logup_staged)
+            hipLaunchKernelGGL(logup_cols_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const LogupBatchFrac*)blob, n_fracs, (const u32* const*)(blob + o_cols),
+                               (const u32*)(blob + o_ap), (u32* const*)(blob + o_out), n);
+        else
+            hipLaunchKernelGGL(logup_cols_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const LogupBatchFrac*)blob, n_fracs, (const u32* const*)(blob + o_cols),
+                               (const u32*)(blob + o_ap), (u32* const*)(blob + o_out), n);
         e = hipGetLastError();
     }
     dev_free(ctx, blob);   // stream-ordered: reused only by later work on this stream

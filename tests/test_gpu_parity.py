@@ -1223,6 +1223,46 @@ def test_logup_cols_batched_matches_oracle(be, oracle, log):
         be.logup_cols_batched(fracs, [0] * F, n_cols=0)
 
 
+@pytest.mark.parametrize("log", [6, 13])
+def test_logup_cols_staged_reads_equal_the_direct_ones_and_the_oracle(be, nz, oracle, log):
+    """nx_logup_cols requests every read of a group of 8 fractions up front and parks the values in LDS ("logup.staged", default on) when
+    the group's tuples are at most 32 columns wide, and reads where it uses them otherwise.  Groups of 21 columns (three request rounds),
+    of exactly 32, of 33 (the direct path) and a ragged last group of 3 fractions, with and without multiplicities, secure and base
+    numerators: staged == direct ("logup.staged" = 0) == the oracle's LogupColGenerator chain, every column."""
+    rng = np.random.default_rng(4100 + log)
+    n = 1 << log
+    widths = [3, 1, 2, 4, 1, 2, 3, 5,   4, 4, 4, 4, 4, 4, 4, 4,   5, 4, 4, 4, 4, 4, 4, 4,   8, 1, 2]
+    F = len(widths)
+    z, alpha = rng.integers(0, P, 4, dtype=np.uint32), rng.integers(0, P, 4, dtype=np.uint32)
+    ap = [np.array([1, 0, 0, 0], np.uint32)]
+    for _ in range(7):
+        ap.append(oracle.qm31_mul(ap[-1], alpha))
+    ap = np.stack(ap)
+    tup = [rng.integers(0, P, (w, n), dtype=np.uint32) for w in widths]
+    mult = [rng.integers(0, 1 << 20, n, dtype=np.uint32) if f % 3 != 1 else None for f in range(F)]
+    scale = [(P - 1, 0, 0, 0) if f % 2 else ((5, 6, 7, 8) if f % 5 == 0 else (1, 0, 0, 0)) for f in range(F)]
+    want, prev = [], None
+    for f in range(F):
+        prev = oracle.logup_finalize_col(oracle.logup_combine(list(tup[f]), ap[:widths[f]], z), scale_a=scale[f], mult_a=mult[f], prev=prev)
+        want.append(np.stack(prev))
+    direct = nz.HipBackend(0)
+    direct.set_option("logup.staged", 0)
+    for b in (be, direct):
+        fracs = []
+        for f in range(F):
+            d = dict(tuple=b.columns_from_host(tup[f]), alphas=ap[:widths[f]], z=z, scale=scale[f])
+            if mult[f] is not None:
+                d["mult"] = b.columns_from_host(mult[f])
+            fracs.append(d)
+        got = b.logup_cols(fracs)
+        for f in range(F):
+            assert np.array_equal(got[f].to_cpu(), want[f]), (b is be, f)
+        pairs = b.logup_cols_batched(fracs)                        # pairs: the running sum after every second fraction (and after the odd last one)
+        for j, g in enumerate(pairs):
+            assert np.array_equal(g.to_cpu(), want[min(2 * j + 1, F - 1)]), (b is be, j)
+    direct.close()
+
+
 @pytest.mark.parametrize("log,batching,segment", [(6, "pairs", 9000), (12, "single", 9000), (12, [2, 0, 1, 1, 0], 200), (15, "pairs", 300)])
 def test_logup_program_matches_oracle(be, nz, oracle, log, batching, segment):
     """nx_logup_program: the interaction trace of a component from the relation entries its recorded AIR declares —
