@@ -275,6 +275,19 @@ typedef struct nx_component_spec {
  *                     a negated multiplicity column of the main trace (reference prover/src/extensions/multiplicity.rs:111-124,
  *                     extensions/keccak/bitwise_table/mod.rs). */
 enum { NX_LOGUP_PAIRS = 1, NX_LOGUP_ODD = 2, NX_LOGUP_TABLE = 4 };
+/* Bits 4..7 of logup_mode: the TUPLE SCHEDULE — how wide the relation tuples of the component's fractions are and what their entries are.
+ *   0                 one- / two-column tuples (rounds 2-5);
+ *   NX_TUPLES_V1      v1's chips: widths cycling 1, 1, 4, 1, 9, 1, 3, 1 — range checks (reference prover/src/chips/range_check/range256.rs:37),
+ *                     [op_type CONSTANT, b, c, a] with a flag COLUMN as numerator (chips/instructions/i/bit_op.rs:31,341-365), register memory
+ *                     (memory_check/register_mem_check.rs:34), and a 3-wide entry list holding a constant and a SUM of two columns;
+ *   NX_TUPLES_KECCAK  3- / 4-wide bitwise lookups (chips/custom.rs:33-37) and, as the component's last two fractions, the 200-wide state
+ *                     lookups with the numerators (is_padding - 1) and (1 - is_padding) (chips/custom.rs:45-46,
+ *                     extensions/keccak/round/constraints.rs:101-110): expression numerators — their interaction trace comes from the
+ *                     recorded relation entries (nx_logup_program);
+ *   NX_TUPLES_V2      prover2's relations: 9, 21, 14, 10, 4, 12, 8 wide (prover2/machine/src/lookups/relations.rs:33-90).
+ * The context option "machine.logup_program" = 1 sends every wide-tuple component through nx_logup_program (same bytes). */
+#define NX_LOGUP_TUPLES(k) ((uint32_t)(k) << 4)
+enum { NX_TUPLES_V1 = 1, NX_TUPLES_KECCAK = 2, NX_TUPLES_V2 = 3 };
 
 typedef struct nx_pcs_config {
     uint32_t pow_bits, log_blowup, n_queries, log_last_layer_degree_bound; /* PcsConfig / FriConfig */
@@ -483,7 +496,10 @@ void nx_air_kernel_destroy(nx_air_kernel* kernel);
  * nx_air_cache_dir: a directory (created if its parent exists; NULL or "" = off; initial value: the environment variable
  * NX_AIR_CACHE_DIR) in which the library keeps those blobs by itself, keyed by a hash of the generated source, the target and the hiprtc
  * version: nx_air_compile / nx_air_compile_subset — and therefore the provers, which compile their components' kernels through them —
- * load from it when they can and store what they compile (write-then-rename: processes may share a directory).  Process-wide.
+ * load from it when they can and store what they compile (write-then-rename, one temporary per writer: processes and threads may
+ * share a directory).  Process-wide.  The directory is TRUSTED INPUT — its files are GPU code objects, accepted on a 64-bit checksum, not a
+ * signature: it is created with mode 0700 and ignored (with one line on stderr) unless it is a directory owned by the calling user that
+ * neither group nor others may write to.
  * nx_air_cache_stats: kernels compiled by hiprtc / loaded from the directory / stored into it by this process (any pointer may be NULL). */
 int nx_air_kernel_save(const nx_air_kernel* kernel, uint8_t** blob, size_t* n_bytes);
 int nx_air_kernel_load(nx_ctx* ctx, const uint8_t* blob, size_t n_bytes, nx_air_kernel** out);
@@ -553,7 +569,9 @@ int nx_prover_tree_commit_host(nx_prover* prover, const uint32_t* const* h_cols,
  * session of the SAME context and mixes its root, exactly as nx_prover_tree_commit would after a fresh commit of the same columns: the
  * proof bytes are those of the fresh commit.  After a commit a tree's buffers are read-only, so any number of sessions may hold one.
  * One GPU; same blowup factor and node hash.  nx_committed_tree_release drops the handle (the buffers go when the last session that
- * adopted it is destroyed); nx_committed_tree_root: the root and the column count (a verifier's preprocessed-root check). */
+ * adopted it is destroyed); nx_committed_tree_root: the root and the column count (a verifier's preprocessed-root check).
+ * LIFETIME: a handle and every session that adopted it belong to the context that committed the tree — release / destroy them BEFORE
+ * nx_ctx_destroy (their buffers return to that context's allocator; afterwards the handle dangles). */
 typedef struct nx_committed_tree nx_committed_tree;
 int nx_prover_tree_share(nx_prover* prover, uint32_t tree_index, nx_committed_tree** out);
 int nx_prover_tree_adopt(nx_prover* prover, const nx_committed_tree* tree, uint8_t root[32]);

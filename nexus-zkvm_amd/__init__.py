@@ -65,6 +65,7 @@ class ComponentSpec(C.Structure):
 
 
 LOGUP_PAIRS, LOGUP_ODD, LOGUP_TABLE = 1, 2, 4                   # nx_component_spec.logup_mode (include/nexus_hip.h NX_LOGUP_*)
+TUPLES_V1, TUPLES_KECCAK, TUPLES_V2 = 1 << 4, 2 << 4, 3 << 4    # | NX_LOGUP_TUPLES(k): the reference's relation widths / entry kinds (NX_TUPLES_*)
 
 
 class PcsConfig(C.Structure):

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <stdio.h>
 #include <sys/stat.h>
+#include <fcntl.h>
 #include <unistd.h>
 
 struct nx_air_kernel {
@@ -361,10 +362,22 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
 }
 struct CacheState { std::mutex mu; bool init = false; std::string dir; std::atomic<uint64_t> compiled{0}, disk_hits{0}, stored{0}; };
 CacheState& cache_state() { static CacheState s; return s; }
+// The cache directory holds CODE OBJECTS that are loaded into the GPU on a 64-bit FNV match — a checksum, not a signature — so it is
+// trusted input: created 0700, and refused (no disk cache, one line on stderr) when it is not a directory owned by this user or when
+// group / others may write to it.
+std::string trusted_cache_dir(const char* dir) {
+    (void)mkdir(dir, 0700);                                        // one level; an existing directory is fine
+    struct stat st;
+    if (stat(dir, &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) {
+        fprintf(stderr, "nexus_hip: the AIR kernel cache directory '%s' is not a directory owned by this user with mode go-w; kernels are not cached on disk\n", dir);
+        return std::string();
+    }
+    return dir;
+}
 std::string cache_dir() {
     CacheState& s = cache_state();
     std::lock_guard<std::mutex> lk(s.mu);
-    if (!s.init) { const char* e = getenv("NX_AIR_CACHE_DIR"); if (e && *e) { s.dir = e; (void)mkdir(e, 0755); } s.init = true; }
+    if (!s.init) { const char* e = getenv("NX_AIR_CACHE_DIR"); if (e && *e) s.dir = trusted_cache_dir(e); s.init = true; }
     return s.dir;
 }
 int load_code(nx_ctx* ctx, const BlobHeader& h, const char* code, nx_air_kernel** out) {
@@ -486,8 +499,12 @@ int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint
     NX_TRY(load_code(ctx, h, code.data(), out));
     if (!path.empty()) {                                  // store: write beside, then rename — a concurrent reader sees the old file or the whole new one
         const std::vector<uint8_t> b = make_blob(*out);
-        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        FILE* f = fopen(tmp.c_str(), "wb");
+        // one temporary per WRITER: several contexts of a process (thread ranks, concurrent sessions) compile the same source at the same time
+        static std::atomic<uint64_t> writer{0};
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string((unsigned long long)writer.fetch_add(1));
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+        FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+        if (!f && fd >= 0) close(fd);
         if (f) {
             const bool ok = fwrite(b.data(), 1, b.size(), f) == b.size();
             if (fclose(f) == 0 && ok && rename(tmp.c_str(), path.c_str()) == 0) cache_state().stored++;
@@ -503,8 +520,7 @@ extern "C" {
 int nx_air_cache_dir(const char* dir) {
     CacheState& s = cache_state();
     std::lock_guard<std::mutex> lk(s.mu);
-    s.init = true; s.dir = dir ? dir : "";
-    if (!s.dir.empty()) (void)mkdir(s.dir.c_str(), 0755);          // one level; an existing directory is fine
+    s.init = true; s.dir = dir && *dir ? trusted_cache_dir(dir) : std::string();
     return NX_OK;
 }
 int nx_air_cache_stats(uint64_t* n_compiled, uint64_t* n_disk_hits, uint64_t* n_stored) {

@@ -82,6 +82,9 @@ struct Flight { LocalComm* c; explicit Flight(LocalComm* x) : c(x) { flight_begi
 // the closing rendezvous of a collective: on failure the peers may still be reading this rank's send buffer
 #define L_MEET_CLOSE(c) do { if (rendezvous(c)) { drain_flights(c); return fail(c, "a peer failed or did not arrive in time (group broken)"); } } while (0)
 #define L_HIP(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(c, hipGetErrorString(e__)); } while (0)
+// Inside a Flight scope: pulls already queued on c->stream may still be READING the peers' send buffers, and ~Flight tells the peers this
+// rank is done with them.  Drain the stream before failing, so that a peer whose closing rendezvous fails frees nothing under a copy.
+#define L_HIP_FLIGHT(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (void)hipStreamSynchronize((c)->stream); return fail(c, hipGetErrorString(e__)); } } while (0)
 
 static int cb_allgather(void* user, const void* h_send, size_t bytes, void* h_recv) {
     LocalComm* c = (LocalComm*)user; nx_comm_group* g = c->g;
@@ -108,7 +111,7 @@ static int cb_allgather_dev(void* user, const uint32_t* d_send, size_t n_words, 
         Flight fl(c);
         for (int k = 0; k < g->world && n_words; k++) {
             const int r = (c->rank + k) % g->world;          // every rank starts with a different peer: the pulls spread over the links
-            L_HIP(c, hipMemcpyAsync(d_recv + (size_t)r * n_words, g->slot[r].p, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
+            L_HIP_FLIGHT(c, hipMemcpyAsync(d_recv + (size_t)r * n_words, g->slot[r].p, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
         }
         L_HIP(c, hipStreamSynchronize(c->stream));
     }
@@ -127,7 +130,7 @@ static int cb_alltoallv(void* user, const uint32_t* d_send, const size_t* soff, 
             const int r = (c->rank + k) % g->world;
             const nx_comm_group::Slot& s = g->slot[r];
             if (s.cnt[c->rank] != rcnt[r]) { (void)hipStreamSynchronize(c->stream); return fail(c, "all-to-all: a peer sends a different count than this rank expects"); }
-            if (rcnt[r]) L_HIP(c, hipMemcpyAsync(d_recv + roff[r], (const uint32_t*)s.p + s.off[c->rank], rcnt[r] * 4, hipMemcpyDeviceToDevice, c->stream));
+            if (rcnt[r]) L_HIP_FLIGHT(c, hipMemcpyAsync(d_recv + roff[r], (const uint32_t*)s.p + s.off[c->rank], rcnt[r] * 4, hipMemcpyDeviceToDevice, c->stream));
         }
         L_HIP(c, hipStreamSynchronize(c->stream));
     }
@@ -196,7 +199,7 @@ static int cb_allreduce_m31(void* user, uint32_t* d_buf, size_t n_words) {
         Flight fl(c);
         for (int k = 1; k < g->world && n_words; k++) {
             const int r = (c->rank + k) % g->world;
-            L_HIP(c, hipMemcpyAsync(pulled, g->slot[r].p, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
+            L_HIP_FLIGHT(c, hipMemcpyAsync(pulled, g->slot[r].p, n_words * 4, hipMemcpyDeviceToDevice, c->stream));
             L_HIP(c, hipStreamSynchronize(c->stream));
             if (nx_m31_add_into(c->ctx, d_buf, pulled, n_words) != NX_OK || nx_sync(c->ctx) != NX_OK) return fail(c, "allreduce: the modular add failed");
         }

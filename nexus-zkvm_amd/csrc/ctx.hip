@@ -325,6 +325,7 @@ static nx_options options_from_env() {
     o.logup_staged = env_int("NX_LOGUP_STAGED", 1) != 0;
     o.logup_per_column = env_int("NX_LOGUP_PER_COLUMN", 0) != 0;
     o.machine_reuse_pre = env_int("NX_MACHINE_REUSE_PREPROCESSED", 0) != 0;
+    o.machine_logup_program = env_int("NX_MACHINE_LOGUP_PROGRAM", 0) != 0;
     o.machine_queue_trees = env_int("NX_MACHINE_QUEUE_TREES", 0) != 0;   // measured: no gain (profiles/r05_queue_trees_ab.txt)
     return o;
 }
@@ -352,6 +353,7 @@ static const OptEntry k_options[] = {
     {"logup.per_column", &nx_options::logup_per_column, 0, 1},
     {"machine.reuse_preprocessed", &nx_options::machine_reuse_pre, 0, 1},
     {"machine.queue_trees", &nx_options::machine_queue_trees, 0, 1},
+    {"machine.logup_program", &nx_options::machine_logup_program, 0, 1},
 };
 int nx_ctx_set_option(nx_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return set_err(ctx, NX_ERR_ARG, "nx_ctx_set_option: NULL argument");

@@ -33,6 +33,7 @@ struct nx_options {
     int logup_scan_tiled;         // "logup.scan_tiled": finalize_last as coalesced tiles
     int logup_staged;             // "logup.staged": nx_logup_cols requests every read of a group of fractions up front (values parked in LDS)
     int logup_per_column;         // "logup.per_column": one nx_logup_col launch per column instead of nx_logup_cols
+    int machine_logup_program;    // "machine.logup_program": nx_prove_machine builds the interaction trace of every wide-tuple component (NX_LOGUP_TUPLES != 0) from its recorded relation entries (nx_logup_program) instead of nx_logup_cols (same bytes; components with expression numerators always do)
     int machine_queue_trees;      // "machine.queue_trees": nx_prove_machine queues the preprocessed and the main tree builds before fetching the first root (1) or commits them one after the other (0; A/B)
     int machine_reuse_pre;        // "machine.reuse_preprocessed": nx_prove_machine keeps the committed preprocessed tree of a statement shape in the context and adopts it in later proofs (nx_prover_tree_adopt's rule; default 0: every proof commits it afresh, as the reference does)
     int air_degree_split;         // "air.degree_split": constraints of degree <= 3 of a component with a bound > 1 are evaluated on the log_size + 1 domain
@@ -85,6 +86,11 @@ struct nx_ctx {
     // point must not abort the transport — an abort cannot be undone (ncclCommAbort; a broken thread-rank group) and an invalid trace
     // is an input error, not a reason to re-bootstrap a prover farm's communicator.
     bool symmetric_failure = false;
+    // Set by the first collective a sharded prove of this context enters (Dist::allgather_host / allgather_dev / alltoallv), cleared by the
+    // entry point.  While it is false no peer can be waiting for this rank, so a refusal needs no transport abort; once it is true every
+    // failure that is not symmetric aborts — also NX_ERR_ARG, which stage(), TreeBuilder, nx_logup_cols* and air_eval_rows can return from
+    // deep inside a prove, on one rank only.
+    bool comm_entered = false;
     // "machine.reuse_preprocessed": committed preprocessed trees by statement shape (nxhip::CommitmentTreeProver, type-erased here)
     std::map<std::string, std::shared_ptr<void>> machine_pre_cache;
 };

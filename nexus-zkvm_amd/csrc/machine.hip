@@ -11,6 +11,7 @@
 // Both run on one GPU or as ONE proof on the GPUs of an nx_comm (row-sharded, prover.h).
 #include "prover.h"
 #include <mutex>
+#include <array>
 
 namespace nxhip {
 
@@ -211,24 +212,152 @@ static int prove_synth(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_c
 // extensions/keccak/round/constraints.rs:116: degree 3 under the bound +1):
 //   (S_j - S_{j-1}) D_j - N_j                                             j < L - 1
 //   (S_j(row) - S_j(row - 1) - S_{j-1}(row) + claimed / N) D_j - N_j      j = L - 1 (mask [-1, 0] on the last column)
-struct FracDef { bool table; uint32_t w, col[2]; bool has_mult; uint32_t mult; };
+// Tuple schedules (NX_LOGUP_TUPLES(k), bits 4..7 of logup_mode; k = 0: the one- / two-element tuples above).  The reference's relations
+// are wider and their entries are expressions: NX_TUPLES_V1 — widths cycling 1, 1, 4, 1, 9, 1, 3, 1 (range checks: chips/range_check/
+// range256.rs:37; bit_op.rs:31,355 [op_type CONSTANT, b, c, a] with the flag column as numerator; register_mem_check.rs:34; the 3-wide
+// one carries a constant and a SUM of two columns); NX_TUPLES_KECCAK — 3- / 4-wide bitwise lookups (chips/custom.rs:33-37) and, as the
+// last two fractions, the 200-wide state lookups with the numerators (is_padding - 1) and (1 - is_padding) (custom.rs:45-46,
+// extensions/keccak/round/constraints.rs:101-110); NX_TUPLES_V2 — prover2's relations, 9 / 21 / 14 / 10 / 4 / 12 / 8 wide
+// (prover2/machine/src/lookups/relations.rs:33-90).  Entry k of fraction f reads column (3 + 7 f + 5 k) % n_main (a table: (2 + 3 f + 5 k)
+// % n_pre); the second column of a sum is (5 + 11 f + 3 k) % n.
+enum { E_COL = 0, E_CONST = 1, E_SUM = 2 };
+enum { N_ONE = 0, N_NEG_MULT = 1, N_MULT_M1 = 2, N_ONE_M_MULT = 3, N_MULT = 4 };   // numerator: 1, -m, m - 1, 1 - m, m  (m = main[mult])
+struct TupleEntry { uint32_t kind, a, b; };
+struct FracDef {
+    bool table; uint32_t w, col[2]; bool has_mult; uint32_t mult;     // (col[]: the tuple of schedule 0)
+    uint32_t num = N_ONE; std::vector<TupleEntry> ent;                // every schedule
+};
+static uint32_t tuple_sched(const nx_component_spec& c) { return (c.logup_mode >> 4) & 15u; }
+static bool logup_mode_ok(uint32_t m) { return (m >> 4) <= NX_TUPLES_V2 && !((m & NX_LOGUP_ODD) && !(m & NX_LOGUP_PAIRS)) && !(m & 8u); }
 static uint32_t n_logup_fracs(const nx_component_spec& c) {
     const uint32_t L = c.n_inter / 4;
     if (!(c.logup_mode & NX_LOGUP_PAIRS) || L == 0) return L;
     return 2 * L - ((c.logup_mode & NX_LOGUP_ODD) ? 1 : 0);
 }
 static FracDef frac_def(const nx_component_spec& c, uint32_t f) {
-    FracDef d; d.table = (c.logup_mode & NX_LOGUP_TABLE) != 0; d.w = (f & 1) ? 2 : 1;
-    if (d.table) { d.col[0] = (2 + 3 * f) % c.n_pre; d.col[1] = (1 + 5 * f) % c.n_pre; d.has_mult = true; }
-    else { d.col[0] = (3 + 7 * f) % c.n_main; d.col[1] = (5 + 11 * f) % c.n_main; d.has_mult = f % 3 == 2; }
+    FracDef d; d.table = (c.logup_mode & NX_LOGUP_TABLE) != 0;
+    const uint32_t sched = tuple_sched(c), n = d.table ? c.n_pre : c.n_main;
     d.mult = (2 + 13 * f) % c.n_main;
+    if (sched == 0) {
+        d.w = (f & 1) ? 2 : 1;
+        if (d.table) { d.col[0] = (2 + 3 * f) % c.n_pre; d.col[1] = (1 + 5 * f) % c.n_pre; d.has_mult = true; }
+        else { d.col[0] = (3 + 7 * f) % c.n_main; d.col[1] = (5 + 11 * f) % c.n_main; d.has_mult = f % 3 == 2; }
+        d.num = d.has_mult ? N_NEG_MULT : N_ONE;
+        for (uint32_t k = 0; k < d.w; k++) d.ent.push_back({E_COL, d.col[k], 0});
+        return d;
+    }
+    const uint32_t F = n_logup_fracs(c);
+    static const uint32_t W1[8] = {1, 1, 4, 1, 9, 1, 3, 1}, W3[7] = {9, 21, 14, 10, 4, 12, 8};
+    const bool state = sched == NX_TUPLES_KECCAK && !d.table && F >= 2 && f + 2 >= F;
+    d.w = sched == NX_TUPLES_V1 ? W1[f % 8] : sched == NX_TUPLES_V2 ? W3[f % 7] : state ? 200 : (f % 4 == 3 ? 4 : 3);
+    for (uint32_t k = 0; k < d.w; k++) d.ent.push_back({E_COL, ((d.table ? 2 + 3 * f : 3 + 7 * f) + 5 * k) % n, 0});
+    auto sum = [&](uint32_t k) { d.ent[k].kind = E_SUM; d.ent[k].b = (5 + 11 * f + 3 * k) % n; };
+    if (sched == NX_TUPLES_V1 && d.w == 4) d.ent[0] = {E_CONST, 1 + f % 3, 0};
+    if (sched == NX_TUPLES_V1 && d.w == 3) { d.ent[1] = {E_CONST, 5, 0}; sum(2); }
+    if (sched == NX_TUPLES_V2 && d.w == 4) { d.ent[1] = {E_CONST, 7, 0}; sum(2); }
+    d.num = d.table ? N_NEG_MULT : f % 3 == 2 ? N_NEG_MULT : N_ONE;
+    if (!d.table) {
+        if (sched == NX_TUPLES_V1 && f % 8 == 2) d.num = N_MULT;
+        if (sched == NX_TUPLES_V2 && f % 5 == 1 && f % 3 != 2) d.num = N_MULT;
+        if (state) d.num = f + 2 == F ? N_MULT_M1 : N_ONE_M_MULT;
+    }
+    d.has_mult = d.num != N_ONE; d.col[0] = d.col[1] = 0;
     return d;
+}
+static uint32_t max_tuple_width(const nx_component_spec& c) {
+    uint32_t w = 2;
+    if (tuple_sched(c)) for (uint32_t f = 0; f < n_logup_fracs(c); f++) w = std::max(w, frac_def(c, f).w);
+    return w;
+}
+// the fractions of logup column j
+static std::vector<uint32_t> batch_of(const nx_component_spec& c, uint32_t j) {
+    if (!(c.logup_mode & NX_LOGUP_PAIRS)) return {j};
+    std::vector<uint32_t> b{2 * j};
+    if (2 * j + 1 < n_logup_fracs(c)) b.push_back(2 * j + 1);
+    return b;
 }
 
 struct ProgEmit {
     std::vector<nx_cinstr> p;
     void op(uint32_t o, uint32_t d, uint32_t a = 0, uint32_t b = 0) { p.push_back(nx_cinstr{o, d, a, b}); }
 };
+
+// ---- the wide-tuple forms (tuple schedule != 0) -------------------------------------------------------------------------------------
+// econsts of such a component: [z, alpha, claimed / N, 0, alpha^0, alpha^1, ..., alpha^(W - 1)] (W = its widest tuple) — LookupElements<N>
+// holds its alpha powers as constants (stwo-constraint-framework relation!).  Registers: B 14..21 a group of 8 tuple values, 22..29 the second
+// columns of sums, 30 / 31 the (negated) numerators, 32 the constant 1; E quads from 36.
+enum { GV = 14, GW = 22, GN0 = 30, GN1 = 31, GONE = 32, GE = 36, GZ = GE, GNZ = GE + 4, GSH = GE + 8, GA = GE + 12, GTMP = GE + 16, GD0 = GE + 20, GD1 = GE + 24,
+       GDD = GE + 28, GTT = GE + 32, GPN = GE + 36, GPR = GE + 40, GS0 = GE + 44, GS1 = GE + 48, GREGS = GE + 52, APOW0 = 4 };
+// dst (an E quad) = sum_k alpha^k entry_k - z   (Relation::combine): the loads of 8 entries, then their arithmetic
+static void emit_den(ProgEmit& e, const FracDef& d, uint32_t dst, uint32_t tuple_base) {
+    for (uint32_t k0 = 0; k0 < d.w; k0 += 8) {
+        const uint32_t k1 = std::min(d.w, k0 + 8);
+        for (uint32_t k = k0; k < k1; k++) {
+            const TupleEntry& t = d.ent[k];
+            if (t.kind == E_CONST) e.op(NX_C_CONST, GV + (k - k0), t.a);
+            else e.op(NX_C_LOAD, GV + (k - k0), tuple_base + t.a, 0);
+            if (t.kind == E_SUM) e.op(NX_C_LOAD, GW + (k - k0), tuple_base + t.b, 0);
+        }
+        for (uint32_t k = k0; k < k1; k++) if (d.ent[k].kind == E_SUM) e.op(NX_C_ADD, GV + (k - k0), GV + (k - k0), GW + (k - k0));
+        for (uint32_t k = k0; k < k1; k++) {
+            if (k == 0) e.op(NX_C_ADDEB, dst, GNZ, GV);                                                   // alpha^0 entry_0 - z
+            else { e.op(NX_C_CONSTE, GA, APOW0 + k); e.op(NX_C_MULEB, GTMP, GA, GV + (k - k0)); e.op(NX_C_ADDE, dst, dst, GTMP); }
+        }
+    }
+}
+// B[dst] = the numerator (neg: its negation, what the constraint adds)
+static void emit_num(ProgEmit& e, const FracDef& d, uint32_t dst, uint32_t main_base, bool neg) {
+    enum { T0 = 0 };
+    switch (d.num) {
+    case N_ONE: e.op(NX_C_CONST, dst, neg ? P - 1 : 1); break;
+    case N_NEG_MULT: if (neg) e.op(NX_C_LOAD, dst, main_base + d.mult, 0); else { e.op(NX_C_LOAD, T0, main_base + d.mult, 0); e.op(NX_C_NEG, dst, T0); } break;
+    case N_MULT: if (!neg) e.op(NX_C_LOAD, dst, main_base + d.mult, 0); else { e.op(NX_C_LOAD, T0, main_base + d.mult, 0); e.op(NX_C_NEG, dst, T0); } break;
+    case N_MULT_M1: e.op(NX_C_LOAD, T0, main_base + d.mult, 0); if (neg) e.op(NX_C_SUB, dst, GONE, T0); else e.op(NX_C_SUB, dst, T0, GONE); break;
+    default: e.op(NX_C_LOAD, T0, main_base + d.mult, 0); if (neg) e.op(NX_C_SUB, dst, T0, GONE); else e.op(NX_C_SUB, dst, GONE, T0); break;   // 1 - m
+    }
+}
+// finalize_logup / finalize_logup_in_pairs over fractions of any width (see the constraint list above)
+static void emit_wide_logup_constraints(ProgEmit& e, const nx_component_spec& c, uint32_t* nc) {
+    const uint32_t L = c.n_inter / 4, MAIN = c.n_pre, INT = c.n_pre + c.n_main, TB = (c.logup_mode & NX_LOGUP_TABLE) ? 0u : MAIN;
+    e.op(NX_C_CONSTE, GZ, 0); e.op(NX_C_CONSTE, GSH, 2); e.op(NX_C_CONSTE, GNZ, 3); e.op(NX_C_SUBE, GNZ, GNZ, GZ); e.op(NX_C_CONST, GONE, 1);
+    for (uint32_t j = 0; j < L; j++) {
+        const std::vector<uint32_t> fs = batch_of(c, j);
+        const bool two = fs.size() == 2;
+        for (size_t i = 0; i < fs.size(); i++) { const FracDef d = frac_def(c, fs[i]); emit_den(e, d, i ? GD1 : GD0, TB); emit_num(e, d, i ? GN1 : GN0, MAIN, true); }
+        const uint32_t cur = (j & 1) ? GS1 : GS0, prev = (j & 1) ? GS0 : GS1;
+        e.op(NX_C_LOADE, cur, INT + 4 * j, 0);
+        uint32_t diff = GTT;
+        if (j + 1 < L) { if (j == 0) diff = cur; else e.op(NX_C_SUBE, GTT, cur, prev); }
+        else {
+            e.op(NX_C_LOADE, GPR, INT + 4 * j, (uint32_t)-1);
+            e.op(NX_C_SUBE, GTT, cur, GPR);
+            if (j > 0) e.op(NX_C_SUBE, GTT, GTT, prev);
+            e.op(NX_C_ADDE, GTT, GTT, GSH);
+        }
+        if (two) {
+            e.op(NX_C_MULE, GDD, GD0, GD1); e.op(NX_C_MULE, GTT, diff, GDD);                             // diff d0 d1 - (n0 d1 + n1 d0)
+            e.op(NX_C_MULEB, GPN, GD1, GN0); e.op(NX_C_ADDE, GTT, GTT, GPN);
+            e.op(NX_C_MULEB, GPN, GD0, GN1); e.op(NX_C_ADDE, GTT, GTT, GPN);
+        } else { e.op(NX_C_MULE, GTT, diff, GD0); e.op(NX_C_ADDEB, GTT, GTT, GN0); }
+        e.op(NX_C_CONSTRAINT_E, 0, GTT); (*nc)++;
+    }
+}
+// The component's relation entries as a fraction program (nx_logup_program): what a recording EvalAtRow hands over for
+// eval.add_to_relation(RelationEntry::new(relation, multiplicity, &values)) — one NX_C_FRACB per entry, batch = its logup column.
+// Columns are numbered like the component's AIR (preprocessed, main, interaction); econsts as above.
+static std::vector<nx_cinstr> machine_fraction_program(const nx_component_spec& c, uint32_t* n_regs) {
+    const uint32_t L = c.n_inter / 4, MAIN = c.n_pre, TB = (c.logup_mode & NX_LOGUP_TABLE) ? 0u : MAIN;
+    ProgEmit e;
+    e.op(NX_C_CONSTE, GZ, 0); e.op(NX_C_CONSTE, GNZ, 3); e.op(NX_C_SUBE, GNZ, GNZ, GZ); e.op(NX_C_CONST, GONE, 1);
+    for (uint32_t j = 0; j < L; j++)
+        for (uint32_t f : batch_of(c, j)) {
+            FracDef d = frac_def(c, f);
+            emit_den(e, d, GD0, TB); emit_num(e, d, GN0, MAIN, false);
+            e.op(NX_C_FRACB, j, GN0, GD0);
+        }
+    *n_regs = GREGS;
+    return std::move(e.p);
+}
 
 // econsts of a component: [z, alpha, claimed / N, 0]
 // A component whose constraint-degree bound is 2 HAS constraints that need it (degree 4 or 5; v1's shift chips, reference
@@ -277,7 +406,10 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc, 
             }
     }
     const uint32_t TB = (c.logup_mode & NX_LOGUP_TABLE) ? (uint32_t)PRE : (uint32_t)MAIN;      // where the tuples are read
-    if (L && !(c.logup_mode & NX_LOGUP_PAIRS)) {
+    if (L && tuple_sched(c)) {
+        g.n_regs = std::max<uint32_t>(g.n_regs, GREGS);
+        emit_wide_logup_constraints(e, c, &nc);
+    } else if (L && !(c.logup_mode & NX_LOGUP_PAIRS)) {
         e.op(NX_C_CONSTE, EZ, 0); e.op(NX_C_CONSTE, EAL, 1); e.op(NX_C_CONSTE, ESH, 2); e.op(NX_C_CONSTE, ENZ, 3); e.op(NX_C_SUBE, ENZ, ENZ, EZ);   // -z
         auto S = [&](uint32_t j) { return (uint32_t)ES + 4 * (j % 5); };       // S_j lives in slot j % 5: a chunk of 4 never overwrites S_{j0 - 1}
         for (uint32_t j0 = 0; j0 < L; j0 += 4) {
@@ -368,7 +500,7 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc, 
     }
     g.prog = std::move(e.p);
     g.n_constraints = nc;
-    g.econsts.assign(16, 0);
+    g.econsts.assign(tuple_sched(c) ? 4 * (size_t)(APOW0 + max_tuple_width(c)) : 16, 0);
     return g;
 }
 
@@ -376,22 +508,56 @@ static GComponent machine_component(const nx_component_spec& c, const Loc& loc, 
 // index -> evaluations (bit-reversed circle-domain order; whole columns, or this GPU's row block of n_rows = 2^log_rows rows): inter =
 // 4 L coordinate columns of n_rows words.
 typedef std::map<uint32_t, const uint32_t*> ColMap;
+// [z, alpha, shift, 0, alpha^0 .. alpha^(W-1)]: the E constants of a wide-tuple component (schedule 0: the first four)
+static void fill_econsts(std::vector<uint32_t>& ec, const uint32_t z[4], const uint32_t alpha[4], const QM31& shift) {
+    memcpy(&ec[0], z, 16); memcpy(&ec[4], alpha, 16); q_store(&ec[8], shift);
+    QM31 pw = q_one(); const QM31 al = q_load(alpha);
+    for (size_t k = APOW0; 4 * k + 4 <= ec.size(); k++) { q_store(&ec[4 * k], pw); pw = q_mul(pw, al); }
+}
 static int logup_columns(nx_ctx* ctx, const nx_component_spec& c, uint32_t log_rows, const ColMap& mainv, const ColMap& prev, const uint32_t z[4], const uint32_t alpha[4],
                          uint32_t* const* inter) {
     const uint32_t L = c.n_inter / 4, F = n_logup_fracs(c);
     const bool pairs = (c.logup_mode & NX_LOGUP_PAIRS) != 0;
     static const uint32_t one[4] = {1, 0, 0, 0}, minus_one[4] = {P - 1, 0, 0, 0};
-    uint32_t ap[8] = {1, 0, 0, 0, alpha[0], alpha[1], alpha[2], alpha[3]};     // LookupElements alpha powers [1, alpha]
     const bool per_column = ctx->opt.logup_per_column != 0;   // A/B: one nx_logup_col launch per column
+    std::vector<FracDef> defs(F);
+    bool affine = false;                                       // a numerator (m - 1) / (1 - m): not a scale times a column
+    for (uint32_t f = 0; f < F; f++) { defs[f] = frac_def(c, f); affine = affine || defs[f].num == N_MULT_M1 || defs[f].num == N_ONE_M_MULT; }
+    if (tuple_sched(c) && (affine || ctx->opt.machine_logup_program)) {
+        // The route of a Rust-side prove without the chips' generators (reference_patch/machine_hip.rs): the interaction trace FROM THE
+        // RECORDED relation entries (nx_logup_program) — any expression as tuple entry or numerator.
+        uint32_t n_regs = 0;
+        const std::vector<nx_cinstr> prog = machine_fraction_program(c, &n_regs);
+        const uint32_t n_cols = c.n_pre + c.n_main + c.n_inter;
+        std::vector<const uint32_t*> cols(n_cols, nullptr);
+        for (auto& kv : prev) cols[kv.first] = kv.second;
+        for (auto& kv : mainv) cols[c.n_pre + kv.first] = kv.second;
+        std::vector<uint32_t> ec(4 * (size_t)(APOW0 + max_tuple_width(c)), 0);
+        fill_econsts(ec, z, alpha, q_zero());
+        return nx_logup_program(ctx, prog.data(), (uint32_t)prog.size(), n_regs, cols.data(), n_cols, ec.data(), (uint32_t)(ec.size() / 4), log_rows, L, inter, nullptr);
+    }
+    // nx_logup_frac takes columns: an entry that is a constant moves into z (z' = z - sum_k alpha^k const_k), a sum of two columns becomes
+    // two tuple columns under the same alpha power — the same field element, by linearity of Relation::combine
+    std::vector<QM31> apow;
+    { QM31 pw = q_one(); const QM31 al = q_load(alpha); for (uint32_t k = 0; k < max_tuple_width(c); k++) { apow.push_back(pw); pw = q_mul(pw, al); } }
+    std::vector<std::vector<const uint32_t*>> tuples(F);
+    std::vector<std::vector<uint32_t>> aps(F);
+    std::vector<std::array<uint32_t, 4>> zs(F);
     std::vector<nx_logup_frac> fr(F);
-    std::vector<const uint32_t*> tuples(2 * (size_t)F);
     for (uint32_t f = 0; f < F; f++) {
-        const FracDef d = frac_def(c, f);
+        const FracDef& d = defs[f];
         const ColMap& src = d.table ? prev : mainv;
-        tuples[2 * f] = src.at(d.col[0]); tuples[2 * f + 1] = d.w == 2 ? src.at(d.col[1]) : nullptr;
+        QM31 zf = q_load(z);
+        auto push = [&](uint32_t col, uint32_t k) { tuples[f].push_back(src.at(col)); aps[f].resize(aps[f].size() + 4); q_store(&aps[f][aps[f].size() - 4], apow[k]); };
+        for (uint32_t k = 0; k < d.w; k++) {
+            const TupleEntry& t = d.ent[k];
+            if (t.kind == E_CONST) zf = q_sub(zf, q_mul_m(apow[k], t.a));
+            else { push(t.a, k); if (t.kind == E_SUM) push(t.b, k); }
+        }
+        q_store(zs[f].data(), zf);
         nx_logup_frac& q = fr[f];
-        q.d_tuple_cols = &tuples[2 * f]; q.n_tuple_cols = d.w; q.alpha_powers = ap; q.z = z;
-        q.d_mult = d.has_mult ? mainv.at(d.mult) : nullptr; q.scale = d.has_mult ? minus_one : one;
+        q.d_tuple_cols = tuples[f].data(); q.n_tuple_cols = (uint32_t)tuples[f].size(); q.alpha_powers = aps[f].data(); q.z = zs[f].data();
+        q.d_mult = d.has_mult ? mainv.at(d.mult) : nullptr; q.scale = d.num == N_NEG_MULT ? minus_one : one;
     }
     if (per_column) {
         for (uint32_t j = 0; j < L; j++) {
@@ -409,7 +575,8 @@ static std::set<uint32_t> logup_needed_columns(const nx_component_spec& c, uint3
     std::set<uint32_t> s;
     for (uint32_t f = 0; f < n_logup_fracs(c); f++) {
         const FracDef d = frac_def(c, f);
-        if ((d.table ? 0u : 1u) == tree) { s.insert(d.col[0]); if (d.w == 2) s.insert(d.col[1]); }
+        if ((d.table ? 0u : 1u) == tree)
+            for (const TupleEntry& t : d.ent) { if (t.kind != E_CONST) s.insert(t.a); if (t.kind == E_SUM) s.insert(t.b); }
         if (tree == 1 && d.has_mult) s.insert(d.mult);
     }
     return s;
@@ -425,8 +592,8 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     for (uint32_t i = 0; i < n_comps; i++) {
         if (comps[i].n_inter % 4) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: n_inter = 4 x (number of logup columns)");
         const uint32_t m = comps[i].logup_mode;
-        if (m > (NX_LOGUP_PAIRS | NX_LOGUP_ODD | NX_LOGUP_TABLE) || ((m & NX_LOGUP_ODD) && !(m & NX_LOGUP_PAIRS)))
-            return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: logup_mode is a set of NX_LOGUP_PAIRS / NX_LOGUP_ODD (with PAIRS only) / NX_LOGUP_TABLE");
+        if (!logup_mode_ok(m))
+            return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: logup_mode is a set of NX_LOGUP_PAIRS / NX_LOGUP_ODD (with PAIRS only) / NX_LOGUP_TABLE, plus NX_LOGUP_TUPLES(0 .. 3)");
     }
     H_TRY(nx_ctx_set_hash_mode(ctx, (int)ucfg->hash_mode));
     uint32_t max_log = 0;
@@ -547,6 +714,9 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         if (!pre_key.empty()) {                                                       // keep it for the next proof of this shape
             auto sp = std::make_shared<CommitmentTreeProver>(std::move(cs.trees[0]));
             cs.trees[0] = borrow_tree(sp);
+            // one entry: the tree of the statement shape proved last (a prover farm proves one program over and over; every further shape would
+            // pin a whole preprocessed tree — coefficients, LDE, Merkle layers — in HBM until the context is destroyed: ADVICE r5)
+            ctx->machine_pre_cache.clear();
             ctx->machine_pre_cache[pre_key] = sp;
         }
     }
@@ -623,7 +793,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         GComponent g = machine_component(comps[i], locs[i], cfg);
         g.log_cd = comps[i].log_constraint_degree_bound;
         const QM31 shift = q_mul_m(claimed[i], m_inv((1u << comps[i].log_size) % P));
-        memcpy(&g.econsts[0], z, 16); memcpy(&g.econsts[4], alpha, 16); q_store(&g.econsts[8], shift);
+        fill_econsts(g.econsts, z, alpha, shift);
         H_TRY(prepare_component_kernels(ctx, cfg, g, D.on()));
         air.comps.push_back(std::move(g));
     }
@@ -642,10 +812,12 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
 using namespace nx;
 
 // A rank whose sharded prove failed leaves its peers waiting in the next collective: tell the transport (nx_comm.abort, optional)
-// — unless the failure is one every rank reached by itself (ctx->symmetric_failure: the vote, ConstraintsNotSatisfied) or an argument
-// error caught before the communicator was touched: an abort cannot be undone, and an invalid trace must not cost a prover farm its group
+// — unless the failure is one every rank reached by itself (ctx->symmetric_failure: the vote, ConstraintsNotSatisfied) or one returned
+// before this rank entered its first collective (ctx->comm_entered false: the argument checks ahead of dist_init and the vote — no peer
+// waits for a rank that never joined): an abort cannot be undone, and an invalid trace must not cost a prover farm its group.  The
+// error CODE does not decide: NX_ERR_ARG also comes from deep inside a sharded prove, one-sided.
 static void abort_peers(nx_ctx* ctx, const nx_comm* comm, int rc) {
-    if (rc != NX_OK && rc != NX_ERR_ARG && !ctx->symmetric_failure && comm && comm->world > 1 && comm->abort) comm->abort(comm->user);
+    if (rc != NX_OK && ctx->comm_entered && !ctx->symmetric_failure && comm && comm->world > 1 && comm->abort) comm->abort(comm->user);
 }
 
 static int hand_out(nx_ctx* ctx, int rc, std::vector<uint32_t>& w, uint32_t** proof_words, size_t* n_words, const char* who) {
@@ -673,7 +845,7 @@ int nx_prove_synth_sharded(nx_ctx* ctx, const nx_component_spec* comps, uint32_t
     NX_GUARD(ctx);
     if (!ctx || !comps || !cfg || !proof_words || !n_words || !comm) return set_err(ctx, NX_ERR_ARG, "nx_prove_synth_sharded: NULL argument");
     std::vector<uint32_t> w;
-    ctx->symmetric_failure = false;
+    ctx->symmetric_failure = false; ctx->comm_entered = false;
     const int rc = nxhip::prove_synth(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
     abort_peers(ctx, comm, rc);
     return hand_out(ctx, rc, w, proof_words, n_words, "nx_prove_synth_sharded");
@@ -690,7 +862,7 @@ int nx_machine_air_source(const nx_component_spec* comp, char** h_source) {
 
 int nx_machine_air_program(const nx_component_spec* comp, uint32_t cfg_log_constraint_degree, nx_cinstr** h_program, uint32_t* n_instr, uint32_t* n_regs, uint32_t* n_constraints) {
     if (!comp || !h_program || !n_instr || !n_regs || !n_constraints || comp->n_inter % 4 || comp->n_pre < 2 || comp->n_main < 2 || cfg_log_constraint_degree < 1 ||
-        cfg_log_constraint_degree > 2 || comp->logup_mode > 7 || ((comp->logup_mode & NX_LOGUP_ODD) && !(comp->logup_mode & NX_LOGUP_PAIRS)))
+        cfg_log_constraint_degree > 2 || !nxhip::logup_mode_ok(comp->logup_mode))
         return set_err(nullptr, NX_ERR_ARG, "nx_machine_air_program: bad argument");
     nxhip::PcsConfig cfg = {0, 1, 1, 0, 0, cfg_log_constraint_degree};
     nxhip::GComponent g = nxhip::machine_component(*comp, nxhip::Loc{0, 0, 0}, cfg);
@@ -706,7 +878,7 @@ int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_com
     NX_GUARD(ctx);
     if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: NULL argument");
     std::vector<uint32_t> w;
-    ctx->symmetric_failure = false;
+    ctx->symmetric_failure = false; ctx->comm_entered = false;
     const int rc = nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
     abort_peers(ctx, comm, rc);
     return hand_out(ctx, rc, w, proof_words, n_words, "nx_prove_machine");

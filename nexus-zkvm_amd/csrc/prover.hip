@@ -43,6 +43,7 @@ int vote_before_exchanges(nx_ctx* ctx, const Dist& D, int rc_local, const char* 
 struct CommClock { const Dist& d; double t0; CommClock(const Dist& x) : d(x), t0(now_ms()) {} ~CommClock() { if (d.comm_ms) *d.comm_ms += now_ms() - t0; } };
 int Dist::allgather_host(nx_ctx* ctx, const void* send, size_t bytes, void* recv) const {
     CommClock clk(*this);
+    ctx->comm_entered = true;
     C_TRY(comm->allgather(comm->user, send, bytes, recv));
     if (comm_bytes) *comm_bytes += bytes * (size_t)(world - 1);
     if (comm_calls) comm_calls[2]++;
@@ -51,6 +52,7 @@ int Dist::allgather_host(nx_ctx* ctx, const void* send, size_t bytes, void* recv
 int Dist::allgather_dev(nx_ctx* ctx, const uint32_t* d_send, size_t words, uint32_t* d_recv) const {
     H_TRY(nx_sync(ctx));                      // the peers read this buffer: it must be complete
     CommClock clk(*this);
+    ctx->comm_entered = true;
     C_TRY(comm->allgather_dev(comm->user, d_send, words, d_recv));
     if (comm_bytes) *comm_bytes += words * 4 * (size_t)(world - 1);
     if (comm_calls) comm_calls[1]++;
@@ -79,6 +81,7 @@ int Dist::alltoallv(nx_ctx* ctx, const uint32_t* d_send, const size_t* soff, con
     if (ready) NX_HIP(ctx, hipEventSynchronize(ready));
     else H_TRY(nx_sync(ctx));
     CommClock clk(*this);
+    ctx->comm_entered = true;
     C_TRY(comm->alltoallv(comm->user, d_send, soff, scnt, d_recv, roff, rcnt));
     if (comm_bytes) for (int r = 0; r < world; r++) if (r != rank) *comm_bytes += scnt[r] * 4;
     if (comm_calls) comm_calls[0]++;

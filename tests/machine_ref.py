@@ -14,6 +14,14 @@ a_f = (3 + 7 f) % n_main, b_f = (5 + 11 f) % n_main, m_f = (2 + 13 f) % n_main. 
 reference prover2/machine/src/lookups/logup_trace_builder.rs:86-101; | ODD: the last column holds the single left-over fraction);
 TABLE = the tuples read PREPROCESSED columns a_f = (2 + 3 f) % n_pre, b_f = (1 + 5 f) % n_pre and every numerator is -main[m_f]
 (reference prover/src/extensions/multiplicity.rs:111-124).
+
+Tuple schedule = bits 4..7 of the logup mode (TUPLES(k); include/nexus_hip.h NX_TUPLES_*): the widths and entry kinds of the reference's
+own relations.  V1: widths cycling 1, 1, 4, 1, 9, 1, 3, 1 (range256.rs:37; bit_op.rs:31,355: [CONSTANT, b, c, a] with a flag column as
+numerator; register_mem_check.rs:34; the 3-wide one = [column, constant 5, column + column]); KECCAK: 3- / 4-wide bitwise lookups
+(chips/custom.rs:33-37) and the component's last two fractions 200 wide with the numerators m - 1 and 1 - m (custom.rs:45-46,
+extensions/keccak/round/constraints.rs:101-110); V2: prover2's 9 / 21 / 14 / 10 / 4 / 12 / 8 (prover2/machine/src/lookups/
+relations.rs:33-90), the 4-wide one = [column, constant 7, column + column, column].  Entry k of fraction f reads column
+(3 + 7 f + 5 k) % n_main (a table: (2 + 3 f + 5 k) % n_pre), the second column of a sum (5 + 11 f + 3 k) % n.
 """
 import os
 
@@ -25,10 +33,19 @@ P = O.P
 
 
 PAIRS, ODD, TABLE = 1, 2, 4
+V1, KECCAK, V2 = 1, 2, 3
+
+
+def TUPLES(k):
+    return k << 4
 
 
 def logup_mode(comp):
     return comp[5] if len(comp) > 5 else 0
+
+
+def tuple_sched(comp):
+    return (logup_mode(comp) >> 4) & 15
 
 
 def n_fracs(comp):
@@ -38,15 +55,59 @@ def n_fracs(comp):
     return 2 * L - (1 if mode & ODD else 0)
 
 
-def frac_def(comp, f):
-    """(tree of the tuple columns, tuple column indices, multiplicity main column or None) of fraction f"""
-    n_pre, n_main, mode = comp[1], comp[2], logup_mode(comp)
+# numerator kinds: the fraction's numerator as (sign, uses the multiplicity column, constant term): sign * m + constant
+ONE, NEG_M, M_MINUS_1, ONE_MINUS_M, PLUS_M = (0, 1), (-1, 0), (1, -1), (-1, 1), (1, 0)     # (coefficient of m, constant)
+
+
+def frac_shape(comp, f):
+    """(tree of the tuple columns, entries, numerator (coefficient of main[m], constant), m) of fraction f.
+    An entry is ('col', k), ('const', c) or ('sum', k, k2)."""
+    n_pre, n_main, mode, sched = comp[1], comp[2], logup_mode(comp), tuple_sched(comp)
+    table = bool(mode & TABLE)
     m = (2 + 13 * f) % n_main
-    if mode & TABLE:
-        tup = [(2 + 3 * f) % n_pre] + ([(1 + 5 * f) % n_pre] if f & 1 else [])
-        return 0, tup, m
-    tup = [(3 + 7 * f) % n_main] + ([(5 + 11 * f) % n_main] if f & 1 else [])
-    return 1, tup, (m if f % 3 == 2 else None)
+    if sched == 0:
+        if table:
+            tup = [(2 + 3 * f) % n_pre] + ([(1 + 5 * f) % n_pre] if f & 1 else [])
+            return 0, [("col", k) for k in tup], NEG_M, m
+        tup = [(3 + 7 * f) % n_main] + ([(5 + 11 * f) % n_main] if f & 1 else [])
+        return 1, [("col", k) for k in tup], (NEG_M if f % 3 == 2 else ONE), m
+    F = n_fracs(comp)
+    n = n_pre if table else n_main
+    state = sched == KECCAK and not table and F >= 2 and f >= F - 2
+    if sched == V1:
+        w = (1, 1, 4, 1, 9, 1, 3, 1)[f % 8]
+    elif sched == V2:
+        w = (9, 21, 14, 10, 4, 12, 8)[f % 7]
+    else:
+        w = 200 if state else (4 if f % 4 == 3 else 3)
+    first = (2 + 3 * f) if table else (3 + 7 * f)
+    ent = [("col", (first + 5 * k) % n) for k in range(w)]
+
+    def as_sum(k):
+        ent[k] = ("sum", ent[k][1], (5 + 11 * f + 3 * k) % n)
+
+    if sched == V1 and w == 4:
+        ent[0] = ("const", 1 + f % 3)
+    if sched == V1 and w == 3:
+        ent[1] = ("const", 5); as_sum(2)
+    if sched == V2 and w == 4:
+        ent[1] = ("const", 7); as_sum(2)
+    num = NEG_M if (table or f % 3 == 2) else ONE
+    if not table:
+        if sched == V1 and f % 8 == 2:
+            num = PLUS_M
+        if sched == V2 and f % 5 == 1 and f % 3 != 2:
+            num = PLUS_M
+        if state:
+            num = M_MINUS_1 if f == F - 2 else ONE_MINUS_M
+    return (0 if table else 1), ent, num, m
+
+
+def frac_def(comp, f):
+    """(tree of the tuple columns, tuple column indices, multiplicity main column or None) of fraction f — schedule 0's form"""
+    tree, ent, num, m = frac_shape(comp, f)
+    assert all(e[0] == "col" for e in ent)
+    return tree, [e[1] for e in ent], (m if num != ONE else None)
 
 
 def batches(comp):
@@ -92,14 +153,46 @@ def machine_component(ap, comp, loc, z, alpha, shift, cfg_lcd=1):
                 pre[k] = pb.next_trace_mask(PRE + k)[0]
             return pre[k]
 
+        apow = {}                                                  # LookupElements' alpha powers are constants of the relation
+
+        def alpha_pow(k):
+            if k == 1:
+                return al
+            if k not in apow:
+                v = np.array([1, 0, 0, 0], np.uint32)
+                for _ in range(k):
+                    v = O.qm31_mul(v, alpha)
+                apow[k] = pb.econst(v)
+            return apow[k]
+
+        def entry(tree, en):
+            if en[0] == "col":
+                return tuple_col(tree, en[1])
+            if en[0] == "const":
+                return pb.const(en[1])
+            return tuple_col(tree, en[1]) + tuple_col(tree, en[2])
+
         prev = None
         for j, fs in enumerate(batches(comp)):
             # Fraction sum of the batch (stwo-constraint-framework Fraction::add): (n0 d1 + n1 d0) / (d0 d1); a single fraction as it is
             num_neg, den = None, None                              # - numerator, denominator
             for f in fs:
-                tree, tup, m = frac_def(comp, f)
-                d = tuple_col(tree, tup[0]) - ze if len(tup) == 1 else al * tuple_col(tree, tup[1]) + tuple_col(tree, tup[0]) - ze   # E arithmetic: B - E lowers to (-E) + B
-                nn = main[m] if m is not None else pb.const(P - 1)                                   # - num
+                tree, ent, (cm, c0), m = frac_shape(comp, f)
+                if tuple_sched(comp) == 0:
+                    tup = [e[1] for e in ent]
+                    d = tuple_col(tree, tup[0]) - ze if len(tup) == 1 else al * tuple_col(tree, tup[1]) + tuple_col(tree, tup[0]) - ze   # E arithmetic: B - E lowers to (-E) + B
+                    nn = main[m] if cm else pb.const(P - 1)                                   # - num
+                else:
+                    # Relation::combine: sum_k alpha^k value_k - z, the values in declaration order
+                    d = None
+                    for k, en in enumerate(ent):
+                        v = entry(tree, en)
+                        term = v if k == 0 else alpha_pow(k) * v
+                        d = term if d is None else d + term
+                    d = d - ze
+                    # - numerator, the numerator being cm * main[m] + c0
+                    nn = {ONE: lambda: pb.const(P - 1), NEG_M: lambda: main[m], PLUS_M: lambda: 0 - main[m],
+                          M_MINUS_1: lambda: 1 - main[m], ONE_MINUS_M: lambda: main[m] - 1}[(cm, c0)]()
                 if den is None:
                     num_neg, den = nn, d
                 else:
@@ -130,15 +223,34 @@ def interaction_trace(comp, main_cols, z, alpha, pre_cols=None):
     L = n_inter // 4
     if L == 0:
         return [], np.zeros(4, np.uint32)
-    ap = np.array([[1, 0, 0, 0], list(alpha)], np.uint32)
+    wmax = max([2] + [len(frac_shape(comp, f)[1]) for f in range(n_fracs(comp))])
+    pw = [np.array([1, 0, 0, 0], np.uint32)]
+    for _ in range(1, wmax):
+        pw.append(O.qm31_mul(pw[-1], alpha))
+    ap = np.array(pw, np.uint32)
     cols, prev = [], None
     for fs in batches(comp):
         args = []
         for f in fs:
-            tree, tup, m = frac_def(comp, f)
+            tree, ent, (cm, c0), m = frac_shape(comp, f)
             src = main_cols if tree == 1 else pre_cols
-            den = O.logup_combine([src[k] for k in tup], ap[:len(tup)], z)
-            args.append((den, (P - 1, 0, 0, 0), main_cols[m]) if m is not None else (den, (1, 0, 0, 0), None))
+            n_rows = len(main_cols[0])
+            vals = []                                                     # the tuple's VALUES, entry by entry (what the chip's generator computes)
+            for en in ent:
+                if en[0] == "col":
+                    vals.append(src[en[1]])
+                elif en[0] == "const":
+                    vals.append(np.full(n_rows, en[1], np.uint32))
+                else:
+                    vals.append(((src[en[1]].astype(np.uint64) + src[en[2]]) % P).astype(np.uint32))
+            den = O.logup_combine(vals, ap[:len(vals)], z)
+            if cm == 0:
+                args.append((den, (c0 % P, 0, 0, 0), None))
+            elif c0 == 0:
+                args.append((den, (cm % P, 0, 0, 0), main_cols[m]))
+            else:                                                         # m - 1 / 1 - m: the numerator column itself
+                numer = ((cm * main_cols[m].astype(np.int64) + c0) % P).astype(np.uint32)
+                args.append((den, (1, 0, 0, 0), numer))
         if len(args) == 2:                                                # LogupTraceBuilder: (a d + b c) / (b d)
             (da, sa, ma), (db, sb, mb) = args
             col = O.logup_finalize_col(da, scale_a=sa, mult_a=ma, den_b=db, scale_b=sb, mult_b=mb, prev=prev)
