@@ -316,6 +316,7 @@ static nx_options options_from_env() {
     o.comm_timeout_ms = std::max(0, env_int("NX_COMM_TIMEOUT_MS", 120000));
     o.fft_kmax = clampi(env_int("NX_FFT_KMAX", 9), 1, 11);
     o.fft_fused = env_int("NX_FFT_FUSED", 1) != 0;
+    o.merkle_fused = clampi(env_int("NX_MERKLE_FUSED", 21), 0, 31);   // profiles/r06_merkle_fused_ab.jsonl: FRI stage 3.48 -> 3.37 ms at 21, the prove within its noise
     o.merkle_subtree = clampi(env_int("NX_MERKLE_SUBTREE", 17), 0, 30);
     o.merkle_pair_levels = env_int("NX_MERKLE_PAIR_LEVELS", 1) != 0;
     { int x = env_int("NX_PIPE_COLS", 0); o.commit_pipe_cols = x < 16 ? 0 : (x / 16) * 16; }
@@ -343,6 +344,7 @@ static const OptEntry k_options[] = {
     {"comm.timeout_ms", &nx_options::comm_timeout_ms, 0, 1 << 30},
     {"fft.kmax", &nx_options::fft_kmax, 1, 11},
     {"fft.fused", &nx_options::fft_fused, 0, 1},
+    {"merkle.fused", &nx_options::merkle_fused, 0, 31},
     {"merkle.subtree", &nx_options::merkle_subtree, 0, 30},
     {"merkle.pair_levels", &nx_options::merkle_pair_levels, 0, 1},
     {"commit.pipe_cols", &nx_options::commit_pipe_cols, 0, 1 << 20},

@@ -26,6 +26,7 @@ struct nx_options {
     // the kernels' launchers — so that a tool can still flip one on ONE context
     int fft_kmax;                 // "fft.kmax": most layers of a non-FIRST pass (runs of 2^(13-K) words), 1..11
     int fft_fused;                // "fft.fused": fused LDE middle launch (lde_mid_kernel)
+    int merkle_fused;             // "merkle.fused": 0 = off, else the smallest log size from which the tree of <= 4 columns of one size (composition tree, FRI layers) gets its leaf hash — for a FRI layer also the fold — and 6 levels in one launch (merkle_fused_kernel)
     int merkle_subtree; int merkle_pair_levels;           // "merkle.subtree": highest tree level built by the fused subtree launch (0 = one launch per level)
     int commit_pipe_cols;         // "commit.pipe_cols": leaf hashing of finished column groups of this many columns beside the next group's LDE (0 = off)
     int fri_device_channel;       // "fri.device_channel": FRI commit phase with the channel on the device
@@ -242,6 +243,8 @@ constexpr int FRI_TAIL_LOG = 11, FRI_TAIL_MAX_LAYERS = 16;   // 2^12 and up: one
 int tree_alloc(nx_ctx* ctx, uint32_t max_log, nx_tree** out);
 // FRI channel state on the device: words [0,8) digest, [8] n_sent, then one record per committed layer at 9 + 12 j: root[8], alpha[4].
 constexpr int FRI_STATE_HEAD = 9, FRI_STATE_REC = 12;
+int merkle_commit_fused(nx_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t log, nx_tree** out);   // <= 4 columns of >= 2^12 rows: leaf hash + 6 levels in one launch
+int fri_fold_commit_fused(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha, uint32_t* const* d_dst4, nx_tree** out);   // fold_line + leaf hash + 6 levels of one FRI layer (>= 2^12 points) in one launch
 int fri_channel_step(nx_ctx* ctx, uint32_t* d_state, const uint32_t* d_root, int j);   // mix_root(root) + draw_secure_felt -> record j
 int fri_tail(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* evals, uint32_t* const* trees, int n_layers, int log0, uint32_t* d_state, int j0);
 int fold_circle_dev(nx_ctx* ctx, const nx_twiddles* tw, uint32_t* const* d_dst4, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha);

@@ -515,6 +515,124 @@ __global__ __launch_bounds__(1024) void fri_tail_kernel(FriTailArgs a) {
     if (tid == 0) a.state[8] = n_sent;
 }
 
+// ---------------------------------------------------------------- leaf hash + 6 levels of a secure column's tree in ONE launch ----
+// Round 6.  A 1024-lane block owns 4096 consecutive rows of <= 4 columns of one size (the composition tree, a FRI
+// layer: the 4 coordinate columns of a secure column):
+//   SRC_COLS     the rows are read from the columns;
+//   SRC_FOLD     the rows ARE FriProver::commit's line fold of the previous layer (fold_line_dev_kernel's rule, alpha from the device
+//                channel's record): the folded evaluations are written out (the next fold and the decommitment read them) and hashed.
+// A lane hashes its 4 leaves and the 3 nodes above them in registers (7 compressions); the block's 1024 nodes two levels up shrink
+// through LDS, one lane per node, while a level still fills whole waves (512 ... 64 nodes).  Every node goes to the tree; the levels
+// above (64 nodes per block) are the level-by-level path's (build_inner_layers).  Replaces fold + leaf + two pair-level launches by one.
+// What was measured on the way (profiles/r06_merkle_fused.txt): the block's cascade continued down to its root (10 barrier-separated
+// levels, quads or lanes) makes a block live 17 compressions long with most of its waves parked — 28.8 G compressions/s on 2^24 leaf
+// digests against 34 G/s of the pair-level kernels, and 73 us for ANY layer below 2^18 points against ~50 us of subtree + top launches:
+// the level-by-level path was already at the compression rate, its launches are not what a big layer waits for.
+enum { SRC_COLS = 1, SRC_FOLD = 2 };
+struct FusedTreeArgs {
+    u32* tree; int leaf_log;
+    const u32* col[4]; u32 n_cols;                                                          // SRC_COLS (1 ... 4 columns)
+    const u32* fsrc[4]; u32* fdst[4]; const u32* itw; u32 tw_log; const u32* alpha;         // SRC_FOLD (fsrc: 2^(leaf_log + 1) words each)
+};
+constexpr u32 FUSED_LDS_WORDS = 2047 * 8, FUSED_MIN_LOG = 12, FUSED_LEVELS = 6;   // LDS: 1024 + 512 + ... nodes, level of m nodes at word (m - 1) * 8; the launch builds levels leaf_log ... leaf_log - 6
+
+template <int MODE>
+__device__ __forceinline__ void node_hash(const u32* m, u32* h) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = MODE == 0 ? B2S_IV_D[k] : 0u;
+    if (MODE == 0) { h[0] ^= 0x01010020u; b2s_compress(h, m, 64, 0xFFFFFFFFu); } else b2s_compress(h, m, 0, 0);
+}
+__device__ __forceinline__ void store_node(u32* tree, int level, u32 idx, const u32* h) {
+    u32* o = tree + (((size_t)1 << level) - 1 + idx) * 8;
+    gst4(o, make_uint4(h[0], h[1], h[2], h[3])); gst4(o + 4, make_uint4(h[4], h[5], h[6], h[7]));
+}
+
+#ifndef NX_FUSED_MINWAVES   // 8 waves per SIMD = two 1024-lane blocks per CU: a block's narrow cascade levels run beside the other block's wide ones
+#define NX_FUSED_MINWAVES 8
+#endif
+template <int MODE, int SRC>
+__global__ __launch_bounds__(1024, NX_FUSED_MINWAVES) void merkle_fused_kernel(FusedTreeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 fz[];
+    const u32 tid = threadIdx.x, g = blockIdx.x * 1024 + tid;       // this lane's node two levels above the leaves
+    const int in_log = a.leaf_log;
+    u32 n1[16], n2[8];                                               // the two nodes one level up (one message), the node two levels up
+    {
+        u32 val[4][4];                                               // [column / coordinate][row]
+        const u32 nc = SRC == SRC_FOLD ? 4u : a.n_cols;
+        if (SRC == SRC_FOLD) {
+            const QM31 alpha = qm(a.alpha[0], a.alpha[1], a.alpha[2], a.alpha[3]);
+            const uint4 x4 = gld4(a.itw + ((1u << a.tw_log) - (2u << in_log) + 4 * g));
+            const u32 xs[4] = {x4.x, x4.y, x4.z, x4.w};
+            uint4 lo[4], hi[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { lo[q] = gld4(a.fsrc[q] + (size_t)8 * g); hi[q] = gld4(a.fsrc[q] + (size_t)8 * g + 4); }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {                           // outputs 4 g + r: the pair (2 i, 2 i + 1) of every coordinate
+                u32 e0[4], e1[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint4 w = r < 2 ? lo[q] : hi[q];
+                    e0[q] = (r & 1) ? w.z : w.x; e1[q] = (r & 1) ? w.w : w.y;
+                }
+                const QM31 f0 = qm(e0[0], e0[1], e0[2], e0[3]), f1 = qm(e1[0], e1[1], e1[2], e1[3]);
+                const QM31 o = q_add(q_add(f0, f1), q_mul(alpha, q_mul_m(q_sub(f0, f1), xs[r])));
+                val[0][r] = o.a.a; val[1][r] = o.a.b; val[2][r] = o.b.a; val[3][r] = o.b.b;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) gst4(a.fdst[q] + (size_t)4 * g, make_uint4(val[q][0], val[q][1], val[q][2], val[q][3]));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if ((u32)c < nc) { const uint4 v = gld4(a.col[c] + (size_t)4 * g); val[c][0] = v.x; val[c][1] = v.y; val[c][2] = v.z; val[c][3] = v.w; }
+                else { val[c][0] = val[c][1] = val[c][2] = val[c][3] = 0; }
+            }
+        }
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+            u32 pr[16];                                              // the two leaf digests under node hlf
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const int r = 2 * hlf + s2;
+                u32 m[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) m[c] = c < 4 ? val[c][r] : 0u;
+                u32* d = pr + 8 * s2;
+#pragma unroll
+                for (int k = 0; k < 8; k++) d[k] = MODE == 0 ? B2S_IV_D[k] : 0u;
+                if (MODE == 0) { d[0] ^= 0x01010020u; b2s_compress(d, m, 4u * nc, 0xFFFFFFFFu); } else b2s_compress(d, m, 0, 0);
+                store_node(a.tree, in_log, 4 * g + r, d);
+            }
+            node_hash<MODE>(pr, n1 + 8 * hlf);
+            store_node(a.tree, in_log - 1, 2 * g + hlf, n1 + 8 * hlf);
+        }
+    }
+    node_hash<MODE>(n1, n2);
+    store_node(a.tree, in_log - 2, g, n2);
+    {
+        u32* o = fz + (size_t)(1023 + tid) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = n2[k];
+    }
+    __syncthreads();
+    int lvl = in_log - 3;                                            // levels in_log - 3 ... in_log - 6: 512 ... 64 nodes of the block, one lane per node
+    for (u32 m = 512; m >= 64; m >>= 1, lvl--) {
+        const u32* in_l = fz + (size_t)(2 * m - 1) * 8;
+        u32* out_l = fz + (size_t)(m - 1) * 8;
+        if (tid < m) {
+            u32 msg[16], h[8];
+#pragma unroll
+            for (int k = 0; k < 16; k++) msg[k] = in_l[(size_t)tid * 16 + k];
+            node_hash<MODE>(msg, h);
+            if (m > 64) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) out_l[(size_t)tid * 8 + k] = h[k];
+            }
+            store_node(a.tree, lvl, blockIdx.x * m + tid, h);
+        }
+        if (m > 64) __syncthreads();
+    }
+}
+
 // An empty tree of 2^max_log leaves (one device allocation, layer k at node offset 2^k - 1).
 int tree_alloc(nx_ctx* ctx, uint32_t max_log, nx_tree** out) {
     nx_tree* t = new nx_tree();
@@ -588,6 +706,53 @@ int leaf_chain_launch(nx_ctx* ctx, hipStream_t stream, ColSet cs, u32 n_cols, u3
     else
         hipLaunchKernelGGL(merkle_leaf_chain_kernel<1>, grid, block, 0, stream, cs, n_cols, col_offset, total_cols, state_in, state_out, row_begin, n_rows);
     NX_LAUNCH_CHECK(ctx);
+    return NX_OK;
+}
+
+
+static int build_inner_layers(nx_ctx* ctx, nx_tree* t, uint32_t max_log, const std::vector<const uint32_t*>& sorted, const std::vector<uint32_t>& logs);
+static int fused_launch(nx_ctx* ctx, int src, FusedTreeArgs a, nx_tree* t) {
+    static std::atomic<uint64_t> attr_set{0};   // one bit per device: function attributes are per device
+    if (!(attr_set.load() & (1ull << (ctx->device & 63)))) {
+        const void* fns[] = {(const void*)merkle_fused_kernel<0, SRC_COLS>, (const void*)merkle_fused_kernel<0, SRC_FOLD>, (const void*)merkle_fused_kernel<1, SRC_COLS>, (const void*)merkle_fused_kernel<1, SRC_FOLD>};
+        for (const void* f : fns) NX_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set.fetch_or(1ull << (ctx->device & 63));
+    }
+    const dim3 grid(1u << (a.leaf_log - 12)), block(1024);
+    const size_t lds = (size_t)FUSED_LDS_WORDS * 4;
+    const bool std_hash = ctx->hash_mode == NX_HASH_BLAKE2S;
+    if (src == SRC_COLS) { if (std_hash) hipLaunchKernelGGL((merkle_fused_kernel<0, SRC_COLS>), grid, block, lds, ctx->stream, a); else hipLaunchKernelGGL((merkle_fused_kernel<1, SRC_COLS>), grid, block, lds, ctx->stream, a); }
+    else { if (std_hash) hipLaunchKernelGGL((merkle_fused_kernel<0, SRC_FOLD>), grid, block, lds, ctx->stream, a); else hipLaunchKernelGGL((merkle_fused_kernel<1, SRC_FOLD>), grid, block, lds, ctx->stream, a); }
+    NX_LAUNCH_CHECK(ctx);
+    return build_inner_layers(ctx, t, (uint32_t)a.leaf_log - FUSED_LEVELS, {}, {});      // level leaf_log - 6 is hashed: the rest level by level
+}
+// MerkleProver::commit of n_cols <= 4 columns of one size: leaf hash and 6 levels in one launch, then the level-by-level path
+int merkle_commit_fused(nx_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t log, nx_tree** out) {
+    if (n_cols < 1 || n_cols > 4 || log < FUSED_MIN_LOG || log > 30) return set_err(ctx, NX_ERR_ARG, "merkle_commit_fused: 1 .. 4 columns of 2^12 .. 2^30 rows");
+    nx_tree* t = nullptr;
+    NX_TRY(tree_alloc(ctx, log, &t));
+    KTimer timer(ctx, NX_T_MERKLE, ((uint64_t)4 * n_cols + 128) << log);
+    FusedTreeArgs a; memset(&a, 0, sizeof a);
+    a.tree = t->layers[0]; a.leaf_log = (int)log; a.n_cols = n_cols;
+    for (uint32_t k = 0; k < n_cols; k++) a.col[k] = d_cols[k];
+    const int rc = fused_launch(ctx, SRC_COLS, a, t);
+    if (rc != NX_OK) { nx_tree_destroy(t); return rc; }
+    *out = t;
+    return NX_OK;
+}
+// One inner layer of FriProver::commit: dst = fold_line(src, alpha) (2^(src_log - 1) points) and its Merkle tree; the fold, the leaf hash and 6 levels are one launch
+int fri_fold_commit_fused(nx_ctx* ctx, const nx_twiddles* tw, const uint32_t* const* d_src4, uint32_t src_log, const uint32_t* d_alpha, uint32_t* const* d_dst4, nx_tree** out) {
+    if (src_log < FUSED_MIN_LOG + 1 || src_log > tw->log_half) return set_err(ctx, NX_ERR_ARG, "fri_fold_commit_fused: layer size out of range");
+    nx_tree* t = nullptr;
+    NX_TRY(tree_alloc(ctx, src_log - 1, &t));
+    KTimer timer(ctx, NX_T_MERKLE, (uint64_t)(16 + 128) << (src_log - 1));
+    FusedTreeArgs a; memset(&a, 0, sizeof a);
+    a.tree = t->layers[0]; a.leaf_log = (int)src_log - 1;
+    for (int q = 0; q < 4; q++) { a.fsrc[q] = d_src4[q]; a.fdst[q] = d_dst4[q]; }
+    a.itw = tw->d_itw; a.tw_log = tw->log_half; a.alpha = d_alpha;
+    const int rc = fused_launch(ctx, SRC_FOLD, a, t);
+    if (rc != NX_OK) { nx_tree_destroy(t); return rc; }
+    *out = t;
     return NX_OK;
 }
 
@@ -715,6 +880,8 @@ int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t*
     std::vector<const uint32_t*> sorted(n_cols);
     for (uint32_t i = 0; i < n_cols; i++) sorted[i] = d_cols[order[i]];
 
+    if (ctx->opt.merkle_fused && n_cols >= 1 && n_cols <= 4 && max_log >= (uint32_t)std::max(ctx->opt.merkle_fused, (int)FUSED_MIN_LOG) && log_sizes[order[n_cols - 1]] == max_log)
+        return merkle_commit_fused(ctx, sorted.data(), n_cols, max_log, out);      // a secure column (composition tree, a FRI layer): leaf hash and 6 levels in one launch
     nx_tree* t = new nx_tree();
     t->ctx = ctx;
     uint32_t* buf = nullptr;

@@ -539,6 +539,7 @@ class FriProver {
             void* staged = nullptr; H_TRY(stage(ctx, h.data(), h.size() * 4, &staged));
             H_TRY(nx_copy(ctx, d_state.p, (const uint32_t*)staged, FRI_STATE_HEAD));
         }
+        const uint32_t fused_min = ctx->opt.merkle_fused ? (uint32_t)std::max(ctx->opt.merkle_fused, 12) : 64u;   // "merkle.fused": from this size a layer's fold, leaf hash and first 6 levels are one launch
         {   // first layer: every circle column in one mixed-degree tree
             std::vector<const uint32_t*> p; std::vector<uint32_t> logs;
             for (auto& c : columns) for (int k = 0; k < 4; k++) { p.push_back(c.c[k]); logs.push_back(c.log); }
@@ -551,9 +552,18 @@ class FriProver {
         H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
         size_t ci = 0;
         const bool use_tail = ctx->opt.fri_tail != 0;
+        // `pending`: `layer` is allocated but not computed yet — it is fold_line(inner.back().eval, alpha of record j_prev), which the fused
+        // launch of the layer's commit computes on its way (or fold_line_dev, where the layer is needed before its commit)
+        bool pending = false;
+        auto materialize = [&]() -> int {
+            if (!pending) return NX_OK;
+            pending = false;
+            return fold_line_dev(ctx, tw, (const uint32_t* const*)inner.back().eval.c, layer_log + 1, rec_alpha(j_prev), layer.c);
+        };
         while (layer_log > last_log) {
             const int j = (int)inner.size() + 1;   // record of the layer committed in this iteration
             if (use_tail && ci == columns.size() && layer_log <= (uint32_t)FRI_TAIL_LOG && layer_log - last_log <= (uint32_t)FRI_TAIL_MAX_LAYERS) {
+                H_TRY(materialize());
                 const int n = (int)(layer_log - last_log);
                 std::vector<FriLayer> tl(n);
                 std::vector<uint32_t*> evals(n + 1), trees(n);
@@ -572,25 +582,31 @@ class FriProver {
                 layer_log = last_log;
                 break;
             }
+            if (ci < columns.size() && columns[ci].log - 1 == layer_log) H_TRY(materialize());     // a circle column joins here: it folds INTO the layer
             while (ci < columns.size() && columns[ci].log - 1 == layer_log) {
                 const uint32_t* a = rec_alpha(cfg.fri_alpha_mode == NX_FRI_ALPHA_PREV ? j_prev : 0);
                 H_TRY(fold_circle_dev(ctx, tw, layer.c, (const uint32_t* const*)columns[ci].c, columns[ci].log, a));
                 ci++;
             }
             FriLayer L; L.eval = std::move(layer);
-            {
+            if (pending && layer_log >= fused_min) {
+                pending = false;
+                H_TRY(fri_fold_commit_fused(ctx, tw, (const uint32_t* const*)inner.back().eval.c, layer_log + 1, rec_alpha(j_prev), L.eval.c, &L.merkle.local));
+            } else {
+                if (pending) { pending = false; H_TRY(fold_line_dev(ctx, tw, (const uint32_t* const*)inner.back().eval.c, layer_log + 1, rec_alpha(j_prev), L.eval.c)); }
                 std::vector<const uint32_t*> p; std::vector<uint32_t> logs;
                 for (int k = 0; k < 4; k++) { p.push_back(L.eval.c[k]); logs.push_back(layer_log); }
-                H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), 4, &L.merkle.local));
-                L.merkle.n_layers = layer_log + 1;
+                H_TRY(nx_merkle_commit(ctx, p.data(), logs.data(), 4, &L.merkle.local));      // ("merkle.fused": leaf hash + 6 levels in one launch from that size up)
             }
             H_TRY(fri_channel_step(ctx, d_state.p, L.merkle.local->layers[0], j));
+            L.merkle.n_layers = layer_log + 1;
             SecureColumn next; H_TRY(next.alloc(ctx, layer_log - 1));
-            H_TRY(fold_line_dev(ctx, tw, (const uint32_t* const*)L.eval.c, layer_log, rec_alpha(j), next.c));
             inner.push_back(std::move(L));
-            layer = std::move(next);
+            layer = std::move(next);               // computed by the next commit's launch (or materialize)
+            pending = true;
             layer_log--; j_prev = j;
         }
+        H_TRY(materialize());
         {   // the one host round trip of the commit phase: channel state and every layer's root
             std::vector<uint32_t> st(st_words);
             H_TRY(nx_download(ctx, st.data(), d_state.p, FRI_STATE_HEAD + FRI_STATE_REC * (1 + inner.size())));

@@ -111,6 +111,19 @@ def test_machine_degree_split_off_gives_the_same_bytes(nz, oracle):
         b.close()
 
 
+def test_secure_column_trees_with_the_fused_leaf_launch(nz, oracle):
+    """"merkle.fused" (round 6): the tree of <= 4 columns of one size — the composition tree, every FRI layer — gets its leaf hash, for a
+    FRI layer also the line fold that produces the layer, and 6 levels in ONE launch from the given log size up (default 21: the sizes
+    where it pays).  Forced down to 2^12 / 2^14 here, both node-hash rules: the same proof as the level-by-level path and the oracle."""
+    for comps, kw in (MACHINE_CASES[5], ([(15, 3, 20, 8)], dict(pow_bits=4, hash_mode=1, fri_alpha_mode=1))):
+        ref = M.prove_machine(comps, O.default_cfg(**kw), seed=12, ad=b"mf", threads=THREADS)
+        for fused in (0, 12, 14):
+            b = nz.HipBackend()
+            b.set_option("merkle.fused", fused)
+            _same(ref, b.prove_machine(comps, nz.default_config(**kw), seed=12, ad=b"mf"))
+            b.close()
+
+
 def test_machine_quotients_from_coefficients_or_rows(nz, oracle):
     """"quotients.coeffs": the DEEP quotients of the wide size group accumulated from the coefficient columns (combine per sample point,
     extend, finish row by row) or row-wise over the extensions like Stwo — the same proof, == the oracle's; also at blowup 4."""
