@@ -500,7 +500,12 @@ void nx_air_kernel_destroy(nx_air_kernel* kernel);
  * share a directory).  Process-wide.  The directory is TRUSTED INPUT — its files are GPU code objects, accepted on a 64-bit checksum, not a
  * signature: it is created with mode 0700 and ignored (with one line on stderr) unless it is a directory owned by the calling user that
  * neither group nor others may write to.
- * nx_air_cache_stats: kernels compiled by hiprtc / loaded from the directory / stored into it by this process (any pointer may be NULL). */
+ * nx_air_cache_stats: kernels compiled by hiprtc / loaded from the directory / stored into it by this process (any pointer may be NULL).
+ * COMPILATION IN PROCESSES: a generated source of >= 4 kernels is cut into one part per kernel and the parts are compiled side by side by
+ * helper processes — the executable nx_air_cc next to this library (environment NX_AIR_CC: another path), at most NX_AIR_COMPILE_PROCS at a
+ * time (default: the host's hardware threads, at most 32; 1 = everything in this process).  hiprtc serialises the threads of a process, not
+ * processes: the first proof of the keccak-shaped statement waits 2.1 s instead of 14 s (profiles/r06_compile_procs.jsonl).  The blob is
+ * the same bytes however it was compiled; without the helper the parts go through hiprtc here. */
 int nx_air_kernel_save(const nx_air_kernel* kernel, uint8_t** blob, size_t* n_bytes);
 int nx_air_kernel_load(nx_ctx* ctx, const uint8_t* blob, size_t n_bytes, nx_air_kernel** out);
 int nx_air_cache_dir(const char* dir);

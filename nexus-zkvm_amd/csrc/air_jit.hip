@@ -22,14 +22,20 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <condition_variable>
+#include <thread>
+#include <dlfcn.h>
+#include <spawn.h>
+#include <sys/wait.h>
+extern char** environ;
 
 struct nx_air_kernel {
     nx_ctx* ctx;
-    hipModule_t module;
+    std::vector<hipModule_t> modules;    // one code object, or one per PART of the program's kernels (compiled side by side in helper processes: compile_parts)
     std::vector<hipFunction_t> fns;      // one kernel per program segment (air_kernel, air_kernel_1, ...), launched back to back
     uint32_t n_cols, n_econsts, n_constraints;
     uint32_t kind = 0;                    // 0: constraint kernels (nx_air_eval's argument list); 1: fraction kernels of nx_logup_program (another argument list)
-    std::vector<char> code;              // the gfx950 code object the module was loaded from (nx_air_kernel_save; the disk cache)
+    std::vector<char> code;              // the gfx950 code object the module was loaded from, or a container of several (nx_air_kernel_save; the disk cache)
 };
 
 namespace nx {
@@ -380,16 +386,41 @@ std::string cache_dir() {
     if (!s.init) { const char* e = getenv("NX_AIR_CACHE_DIR"); if (e && *e) s.dir = trusted_cache_dir(e); s.init = true; }
     return s.dir;
 }
+// The code region of a kernel blob: ONE gfx950 code object (an ELF image), or — a program of many kernels, compiled in parts — a container
+// "NXMM", u32 n_parts, then per part {u32 first_kernel, u32 n_kernels, u64 size}, then the parts' code objects, each 8-byte aligned.
+constexpr uint32_t PARTS_MAGIC = 0x4D4D584Eu /* "NXMM" */;
+struct PartDesc { uint32_t first_kernel, n_kernels; uint64_t size; };
+static void unload_modules(nx_air_kernel* k) { for (hipModule_t m : k->modules) (void)hipModuleUnload(m); k->modules.clear(); }
 int load_code(nx_ctx* ctx, const BlobHeader& h, const char* code, nx_air_kernel** out) {
     nx_air_kernel* k = new nx_air_kernel();
     k->ctx = ctx; k->n_cols = h.n_cols; k->n_econsts = h.n_econsts; k->n_constraints = h.n_constraints; k->kind = (uint32_t)h.reserved;
     k->code.assign(code, code + h.code_size);
-    hipError_t e = hipModuleLoadData(&k->module, k->code.data());
-    if (e != hipSuccess) { delete k; return hip_fail(ctx, e, "hipModuleLoadData(air kernel)", __FILE__, __LINE__); }
-    k->fns.resize(h.n_kernels);
-    for (uint32_t f = 0; f < h.n_kernels && e == hipSuccess; f++)
-        e = hipModuleGetFunction(&k->fns[f], k->module, f == 0 ? "air_kernel" : ("air_kernel_" + std::to_string(f)).c_str());
-    if (e != hipSuccess) { (void)hipModuleUnload(k->module); delete k; return hip_fail(ctx, e, "hipModuleGetFunction(air kernel)", __FILE__, __LINE__); }
+    std::vector<PartDesc> parts; std::vector<size_t> offs;
+    uint32_t magic = 0; if (h.code_size >= 8) memcpy(&magic, k->code.data(), 4);
+    if (magic == PARTS_MAGIC) {
+        uint32_t n_parts = 0; memcpy(&n_parts, k->code.data() + 4, 4);
+        size_t off = 8 + (size_t)n_parts * sizeof(PartDesc);
+        if (n_parts == 0 || n_parts > 4096 || off > h.code_size) { delete k; return set_err(ctx, NX_ERR_ARG, "air kernel blob: malformed part table"); }
+        parts.resize(n_parts);
+        memcpy(parts.data(), k->code.data() + 8, (size_t)n_parts * sizeof(PartDesc));
+        for (const PartDesc& pd : parts) {
+            off = (off + 7) & ~(size_t)7;
+            if (pd.size > h.code_size || off > h.code_size - pd.size || (uint64_t)pd.first_kernel + pd.n_kernels > h.n_kernels) { delete k; return set_err(ctx, NX_ERR_ARG, "air kernel blob: malformed part table"); }
+            offs.push_back(off); off += pd.size;
+        }
+    } else { parts.push_back({0u, h.n_kernels, h.code_size}); offs.push_back(0); }
+    k->fns.assign(h.n_kernels, nullptr);
+    hipError_t e = hipSuccess;
+    for (size_t q = 0; q < parts.size() && e == hipSuccess; q++) {
+        hipModule_t m;
+        e = hipModuleLoadData(&m, k->code.data() + offs[q]);
+        if (e != hipSuccess) break;
+        k->modules.push_back(m);
+        for (uint32_t f = parts[q].first_kernel; f < parts[q].first_kernel + parts[q].n_kernels && e == hipSuccess; f++)
+            e = hipModuleGetFunction(&k->fns[f], m, f == 0 ? "air_kernel" : ("air_kernel_" + std::to_string(f)).c_str());
+    }
+    for (hipFunction_t f : k->fns) if (e == hipSuccess && !f) e = hipErrorNotFound;
+    if (e != hipSuccess) { unload_modules(k); delete k; return hip_fail(ctx, e, "hipModuleLoadData / hipModuleGetFunction(air kernel)", __FILE__, __LINE__); }
     *out = k;
     return NX_OK;
 }
@@ -463,6 +494,129 @@ int nx_air_compile_subset(nx_ctx* ctx, const nx_cinstr* program, uint32_t n_inst
 }  // extern "C"
 
 namespace nx {
+// ---- compilation: in this process, or — a program of many kernels — its parts side by side in helper PROCESSES ---------------------------
+// hiprtc serialises the threads of a process (measured in round 5: 8 threads, no gain), and the first proof of a wide AIR waited 10 s (the
+// keccak-shaped statement; 31 s at the reference's tuple widths) for ~80 kernels compiled one after the other.  The kernels of a generated
+// source are independent: the source is cut into PARTS of PART_KERNELS kernels (prelude + that kernel: a function of the source alone, so
+// the blob is the same bytes however it was compiled), and up to "NX_AIR_COMPILE_PROCS" helpers — the executable nx_air_cc beside this
+// library (csrc/host/air_cc.cpp; NX_AIR_CC overrides the path) — compile one part each.  No helper, one process allowed, or a short
+// program: the parts (or the whole source) go through hiprtc here.
+constexpr uint32_t PART_KERNELS = 1, PARTS_MIN_KERNELS = 4;
+static const char* KERNEL_MARK = "extern \"C\" __attribute__((global))";
+
+static int hiprtc_compile(nx_ctx* ctx, const std::string& src, std::vector<char>* code) {
+    hiprtcProgram rp;
+    if (hiprtcCreateProgram(&rp, src.c_str(), "nx_air_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return set_err(ctx, NX_ERR_HIP, "hiprtcCreateProgram failed");
+    const char* opts[] = {"--offload-arch=gfx950", hiprtc_opt_level()};
+    hiprtcResult cr = hiprtcCompileProgram(rp, 2, opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t ls = 0; (void)hiprtcGetProgramLogSize(rp, &ls);
+        std::string log(ls, '\0'); if (ls) (void)hiprtcGetProgramLog(rp, &log[0]);
+        (void)hiprtcDestroyProgram(&rp);
+        return set_err(ctx, NX_ERR_HIP, "hiprtc compilation of the recorded AIR failed: " + log.substr(0, 400));
+    }
+    size_t cs = 0; (void)hiprtcGetCodeSize(rp, &cs);
+    code->resize(cs);
+    (void)hiprtcGetCode(rp, code->data());
+    (void)hiprtcDestroyProgram(&rp);
+    return NX_OK;
+}
+static int compile_procs() { const char* e = getenv("NX_AIR_COMPILE_PROCS"); const int hw = (int)std::thread::hardware_concurrency(); return e && *e ? atoi(e) : std::max(1, std::min(32, hw)); }   // read per compilation: a tool may flip it; more than 32 measured no faster (profiles/r06_compile_procs.jsonl)
+static std::string helper_path() {
+    static const std::string path = [] {
+        const char* e = getenv("NX_AIR_CC");
+        std::string p;
+        if (e && *e) p = e;
+        else { Dl_info info; if (dladdr((const void*)&helper_path, &info) && info.dli_fname) { p = info.dli_fname; const size_t sl = p.rfind('/'); p = (sl == std::string::npos ? std::string(".") : p.substr(0, sl)) + "/nx_air_cc"; } }
+        return !p.empty() && access(p.c_str(), X_OK) == 0 ? p : std::string();
+    }();
+    return path;
+}
+// at most compile_procs() helpers of this process at a time, whichever thread started them
+struct ProcGate { std::mutex mu; std::condition_variable cv; int running = 0; };
+static ProcGate& proc_gate() { static ProcGate g; return g; }
+static bool read_file(const std::string& path, std::vector<char>* out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[1 << 16]; size_t got; out->clear();
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) out->insert(out->end(), buf, buf + got);
+    fclose(f);
+    return true;
+}
+// src -> the code region of its blob (one code object, or the "NXMM" container of its parts)
+static int compile_parts(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, std::vector<char>* code) {
+    std::vector<size_t> marks;
+    for (size_t p = src.find(KERNEL_MARK); p != std::string::npos; p = src.find(KERNEL_MARK, p + 1)) marks.push_back(p);
+    if (n_kernels < PARTS_MIN_KERNELS || marks.size() != n_kernels) return hiprtc_compile(ctx, src, code);
+    const std::string prelude = src.substr(0, marks[0]);
+    std::vector<std::string> part_src; std::vector<PartDesc> parts;
+    for (uint32_t k0 = 0; k0 < n_kernels; k0 += PART_KERNELS) {
+        const uint32_t k1 = std::min(n_kernels, k0 + PART_KERNELS);
+        part_src.push_back(prelude + src.substr(marks[k0], (k1 < n_kernels ? marks[k1] : src.size()) - marks[k0]));
+        parts.push_back({k0, k1 - k0, 0});
+    }
+    std::vector<std::vector<char>> objs(parts.size());
+    const std::string helper = helper_path();
+    const int procs = compile_procs();
+    // the hiprtc this process runs (PyTorch carries its own): the helpers load the same file, so a part is the same bytes wherever it is compiled
+    const std::string rtc_lib = [] { Dl_info info; return dladdr((const void*)&hiprtcCompileProgram, &info) && info.dli_fname ? std::string(info.dli_fname) : std::string(); }();
+    std::vector<char> done(parts.size(), 0);
+    if (procs > 1 && !helper.empty()) {
+        const char* tmp = getenv("TMPDIR");
+        std::string dir = std::string(tmp && *tmp ? tmp : "/tmp") + "/nxaircc.XXXXXX";
+        if (mkdtemp(&dir[0])) {
+            std::vector<pid_t> pid(parts.size(), -1);
+            ProcGate& g = proc_gate();
+            auto reap = [&](size_t q) {
+                int st = 0;
+                if (pid[q] > 0 && waitpid(pid[q], &st, 0) == pid[q]) {
+                    { std::lock_guard<std::mutex> lk(g.mu); g.running--; } g.cv.notify_one();
+                    if (WIFEXITED(st) && WEXITSTATUS(st) == 0 && read_file(dir + "/p" + std::to_string(q) + ".co", &objs[q]) && !objs[q].empty()) done[q] = 1;
+                }
+                pid[q] = -1;
+            };
+            size_t next_reap = 0;
+            for (size_t q = 0; q < parts.size(); q++) {
+                const std::string in = dir + "/p" + std::to_string(q) + ".hip", outp = dir + "/p" + std::to_string(q) + ".co";
+                FILE* f = fopen(in.c_str(), "wb");
+                if (!f) continue;
+                const bool ok = fwrite(part_src[q].data(), 1, part_src[q].size(), f) == part_src[q].size();
+                if (fclose(f) != 0 || !ok) continue;
+                {   // wait for a slot; a thread that holds every slot itself reaps its oldest helper first
+                    std::unique_lock<std::mutex> lk(g.mu);
+                    while (g.running >= procs) {
+                        if (next_reap < q) { lk.unlock(); while (next_reap < q && pid[next_reap] <= 0) next_reap++; if (next_reap < q) reap(next_reap++); lk.lock(); }
+                        else g.cv.wait(lk);
+                    }
+                    g.running++;
+                }
+                const char* argv[] = {helper.c_str(), in.c_str(), outp.c_str(), hiprtc_opt_level(), rtc_lib.c_str(), nullptr};
+                pid_t child = -1;
+                if (posix_spawn(&child, helper.c_str(), nullptr, nullptr, (char* const*)argv, environ) != 0) { std::lock_guard<std::mutex> lk(g.mu); g.running--; child = -1; }
+                pid[q] = child;
+            }
+            for (size_t q = 0; q < parts.size(); q++) if (pid[q] > 0) reap(q);
+            for (size_t q = 0; q < parts.size(); q++) { (void)remove((dir + "/p" + std::to_string(q) + ".hip").c_str()); (void)remove((dir + "/p" + std::to_string(q) + ".co").c_str()); (void)remove((dir + "/p" + std::to_string(q) + ".co.log").c_str()); }
+            (void)rmdir(dir.c_str());
+        }
+    }
+    for (size_t q = 0; q < parts.size(); q++)            // whatever no helper delivered (no helper at all; a compile error: hiprtc reports it here)
+        if (!done[q]) NX_TRY(hiprtc_compile(ctx, part_src[q], &objs[q]));
+    const uint32_t n_parts = (uint32_t)parts.size();
+    code->clear();
+    code->resize(8 + (size_t)n_parts * sizeof(PartDesc));
+    memcpy(code->data(), &PARTS_MAGIC, 4); memcpy(code->data() + 4, &n_parts, 4);
+    for (size_t q = 0; q < parts.size(); q++) {
+        parts[q].size = objs[q].size();
+        code->resize((code->size() + 7) & ~(size_t)7, 0);
+        code->insert(code->end(), objs[q].begin(), objs[q].end());
+    }
+    memcpy(code->data() + 8, parts.data(), (size_t)n_parts * sizeof(PartDesc));
+    return NX_OK;
+}
+}  // namespace nx
+
+namespace nx {
 // generated source -> loaded kernels: the cache directory first, else hiprtc (and the directory is fed)
 int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint32_t n_cols, uint32_t n_econsts, uint32_t n_constraints, nx_air_kernel** out, uint32_t kind) {
     const std::string dir = cache_dir();
@@ -480,20 +634,8 @@ int compile_source(nx_ctx* ctx, const std::string& src, uint32_t n_kernels, uint
             // a damaged or foreign file: fall through to the compiler (and overwrite it)
         }
     }
-    hiprtcProgram rp;
-    if (hiprtcCreateProgram(&rp, src.c_str(), "nx_air_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return set_err(ctx, NX_ERR_HIP, "hiprtcCreateProgram failed");
-    const char* opts[] = {"--offload-arch=gfx950", hiprtc_opt_level()};
-    hiprtcResult cr = hiprtcCompileProgram(rp, 2, opts);
-    if (cr != HIPRTC_SUCCESS) {
-        size_t ls = 0; (void)hiprtcGetProgramLogSize(rp, &ls);
-        std::string log(ls, '\0'); if (ls) (void)hiprtcGetProgramLog(rp, &log[0]);
-        (void)hiprtcDestroyProgram(&rp);
-        return set_err(ctx, NX_ERR_HIP, "hiprtc compilation of the recorded AIR failed: " + log.substr(0, 400));
-    }
-    size_t cs = 0; (void)hiprtcGetCodeSize(rp, &cs);
-    std::vector<char> code(cs);
-    (void)hiprtcGetCode(rp, code.data());
-    (void)hiprtcDestroyProgram(&rp);
+    std::vector<char> code;
+    NX_TRY(compile_parts(ctx, src, n_kernels, &code));
     cache_state().compiled++;
     BlobHeader h = {BLOB_MAGIC, BLOB_VERSION, n_kernels, n_cols, n_econsts, n_constraints, (uint64_t)code.size(), 0, kind};
     NX_TRY(load_code(ctx, h, code.data(), out));
@@ -552,7 +694,7 @@ void nx_air_kernel_destroy(nx_air_kernel* k) {
     if (!k) return;
     NX_GUARD(k->ctx);
     (void)hipStreamSynchronize(k->ctx->stream);
-    (void)hipModuleUnload(k->module);
+    for (hipModule_t m : k->modules) (void)hipModuleUnload(m);
     delete k;
 }
 

@@ -847,6 +847,43 @@ def test_air_kernels_ahead_of_time_blob_and_cache_directory(be, nz, oracle, tmp_
     assert len(list((tmp_path / "kernels").glob("nxair-*.nxak"))) == c1
 
 
+def test_many_kernel_program_compiled_in_helper_processes(be, nz, oracle, monkeypatch):
+    """Round 6: a program of many kernels ("air.segment" small: >= 4 segments) is cut into one part per kernel, and the
+    parts are compiled side by side by nx_air_cc helper PROCESSES (hiprtc serialises threads, not processes) — NX_AIR_COMPILE_PROCS=1
+    compiles the same parts in this process.  The blob is the same bytes either way ("NXMM" container behind the header), a kernel loaded
+    from it evaluates like the compiled one, and both match the oracle's interpreter."""
+    import nexus_zkvm_amd.air_program as ap
+    from test_air_program_cpu import denominators
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.access(os.path.join(root, "nexus-zkvm_amd", "nx_air_cc"), os.X_OK), "the helper is built by csrc/Makefile next to libnexus_hip.so"
+    rng = np.random.default_rng(78)
+    log, e, n_cols = 8, 9, 12
+    prog = _random_program(ap, rng, n_cols, 400)
+    cols = rng.integers(0, P, (n_cols, 1 << e), dtype=np.uint32)
+    pw = rng.integers(0, P, (prog.n_constraints, 4), dtype=np.uint32)
+    den = denominators(log, e)
+    start = rng.integers(0, P, (4, 1 << e), dtype=np.uint32)
+    want = np.stack(oracle.eval_constraint_program(prog, list(cols), pw, den, log, e, acc4=list(start)))
+    blobs = []
+    for procs in ("1", "8"):
+        monkeypatch.setenv("NX_AIR_COMPILE_PROCS", procs)
+        b = nz.HipBackend(0)
+        b.set_option("air.segment", 300)
+        kern = b.compile_air(prog, n_cols)
+        blob = kern.save()
+        assert blob[48:52] == b"NXMM" and int.from_bytes(blob[52:56], "little") >= 4        # one part per kernel
+        d_cols, acc = b.columns_from_host(cols), b.columns_from_host(start)
+        kern.eval([d_cols.ptr.value + k * (4 << e) for k in range(n_cols)], pw, den, log, e, acc)
+        assert np.array_equal(acc.to_cpu(), want)
+        k2 = nz.AirKernel(b, prog, n_cols, blob=blob)
+        a2 = b.columns_from_host(start)
+        k2.eval([d_cols.ptr.value + k * (4 << e) for k in range(n_cols)], pw, den, log, e, a2)
+        assert np.array_equal(a2.to_cpu(), want)
+        blobs.append(blob)
+        k2.close(); kern.close(); b.close()
+    assert blobs[0] == blobs[1]
+
+
 def test_air_jit_rejects_malformed_programs(be, nz):
     import nexus_zkvm_amd.air_program as ap
     pb = ap.ProgramBuilder()
