@@ -72,20 +72,21 @@ def test_oracle_machine_proves_and_verifies(oracle, comps, kw):
     assert v2.verify(components, bad) is not None
 
 
-@pytest.mark.parametrize("mode", [0, M.PAIRS, M.PAIRS | M.ODD, M.TABLE | M.PAIRS])
+@pytest.mark.parametrize("mode", [0, M.PAIRS, M.PAIRS | M.ODD, M.TABLE | M.PAIRS, M.TUPLES(M.V1), M.PAIRS | M.TUPLES(M.KECCAK), M.PAIRS | M.ODD | M.TUPLES(M.V2)])
 def test_logup_constraints_catch_a_wrong_interaction_trace(oracle, mode):
     """A trace built from other tuple columns than the AIR constrains breaks the recorded logup constraints — in every logup form: the
     oracle prover's OODS check refuses."""
     import ref_emitter as ap
     comps = [(5, 4, 6, 8, 1, mode)]
     cfg = O.default_cfg(pow_bits=2)
-    real = M.frac_def
+    real = M.frac_shape
 
     def shifted(comp, f):
-        tree, tup, m = real(comp, f)
-        return tree, [(tup[0] + 1) % comp[1 + tree]] + tup[1:], m
+        tree, ent, num, m = real(comp, f)
+        k = next(i for i, e in enumerate(ent) if e[0] != "const")                               # the first entry that reads a column: the next column instead
+        return tree, ent[:k] + [(ent[k][0], (ent[k][1] + 1) % comp[1 + tree]) + tuple(ent[k][2:])] + ent[k + 1:], num, m
     try:
-        M.frac_def = shifted                                                                     # trace built for other tuple columns ...
+        M.frac_shape = shifted                                                                   # trace built for other tuple columns ...
         main, pre = O.synth_tree_columns(comps, 1, 3), O.synth_tree_columns(comps, 0, 3)
         s = O.ProverSession(cfg, 5, 2)
         s.mix_u64(5)
@@ -93,13 +94,13 @@ def test_logup_constraints_catch_a_wrong_interaction_trace(oracle, mode):
         z, alpha = s.draw_felts(2)
         cols, cs = M.interaction_trace(comps[0], main, z, alpha, pre)
         s.mix_felts(np.array([cs], np.uint32)); s.commit(cols)
-        M.frac_def = real                                                                        # ... than the AIR constrains
+        M.frac_shape = real                                                                      # ... than the AIR constrains
         n_inv = pow(32, P - 2, P)
         comp = M.machine_component(ap, comps[0], (0, 0, 0), z, alpha, np.array([(int(x) * n_inv) % P for x in cs], np.uint32))
         with pytest.raises(RuntimeError):
             s.prove([comp])
     finally:
-        M.frac_def = real
+        M.frac_shape = real
 
 
 def test_per_component_degree_bound_sets_the_composition_size(oracle):
