@@ -255,6 +255,19 @@ def main():
                   "stages_ms": {k: round(v1_stats[k], 3) for k in STAGES},
                   "roofline": lde_roofline(v1_stats, args.log_rows, n_cols),
                   "merkle": {"kernel_ms": v1_stats["merkle_kernel_ms"], "algorithmic_bytes": v1_stats["merkle_algorithmic_bytes"]}}
+            # round 6: the same statement with the main component's relations at the reference's tuple WIDTHS and entry kinds (NX_TUPLES_V1:
+            # 1 / 4 = [constant, b, c, a] with a flag-column numerator / 9 / 3 = [column, constant, column + column] — range256.rs:37,
+            # bit_op.rs:31,341-365, register_mem_check.rs:34) instead of one- / two-column tuples: what the interaction stage and the
+            # logup constraints of the reference's shape cost
+            try:
+                t_comps = [v1_comps[0] + (nz.TUPLES_V1,)] + v1_comps[1:]
+                t_el = timed(t_comps, v1_cfg, v1_steps, 1)
+                _, t_stats = prove(t_comps, v1_cfg, 4244, want_stats=True)
+                v1["reference_tuple_widths"] = {"what": "main component with NX_TUPLES_V1 (tuple widths 1, 1, 4, 1, 9, 1, 3, 1 cycling; constant and column-sum entries; +1 / -m / +m numerators)",
+                                                "ms_per_step": 1e3 * t_el / v1_steps, "value": (1 << args.log_rows) * v1_steps / t_el, "unit": "cycles/s",
+                                                "stages_ms": {k: round(t_stats[k], 3) for k in STAGES}}
+            except Exception as e:   # noqa: BLE001
+                v1["reference_tuple_widths"] = {"error": repr(e)[:300]}
         except Exception as e:   # noqa: BLE001 — the headline line must still be printed
             v1 = {"error": repr(e)[:300]}
 

@@ -851,6 +851,44 @@ std::vector<uint32_t> vanishing_denominators(uint32_t log_size, uint32_t e) {
     return den;
 }
 
+// Row-sharded prove: every GPU evaluates the polynomials IT holds of the selected columns on the 2^out_log-point domain of `tw_sub`
+// (nx_evaluate_batch, expansion out_log - log_size), and one all-to-all hands out row blocks: (*blk)[i] = this GPU's rows
+// [D.begin(out_log), + D.block(out_log)) of column sel[i] (not biased).  Receive layout: by source GPU, the source's columns in `sel` order.
+static int sharded_evaluate_exchange(CommitmentSchemeProver& cs, const std::vector<std::pair<uint32_t, uint32_t>>& comp_cols, const std::vector<size_t>& sel, const nx_twiddles* tw_sub,
+                                     uint32_t log_size, uint32_t out_log, std::vector<uint32_t*>* blk, std::vector<DevBuf>* keep) {
+    nx_ctx* ctx = cs.ctx;
+    const Dist& D = cs.dist;
+    const size_t ns = sel.size();
+    blk->assign(ns, nullptr);
+    if (out_log < (uint32_t)D.log_w + 2) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: the constraint domain needs at least 4 rows per GPU");
+    const uint64_t mb = D.block(out_log);
+    std::vector<int> own(ns, -1); std::vector<uint32_t> pos(ns, 0); std::vector<uint32_t> cnt(D.world, 0);
+    for (size_t i = 0; i < ns; i++) {
+        own[i] = cs.trees[comp_cols[sel[i]].first].owner[comp_cols[sel[i]].second];
+        if (own[i] < 0) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: a trace column is not column-sharded");
+        pos[i] = cnt[own[i]]++;
+    }
+    const uint32_t n_loc = cnt[D.rank];
+    DevBuf ext, send, rows;
+    H_TRY(rows.alloc(ctx, std::max<size_t>(ns, 1) * mb));
+    if (n_loc) {
+        H_TRY(ext.alloc(ctx, (size_t)n_loc << out_log));
+        std::vector<const uint32_t*> src;
+        for (size_t i = 0; i < ns; i++) if (own[i] == D.rank) src.push_back(cs.trees[comp_cols[sel[i]].first].polys[comp_cols[sel[i]].second].ptr);
+        auto dst = col_ptrs(ext.p, n_loc, out_log);
+        H_TRY(nx_evaluate_batch(ctx, tw_sub, src.data(), n_loc, log_size, out_log - log_size, dst.data()));
+        H_TRY(send.alloc(ctx, (size_t)n_loc << out_log));
+        H_TRY(transpose_blocks(ctx, ext.p, (uint64_t)1 << out_log, send.p, n_loc, (uint64_t)1 << out_log, (uint32_t)D.world, false));
+    }
+    std::vector<size_t> soff(D.world), scnt(D.world), roff(D.world), rcnt(D.world);
+    size_t acc = 0;
+    for (int r = 0; r < D.world; r++) { soff[r] = (size_t)r * n_loc * mb; scnt[r] = (size_t)n_loc * mb; roff[r] = acc; rcnt[r] = (size_t)cnt[r] * mb; acc += rcnt[r]; }
+    H_TRY(D.alltoallv(ctx, send.p, soff.data(), scnt.data(), rows.p, roff.data(), rcnt.data()));
+    for (size_t i = 0; i < ns; i++) (*blk)[i] = rows.p + roff[own[i]] + (size_t)pos[i] * mb;
+    keep->push_back(std::move(rows));
+    return NX_OK;
+}
+
 // `used` (optional): the component columns the kernel will read; the others get a NULL pointer and cost nothing (no re-evaluation, no
 // exchange) — the high-degree part of a degree-split component reads a fraction of the columns.
 int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pair<uint32_t, uint32_t>>& comp_cols, uint32_t log_size, uint32_t e,
@@ -880,32 +918,9 @@ int columns_on_eval_domain(CommitmentSchemeProver& cs, const std::vector<std::pa
     if (committed) {
         for (size_t k : sel) blk[k] = cs.trees[comp_cols[k].first].evals[comp_cols[k].second].ptr;
     } else {
-        // every GPU re-evaluates the polynomials it holds; one all-to-all hands out the rows.  Receive layout: by source GPU, the
-        // source's columns in the component's column order.
-        std::vector<int> own(n, -1); std::vector<uint32_t> pos(n, 0); std::vector<uint32_t> cnt(D.world, 0);
-        for (size_t k : sel) {
-            own[k] = cs.trees[comp_cols[k].first].owner[comp_cols[k].second];
-            if (own[k] < 0) return set_err(ctx, NX_ERR_ARG, "row-sharded prove: a trace column is not column-sharded");
-            pos[k] = cnt[own[k]]++;
-        }
-        const uint32_t n_loc = cnt[D.rank];
-        DevBuf ext, send, rows;
-        H_TRY(rows.alloc(ctx, std::max<size_t>(ns, 1) * mb));
-        if (n_loc) {
-            H_TRY(ext.alloc(ctx, (size_t)n_loc << e));
-            std::vector<const uint32_t*> src;
-            for (size_t k : sel) if (own[k] == D.rank) src.push_back(cs.trees[comp_cols[k].first].polys[comp_cols[k].second].ptr);
-            auto dst = col_ptrs(ext.p, n_loc, e);
-            H_TRY(nx_evaluate_batch(ctx, cs.tw, src.data(), n_loc, log_size, e - log_size, dst.data()));
-            H_TRY(send.alloc(ctx, (size_t)n_loc << e));
-            H_TRY(transpose_blocks(ctx, ext.p, (uint64_t)1 << e, send.p, n_loc, (uint64_t)1 << e, (uint32_t)D.world, false));
-        }
-        std::vector<size_t> soff(D.world), scnt(D.world), roff(D.world), rcnt(D.world);
-        size_t acc = 0;
-        for (int r = 0; r < D.world; r++) { soff[r] = (size_t)r * n_loc * mb; scnt[r] = (size_t)n_loc * mb; roff[r] = acc; rcnt[r] = (size_t)cnt[r] * mb; acc += rcnt[r]; }
-        H_TRY(D.alltoallv(ctx, send.p, soff.data(), scnt.data(), rows.p, roff.data(), rcnt.data()));
-        for (size_t k : sel) blk[k] = rows.p + roff[own[k]] + (size_t)pos[k] * mb;
-        out->keep.push_back(std::move(rows));
+        std::vector<uint32_t*> b2;
+        H_TRY(sharded_evaluate_exchange(cs, comp_cols, sel, cs.tw, log_size, e, &b2, &out->keep));
+        for (size_t i = 0; i < ns; i++) blk[sel[i]] = b2[i];
     }
     {   // columns read at a non-zero mask offset: neighbour rows live in other blocks, so the whole columns — one all-gather for all of them
         std::vector<const uint32_t*> mblk; std::vector<size_t> mk;
@@ -1249,7 +1264,7 @@ int prepare_component_kernels(nx_ctx* ctx, const PcsConfig& cfg, GComponent& g, 
     const uint32_t bound = comp_log_cd(g.log_cd, cfg);
     const bool can_half = ctx->opt.air_half_domain && !sharded && cfg.log_blowup == 1 && g.log_size >= 4 && g.n_constraints > 0;
     const bool can_low = ctx->opt.air_degree_split && bound > 1 && bound != cfg.log_blowup && g.n_constraints > 0;
-    const bool can_quarter = ctx->opt.air_quarter_domain && !sharded && cfg.log_blowup == 1 && bound == 2 && g.log_size >= 4 && g.n_constraints > 0;
+    const bool can_quarter = ctx->opt.air_quarter_domain && cfg.log_blowup == 1 && bound == 2 && g.log_size >= 4 && g.n_constraints > 0;   // also row-sharded (round 6): the quarter's columns are an N-point transform on their owner and an N-row exchange instead of 4N / 4N
     if (!can_half && !can_low && !can_quarter) {
         GComponent::Part whole; whole.whole = true; whole.where = GComponent::ON_FULL;
         if (g.kernel) whole.kernel = g.kernel; else H_TRY(cached_air_kernel(ctx, g, nullptr, &whole.kernel));
@@ -1378,7 +1393,7 @@ static int axpy_scale(nx_ctx* ctx, u32* out, const u32* a, const u32* b, u32 s1,
 // 3N + 1 constraint evaluations instead of 4N, and per column an N-point transform + one sweep instead of a 4N-point transform.  The
 // 4N coefficients [F0 | I - t z0 | t, 0 ...] are those of the plain evaluation on all 4N rows, exactly; they enter
 // finalize_accumulation as a coefficient-form contribution.  Only for constraints that read no neighbour row (the quarter holds none).
-struct QuarterGroup { SecureColumn acc2n, accq; };     // accq: N + 4 rows per coordinate (rows [0, N) of the quarter and row N)
+struct QuarterGroup { SecureColumn acc2n, accq, rown; };     // accq: N + 4 rows per coordinate (rows [0, N) of the quarter and row N).  Row-sharded: this GPU's blocks of the 2N / N rows; rown: row N (every GPU computes it)
 static int quarter_group_finish(nx_ctx* ctx, CommitmentSchemeProver& cs, uint32_t n, QuarterGroup& qg, SecureColumn* out_coef) {
     const uint32_t N = 1u << n;
     nx_twiddles* qtw = nullptr;
@@ -1466,6 +1481,86 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
                 H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, el, a4, 0, N + hg.n_extra));
                 continue;
             }
+            if (part.where == GComponent::ON_QUARTER && cs.dist.on()) {
+                // One proof on several GPUs.  The same three sample sets, placed where the data is: (1) the committed
+                // 2N rows are row blocks already — no transform, no exchange; (2) the first quarter of the 4N-point domain: every GPU
+                // transforms the polynomials IT holds on N points and one all-to-all hands out blocks of N / W rows — a quarter of the
+                // transform work and of the bytes of the 4N-point re-evaluation this replaces; the neighbour-read columns (a handful: Pc,
+                // IsPadding) are transformed on 2N points and all-gathered whole; (3) row N: one eval_at_point sweep per column on its
+                // owner, the values all-gathered by the hosts, the row evaluated by every GPU.  quarter_group_finish then runs on the
+                // gathered accumulators, replicated like finalize_accumulation.
+                const Dist& D = cs.dist;
+                const uint32_t n = c.log_size, N = 1u << n;
+                QuarterGroup& qg = quarters[n];
+                if (!qg.acc2n.buf.p) {
+                    H_TRY(qg.acc2n.alloc_rows(ctx, n + 1, D.block(n + 1), true)); H_TRY(nx_memset_zero(ctx, qg.acc2n.buf.p, qg.acc2n.buf.words));
+                    H_TRY(qg.accq.alloc_rows(ctx, n, D.block(n), true)); H_TRY(nx_memset_zero(ctx, qg.accq.buf.p, qg.accq.buf.words));
+                    H_TRY(qg.rown.alloc_rows(ctx, n, 4, false)); H_TRY(nx_memset_zero(ctx, qg.rown.buf.p, qg.rown.buf.words));
+                    H_TRY(twiddles_first_part(ctx, cs.tw, n, 2, &qtw[n]));
+                }
+                {
+                    const std::vector<uint32_t> den = vanishing_denominators(n, n + 1);
+                    EvalDomainCols cols;
+                    H_TRY(columns_on_eval_domain(cs, c.cols, n, n + 1, masked, &cols, used));
+                    const uint64_t rb = D.begin(n + 1);
+                    uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = bias_rows(qg.acc2n.c[k], rb);
+                    H_TRY(air_eval_rows(ctx, part.kernel, cols.ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 1, a4, (uint32_t)rb, (uint32_t)D.block(n + 1)));
+                }
+                std::vector<size_t> sel, selm;
+                for (size_t k = 0; k < c.cols.size(); k++) if (!used || (k < used->size() && (*used)[k])) (masked[k] ? selm : sel).push_back(k);
+                const size_t ns = sel.size(), nm = selm.size();
+                std::vector<DevBuf> keep;
+                std::vector<const uint32_t*> ptrs(c.cols.size(), nullptr);
+                const uint64_t rbq = D.begin(n), mbq = D.block(n);
+                std::vector<uint32_t*> blk;
+                if (ns) H_TRY(sharded_evaluate_exchange(cs, c.cols, sel, qtw[n], n, n, &blk, &keep));
+                for (size_t i = 0; i < ns; i++) ptrs[sel[i]] = bias_rows((const uint32_t*)blk[i], rbq);
+                DevBuf wholem;
+                if (nm) {
+                    nx_twiddles* htw = nullptr;                      // the first half of the 4N-point domain as a 2N-point circle domain
+                    H_TRY(twiddles_first_part(ctx, cs.tw, n + 1, 1, &htw));
+                    struct Guard { nx_twiddles* t; ~Guard() { nx_twiddles_destroy(t); } } guard{htw};
+                    std::vector<uint32_t*> bm;
+                    H_TRY(sharded_evaluate_exchange(cs, c.cols, selm, htw, n, n + 1, &bm, &keep));
+                    H_TRY(wholem.alloc(ctx, nm << (n + 1)));
+                    std::vector<const uint32_t*> mb(bm.begin(), bm.end());
+                    H_TRY(D.allgather_cols(ctx, mb, (size_t)D.block(n + 1), wholem.p, (uint64_t)1 << (n + 1)));
+                    for (size_t i = 0; i < nm; i++) ptrs[selm[i]] = wholem.p + (i << (n + 1));
+                }
+                const std::vector<uint32_t> den = vanishing_denominators(n, n + 2);
+                {
+                    uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = bias_rows(qg.accq.c[k], rbq);
+                    H_TRY(air_eval_rows(ctx, part.kernel, ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 2, a4, (uint32_t)rbq, (uint32_t)mbq));
+                }
+                DevBuf wv; H_TRY(wv.alloc(ctx, std::max<size_t>(ns, 4)));
+                if (ns) {
+                    // the columns' values at w = row N of the 4N-point domain: swept by their owners, all-gathered as host words
+                    std::vector<uint32_t> mine(ns, 0), all((size_t)D.world * ns);
+                    std::vector<const uint32_t*> src; std::vector<size_t> slot;
+                    for (size_t i = 0; i < ns; i++)
+                        if (cs.trees[c.cols[sel[i]].first].owner[c.cols[sel[i]].second] == D.rank) { src.push_back(cs.trees[c.cols[sel[i]].first].polys[c.cols[sel[i]].second].ptr); slot.push_back(i); }
+                    if (!src.empty()) {
+                        const Pt w = pt_from_index(circle_domain_index((int)n + 2, bitrev(N, (int)n + 2)));
+                        const size_t nl = src.size();
+                        std::vector<uint32_t> pidx(nl), pts(8 * nl), ev(4 * nl);
+                        uint32_t pw8[8]; { QPt qp; qp.x = q_from_m(w.x); qp.y = q_from_m(w.y); q_store(pw8, qp.x); q_store(pw8 + 4, qp.y); }
+                        for (size_t i = 0; i < nl; i++) { pidx[i] = (uint32_t)i; memcpy(&pts[8 * i], pw8, 32); }
+                        H_TRY(nx_eval_at_points(ctx, src.data(), n, pidx.data(), pts.data(), (uint32_t)nl, ev.data()));
+                        for (size_t i = 0; i < nl; i++) mine[slot[i]] = ev[4 * i];
+                    }
+                    H_TRY(D.allgather_host(ctx, mine.data(), ns * 4, all.data()));
+                    std::vector<uint32_t> wh(ns);
+                    for (size_t i = 0; i < ns; i++) wh[i] = all[(size_t)cs.trees[c.cols[sel[i]].first].owner[c.cols[sel[i]].second] * ns + i];
+                    H_TRY(nx_upload(ctx, wv.p, wh.data(), ns));
+                    for (size_t i = 0; i < ns; i++) ptrs[sel[i]] = bias_rows((const uint32_t*)(wv.p + i), N);
+                }
+                if (ns + nm) {
+                    uint32_t* a4[4]; for (int k = 0; k < 4; k++) a4[k] = bias_rows(qg.rown.c[k], N);
+                    H_TRY(air_eval_rows(ctx, part.kernel, ptrs.data(), c.econsts.data(), pw.data(), den.data(), n, n + 2, a4, N, 1));
+                    H_TRY(nx_sync(ctx));                                                   // keep / wholem / wv are released at the end of this block
+                }
+                continue;
+            }
             if (part.where == GComponent::ON_QUARTER) {
                 const uint32_t n = c.log_size, N = 1u << n;
                 QuarterGroup& qg = quarters[n];
@@ -1545,6 +1640,18 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
     for (auto& kv : quarters) {
         // components of 2N rows may have put a half-domain contribution at the same size: coefficient vectors add
         SecureColumn q4;
+        if (cs.dist.on()) {                                     // the blocks become whole accumulators on every GPU; the finish is replicated
+            QuarterGroup& qg = kv.second;
+            const uint32_t n = kv.first, N = 1u << n;
+            SecureColumn w2, wq, full;
+            H_TRY(gather_secure(ctx, cs.dist, qg.acc2n, &w2));
+            H_TRY(gather_secure(ctx, cs.dist, qg.accq, &wq));
+            H_TRY(full.alloc_rows(ctx, n, (uint64_t)N + 4, false));
+            H_TRY(nx_memset_zero(ctx, full.buf.p, full.buf.words));
+            for (int k = 0; k < 4; k++) { H_TRY(nx_copy(ctx, full.c[k], wq.c[k], N)); H_TRY(nx_copy(ctx, full.c[k] + N, qg.rown.c[k], 1)); }
+            H_TRY(nx_sync(ctx));                                // wq is released here
+            qg.acc2n = std::move(w2); qg.accq = std::move(full);
+        }
         H_TRY(quarter_group_finish(ctx, cs, kv.first, kv.second, &q4));
         auto it = coef.find(kv.first + 2);
         if (it == coef.end()) { coef[kv.first + 2] = std::move(q4); continue; }
