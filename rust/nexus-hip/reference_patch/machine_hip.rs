@@ -44,7 +44,7 @@ use crate::{
 
 use nexus_hip::record::{record_component, TraceLocations};
 // the steps both reference patches share (this one and prove2_hip.rs): rust/nexus-hip/src/simd_host.rs
-use nexus_hip::simd_host::{commit_tree_keeping_evaluations, host_channel_at, interaction_tree_on_device, pcs_config, secure_from_words, SimdEval};
+use nexus_hip::simd_host::{columns_read_by_fractions, commit_tree_keeping_evaluations, host_channel_at, interaction_tree_on_device, pcs_config, secure_from_words, SimdEval};
 use nexus_hip::{proof_bytes, HipError, RecordedComponent, Session};
 
 fn to_proving_error(e: HipError) -> ProvingError {
@@ -113,7 +113,24 @@ impl<C: MachineChip + Sync> Machine<C> {
         for extension_trace in &extension_traces {
             tree0.extend(extension_trace.to_circle_evaluation(PREPROCESSED_TRACE_IDX));
         }
-        let kept0 = commit_tree_keeping_evaluations(&mut session, &tree0).map_err(to_proving_error)?;
+        // Shape pass: which columns of trees 0 / 1 the relation entries read is a property of the AIR, not of the lookup elements — the
+        // components recorded once with dummy elements say it, and only those columns' evaluations are kept beyond their commit.
+        let reads = {
+            let dummy = AllLookupElements::dummy();
+            let mut shape_pass = TraceLocations::default();
+            let mut shape: Vec<RecordedComponent> = vec![record_component(
+                &MachineEval::<C>::new(log_size, dummy.clone(), extensions_config.clone()),
+                &mut shape_pass,
+                SecureField::zero(),
+            )];
+            for (ext, log_size) in extensions_iter.clone().zip(all_log_sizes.get(1..).unwrap_or_default()) {
+                shape.push(ext.to_recorded_component(&mut shape_pass, &dummy, *log_size, SecureField::zero()));
+            }
+            let n_main = finalized_trace.clone().into_circle_evaluation().len()
+                + extension_traces.iter().map(|t| t.to_circle_evaluation(ORIGINAL_TRACE_IDX).len()).sum::<usize>();
+            columns_read_by_fractions(&shape, [tree0.len(), n_main])
+        };
+        let kept0 = commit_tree_keeping_evaluations(&mut session, &tree0, Some(&reads[0])).map_err(to_proving_error)?;
         drop(tree0);
 
         // ---- machine.rs:230-237: main tree
@@ -121,7 +138,7 @@ impl<C: MachineChip + Sync> Machine<C> {
         for extension_trace in &extension_traces {
             tree1.extend(extension_trace.to_circle_evaluation(ORIGINAL_TRACE_IDX));
         }
-        let kept1 = commit_tree_keeping_evaluations(&mut session, &tree1).map_err(to_proving_error)?;
+        let kept1 = commit_tree_keeping_evaluations(&mut session, &tree1, Some(&reads[1])).map_err(to_proving_error)?;
         drop(tree1);
 
         // ---- machine.rs:239-263: lookup elements from the session's channel; the interaction trace from the components' own relation
@@ -141,6 +158,7 @@ impl<C: MachineChip + Sync> Machine<C> {
         }
         let claimed = interaction_tree_on_device(&mut session, &generators, [&kept0, &kept1]).map_err(to_proving_error)?;
         drop(generators);
+        session.free_columns();                                  // the kept evaluations: nothing reads them after the interaction tree
         let all_claimed_sums: Vec<SecureField> = claimed
             .iter()
             .map(secure_from_words)

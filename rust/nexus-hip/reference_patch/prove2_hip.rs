@@ -40,7 +40,7 @@ use crate::{lookups::AllLookupElements, side_note::SideNote};
 
 use nexus_hip::record::TraceLocations;
 // the steps both reference patches share (this one and machine_hip.rs): rust/nexus-hip/src/simd_host.rs
-use nexus_hip::simd_host::{commit_tree_keeping_evaluations, host_channel_at, interaction_tree_on_device, pcs_config, secure_from_words, SimdEval};
+use nexus_hip::simd_host::{columns_read_by_fractions, commit_tree_keeping_evaluations, host_channel_at, interaction_tree_on_device, pcs_config, secure_from_words, SimdEval};
 use nexus_hip::{proof_bytes, HipError, RecordedComponent, Session};
 
 fn to_proving_error(e: HipError) -> ProvingError {
@@ -82,10 +82,22 @@ pub fn prove_hip(trace: &impl Trace, view: &View) -> Result<Proof, ProvingError>
 
     // ---- prove.rs:70-84: preprocessed tree, main tree — every component's columns, component after component
     let tree0: Vec<SimdEval> = traces.iter().flat_map(|t| t.to_circle_evaluation(PREPROCESSED_TRACE_IDX)).collect();
-    let kept0 = commit_tree_keeping_evaluations(&mut session, &tree0).map_err(to_proving_error)?;
-    drop(tree0);
     let tree1: Vec<SimdEval> = traces.iter().flat_map(|t| t.to_circle_evaluation(ORIGINAL_TRACE_IDX)).collect();
-    let kept1 = commit_tree_keeping_evaluations(&mut session, &tree1).map_err(to_proving_error)?;
+    // Shape pass: the columns the relation entries read are a property of the AIR, not of the lookup elements — the components recorded
+    // once with dummy elements (lookups/mod.rs `AllLookupElements::dummy`) say which evaluations must outlive their commit.
+    let reads = {
+        let dummy = AllLookupElements::dummy();
+        let mut shape_pass = TraceLocations::default();
+        let shape: Vec<RecordedComponent> = components
+            .iter()
+            .zip(&log_sizes)
+            .map(|(c, log_size)| c.to_recorded_component(&mut shape_pass, &dummy, *log_size, SecureField::zero()))
+            .collect();
+        columns_read_by_fractions(&shape, [tree0.len(), tree1.len()])
+    };
+    let kept0 = commit_tree_keeping_evaluations(&mut session, &tree0, Some(&reads[0])).map_err(to_proving_error)?;
+    drop(tree0);
+    let kept1 = commit_tree_keeping_evaluations(&mut session, &tree1, Some(&reads[1])).map_err(to_proving_error)?;
     drop(tree1);
     drop(traces);                                            // the reference moves them into generate_interaction_trace (prove.rs:96-99)
 
@@ -107,6 +119,7 @@ pub fn prove_hip(trace: &impl Trace, view: &View) -> Result<Proof, ProvingError>
         .collect();
     let claimed = interaction_tree_on_device(&mut session, &generators, [&kept0, &kept1]).map_err(to_proving_error)?;
     drop(generators);
+    session.free_columns();                                      // the kept evaluations: nothing reads them after the interaction tree
     let claimed_sums: Vec<SecureField> = claimed.iter().map(secure_from_words).collect();
     let claimed_words: Vec<u32> = claimed.iter().flatten().copied().collect();
     session.mix_felts(&claimed_words);

@@ -379,6 +379,11 @@ impl Session {
         self.owned.push(base);
         Ok((0..n_cols).map(|k| unsafe { base.add(k << log_size) }).collect())
     }
+    /// Releases every buffer handed out by `alloc_columns` (the kept evaluations): after the interaction tree is built nothing reads
+    /// them, and `prove` needs the HBM.  The pointers dangle afterwards.
+    pub fn free_columns(&mut self) {
+        for p in self.owned.drain(..) { unsafe { sys::nx_free(self.ctx, p) }; }
+    }
     /// The component's interaction trace from its recorded relation entries, on the device (`nx_logup_program`), finalised
     /// (`LogupTraceGenerator::finalize_last`: `nx_logup_finalize_last`).  `cols[k]`: the evaluations (bit-reversed circle-domain order)
     /// of component column k, null where the fraction program loads nothing (the interaction columns themselves); `out`: the

@@ -68,24 +68,52 @@ pub fn host_columns(evals: &[SimdEval]) -> (Vec<*const u32>, Vec<u32>) {
     (ptrs, logs)
 }
 
+/// Which columns of trees 0 / 1 the components' FRACTION PROGRAMS load (`NX_C_LOAD` / `NX_C_LOADE` of a component column whose
+/// `col_tree` is < 2): the only evaluations that have to outlive their tree's commit.  The load set of a recorded component does not
+/// depend on the lookup elements (they are E constants of the program), so a "shape pass" — the components recorded once with
+/// `AllLookupElements::dummy()` before anything is committed (reference prover/src/components/lookups.rs:66-68, prover2/machine/src/
+/// lookups/mod.rs) — yields it.  `n_cols[t]`: the column count of tree t.  (keeping EVERY column of both trees added ~50 % to
+/// the peak HBM of the commit and prove phases of a v1-sized trace.)
+pub fn columns_read_by_fractions(recorded: &[RecordedComponent], n_cols: [usize; 2]) -> [Vec<bool>; 2] {
+    let mut reads = [vec![false; n_cols[0]], vec![false; n_cols[1]]];
+    for c in recorded {
+        for ins in &c.logup_program {
+            let width = if ins.op == sys::NX_C_LOAD as u32 { 1 } else if ins.op == sys::NX_C_LOADE as u32 { 4 } else { 0 };
+            for k in 0..width {
+                let col = ins.a as usize + k;
+                let (t, i) = (c.col_tree[col] as usize, c.col_index[col] as usize);
+                if t < 2 { reads[t][i] = true; }
+            }
+        }
+    }
+    reads
+}
+
 /// TreeBuilder::extend_evals(..) + commit(channel) for one trace tree: the columns stay in the SimdBackend evaluations' memory and go up
-/// in chunks under the commit's own transforms (nx_prover_tree_commit_host).  Every column's EVALUATIONS are also kept on the device
-/// (cloned as the chunks arrive: the reference's `finalized_trace.clone()`, machine.rs:232; `to_circle_evaluation`'s clone,
-/// prover2/trace/src/component.rs:63-79) — the fraction programs read them after the commit has turned the tree's own columns into
-/// coefficients.  Returns the kept columns, in commit order.
-pub fn commit_tree_keeping_evaluations(session: &mut Session, evals: &[SimdEval]) -> Result<Vec<*const u32>, HipError> {
+/// in chunks under the commit's own transforms (nx_prover_tree_commit_host).  The EVALUATIONS of the columns marked in `keep_mask`
+/// (`columns_read_by_fractions`; `None`: every column) are also kept on the device (cloned as the chunks arrive: the reference's
+/// `finalized_trace.clone()`, machine.rs:232; `to_circle_evaluation`'s clone, prover2/trace/src/component.rs:63-79) — the fraction
+/// programs read them after the commit has turned the tree's own columns into coefficients.  Returns one pointer per column of the tree,
+/// in commit order: the kept evaluations, null for a column that was not kept.  `Session::free_columns` releases them (call it right
+/// after `interaction_tree_on_device`: they are not needed by `Session::prove`).
+pub fn commit_tree_keeping_evaluations(session: &mut Session, evals: &[SimdEval], keep_mask: Option<&[bool]>) -> Result<Vec<*const u32>, HipError> {
     let (host, logs) = host_columns(evals);
     session.tree_begin(&logs)?;
-    let mut keep: Vec<(u32, *mut u32)> = Vec::with_capacity(logs.len());
+    let wanted = |i: usize| keep_mask.map_or(true, |m| m.get(i).copied().unwrap_or(false));
+    let mut keep: Vec<(u32, *mut u32)> = Vec::new();
+    let mut kept: Vec<*const u32> = vec![std::ptr::null(); logs.len()];
     let mut i = 0;
-    while i < logs.len() {                                   // one allocation per run of equally sized columns
+    while i < logs.len() {                                   // one allocation per run of equally sized columns: the kept ones of the run
         let mut j = i;
         while j < logs.len() && logs[j] == logs[i] { j += 1; }
-        for (k, p) in session.alloc_columns(j - i, logs[i])?.into_iter().enumerate() { keep.push(((i + k) as u32, p)); }
+        let run: Vec<usize> = (i..j).filter(|&k| wanted(k)).collect();
+        if !run.is_empty() {
+            for (k, p) in run.iter().zip(session.alloc_columns(run.len(), logs[i])?) { keep.push((*k as u32, p)); kept[*k] = p as *const u32; }
+        }
         i = j;
     }
     session.tree_commit_host(&host, false, &keep)?;
-    Ok(keep.iter().map(|k| k.1 as *const u32).collect())
+    Ok(kept)
 }
 
 /// The interaction tree from the components' recorded relation entries: `recorded[c]` is component c recorded with a ZERO claimed sum

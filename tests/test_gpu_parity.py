@@ -1337,6 +1337,23 @@ def test_logup_program_matches_oracle(be, nz, oracle, log, batching, segment):
     b.close()
 
 
+def test_known_answers_of_the_reference_dump_on_the_device(be, nz, oracle):
+    """tools/replay_reference_dump.py's two logup known answers ("logup_pairs": LogupTraceGenerator in pairs; "logup_wide": the 200-element
+    state relation with a constant entry, a column-sum entry and the numerator (m - 1)) as the DEVICE computes them — nx_logup_cols_batched
+    resp. nx_logup_program — against the oracle's literal evaluation.  On a box with cargo the same functions are compared with what
+    tools/dump_reference.rs prints from Stwo's own LookupElements::combine / LogupTraceGenerator."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("replay_reference_dump", os.path.join(root, "tools", "replay_reference_dump.py"))
+    rp = importlib.util.module_from_spec(spec); spec.loader.exec_module(rp)
+    rng = np.random.default_rng(200)
+    z, alpha = rng.integers(1, P, 4, dtype=np.uint32), rng.integers(1, P, 4, dtype=np.uint32)
+    for fn in (rp.logup_pairs_columns, rp.logup_wide_columns):
+        want, wclaimed = fn(z, alpha)
+        got, gclaimed = fn(z, alpha, be)
+        assert len(want) == len(got) and all(np.array_equal(a, b) for a, b in zip(want, got)) and np.array_equal(wclaimed, gclaimed), fn.__name__
+
+
 def test_session_with_the_interaction_trace_generated_from_the_recorded_air(be, nz, oracle):
     """The whole flow a Rust-side prove takes once the chips' generators are gone (reference_patch/machine_hip.rs): the main tree
     goes up from host memory with its evaluations KEPT on the device, the lookup elements are drawn, nx_logup_program + finalize_last

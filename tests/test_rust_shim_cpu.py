@@ -230,7 +230,8 @@ def test_the_two_reference_patches_share_their_device_steps():
     (commit while keeping the evaluations, the host channel the lookup elements are drawn from, the interaction tree from the recorded
     relation entries); neither patch carries a private copy."""
     host = open(os.path.join(HIP_DIR, "src", "simd_host.rs")).read()
-    for needle in ("pub fn commit_tree_keeping_evaluations(session: &mut Session, evals: &[SimdEval])", "pub fn host_channel_at(session: &Session) -> Blake2sChannel",
+    for needle in ("pub fn commit_tree_keeping_evaluations(session: &mut Session, evals: &[SimdEval], keep_mask: Option<&[bool]>)", "pub fn host_channel_at(session: &Session) -> Blake2sChannel",
+                   "pub fn columns_read_by_fractions(recorded: &[RecordedComponent], n_cols: [usize; 2]) -> [Vec<bool>; 2]",
                    "pub fn interaction_tree_on_device(session: &mut Session, recorded: &[RecordedComponent], kept: [&[*const u32]; 2])", "pub fn pcs_config(config: &PcsConfig, log_constraint_degree: u32)",
                    "session.tree_commit_host(&host, false, &keep)", "session.logup_trace(c, &cols, &out)", "ch.update_digest(Blake2sHash(session.channel_digest()))"):
         assert needle in host, needle
@@ -240,7 +241,9 @@ def test_the_two_reference_patches_share_their_device_steps():
     assert "#[cfg(stwo_traits)]\npub mod simd_host;" in open(HIP).read()
     for f in ("machine_hip.rs", "prove2_hip.rs"):
         patch = open(os.path.join(HIP_DIR, "reference_patch", f)).read()
-        assert "use nexus_hip::simd_host::{commit_tree_keeping_evaluations, host_channel_at, interaction_tree_on_device, pcs_config, secure_from_words, SimdEval};" in patch, f
+        assert "use nexus_hip::simd_host::{columns_read_by_fractions, commit_tree_keeping_evaluations, host_channel_at, interaction_tree_on_device, pcs_config, secure_from_words, SimdEval};" in patch, f
+        # only the columns the fraction programs read stay on the device beyond their commit, and they go before the prove
+        assert "AllLookupElements::dummy()" in patch and "Some(&reads[0])" in patch and "Some(&reads[1])" in patch and "session.free_columns();" in patch, f
         for private in ("fn commit_tree_keeping_evaluations", "fn interaction_tree_on_device", "fn host_channel_at", "sys::nx_pcs_config {"):
             assert private not in patch, (f, private)
 

@@ -22,7 +22,8 @@
 //!     mixed-degree commit (columns of 2^6, 2^6 (x17), 2^4); Blake2sChannel digests after mix_u64 / mix_felts / mix_root and the felts /
 //!     bytes it draws; grind nonces; eval_at_point; accumulate_quotients of 3 columns / 2 sample batches; fold_circle_into_line and
 //!     fold_line; FriOps::decompose if the trait still has it (Appendix B.5); a LogupTraceGenerator driven in pairs + finalize_last
-//!     ("logup_pairs").  These settle SURVEY.md Appendix B.1-B.6 and pin the logup forms of VERDICT r4 #2.
+//!     ("logup_pairs"), and a 200-element relation with constant / sum entries and an expression numerator ("logup_wide": the
+//!     reference's widest tuple).  These settle SURVEY.md Appendix B.1-B.6 and pin the logup forms of VERDICT r4 #2.
 //!   "prove": for the `stark_prove` bench program (prover-benches/benches/stark_prove.rs:55-82) at log sizes 8, 12, 16:
 //!     the 4 commitments, claimed sums, log sizes, proof_of_work, every FRI layer commitment, the last layer polynomial, the
 //!     size of sampled / queried values, a hash + (for log 8) the full hex of postcard::to_stdvec(&proof)  (nx_proof_serialize_stwo).
@@ -40,11 +41,12 @@ use stwo::core::poly::circle::CanonicCoset;
 use stwo::core::poly::line::LineDomain;
 use stwo::core::vcs::blake2_merkle::{Blake2sMerkleChannel, Blake2sMerkleHasher};
 use num_traits::One;
-use stwo::prover::backend::simd::m31::LOG_N_LANES;
+use stwo::prover::backend::simd::m31::{PackedBaseField, LOG_N_LANES};
 use stwo::prover::backend::simd::qm31::PackedSecureField;
 use stwo::prover::backend::simd::SimdBackend;
 use stwo::prover::backend::{Col, Column};
 use stwo_constraint_framework::LogupTraceGenerator;
+stwo_constraint_framework::relation!(WideLookupElements, 200);
 use stwo::prover::fri::FriOps;
 use stwo::prover::line::LineEvaluation;
 use stwo::prover::pcs::quotient_ops::QuotientOps;
@@ -129,6 +131,34 @@ fn kat() -> Value {
         let (trace, claimed) = gen.finalize_last();
         out.insert("logup_pairs".into(), json!({"seed": 3, "z": qm31(z), "alpha": qm31(alpha), "columns": trace.iter().map(|e| m31s(e.values.to_cpu())).collect::<Vec<_>>(),
                                                  "claimed_sum": qm31(claimed)}));
+    }
+    // R8 at the reference's tuple WIDTH: a 200-element relation — the keccak chips' state lookup (reference
+    // prover/src/chips/custom.rs:45-46 `relation!(RawStateLookupElements, 25 * 8)`, extensions/keccak/round/constraints.rs:101-110) — combined
+    // by Stwo's own LookupElements::combine, with a CONSTANT entry and a SUM-of-two-columns entry in the tuple (bit_op.rs:355; bitwise_table/
+    // constraints.rs:50-71) and the expression numerator (is_padding - 1), one fraction per column, finalize_last.  Pins nx_logup_program /
+    // nx_logup_cols at 200 tuple columns and the alpha powers alpha^0 .. alpha^199 ("logup_wide").
+    {
+        let log = 6u32;
+        let wide = WideLookupElements::draw(&mut ch);
+        let t: Vec<Col<SimdBackend, BaseField>> = (0..5).map(|c| col(4, c, log)).collect();
+        let n_vec = 1usize << (log - LOG_N_LANES);
+        let mut gen = LogupTraceGenerator::new(log);
+        let mut c0 = gen.new_col();
+        for vr in 0..n_vec {
+            let tuple: Vec<PackedBaseField> = (0..200usize)
+                .map(|k| match k {
+                    1 => PackedBaseField::broadcast(BaseField::from(5u32)),
+                    2 => t[1].data[vr] + t[2].data[vr],
+                    _ => t[k % 5].data[vr],
+                })
+                .collect();
+            let denom: PackedSecureField = wide.combine(&tuple);
+            c0.write_frac(vr, PackedSecureField::from(t[3].data[vr]) - PackedSecureField::one(), denom);
+        }
+        c0.finalize_col();
+        let (trace, claimed) = gen.finalize_last();
+        out.insert("logup_wide".into(), json!({"seed": 4, "z": qm31(wide.z), "alpha": qm31(wide.alpha), "columns": trace.iter().map(|e| m31s(e.values.to_cpu())).collect::<Vec<_>>(),
+                                                "claimed_sum": qm31(claimed)}));
     }
     // K8: DEEP quotients of 3 LDE columns, two sample batches (points p and p + step; values = the true evaluations, so the result is low degree)
     let polys: Vec<_> = (0..3).map(|c| CircleEvaluation::<SimdBackend, BaseField, BitReversedOrder>::new(dom6, col(2, c, 6)).interpolate_with_twiddles(&tw7)).collect();

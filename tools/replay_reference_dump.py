@@ -63,6 +63,35 @@ def logup_pairs_columns(z, alpha, be=None):
     return [x for c in cols for x in c.to_cpu()], np.asarray(claimed)
 
 
+def logup_wide_columns(z, alpha, be=None):
+    """The "logup_wide" known answer of tools/dump_reference.rs restated: ONE fraction over the 200-element relation of the keccak state
+    lookup (reference prover/src/chips/custom.rs:45-46) — tuple entry k = seeded column k % 5, except entry 1 = the constant 5 and entry 2 =
+    t1 + t2 —, numerator (t3 - 1), finalize_last.  Oracle: the entries evaluated literally; `be`: the device, through nx_logup_program
+    (the recorded relation entry)."""
+    import oracle_lib as O
+    t = [col(4, c, 6) for c in range(5)]
+    if be is None:
+        pw = [np.array([1, 0, 0, 0], np.uint32)]
+        for _ in range(199):
+            pw.append(O.qm31_mul(pw[-1], alpha))
+        vals = [np.full(64, 5, np.uint32) if k == 1 else ((t[1].astype(np.uint64) + t[2]) % P).astype(np.uint32) if k == 2 else t[k % 5] for k in range(200)]
+        numer = ((t[3].astype(np.uint64) + P - 1) % P).astype(np.uint32)
+        c0 = O.logup_finalize_col(O.logup_combine(vals, np.array(pw, np.uint32), z), scale_a=(1, 0, 0, 0), mult_a=numer)
+        c0, claimed = O.logup_finalize_last(c0)
+        return [np.asarray(x) for x in c0], np.asarray(claimed)
+    import nexus_zkvm_amd.air_program as ap
+    pb = ap.ProgramBuilder()
+    c = [pb.next_trace_mask(k)[0] for k in range(5)]
+    rel = pb.relation(z, alpha, 200)
+    pb.add_to_relation(rel, c[3] - 1, [5 if k == 1 else c[1] + c[2] if k == 2 else c[k % 5] for k in range(200)])
+    pb.finalize_logup(5, (0, 0, 0, 0))
+    frac = pb.build_logup()
+    d = be.columns_from_host(np.stack(t))
+    cols = be.logup_program(frac, [d.ptr.value + k * (4 << 6) for k in range(5)] + [None] * 4, 6)
+    claimed = be.logup_finalize_last(cols[-1])
+    return [x for x in cols[-1].to_cpu()], np.asarray(claimed)
+
+
 def synth_dump(hash_mode):
     """The "kat" section of tools/dump_reference.rs, produced by the oracle instead of Stwo (self-test input)."""
     import ctypes as C
@@ -87,9 +116,13 @@ def synth_dump(hash_mode):
     zl, al = np.zeros(4, np.uint32), np.zeros(4, np.uint32)
     L.orc_channel_draw_secure_felt(ch, O.ptr(zl)); L.orc_channel_draw_secure_felt(ch, O.ptr(al))
     lc, lclaimed = logup_pairs_columns(zl, al)
+    zw, aw = np.zeros(4, np.uint32), np.zeros(4, np.uint32)               # LookupElements::draw: z, then alpha
+    L.orc_channel_draw_secure_felt(ch, O.ptr(zw)); L.orc_channel_draw_secure_felt(ch, O.ptr(aw))
+    wc, wclaimed = logup_wide_columns(zw, aw)
     L.orc_channel_free(ch)
     logup = {"z": [int(x) for x in zl], "alpha": [int(x) for x in al], "columns": [[int(v) for v in c] for c in lc], "claimed_sum": [int(x) for x in lclaimed]}
-    return {"kat": {"logup_pairs": logup, "twiddles_log5": {"twiddles": [int(x) for x in tw], "itwiddles": [int(x) for x in itw]},
+    wide = {"z": [int(x) for x in zw], "alpha": [int(x) for x in aw], "columns": [[int(v) for v in c] for c in wc], "claimed_sum": [int(x) for x in wclaimed]}
+    return {"kat": {"logup_pairs": logup, "logup_wide": wide, "twiddles_log5": {"twiddles": [int(x) for x in tw], "itwiddles": [int(x) for x in itw]},
                     "lde_log6": {"coeffs": [int(x) for x in co], "lde": [int(x) for x in otw.evaluate(co, 7)]},
                     "eval_at_point": {"point": [[int(x) for x in pt[:4]], [int(x) for x in pt[4:]]], "value": [int(x) for x in O.eval_at_point(co, pt)]},
                     "merkle": {"root": root.hex()}, "channel": steps},
@@ -189,6 +222,13 @@ def replay(d, be, found_modes):
         if be:
             gc, gclaimed = logup_pairs_columns(np.array(lp["z"], np.uint32), np.array(lp["alpha"], np.uint32), be)
             check("logup in pairs + finalize_last (GPU)", all(np.array_equal(a, b) for a, b in zip(gc, lp["columns"])) and list(gclaimed) == lp["claimed_sum"])
+    if "logup_wide" in k:
+        lw = k["logup_wide"]
+        wc, wclaimed = logup_wide_columns(np.array(lw["z"], np.uint32), np.array(lw["alpha"], np.uint32))
+        check("200-wide relation with constant / sum entries and an expression numerator + finalize_last (oracle)", all(np.array_equal(a, b) for a, b in zip(wc, lw["columns"])) and list(wclaimed) == lw["claimed_sum"])
+        if be:
+            gc, gclaimed = logup_wide_columns(np.array(lw["z"], np.uint32), np.array(lw["alpha"], np.uint32), be)
+            check("200-wide relation ... (GPU, nx_logup_program)", all(np.array_equal(a, b) for a, b in zip(gc, lw["columns"])) and list(gclaimed) == lw["claimed_sum"])
     print("     (grind / quotient / fold known answers: compare `channel[6:]`, `quotients`, `folds`, `decompose` with orc_channel_grind, orc_accumulate_quotients,")
     print("      orc_fold_circle_into_line, orc_fold_line_dom, orc_fri_decompose on the same seeded columns — see tests/test_gpu_parity.py for the call shapes)")
     # proofs: structure and the serializer's field order

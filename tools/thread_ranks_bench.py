@@ -2,7 +2,8 @@
 GPU.  The total work equals the single-rank prove's, so  T(W ranks) - T(1 rank)  is what sharding adds apart from the wire: the pack /
 unpack passes, the collectives' copies (device-to-device here instead of xGMI), the host round trips at every collective, the
 replicated parts (tree tops, FRI tail, finalize_last) and the smaller launches.  Not a scaling measurement.
-  python tools/thread_ranks_bench.py [log=22] [worlds=2,4,8]"""
+  python tools/thread_ranks_bench.py [log=22] [worlds=2,4,8] [options, e.g. air.quarter_domain=0 or -] [statement: headline | v1]
+v1: the v1-shaped statement of bench.py (main component with the +2 bound and 250 logup columns, 8 extension components)."""
 import json, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,11 +13,25 @@ from nexus_zkvm_amd.sharded import ThreadGroup
 
 log = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "2,4,8").split(",")]
-comps = [(log, 27, 347, 64)]
-cfg = nz.default_config(pow_bits=10)
+OPTS = [kv.split("=") for kv in (sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else "").split(",") if kv]
+STATEMENT = sys.argv[4] if len(sys.argv) > 4 else "headline"
+if STATEMENT == "v1":
+    comps = [(log, 27, 347, 1000, 2)] + [(8 + k, 2, 6 + k, 4, 1) for k in range(8)]
+    cfg = nz.default_config(pow_bits=10, log_constraint_degree=2)
+else:
+    comps = [(log, 27, 347, 64)]
+    cfg = nz.default_config(pow_bits=10)
 REPS = 3
 
-be = nz.HipBackend(0)
+
+def backend():
+    b = nz.HipBackend(0)
+    for k, v in OPTS:
+        b.set_option(k, int(v))
+    return b
+
+
+be = backend()
 ref, best1 = None, 1e9
 for rep in range(REPS + 1):
     be.sync(); t0 = time.perf_counter()
@@ -25,7 +40,7 @@ for rep in range(REPS + 1):
     if rep: best1 = min(best1, time.perf_counter() - t0)
 _, st1 = be.prove_machine(comps, cfg, seed=77, want_stats=True)
 be.close()
-out = {"log_rows": log, "single_rank_ms": best1 * 1e3, "worlds": {}}
+out = {"log_rows": log, "statement": STATEMENT, "options": dict((k, int(v)) for k, v in OPTS), "single_rank_ms": best1 * 1e3, "worlds": {}}
 
 
 class Counting:
@@ -51,7 +66,7 @@ def run_world(world):
 
     def run(rank):
         try:
-            b = nz.HipBackend(0)
+            b = backend()
             if NATIVE:
                 cnt, comm = None, b.local_comm(group, rank)
             else:
