@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <map>
+#include <set>
 #include <mutex>
 #include <stdio.h>
 #include <sys/stat.h>
@@ -100,6 +101,104 @@ static uint32_t segment_budget(const nx_ctx* ctx) {
     return (uint32_t)std::max(200, e ? atoi(e) : 9000);
 }
 
+// ---- dot-product peephole (round 6) ---------------------------------------------------------------------------------------------------
+// `MULEB T, A, v` immediately followed by `ADDE D, D, T` (either operand order) where T dies there is one term of Relation::combine's
+// sum_k alpha^k value_k — what machine.hip's emit_den and a recorder's lowering of LookupElements::combine produce, 200 terms long for the
+// reference's widest relation.  Emitted literally a term is 4 reduced products and 4 reduced sums (~36 VALU instructions); fused it is 4
+// raw 64-bit multiply-adds (v_mad_u64_u32 with its free 64-bit addend) into a lazy accumulator of D that is folded every 4 terms and
+// reduced ONCE, when D is next read — the same residue, a third of the instructions.  `NX_AIR_FUSE_DOT=0` emits the literal form (A/B).
+struct RegRange { uint32_t reg, w; };
+static void instr_ranges(const nx_cinstr& in, std::vector<RegRange>* reads, RegRange* write) {
+    reads->clear(); *write = {0, 0};
+    switch (in.op) {
+    case NX_C_LOAD: case NX_C_CONST: *write = {in.dst, 1}; break;
+    case NX_C_ADD: case NX_C_SUB: case NX_C_MUL: reads->push_back({in.a, 1}); reads->push_back({in.b, 1}); *write = {in.dst, 1}; break;
+    case NX_C_NEG: reads->push_back({in.a, 1}); *write = {in.dst, 1}; break;
+    case NX_C_CONSTE: case NX_C_LOADE: *write = {in.dst, 4}; break;
+    case NX_C_ADDE: case NX_C_SUBE: case NX_C_MULE: reads->push_back({in.a, 4}); reads->push_back({in.b, 4}); *write = {in.dst, 4}; break;
+    case NX_C_MULEB: case NX_C_ADDEB: reads->push_back({in.a, 4}); reads->push_back({in.b, 1}); *write = {in.dst, 4}; break;
+    case NX_C_CONSTRAINT_B: reads->push_back({in.a, 1}); break;
+    case NX_C_CONSTRAINT_E: reads->push_back({in.a, 4}); break;
+    case NX_C_FRAC: reads->push_back({in.a, 4}); reads->push_back({in.b, 4}); break;
+    case NX_C_FRACB: reads->push_back({in.a, 1}); reads->push_back({in.b, 4}); break;
+    default: break;
+    }
+}
+static bool fuse_dot_enabled() { static const bool on = [] { const char* e = getenv("NX_AIR_FUSE_DOT"); return !(e && *e == '0'); }(); return on; }
+struct DotFusion { std::vector<char> skip, fused; };      // by position in `keep`: the MULEB that is not emitted, the ADDE that becomes 4 multiply-adds
+static DotFusion find_dot_fusions(const nx_cinstr* prog, const std::vector<uint32_t>& keep, uint32_t n_regs) {
+    DotFusion f; f.skip.assign(keep.size(), 0); f.fused.assign(keep.size(), 0);
+    if (!fuse_dot_enabled()) return f;
+    std::vector<char> live(n_regs + 8, 0);             // backward: is the register read again before it is rewritten (within this kernel)?
+    std::vector<RegRange> reads; RegRange wr;
+    auto disjoint = [](uint32_t a, uint32_t b) { return a + 4 <= b || b + 4 <= a; };
+    for (size_t pos = keep.size(); pos-- > 0;) {
+        const nx_cinstr& in = prog[keep[pos]];
+        if (in.op == NX_C_ADDE && pos >= 1 && prog[keep[pos - 1]].op == NX_C_MULEB) {
+            const nx_cinstr& mu = prog[keep[pos - 1]];
+            const uint32_t T = mu.dst, D = in.dst;
+            const bool a_is_t = in.a == T, b_is_t = in.b == T;
+            const uint32_t other = a_is_t ? in.b : in.a;
+            bool dead = true; for (uint32_t k = 0; k < 4; k++) dead = dead && !live[T + k];
+            if (a_is_t != b_is_t && other == D && disjoint(T, D) && disjoint(T, mu.a) && disjoint(D, mu.a) && !(mu.b >= D && mu.b < D + 4) && !(mu.b >= T && mu.b < T + 4) && dead) {
+                f.fused[pos] = 1; f.skip[pos - 1] = 1;
+            }
+        }
+        instr_ranges(in, &reads, &wr);
+        for (uint32_t k = 0; k < wr.w; k++) live[wr.reg + k] = 0;
+        for (const RegRange& r : reads) for (uint32_t k = 0; k < r.w; k++) live[r.reg + k] = 1;
+    }
+    return f;
+}
+// the lazy accumulators of a kernel being emitted
+struct LazyAcc {
+    std::map<uint32_t, int> pending;            // D -> products since the last fold
+    std::set<uint32_t> declared;
+    static std::string z(uint32_t d, int k) { return "z" + std::to_string(d) + "_" + std::to_string(k); }
+    std::string materialize(uint32_t d) {
+        std::string s = "  ";
+        for (int k = 0; k < 4; k++) s += "r" + std::to_string(d + k) + " = acc_final(" + z(d, k) + "); ";
+        pending.erase(d);
+        return s + "\n";
+    }
+    // everything a (literal) instruction touches must be in its registers
+    std::string before(const nx_cinstr& in) {
+        std::string s;
+        if (pending.empty()) return s;
+        std::vector<RegRange> reads; RegRange wr;
+        instr_ranges(in, &reads, &wr);
+        reads.push_back(wr);
+        std::vector<uint32_t> hit;
+        for (auto& kv : pending) for (const RegRange& r : reads) if (r.w && r.reg < kv.first + 4 && kv.first < r.reg + r.w) { hit.push_back(kv.first); break; }
+        for (uint32_t d : hit) s += materialize(d);
+        return s;
+    }
+    std::string accumulate(const nx_cinstr& mu, const nx_cinstr& add) {
+        std::string s;
+        const uint32_t D = add.dst;
+        {   // the factors themselves must not be lazy
+            nx_cinstr probe = mu; probe.dst = mu.a;           // reads of A (4) and v (1) through MULEB's own ranges; the write range points at A: harmless
+            s += before(probe);
+        }
+        if (!pending.count(D)) {
+            s += "  ";
+            if (!declared.count(D)) { s += "u64 "; declared.insert(D); }
+            for (int k = 0; k < 4; k++) s += z(D, k) + " = r" + std::to_string(D + k) + (k < 3 ? ", " : ";\n");
+            pending[D] = 0;
+        }
+        s += "  ";
+        for (int k = 0; k < 4; k++) s += z(D, k) + " = acc_mad(" + z(D, k) + ", r" + std::to_string(mu.a + k) + ", r" + std::to_string(mu.b) + "); ";
+        s += "\n";
+        if (++pending[D] == 4) {
+            s += "  ";
+            for (int k = 0; k < 4; k++) s += z(D, k) + " = acc_fold(" + z(D, k) + "); ";
+            s += "\n";
+            pending[D] = 0;
+        }
+        return s;
+    }
+};
+
 static std::string generate_kernel(const nx_cinstr* prog, const std::vector<uint32_t>& keep, const std::vector<uint32_t>& cons_index, uint32_t n_regs, const std::string& name) {
     std::string s;
     s += "extern \"C\" __attribute__((global)) __attribute__((amdgpu_flat_work_group_size(256, 256))) void " + name + "(const u32* const* __restrict__ cols, const u32* __restrict__ econst, const u32* __restrict__ pw,\n"
@@ -120,8 +219,14 @@ static std::string generate_kernel(const nx_cinstr* prog, const std::vector<uint
     };
     uint32_t pending = 0;
     const std::string fold = "  s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3);\n";
-    for (uint32_t i : keep) {
+    const DotFusion fu = find_dot_fusions(prog, keep, n_regs);
+    LazyAcc lazy;
+    for (size_t pos = 0; pos < keep.size(); pos++) {
+        const uint32_t i = keep[pos];
         const nx_cinstr& in = prog[i];
+        if (fu.skip[pos]) continue;
+        if (fu.fused[pos]) { s += lazy.accumulate(prog[keep[pos - 1]], in); continue; }
+        s += lazy.before(in);
         switch (in.op) {
         case NX_C_LOAD: s += "  " + R(in.dst) + " = G(cols[" + std::to_string(in.a) + "])[" + off_name((int)in.b) + "];\n"; break;
         case NX_C_CONST: s += "  " + R(in.dst) + " = " + std::to_string(in.a) + "u;\n"; break;
@@ -834,8 +939,14 @@ static std::string generate_logup_kernel(const nx_cinstr* prog, const std::vecto
         s += "  }\n";
         group.clear(); uid++;
     };
-    for (uint32_t i : keep) {
+    const DotFusion fu = find_dot_fusions(prog, keep, n_regs);
+    LazyAcc lazy;
+    for (size_t pos = 0; pos < keep.size(); pos++) {
+        const uint32_t i = keep[pos];
         const nx_cinstr& in = prog[i];
+        if (fu.skip[pos]) continue;
+        if (fu.fused[pos]) { s += lazy.accumulate(prog[keep[pos - 1]], in); continue; }
+        s += lazy.before(in);
         switch (in.op) {
         case NX_C_LOAD: s += "  " + R(in.dst) + " = G(cols[" + std::to_string(in.a) + "])[" + off_name((int)in.b) + "];\n"; break;
         case NX_C_CONST: s += "  " + R(in.dst) + " = " + std::to_string(in.a) + "u;\n"; break;
@@ -950,8 +1061,16 @@ extern "C" int nx_logup_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t 
     if (!program || (n_econsts && !econsts)) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: NULL argument");
     if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: log_size out of range");
     NX_TRY(validate_logup_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, n_logup_cols));
+    // The kernels are cached per context by the PROGRAM (its bytes and shape, the segment budget): the generated source of a wide component
+    // is megabytes of text, and building it only to look the kernels up cost a keccak-shaped prove 5 ms of GPU idle time per round
+    // component (profiles/r06_keccak_tuples_sequence.txt, before).  The source is generated on a miss (and for h_source_out).
+    std::string key((const char*)program, (size_t)n_instr * sizeof(nx_cinstr));
+    key += "|" + std::to_string(n_regs) + "|" + std::to_string(n_cols) + "|" + std::to_string(n_econsts) + "|" + std::to_string(n_logup_cols) + "|" + std::to_string(segment_budget(ctx));
+    const nx_air_kernel* k = nullptr;
+    if (ctx) { LogupKernelCache& kc = logup_kernel_cache(); std::lock_guard<std::mutex> lk(kc.mu); auto it = kc.map.find({ctx, key}); if (it != kc.map.end()) k = it->second; }
     uint32_t n_kernels = 1;
-    const std::string src = generate_logup_source(ctx, program, n_instr, n_regs, &n_kernels);
+    std::string src;
+    if (!k || h_source_out) src = generate_logup_source(ctx, program, n_instr, n_regs, &n_kernels);
     if (h_source_out) { *h_source_out = (char*)malloc(src.size() + 1); if (*h_source_out) std::copy(src.c_str(), src.c_str() + src.size() + 1, *h_source_out); }
     if (!ctx || !d_out) { if (h_source_out) return NX_OK; return set_err(ctx, NX_ERR_ARG, "nx_logup_program: a context and output columns are needed to run"); }
     if (n_logup_cols == 0) return NX_OK;
@@ -962,17 +1081,13 @@ extern "C" int nx_logup_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t 
         if (in.op == NX_C_LOADE) for (uint32_t k = 0; k < 4; k++) if (!d_cols[in.a + k]) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: the program loads a column that was passed as NULL");
     }
     for (size_t k = 0; k < 4 * (size_t)n_logup_cols; k++) if (!d_out[k]) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: NULL output column");
-    const nx_air_kernel* k = nullptr;
-    {
+    if (!k) {
         LogupKernelCache& kc = logup_kernel_cache();
-        { std::lock_guard<std::mutex> lk(kc.mu); auto it = kc.map.find({ctx, src}); if (it != kc.map.end()) k = it->second; }
-        if (!k) {
-            nx_air_kernel* nk = nullptr;
-            NX_TRY(compile_source(ctx, src, n_kernels, n_cols, n_econsts, n_logup_cols, &nk, 1));      // outside the lock: entries are per context
-            std::lock_guard<std::mutex> lk(kc.mu);
-            kc.map.insert({{ctx, src}, nk});
-            k = nk;
-        }
+        nx_air_kernel* nk = nullptr;
+        NX_TRY(compile_source(ctx, src, n_kernels, n_cols, n_econsts, n_logup_cols, &nk, 1));      // outside the lock: entries are per context
+        std::lock_guard<std::mutex> lk(kc.mu);
+        kc.map.insert({{ctx, key}, nk});
+        k = nk;
     }
     const size_t b_cols = (size_t)n_cols * 8, b_ec = (size_t)n_econsts * 16, b_out = (size_t)n_logup_cols * 32;
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
