@@ -880,7 +880,9 @@ int nx_merkle_commit(nx_ctx* ctx, const uint32_t* const* d_cols, const uint32_t*
     std::vector<const uint32_t*> sorted(n_cols);
     for (uint32_t i = 0; i < n_cols; i++) sorted[i] = d_cols[order[i]];
 
-    if (ctx->opt.merkle_fused && n_cols >= 1 && n_cols <= 4 && max_log >= (uint32_t)std::max(ctx->opt.merkle_fused, (int)FUSED_MIN_LOG) && log_sizes[order[n_cols - 1]] == max_log)
+    bool aligned16 = true;                                         // the fused launch reads 4 rows of a column as one 16-byte word
+    for (uint32_t i = 0; i < n_cols; i++) aligned16 = aligned16 && ((uintptr_t)sorted[i] & 15u) == 0;
+    if (ctx->opt.merkle_fused && aligned16 && n_cols >= 1 && n_cols <= 4 && max_log >= (uint32_t)std::max(ctx->opt.merkle_fused, (int)FUSED_MIN_LOG) && log_sizes[order[n_cols - 1]] == max_log)
         return merkle_commit_fused(ctx, sorted.data(), n_cols, max_log, out);      // a secure column (composition tree, a FRI layer): leaf hash and 6 levels in one launch
     nx_tree* t = new nx_tree();
     t->ctx = ctx;
