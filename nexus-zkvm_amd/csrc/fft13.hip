@@ -76,6 +76,18 @@ __device__ __forceinline__ void bfly13(u32& x0, u32& x1, u32 t2, bool neg) {
     }
 }
 
+#ifndef NX_FFT_SCALAR_TW   // A/B knob: 0 = the twiddles of every round through vector loads
+#define NX_FFT_SCALAR_TW 1
+#endif
+// Twiddle tables are never written while a transform runs: through the constant address space a WAVE-UNIFORM address becomes a scalar load
+// (s_load_dwordx8 ...: no VMEM instruction, no VGPRs), any other address an ordinary global load.
+#define NX_CONSTANT __attribute__((address_space(4)))
+template <int CNT>
+__device__ __forceinline__ void load_tw13_uniform(const u32* __restrict__ p, u32* dst) {
+    NX_CONSTANT const u32* q = (NX_CONSTANT const u32*)p;
+#pragma unroll
+    for (int k = 0; k < CNT; k++) dst[k] = q[k];
+}
 template <int CNT>
 __device__ __forceinline__ void load_tw13(const u32* __restrict__ p, u32* dst) {
     if constexpr (CNT == 8) {
@@ -93,12 +105,14 @@ __device__ __forceinline__ void load_tw13(const u32* __restrict__ p, u32* dst) {
 }
 
 // twiddles of layers l0+Q .. l0+R-1 for the 2^R rows starting at global index g0: layer q at tw[2^R - 2^(R-q)], 2^(R-1-q) words
-template <int R, int Q, bool CIRCLE>
+template <int R, int Q, bool CIRCLE, bool UNIFORM = false>
 __device__ __forceinline__ void load_round_tw13(const u32* const __restrict__* twl, u32 g0, int l0, u32* tw) {
     if constexpr (Q < R) {
-        if constexpr (!(CIRCLE && Q == 0))
-            load_tw13<(1 << (R - 1 - Q))>(twl[Q] + (g0 >> (l0 + Q + 1)), tw + ((1 << R) - (1 << (R - Q))));
-        load_round_tw13<R, Q + 1, CIRCLE>(twl, g0, l0, tw);
+        if constexpr (!(CIRCLE && Q == 0)) {
+            if constexpr (UNIFORM) load_tw13_uniform<(1 << (R - 1 - Q))>(twl[Q] + (g0 >> (l0 + Q + 1)), tw + ((1 << R) - (1 << (R - Q))));
+            else load_tw13<(1 << (R - 1 - Q))>(twl[Q] + (g0 >> (l0 + Q + 1)), tw + ((1 << R) - (1 << (R - Q))));
+        }
+        load_round_tw13<R, Q + 1, CIRCLE, UNIFORM>(twl, g0, l0, tw);
     }
 }
 
@@ -130,9 +144,13 @@ __device__ __forceinline__ void butterflies(Row<CB>* v, const u32* tw) {
 }
 
 // twiddle request for the full round at tile bit `bp`, for the 2^RB rows this lane owns
+// From tile bit 6 up a round's twiddles are the same for the 64 lanes of a wave: the lane bits below `bp` are shifted out of every twiddle
+// index (they address rows INSIDE a butterfly group) and the bits from `bp` up are the wave's.  Lane 0's index then stands for the wave, the
+// addresses are wave-uniform and the loads scalar (round 6; NX_FFT_SCALAR_TW).
 template <int RB, bool CIRCLE>
 __device__ __forceinline__ void tw_request(const Pass13& a, int bp, u32 tile_base, u32* tw) {
-    const u32 w = threadIdx.x;
+    const bool uniform = NX_FFT_SCALAR_TW && !CIRCLE && bp >= 6;
+    const u32 w = uniform ? (u32)__builtin_amdgcn_readfirstlane((int)threadIdx.x) : threadIdx.x;
     const u32 wl = w & ((1u << bp) - 1), wh = w >> bp;
     const u32 t0 = (wh << (bp + RB)) | wl;
     const u32 g0 = tile_base + ((t0 >> a.B) << a.lo) + (t0 & ((1u << a.B) - 1));
@@ -140,7 +158,8 @@ __device__ __forceinline__ void tw_request(const Pass13& a, int bp, u32 tile_bas
     const u32* __restrict__ twl[RB];
 #pragma unroll
     for (int q = 0; q < RB; q++) twl[q] = a.tw + ((1u << a.tw_log) - (1u << (a.n - (l0 + q))));
-    load_round_tw13<RB, 0, CIRCLE>(twl, g0, l0, tw);
+    if (uniform) load_round_tw13<RB, 0, CIRCLE, true>(twl, g0, l0, tw);
+    else load_round_tw13<RB, 0, CIRCLE, false>(twl, g0, l0, tw);
 }
 
 // One full LDS round trip (every lane owns 2^RB rows): tile bits [bp, bp+RB), twiddles already in registers.
