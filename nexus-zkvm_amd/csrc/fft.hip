@@ -369,7 +369,10 @@ static int evaluate_cols(nx_ctx* ctx, const nx_twiddles* tw, ColSet polys, u32 n
 // Columns per launch: g_tune.batch_cols (2) is sized for 2^22-row columns — four of them in flight fill the Infinity Cache.  Smaller
 // columns get proportionally more per launch (the same bytes in flight): at 2^18 rows a 2-column launch is ~10 us of work behind
 // ~5 us of launch latency, and a 438-column tree needs 657 of them.
+// Larger columns get fewer: at 2^23 / 2^24 rows one column per launch on the two streams measured 6 % faster than two
+// (profiles/r06_big_batch.txt) — four 2^24-row columns in flight are 3x the Infinity Cache.
 static u32 batch_for(const nx_ctx* ctx, uint32_t log_size) {
+    if (log_size > 22) return (u32)std::max(1, ctx->opt.fft_batch_cols >> std::min<uint32_t>(log_size - 22, 8));
     const int shift = log_size < 22 ? (int)(22 - log_size) : 0;
     return (u32)std::min<uint64_t>((uint64_t)ctx->opt.fft_batch_cols << std::min(shift, 8), 256);
 }

@@ -608,7 +608,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = now_ms(); }
 
     nx_twiddles* tw = nullptr;
-    H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw));      // machine.rs:184-194
+    { HostSpan hs("pm.twiddles_create"); H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw)); }      // machine.rs:184-194
     struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
     Blake2sChannel channel;
     for (size_t i = 0; i < ad_len; i++) channel.mix_u64(ad[i]);                       // machine.rs:198-200
@@ -621,6 +621,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     // assembling the components' programs, looking their kernels up, the vote of a row-sharded prove — runs while the GPU fills, and
     // only then the two commits (each ends in the synchronisation that fetches its root): the GPU does not idle through the set-up.
     TreeBuilder tb0 = cs.tree_builder(), tb1 = cs.tree_builder();
+    GenericAir air; air.ctx = ctx;           // declared after cs: destroyed first
     // A trace tree is consumed by its commitment (the columns become coefficients), and the interaction trace needs evaluations
     // afterwards: the reference clones the whole finalized trace (machine.rs:232) and keeps the preprocessed one; here only the columns
     // the logup fractions read are kept — main columns, and the preprocessed columns of a table component (NX_LOGUP_TABLE).  One GPU:
@@ -688,9 +689,10 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
             if (it != ctx->machine_pre_cache.end()) pre_shared = std::static_pointer_cast<CommitmentTreeProver>(it->second);
         }
     }
-    if (!pre_shared) H_TRY(stage_tree(0, tb0));
-    H_TRY(stage_tree(1, tb1));
+    { HostSpan hs("pm.stage_trees(fill queued)"); if (!pre_shared) H_TRY(stage_tree(0, tb0));
+    H_TRY(stage_tree(1, tb1)); }
     {
+        HostSpan hs("pm.components+prepare #1");
         // Everything that can fail on ONE rank only before the exchanges start — the hiprtc compilation of the components' kernels
         // (the text does not depend on the proof: lookup elements and claimed sums are run-time constants) — happens here, followed
         // by a vote: a rank that failed must not leave its peers blocked in the first all-to-all.
@@ -699,6 +701,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
             GComponent g = machine_component(comps[i], locs[i], cfg);
             g.log_cd = comps[i].log_constraint_degree_bound;
             rc_local = prepare_component_kernels(ctx, cfg, g, D.on());
+            air.comps.push_back(std::move(g));             // kept: only the run-time constants (lookup elements, claimed-sum shift) are filled in later
         }
         H_TRY(vote_before_exchanges(ctx, D, rc_local, "nx_prove_machine"));
     }
@@ -709,6 +712,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         // "machine.queue_trees": both tree builds are queued before the first root is fetched — the main tree's transforms do not depend
         // on the preprocessed root, so the GPU does not idle through that download (the roots still enter the transcript in order)
         main_queued = !host && !D.on() && ctx->opt.machine_queue_trees;
+        HostSpan hs("pm.commit tree0 (+begin tree1)");
         if (main_queued) { H_TRY(tb0.commit_begin()); H_TRY(tb1.commit_begin()); H_TRY(tb0.commit_end(channel)); }
         else H_TRY(tb0.commit(channel));                                              // machine.rs:208-228
         if (!pre_key.empty()) {                                                       // keep it for the next proof of this shape
@@ -720,7 +724,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
             ctx->machine_pre_cache[pre_key] = sp;
         }
     }
-    if (main_queued) H_TRY(tb1.commit_end(channel)); else H_TRY(tb1.commit(channel));   // machine.rs:230-237
+    { HostSpan hs("pm.commit tree1 end (sync)"); if (main_queued) H_TRY(tb1.commit_end(channel)); else H_TRY(tb1.commit(channel)); }   // machine.rs:230-237
     lap(&st->commit);
 
     // machine.rs:239-247: draw_lookup_elements, generate_interaction_trace
@@ -742,10 +746,10 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
                 DevBuf rows; H_TRY(rows.alloc(ctx, (size_t)c.n_inter * nb));                  // every logup column, this GPU's rows
                 std::vector<uint32_t*> ip(c.n_inter);
                 for (uint32_t k = 0; k < c.n_inter; k++) ip[k] = rows.p + (size_t)k * nb;
-                H_TRY(logup_columns(ctx, c, log_rows, kept_ptr[1][i], kept_ptr[0][i], z, alpha, ip.data()));
+                { HostSpan hs("pm.logup_columns"); H_TRY(logup_columns(ctx, c, log_rows, kept_ptr[1][i], kept_ptr[0][i], z, alpha, ip.data())); }
                 uint32_t cs4[4];
                 if (!D.on()) {
-                    H_TRY(nx_logup_finalize_last(ctx, log, ip.data() + 4 * (L - 1), cs4));
+                    { HostSpan hs("pm.logup_finalize_last (sync)"); H_TRY(nx_logup_finalize_last(ctx, log, ip.data() + 4 * (L - 1), cs4)); }
                     slab = std::move(rows);
                 } else {
                     // finalize_last is a prefix sum over ALL rows in natural order: the last column is all-gathered and finalised by
@@ -784,26 +788,26 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     kept[0].clear(); kept[1].clear();
     lap(&st->interaction);
     channel.mix_felts(claimed);                                                       // machine.rs:262
-    H_TRY(tb2.commit_begin());                                                        // machine.rs:263, queued; its root is fetched below
+    { HostSpan hs("pm.tb2.commit_begin"); H_TRY(tb2.commit_begin()); }                                                        // machine.rs:263, queued; its root is fetched below
 
     // machine.rs:265-285: the components (recorded programs; lookup elements and claimed-sum shifts are run-time constants), assembled
     // while the GPU builds the interaction tree
-    GenericAir air; air.ctx = ctx;
     for (uint32_t i = 0; i < n_comps; i++) {
-        GComponent g = machine_component(comps[i], locs[i], cfg);
-        g.log_cd = comps[i].log_constraint_degree_bound;
+        HostSpan hs("pm.components econsts");
         const QM31 shift = q_mul_m(claimed[i], m_inv((1u << comps[i].log_size) % P));
-        fill_econsts(g.econsts, z, alpha, shift);
-        H_TRY(prepare_component_kernels(ctx, cfg, g, D.on()));
-        air.comps.push_back(std::move(g));
+        fill_econsts(air.comps[i].econsts, z, alpha, shift);
     }
-    H_TRY(tb2.commit_end(channel));
+    // one GPU: the interaction tree's polynomials are listed once its build is queued, so the components are checked against the committed
+    // trees while the GPU hashes (row-sharded: commit_end does the whole commit, the check follows it)
+    if (!D.on()) { HostSpan hs("pm.air.check"); H_TRY(air.check(cs)); }
+    { HostSpan hs("pm.tb2.commit_end (sync)"); H_TRY(tb2.commit_end(channel)); }
     lap(&st->commit);
-    H_TRY(air.check(cs));
+    if (D.on()) { HostSpan hs("pm.air.check"); H_TRY(air.check(cs)); }
     H_TRY(prove_core(ctx, cs, channel, cfg, tw, air, words, st, lap));               // machine.rs:286-290
     ctx->last_claimed.resize(4 * (size_t)n_comps);                                    // Proof.claimed_sum (machine.rs:93-98, :291-296)
     for (uint32_t i = 0; i < n_comps; i++) q_store(&ctx->last_claimed[4 * (size_t)i], claimed[i]);
     if (timed) finish_stats(ctx, st, t_start);
+    host_prof_dump("nx_prove_machine");
     return NX_OK;
 }
 

@@ -991,6 +991,23 @@ int finalize_accumulation(CommitmentSchemeProver& cs, std::map<uint32_t, SecureC
     return NX_OK;
 }
 
+bool host_prof_on() { static const bool on = [] { const char* e = getenv("NX_HOST_PROF"); return e && *e && *e != '0'; }(); return on; }
+namespace { struct HostProf { std::mutex mu; std::vector<std::pair<std::string, std::pair<double, unsigned>>> rows; }; HostProf& host_prof() { static HostProf h; return h; } }
+void host_prof_add(const char* name, double ms) {
+    HostProf& h = host_prof();
+    std::lock_guard<std::mutex> lk(h.mu);
+    for (auto& r : h.rows) if (r.first == name) { r.second.first += ms; r.second.second++; return; }
+    h.rows.push_back({name, {ms, 1u}});
+}
+void host_prof_dump(const char* title) {
+    if (!host_prof_on()) return;
+    HostProf& h = host_prof();
+    std::lock_guard<std::mutex> lk(h.mu);
+    fprintf(stderr, "[NX_HOST_PROF] %s\n", title);
+    for (auto& r : h.rows) fprintf(stderr, "[NX_HOST_PROF]   %-44s %9.3f ms  x%u\n", r.first.c_str(), r.second.first, r.second.second);
+    h.rows.clear();
+}
+
 void finish_stats(nx_ctx* ctx, nx_prove_stats* st, double t_start) {
     (void)nx_sync(ctx);
     st->total = now_ms() - t_start;
@@ -1011,14 +1028,14 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     // ---------------- stwo::prover::prove ----------------
     QM31 random_coeff = channel.draw_secure_felt();
     DevBuf comp_polys; uint32_t clog = 0;
-    H_TRY(air.compute_composition(cs, random_coeff, &comp_polys, &clog));
+    { HostSpan hs("pc.compute_composition"); H_TRY(air.compute_composition(cs, random_coeff, &comp_polys, &clog)); }
     lap(&st->composition);
-    { TreeBuilder tb = cs.tree_builder(); tb.extend_polys(std::move(comp_polys), 4, clog); H_TRY(tb.commit(channel)); }
+    { HostSpan hs("pc.composition tree commit (sync)"); TreeBuilder tb = cs.tree_builder(); tb.extend_polys(std::move(comp_polys), 4, clog); H_TRY(tb.commit(channel)); }
     lap(&st->commit);
     QPt oods = get_random_point(channel);
 
     MaskPoints points;                                                    // tree -> column -> points
-    air.mask_points(oods, &points);
+    { HostSpan hs("pc.mask_points"); air.mask_points(oods, &points); }
     points.resize(T + 1);
     points[T].assign(4, std::vector<QPt>{oods});
 
@@ -1056,7 +1073,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
                 H_TRY(eval_at_points_enqueue(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), pd.out.data(), &jobs));
             }
         }
-        H_TRY(eval_at_points_collect(ctx, &jobs));
+        { HostSpan hs("pc.oods collect (sync)"); H_TRY(eval_at_points_collect(ctx, &jobs)); }
         for (auto& pd : pend)
             for (size_t i = 0; i < pd.where.size(); i++) proof.sampled_values[pd.t][pd.where[i].first][pd.where[i].second] = q_load(&pd.out[4 * i]);
         if (D.on()) {
@@ -1072,19 +1089,23 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         }
     }
     { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); channel.mix_felts(flat); }
-    {   // ProvingError::ConstraintsNotSatisfied: the composition polynomial at the OODS point against the constraints over the sampled
-        // values.  Stwo checks it at the end of prove(); here as soon as the values exist (same inputs, same verdict): a trace that
-        // violates its constraints is refused BEFORE the quotients, FRI, the proof of work and the decommitment are paid for — and
-        // under every evaluation strategy: with "air.half_domain" / "air.quarter_domain" the composition is low-degree by construction
-        // even for an invalid trace (Q0 + t Z is what the interpolation returns), so this equality — not the FRI degree check — is
-        // what catches it.
+    auto check_oods = [&]() -> int {
+        // ProvingError::ConstraintsNotSatisfied: the composition polynomial at the OODS point against the constraints over the sampled
+        // values.  Stwo checks it at the end of prove(); here once the DEEP quotients are QUEUED (same inputs, same verdict): the host
+        // interprets every component's program at the point while the GPU computes the quotients (0.1 ms for the headline's AIR, 0.8 ms
+        // for a keccak-shaped one — GPU-idle time when it ran between the sampling and the quotients), and a trace that violates its
+        // constraints is still refused BEFORE FRI, the proof of work and the decommitment are paid for — under every evaluation
+        // strategy: with "air.half_domain" / "air.quarter_domain" the composition is low-degree by construction even for an invalid
+        // trace (Q0 + t Z is what the interpolation returns), so this equality — not the FRI degree check — is what catches it.
+        HostSpan hs("pc.oods host check (interpreter)");
         QM31 ce[4]; for (int k = 0; k < 4; k++) ce[k] = proof.sampled_values[T][k][0];
         QM31 lhs = q_add(q_add(ce[0], q_mul(ce[1], qm(0, 1, 0, 0))), q_add(q_mul(ce[2], qm(0, 0, 1, 0)), q_mul(ce[3], qm(0, 0, 0, 1))));
         if (!q_eq(lhs, air.eval_composition_at_point(oods, proof.sampled_values, random_coeff))) {
             ctx->symmetric_failure = true;       // every rank holds the same all-gathered sampled values and reaches this verdict by itself
             return set_err(ctx, NX_ERR_PROTOCOL, "ProvingError::ConstraintsNotSatisfied (composition OODS mismatch)");
         }
-    }
+        return NX_OK;
+    };
     lap(&st->oods);
     QM31 q_coeff = channel.draw_secure_felt();
     // compute_fri_quotients: all columns flattened, stable-sorted by LDE size (descending), grouped by size
@@ -1138,11 +1159,12 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         quotients.push_back(std::move(qc));
         i = j;
     }
+    H_TRY(check_oods());
     lap(&st->quotients);
     FriProver fri(ctx, tw, cfg, D);
-    H_TRY(fri.commit(channel, std::move(quotients)));                                                                                 // K9
+    { HostSpan hs("pc.fri.commit (sync)"); H_TRY(fri.commit(channel, std::move(quotients))); }                                                                                 // K9
     lap(&st->fri);
-    H_TRY(nx_grind(ctx, (const uint8_t*)channel.digest.w, cfg.pow_bits, &proof.proof_of_work));                                       // K10
+    { HostSpan hs("pc.grind (sync)"); H_TRY(nx_grind(ctx, (const uint8_t*)channel.digest.w, cfg.pow_bits, &proof.proof_of_work)); }                                       // K10
     channel.mix_u64(proof.proof_of_work);
     lap(&st->pow);
     std::map<uint32_t, std::vector<size_t>> qpos;
@@ -1151,7 +1173,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     fri.decommit_plan(&gb);
     std::vector<DecommitPlan> tree_plans(T + 1);
     for (int t = 0; t <= T; t++) tree_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, cs.trees[t].evals, &gb);
-    H_TRY(gb.run(ctx));
+    { HostSpan hs("pc.decommit gather (sync)"); H_TRY(gb.run(ctx)); }
     fri.decommit_fill(gb, &proof);
     proof.decommitments.resize(T + 1); proof.queried_values.resize(T + 1);
     for (int t = 0; t <= T; t++) {
@@ -1457,7 +1479,7 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
         remaining -= nc;
         std::vector<char> masked(c.cols.size(), 0);
         for (size_t k = 0; k < c.cols.size(); k++) for (int o : c.masks[k]) if (o != 0) masked[k] = 1;
-        H_TRY(prepare_component_kernels(ctx, cs.cfg, c, cs.dist.on()));
+        { HostSpan hs("cc.prepare_component_kernels"); H_TRY(prepare_component_kernels(ctx, cs.cfg, c, cs.dist.on())); }
         {   // the composition keeps the size the bound declares, whatever domains the parts are evaluated on
             bool any_full = false;       // ... or a quarter part: its contribution has the declared size too (4N coefficients)
             for (auto& part : c.parts) any_full = any_full || part.where == GComponent::ON_FULL || part.where == GComponent::ON_QUARTER;
@@ -1636,7 +1658,7 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
         }
     }
     std::map<uint32_t, SecureColumn> coef;
-    for (auto& kv : halves) H_TRY(half_group_finish(ctx, cs, kv.first, kv.second, &coef[kv.first + 1]));
+    { HostSpan hs("cc.half_group_finish"); for (auto& kv : halves) H_TRY(half_group_finish(ctx, cs, kv.first, kv.second, &coef[kv.first + 1])); }
     for (auto& kv : quarters) {
         // components of 2N rows may have put a half-domain contribution at the same size: coefficient vectors add
         SecureColumn q4;
@@ -1659,6 +1681,7 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
         H_TRY(secure_accumulate(ctx, it->second.c, s4, 1u << (kv.first + 2)));
         H_TRY(nx_sync(ctx));                                   // q4 is released here
     }
+    HostSpan hs("cc.finalize_accumulation");
     return finalize_accumulation(cs, sub, out_polys, out_log, coef.empty() ? nullptr : &coef);
 }
 
