@@ -113,6 +113,19 @@ struct nx_tree {
 
 namespace nx { void logup_kernels_release(nx_ctx* ctx); }       // air_jit.hip: compiled logup fraction programs cached per context
 namespace nxhip { void machine_kernels_release(nx_ctx* ctx); }   // machine.hip: compiled AIR kernels cached per context
+namespace nxhip {
+double now_ms();
+// NX_HOST_PROF=1: wall time of named HOST sections of a prove (a section that contains a synchronisation includes the wait), printed to
+// stderr by host_prof_dump at the end of every prove entry point.  A diagnosis aid for the GPU-idle gaps of tools/kernel_sequence.py.
+bool host_prof_on();
+void host_prof_add(const char* name, double ms);
+void host_prof_dump(const char* title);
+struct HostSpan {
+    const char* name; double t0;
+    explicit HostSpan(const char* n) : name(n), t0(host_prof_on() ? now_ms() : 0) {}
+    ~HostSpan() { if (host_prof_on()) host_prof_add(name, now_ms() - t0); }
+};
+}
 
 namespace nx {
 

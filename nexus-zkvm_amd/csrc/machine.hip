@@ -527,7 +527,9 @@ static int logup_columns(nx_ctx* ctx, const nx_component_spec& c, uint32_t log_r
         // The route of a Rust-side prove without the chips' generators (reference_patch/machine_hip.rs): the interaction trace FROM THE
         // RECORDED relation entries (nx_logup_program) — any expression as tuple entry or numerator.
         uint32_t n_regs = 0;
+        HostSpan* hs_p = new HostSpan("pm.machine_fraction_program");
         const std::vector<nx_cinstr> prog = machine_fraction_program(c, &n_regs);
+        delete hs_p;
         const uint32_t n_cols = c.n_pre + c.n_main + c.n_inter;
         std::vector<const uint32_t*> cols(n_cols, nullptr);
         for (auto& kv : prev) cols[kv.first] = kv.second;
@@ -588,6 +590,8 @@ struct HostTrace { const uint32_t* const* pre = nullptr; const uint32_t* const* 
 static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_comps, const nx_pcs_config* ucfg, uint64_t seed, const uint8_t* ad,
                          size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st, const HostTrace* host = nullptr) {
     PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
+    HostSpan hs_whole("pm.body (to the return statement)");
+    HostSpan* hs_pro = new HostSpan("pm.prologue");
     H_TRY(check_components(ctx, comps, n_comps, ucfg));
     for (uint32_t i = 0; i < n_comps; i++) {
         if (comps[i].n_inter % 4) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: n_inter = 4 x (number of logup columns)");
@@ -607,6 +611,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     Lap lap{ctx, timed, 0};
     if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = now_ms(); }
 
+    delete hs_pro;
     nx_twiddles* tw = nullptr;
     { HostSpan hs("pm.twiddles_create"); H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw)); }      // machine.rs:184-194
     struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
@@ -729,6 +734,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
 
     // machine.rs:239-247: draw_lookup_elements, generate_interaction_trace
     uint32_t z[4], alpha[4];
+    HostSpan* hs_int = new HostSpan("pm.interaction (whole stage, host)");
     { std::vector<QM31> za = channel.draw_secure_felts(2); q_store(z, za[0]); q_store(alpha, za[1]); }
     std::vector<QM31> claimed(n_comps, q_zero());
     TreeBuilder tb2 = cs.tree_builder();
@@ -786,6 +792,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         }
     }
     kept[0].clear(); kept[1].clear();
+    delete hs_int;
     lap(&st->interaction);
     channel.mix_felts(claimed);                                                       // machine.rs:262
     { HostSpan hs("pm.tb2.commit_begin"); H_TRY(tb2.commit_begin()); }                                                        // machine.rs:263, queued; its root is fetched below
@@ -807,7 +814,6 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     ctx->last_claimed.resize(4 * (size_t)n_comps);                                    // Proof.claimed_sum (machine.rs:93-98, :291-296)
     for (uint32_t i = 0; i < n_comps; i++) q_store(&ctx->last_claimed[4 * (size_t)i], claimed[i]);
     if (timed) finish_stats(ctx, st, t_start);
-    host_prof_dump("nx_prove_machine");
     return NX_OK;
 }
 
@@ -883,7 +889,9 @@ int nx_prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n_com
     if (!ctx || !comps || !cfg || !proof_words || !n_words) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: NULL argument");
     std::vector<uint32_t> w;
     ctx->symmetric_failure = false; ctx->comm_entered = false;
-    const int rc = nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats);
+    int rc;
+    { nxhip::HostSpan hs("nx_prove_machine (whole call, destructors included)"); rc = nxhip::prove_machine(ctx, comps, n_comps, cfg, seed, ad, ad_len, comm, &w, stats); }
+    nxhip::host_prof_dump("nx_prove_machine");
     abort_peers(ctx, comm, rc);
     return hand_out(ctx, rc, w, proof_words, n_words, "nx_prove_machine");
 }

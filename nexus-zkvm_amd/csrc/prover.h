@@ -264,16 +264,6 @@ struct Lap {   // per-stage wall clock of nx_prove_stats (only when the caller a
 };
 void finish_stats(nx_ctx* ctx, nx_prove_stats* st, double t_start);
 
-// NX_HOST_PROF=1: wall time of named HOST sections of a prove (a section that contains a synchronisation includes the wait), printed to
-// stderr by host_prof_dump at the end of every prove entry point.  A diagnosis aid for the GPU-idle gaps of tools/kernel_sequence.py.
-bool host_prof_on();
-void host_prof_add(const char* name, double ms);
-void host_prof_dump(const char* title);
-struct HostSpan {
-    const char* name; double t0;
-    explicit HostSpan(const char* n) : name(n), t0(host_prof_on() ? now_ms() : 0) {}
-    ~HostSpan() { if (host_prof_on()) host_prof_add(name, now_ms() - t0); }
-};
 
 // stwo::prover::prove from the point where the three trace trees are committed
 int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel, const PcsConfig& cfg, const nx_twiddles* tw, AirProver& air,

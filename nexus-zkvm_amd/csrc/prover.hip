@@ -1045,6 +1045,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     {   // every tree and size is enqueued first; ONE synchronisation collects all the sampled values (K7).  Row-sharded: each GPU
         // samples the polynomials it holds; the values (KBs) are all-gathered.
         struct Pending { std::vector<uint32_t> out; std::vector<std::pair<uint32_t, uint32_t>> where; int t; };
+        HostSpan* hs_enq = new HostSpan("pc.oods enqueue");
         std::vector<Pending> pend;
         std::vector<EvalJob> jobs;
         size_t n_req = 0;
@@ -1073,7 +1074,9 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
                 H_TRY(eval_at_points_enqueue(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), pd.out.data(), &jobs));
             }
         }
+        delete hs_enq;
         { HostSpan hs("pc.oods collect (sync)"); H_TRY(eval_at_points_collect(ctx, &jobs)); }
+        HostSpan hs_scatter("pc.oods scatter");
         for (auto& pd : pend)
             for (size_t i = 0; i < pd.where.size(); i++) proof.sampled_values[pd.t][pd.where[i].first][pd.where[i].second] = q_load(&pd.out[4 * i]);
         if (D.on()) {
@@ -1088,7 +1091,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
             }
         }
     }
-    { std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); channel.mix_felts(flat); }
+    { HostSpan hs("pc.oods mix_felts"); std::vector<QM31> flat; for (auto& t : proof.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); channel.mix_felts(flat); }
     auto check_oods = [&]() -> int {
         // ProvingError::ConstraintsNotSatisfied: the composition polynomial at the OODS point against the constraints over the sampled
         // values.  Stwo checks it at the end of prove(); here once the DEEP quotients are QUEUED (same inputs, same verdict): the host
@@ -1108,6 +1111,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     };
     lap(&st->oods);
     QM31 q_coeff = channel.draw_secure_felt();
+    HostSpan* hs_q = new HostSpan("pc.quotients (host grouping + launches)");
     // compute_fri_quotients: all columns flattened, stable-sorted by LDE size (descending), grouped by size
     struct Flat { const uint32_t* ptr; uint32_t log; int t; uint32_t c; };
     std::vector<Flat> all;
@@ -1159,6 +1163,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         quotients.push_back(std::move(qc));
         i = j;
     }
+    delete hs_q;
     H_TRY(check_oods());
     lap(&st->quotients);
     FriProver fri(ctx, tw, cfg, D);
@@ -1168,12 +1173,16 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     channel.mix_u64(proof.proof_of_work);
     lap(&st->pow);
     std::map<uint32_t, std::vector<size_t>> qpos;
-    fri.draw_queries(channel, &qpos);
     GatherBatch gb; gb.dist = &D;
-    fri.decommit_plan(&gb);
     std::vector<DecommitPlan> tree_plans(T + 1);
-    for (int t = 0; t <= T; t++) tree_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, cs.trees[t].evals, &gb);
+    {
+        HostSpan hs("pc.decommit plan");
+        fri.draw_queries(channel, &qpos);
+        fri.decommit_plan(&gb);
+        for (int t = 0; t <= T; t++) tree_plans[t] = merkle_decommit_plan(cs.trees[t].merkle, qpos, cs.trees[t].evals, &gb);
+    }
     { HostSpan hs("pc.decommit gather (sync)"); H_TRY(gb.run(ctx)); }
+    HostSpan hs_fill("pc.decommit fill");
     fri.decommit_fill(gb, &proof);
     proof.decommitments.resize(T + 1); proof.queried_values.resize(T + 1);
     for (int t = 0; t <= T; t++) {
@@ -1181,7 +1190,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         proof.commitments.push_back(cs.trees[t].root);
     }
     lap(&st->decommit);
-    *words = serialize(proof, cfg);
+    { HostSpan hs("pc.serialize"); *words = serialize(proof, cfg); }
     return NX_OK;
 }
 
@@ -1687,18 +1696,26 @@ int GenericAir::compute_composition(CommitmentSchemeProver& cs, QM31 random_coef
 
 void GenericAir::mask_points(QPt oods, MaskPoints* points) {
     points->assign(offs.size(), {});
-    for (size_t t = 0; t < offs.size(); t++)
+    std::map<std::pair<uint32_t, int>, QPt> shifted;          // (column log size, offset) -> oods + offset x the trace step: a few distinct pairs for thousands of columns
+    for (size_t t = 0; t < offs.size(); t++) {
+        points->at(t).reserve(offs[t].size());
         for (size_t c = 0; c < offs[t].size(); c++) {
             std::vector<QPt> pts;
+            pts.reserve(offs[t][c].size());
             for (int o : offs[t][c]) {
                 if (o == 0) { pts.push_back(oods); continue; }
-                const int64_t idx = ((int64_t)o * ((int64_t)1 << (31 - tree_logs[t][c]))) & 0x7fffffffLL;
-                Pt s = pt_from_index((u32)idx);
-                QPt step; step.x = q_from_m(s.x); step.y = q_from_m(s.y);
-                pts.push_back(qpt_add(oods, step));
+                auto it = shifted.find({tree_logs[t][c], o});
+                if (it == shifted.end()) {
+                    const int64_t idx = ((int64_t)o * ((int64_t)1 << (31 - tree_logs[t][c]))) & 0x7fffffffLL;
+                    Pt s = pt_from_index((u32)idx);
+                    QPt step; step.x = q_from_m(s.x); step.y = q_from_m(s.y);
+                    it = shifted.insert({{tree_logs[t][c], o}, qpt_add(oods, step)}).first;
+                }
+                pts.push_back(it->second);
             }
-            points->at(t).push_back(pts);
+            points->at(t).push_back(std::move(pts));
         }
+    }
 }
 
 // the recorded program over QM31: every register holds the value of its expression at the OODS point
