@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-6 evidence run on the GPU box: everything lands under gpurun_out/r06/ev/ (copy what is to be judged into profiles/).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r06/ev; mkdir -p $O
+O=${EV_OUT:-gpurun_out/r06/ev}; mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
 # 1. the driver's line (N = 1): headline + v1-shaped (+ the reference's tuple widths) + host trace + preprocessed reuse + cpu_baseline
@@ -9,10 +9,21 @@ timeout 1200 python bench.py --steps 20 > $O/bench.json 2> $O/bench.err; tail -1
 # 2. rocprofv3 kernel traces of the same command (headline) and of the v1-shaped statement; the kernel sequence / GPU idle gaps of one headline prove
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_bench -o kt -- python bench.py --no-cpu-baseline --no-v1-shaped --no-host-trace --steps 5 > /dev/null 2>&1
 python tools/rocprof_summary.py $O/kt_bench/kt_results.db $O/bench_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-v1-shaped --no-host-trace --steps 5"
-python tools/kernel_sequence.py $O/kt_bench/kt_results.db $O/bench_kernel_sequence.txt
+# (kernel sequences come from step 2b: bench.py ends with a statistics prove, whose stages end in synchronisations — not what a timed prove does)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt_v1 -o kt -- python bench.py --lcd 2 --n-logup 250 --extra-comps 8 --no-cpu-baseline --no-v1-shaped --no-host-trace --steps 2 > /dev/null 2>&1
 python tools/rocprof_summary.py $O/kt_v1/kt_results.db $O/v1_shaped_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --lcd 2 --n-logup 250 --extra-comps 8 --no-cpu-baseline --no-v1-shaped --no-host-trace --steps 2"
 rm -rf $O/kt_bench $O/kt_v1
+# 2b. where the GPU idles inside a TIMED prove: kernel sequences of plain proves (no statistics call) of the headline, the v1 shape and config #5 at the reference's tuple widths
+for W in headline v1 keccakw; do
+  rm -rf /tmp/kt_$W
+  timeout 600 rocprofv3 --kernel-trace -d /tmp/kt_$W -o kt -- python tools/prove_loop.py $W --steps 2 > /dev/null 2>&1
+  python tools/kernel_sequence.py $(find /tmp/kt_$W -name '*_results.db' | head -1) $O/seq_nostats_$W.txt
+  timeout 300 python tools/prove_loop.py $W --steps 5 >> $O/prove_loop.jsonl 2>/dev/null
+  rm -rf /tmp/kt_$W
+done
+NX_HOST_PROF=1 timeout 300 python tools/prove_loop.py keccakw --steps 1 > /dev/null 2> $O/host_prof_keccakw.txt
+NX_HOST_PROF=1 timeout 300 python tools/prove_loop.py headline --steps 1 > /dev/null 2> $O/host_prof_headline.txt
+timeout 100 tools/ubench/mall_bw > $O/mall_bw.jsonl 2>/dev/null
 # 3. HBM-side traffic of the Circle-FFT LDE (separate --pmc passes)
 timeout 400 python tools/pmc_traffic.py --out $O/fft_traffic.json > /dev/null 2>&1
 # 4. the headline statement at other sizes
