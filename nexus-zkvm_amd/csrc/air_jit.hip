@@ -1061,7 +1061,7 @@ extern "C" int nx_logup_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t 
     if (!program || (n_econsts && !econsts)) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: NULL argument");
     if (log_size < 1 || log_size > 30) return set_err(ctx, NX_ERR_ARG, "nx_logup_program: log_size out of range");
     { nxhip::HostSpan hs("lp.validate"); NX_TRY(validate_logup_program(ctx, program, n_instr, n_regs, n_cols, n_econsts, n_logup_cols)); }
-    nxhip::HostSpan* hs_key = new nxhip::HostSpan("lp.key+lookup");
+    nxhip::HostSpan hs_key("lp.key+lookup");
     // The kernels are cached per context by the PROGRAM (its bytes and shape, the segment budget): the generated source of a wide component
     // is megabytes of text, and building it only to look the kernels up cost a keccak-shaped prove 5 ms of GPU idle time per round
     // component (profiles/r06_keccak_tuples_sequence.txt, before).  The source is generated on a miss (and for h_source_out).
@@ -1069,7 +1069,7 @@ extern "C" int nx_logup_program(nx_ctx* ctx, const nx_cinstr* program, uint32_t 
     key += "|" + std::to_string(n_regs) + "|" + std::to_string(n_cols) + "|" + std::to_string(n_econsts) + "|" + std::to_string(n_logup_cols) + "|" + std::to_string(segment_budget(ctx));
     const nx_air_kernel* k = nullptr;
     if (ctx) { LogupKernelCache& kc = logup_kernel_cache(); std::lock_guard<std::mutex> lk(kc.mu); auto it = kc.map.find({ctx, key}); if (it != kc.map.end()) k = it->second; }
-    delete hs_key;
+    hs_key.stop();
     nxhip::HostSpan hs_rest("lp.checks+stage+launch");
     uint32_t n_kernels = 1;
     std::string src;

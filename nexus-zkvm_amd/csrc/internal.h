@@ -121,9 +121,12 @@ bool host_prof_on();
 void host_prof_add(const char* name, double ms);
 void host_prof_dump(const char* title);
 struct HostSpan {
-    const char* name; double t0;
-    explicit HostSpan(const char* n) : name(n), t0(host_prof_on() ? now_ms() : 0) {}
-    ~HostSpan() { if (host_prof_on()) host_prof_add(name, now_ms() - t0); }
+    const char* name; double t0; bool live;
+    explicit HostSpan(const char* n) : name(n), t0(host_prof_on() ? now_ms() : 0), live(host_prof_on()) {}
+    void stop() { if (live) { host_prof_add(name, now_ms() - t0); live = false; } }     // a section that ends before its scope does
+    ~HostSpan() { stop(); }
+    HostSpan(const HostSpan&) = delete;
+    HostSpan& operator=(const HostSpan&) = delete;
 };
 }
 

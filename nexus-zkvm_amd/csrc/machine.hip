@@ -527,9 +527,9 @@ static int logup_columns(nx_ctx* ctx, const nx_component_spec& c, uint32_t log_r
         // The route of a Rust-side prove without the chips' generators (reference_patch/machine_hip.rs): the interaction trace FROM THE
         // RECORDED relation entries (nx_logup_program) — any expression as tuple entry or numerator.
         uint32_t n_regs = 0;
-        HostSpan* hs_p = new HostSpan("pm.machine_fraction_program");
+        HostSpan hs_p("pm.machine_fraction_program");
         const std::vector<nx_cinstr> prog = machine_fraction_program(c, &n_regs);
-        delete hs_p;
+        hs_p.stop();
         const uint32_t n_cols = c.n_pre + c.n_main + c.n_inter;
         std::vector<const uint32_t*> cols(n_cols, nullptr);
         for (auto& kv : prev) cols[kv.first] = kv.second;
@@ -591,7 +591,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
                          size_t ad_len, const nx_comm* comm, std::vector<uint32_t>* words, nx_prove_stats* st, const HostTrace* host = nullptr) {
     PcsConfig cfg = {ucfg->pow_bits, ucfg->log_blowup, ucfg->n_queries, ucfg->log_last_layer_degree_bound, ucfg->fri_alpha_mode, ucfg->log_constraint_degree};
     HostSpan hs_whole("pm.body (to the return statement)");
-    HostSpan* hs_pro = new HostSpan("pm.prologue");
+    HostSpan hs_pro("pm.prologue");
     H_TRY(check_components(ctx, comps, n_comps, ucfg));
     for (uint32_t i = 0; i < n_comps; i++) {
         if (comps[i].n_inter % 4) return set_err(ctx, NX_ERR_ARG, "nx_prove_machine: n_inter = 4 x (number of logup columns)");
@@ -611,7 +611,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
     Lap lap{ctx, timed, 0};
     if (timed) { (void)nx_sync(ctx); t_start = lap.t0 = now_ms(); }
 
-    delete hs_pro;
+    hs_pro.stop();
     nx_twiddles* tw = nullptr;
     { HostSpan hs("pm.twiddles_create"); H_TRY(nx_twiddles_create(ctx, max_log + cfg.log_constraint_degree + cfg.log_blowup - 1, &tw)); }      // machine.rs:184-194
     struct TwGuard { nx_twiddles* t; ~TwGuard() { nx_twiddles_destroy(t); } } twg{tw};
@@ -734,7 +734,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
 
     // machine.rs:239-247: draw_lookup_elements, generate_interaction_trace
     uint32_t z[4], alpha[4];
-    HostSpan* hs_int = new HostSpan("pm.interaction (whole stage, host)");
+    HostSpan hs_int("pm.interaction (whole stage, host)");
     { std::vector<QM31> za = channel.draw_secure_felts(2); q_store(z, za[0]); q_store(alpha, za[1]); }
     std::vector<QM31> claimed(n_comps, q_zero());
     TreeBuilder tb2 = cs.tree_builder();
@@ -792,7 +792,7 @@ static int prove_machine(nx_ctx* ctx, const nx_component_spec* comps, uint32_t n
         }
     }
     kept[0].clear(); kept[1].clear();
-    delete hs_int;
+    hs_int.stop();
     lap(&st->interaction);
     channel.mix_felts(claimed);                                                       // machine.rs:262
     { HostSpan hs("pm.tb2.commit_begin"); H_TRY(tb2.commit_begin()); }                                                        // machine.rs:263, queued; its root is fetched below

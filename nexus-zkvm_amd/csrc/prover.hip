@@ -1045,7 +1045,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     {   // every tree and size is enqueued first; ONE synchronisation collects all the sampled values (K7).  Row-sharded: each GPU
         // samples the polynomials it holds; the values (KBs) are all-gathered.
         struct Pending { std::vector<uint32_t> out; std::vector<std::pair<uint32_t, uint32_t>> where; int t; };
-        HostSpan* hs_enq = new HostSpan("pc.oods enqueue");
+        HostSpan hs_enq("pc.oods enqueue");
         std::vector<Pending> pend;
         std::vector<EvalJob> jobs;
         size_t n_req = 0;
@@ -1074,7 +1074,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
                 H_TRY(eval_at_points_enqueue(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), pd.out.data(), &jobs));
             }
         }
-        delete hs_enq;
+        hs_enq.stop();
         { HostSpan hs("pc.oods collect (sync)"); H_TRY(eval_at_points_collect(ctx, &jobs)); }
         HostSpan hs_scatter("pc.oods scatter");
         for (auto& pd : pend)
@@ -1111,7 +1111,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     };
     lap(&st->oods);
     QM31 q_coeff = channel.draw_secure_felt();
-    HostSpan* hs_q = new HostSpan("pc.quotients (host grouping + launches)");
+    HostSpan hs_q("pc.quotients (host grouping + launches)");
     // compute_fri_quotients: all columns flattened, stable-sorted by LDE size (descending), grouped by size
     struct Flat { const uint32_t* ptr; uint32_t log; int t; uint32_t c; };
     std::vector<Flat> all;
@@ -1163,7 +1163,7 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
         quotients.push_back(std::move(qc));
         i = j;
     }
-    delete hs_q;
+    hs_q.stop();
     H_TRY(check_oods());
     lap(&st->quotients);
     FriProver fri(ctx, tw, cfg, D);
