@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <string.h>
+#include <errno.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -674,9 +675,13 @@ static int compile_parts(nx_ctx* ctx, const std::string& src, uint32_t n_kernels
             ProcGate& g = proc_gate();
             auto reap = [&](size_t q) {
                 int st = 0;
-                if (pid[q] > 0 && waitpid(pid[q], &st, 0) == pid[q]) {
+                if (pid[q] > 0) {
+                    pid_t w;
+                    do w = waitpid(pid[q], &st, 0); while (w < 0 && errno == EINTR);
+                    // the slot is given back whatever waitpid said (ECHILD: the embedding process ignores SIGCHLD and the kernel reaped the
+                    // helper — its part is then compiled here): a slot that is never returned would park a later compilation for ever
                     { std::lock_guard<std::mutex> lk(g.mu); g.running--; } g.cv.notify_one();
-                    if (WIFEXITED(st) && WEXITSTATUS(st) == 0 && read_file(dir + "/p" + std::to_string(q) + ".co", &objs[q]) && !objs[q].empty()) done[q] = 1;
+                    if (w == pid[q] && WIFEXITED(st) && WEXITSTATUS(st) == 0 && read_file(dir + "/p" + std::to_string(q) + ".co", &objs[q]) && !objs[q].empty()) done[q] = 1;
                 }
                 pid[q] = -1;
             };
