@@ -317,11 +317,12 @@ static nx_options options_from_env() {
     o.fft_kmax = clampi(env_int("NX_FFT_KMAX", 9), 1, 11);
     o.fft_fused = env_int("NX_FFT_FUSED", 1) != 0;
     o.merkle_fused = clampi(env_int("NX_MERKLE_FUSED", 21), 0, 31);   // profiles/r06_merkle_fused_ab.jsonl: FRI stage 3.48 -> 3.37 ms at 21, the prove within its noise
-    o.merkle_subtree = clampi(env_int("NX_MERKLE_SUBTREE", 17), 0, 30);
+    o.merkle_subtree = clampi(env_int("NX_MERKLE_SUBTREE", 14), 0, 30);   // profiles/r06_merkle_top_ab.jsonl: top 7 / subtree 14 against 10 / 17
+    o.merkle_top = clampi(env_int("NX_MERKLE_TOP", 7), 1, 10);
     o.merkle_pair_levels = env_int("NX_MERKLE_PAIR_LEVELS", 1) != 0;
     { int x = env_int("NX_PIPE_COLS", 0); o.commit_pipe_cols = x < 16 ? 0 : (x / 16) * 16; }
     o.fri_device_channel = env_int("NX_FRI_DEVICE_CHANNEL", 1) != 0;
-    o.fri_tail = env_int("NX_FRI_TAIL", 1) != 0;
+    o.fri_tail = clampi(env_int("NX_FRI_TAIL", 1), 0, 11);
     o.logup_scan_tiled = env_int("NX_LOGUP_SCAN_TILED", 1) != 0;
     o.logup_staged = env_int("NX_LOGUP_STAGED", 1) != 0;
     o.logup_per_column = env_int("NX_LOGUP_PER_COLUMN", 0) != 0;
@@ -346,10 +347,11 @@ static const OptEntry k_options[] = {
     {"fft.fused", &nx_options::fft_fused, 0, 1},
     {"merkle.fused", &nx_options::merkle_fused, 0, 31},
     {"merkle.subtree", &nx_options::merkle_subtree, 0, 30},
+    {"merkle.top", &nx_options::merkle_top, 1, 10},
     {"merkle.pair_levels", &nx_options::merkle_pair_levels, 0, 1},
     {"commit.pipe_cols", &nx_options::commit_pipe_cols, 0, 1 << 20},
     {"fri.device_channel", &nx_options::fri_device_channel, 0, 1},
-    {"fri.tail", &nx_options::fri_tail, 0, 1},
+    {"fri.tail", &nx_options::fri_tail, 0, 11},
     {"logup.scan_tiled", &nx_options::logup_scan_tiled, 0, 1},
     {"logup.staged", &nx_options::logup_staged, 0, 1},
     {"logup.per_column", &nx_options::logup_per_column, 0, 1},

@@ -27,10 +27,11 @@ struct nx_options {
     int fft_kmax;                 // "fft.kmax": most layers of a non-FIRST pass (runs of 2^(13-K) words), 1..11
     int fft_fused;                // "fft.fused": fused LDE middle launch (lde_mid_kernel)
     int merkle_fused;             // "merkle.fused": 0 = off, else the smallest log size from which the tree of <= 4 columns of one size (composition tree, FRI layers) gets its leaf hash — for a FRI layer also the fold — and 6 levels in one launch (merkle_fused_kernel)
+    int merkle_top;               // "merkle.top": highest level the one-block top launch (merkle_top_kernel) starts from: 2^top nodes, <= 10
     int merkle_subtree; int merkle_pair_levels;           // "merkle.subtree": highest tree level built by the fused subtree launch (0 = one launch per level)
     int commit_pipe_cols;         // "commit.pipe_cols": leaf hashing of finished column groups of this many columns beside the next group's LDE (0 = off)
     int fri_device_channel;       // "fri.device_channel": FRI commit phase with the channel on the device
-    int fri_tail;                 // "fri.tail": last FRI layers in one launch
+    int fri_tail;                 // "fri.tail": last FRI layers in one launch: 0 = off, 1 = from 2^11 points (FRI_TAIL_LOG), 2 .. 11 = from 2^that many
     int logup_scan_tiled;         // "logup.scan_tiled": finalize_last as coalesced tiles
     int logup_staged;             // "logup.staged": nx_logup_cols requests every read of a group of fractions up front (values parked in LDS)
     int logup_per_column;         // "logup.per_column": one nx_logup_col launch per column instead of nx_logup_cols

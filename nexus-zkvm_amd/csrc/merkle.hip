@@ -762,7 +762,7 @@ static int build_inner_layers(nx_ctx* ctx, nx_tree* t, uint32_t max_log, const s
     size_t ci = 0;
     const size_t n = sorted.size();
     int smallest_col_log = n ? (int)logs[n - 1] : (int)max_log;
-    int top_fused = std::min(10, std::min((int)max_log - 1, smallest_col_log - 1));
+    int top_fused = std::min(ctx->opt.merkle_top, std::min((int)max_log - 1, smallest_col_log - 1));
     // levels [top_fused + 1, SUBTREE_TOP] without injected columns: one launch (merkle_subtree_kernel) instead of one per level
     const int SUBTREE_TOP = ctx->opt.merkle_subtree;   // 0 = off
     for (int log = (int)max_log - 1; log >= 0; log--) {
@@ -946,7 +946,7 @@ int nx_merkle_from_leaves(nx_ctx* ctx, const uint32_t* d_leaf_digests, uint32_t 
     for (uint32_t k = 0; k <= log_size; k++) t->layers[k] = buf + (((size_t)1 << k) - 1) * 8;
     int rc = nx_copy(ctx, t->layers[log_size], d_leaf_digests, (size_t)8 << log_size);
     KTimer timer(ctx, NX_T_MERKLE, (uint64_t)96 << log_size);
-    const int top_fused = std::min(10, (int)log_size - 1);
+    const int top_fused = std::min(ctx->opt.merkle_top, (int)log_size - 1);
     ColSet none; none.base = nullptr; none.stride = 0; none.table = nullptr;
     for (int log = (int)log_size - 1; log >= 0 && rc == NX_OK; log--) {
         if (log == top_fused && log >= 1) {

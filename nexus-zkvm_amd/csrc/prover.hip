@@ -552,6 +552,7 @@ class FriProver {
         H_TRY(nx_memset_zero(ctx, layer.buf.p, layer.buf.words));
         size_t ci = 0;
         const bool use_tail = ctx->opt.fri_tail != 0;
+        const uint32_t tail_log = ctx->opt.fri_tail == 1 ? (uint32_t)FRI_TAIL_LOG : (uint32_t)std::min(ctx->opt.fri_tail, FRI_TAIL_LOG);   // "fri.tail": 1 = from 2^11 points, 2 .. 11 = from that size
         // `pending`: `layer` is allocated but not computed yet — it is fold_line(inner.back().eval, alpha of record j_prev), which the fused
         // launch of the layer's commit computes on its way (or fold_line_dev, where the layer is needed before its commit)
         bool pending = false;
@@ -562,7 +563,7 @@ class FriProver {
         };
         while (layer_log > last_log) {
             const int j = (int)inner.size() + 1;   // record of the layer committed in this iteration
-            if (use_tail && ci == columns.size() && layer_log <= (uint32_t)FRI_TAIL_LOG && layer_log - last_log <= (uint32_t)FRI_TAIL_MAX_LAYERS) {
+            if (use_tail && ci == columns.size() && layer_log <= tail_log && layer_log - last_log <= (uint32_t)FRI_TAIL_MAX_LAYERS) {
                 H_TRY(materialize());
                 const int n = (int)(layer_log - last_log);
                 std::vector<FriLayer> tl(n);
