@@ -205,10 +205,28 @@ __global__ __launch_bounds__(256) void quotient_combine_kernel(ColSet polys, u32
         for (int i = 0; i < 4; i++) for (int q = 0; q < 4; q++) n[i][q] = 0;
         const u32 end = B.first + B.count;
         u32 k = B.first;
+#ifndef NX_QC_NO_PIPELINE
+        // the next four columns are requested before the current four are consumed (a wave no longer sits without a load in flight while it
+        // multiplies; quotient stage 2.50 -> 2.47 ms in a same-box A/B of 4 alternating rounds, profiles/r06_quotient_pipeline_ab.jsonl: the kernel is at ~0.8 of its HBM floor either way)
+        uint4 g[4];
+        if (k + 4 <= end) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) g[u] = gld4(polys.col(col_idx[k + u]) + r);
+        }
+#endif
         for (; k + 4 <= end; k += 4) {
             uint4 f[4];
+#ifndef NX_QC_NO_PIPELINE
+#pragma unroll
+            for (int u = 0; u < 4; u++) f[u] = g[u];
+            if (k + 8 <= end) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) g[u] = gld4(polys.col(col_idx[k + 4 + u]) + r);
+            }
+#else
 #pragma unroll
             for (int u = 0; u < 4; u++) f[u] = gld4(polys.col(col_idx[k + u]) + r);
+#endif
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const u32 c0 = cks[4 * (k + u)], c1 = cks[4 * (k + u) + 1], c2 = cks[4 * (k + u) + 2], c3 = cks[4 * (k + u) + 3];
