@@ -1045,41 +1045,45 @@ int prove_core(nx_ctx* ctx, CommitmentSchemeProver& cs, Blake2sChannel& channel,
     proof.sampled_values.resize(T + 1);
     {   // every tree and size is enqueued first; ONE synchronisation collects all the sampled values (K7).  Row-sharded: each GPU
         // samples the polynomials it holds; the values (KBs) are all-gathered.
-        struct Pending { std::vector<uint32_t> out; std::vector<std::pair<uint32_t, uint32_t>> where; int t; };
+        // One request per polynomial SIZE, across the trees (the columns of the three trace trees of a component share size and point: one table
+        // build and one sweep launch instead of one per tree — the launches of a small statement are latency, not bytes).
+        struct Where { int t; uint32_t c, s; };
+        struct Pending { std::vector<uint32_t> out; std::vector<Where> where; };
         HostSpan hs_enq("pc.oods enqueue");
         std::vector<Pending> pend;
         std::vector<EvalJob> jobs;
-        size_t n_req = 0;
-        for (int t = 0; t <= T; t++) { std::set<uint32_t> logs; for (auto& c : cs.trees[t].polys) logs.insert(c.log); n_req += logs.size(); }
-        pend.reserve(n_req);                                       // `out` buffers must not move while jobs point into them
+        std::map<uint32_t, std::vector<std::pair<int, uint32_t>>> by_log;   // poly log -> (tree, column) held by this GPU, in tree / column order
         for (int t = 0; t <= T; t++) {
             auto& tr = cs.trees[t];
             proof.sampled_values[t].resize(tr.polys.size());
-            for (uint32_t c = 0; c < tr.polys.size(); c++) proof.sampled_values[t][c].assign(points[t][c].size(), q_zero());
-            std::map<uint32_t, std::vector<uint32_t>> by_log;  // poly log -> column indices held by this GPU
-            for (uint32_t c = 0; c < tr.polys.size(); c++) if (tr.polys[c].ptr) by_log[tr.polys[c].log].push_back(c);
-            for (auto& kv : by_log) {
-                std::vector<const uint32_t*> pp; std::vector<uint32_t> pidx, pts;
-                pend.emplace_back(); Pending& pd = pend.back(); pd.t = t;
-                for (uint32_t li = 0; li < kv.second.size(); li++) {
-                    uint32_t c = kv.second[li];
-                    pp.push_back(tr.polys[c].ptr);
-                    for (uint32_t s = 0; s < points[t][c].size(); s++) {
-                        pidx.push_back(li);
-                        uint32_t w[8]; q_store(w, points[t][c][s].x); q_store(w + 4, points[t][c][s].y);
-                        pts.insert(pts.end(), w, w + 8);
-                        pd.where.push_back({c, s});
-                    }
-                }
-                pd.out.assign(4 * pidx.size(), 0);
-                H_TRY(eval_at_points_enqueue(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), pd.out.data(), &jobs));
+            for (uint32_t c = 0; c < tr.polys.size(); c++) {
+                proof.sampled_values[t][c].assign(points[t][c].size(), q_zero());
+                if (tr.polys[c].ptr) by_log[tr.polys[c].log].push_back({t, c});
             }
+        }
+        pend.reserve(by_log.size());                               // `out` buffers must not move while jobs point into them
+        for (auto& kv : by_log) {
+            std::vector<const uint32_t*> pp; std::vector<uint32_t> pidx, pts;
+            pend.emplace_back(); Pending& pd = pend.back();
+            pp.reserve(kv.second.size()); pidx.reserve(kv.second.size()); pts.reserve(8 * kv.second.size()); pd.where.reserve(kv.second.size());
+            for (uint32_t li = 0; li < kv.second.size(); li++) {
+                const int t = kv.second[li].first; const uint32_t c = kv.second[li].second;
+                pp.push_back(cs.trees[t].polys[c].ptr);
+                for (uint32_t sidx = 0; sidx < points[t][c].size(); sidx++) {
+                    pidx.push_back(li);
+                    uint32_t w[8]; q_store(w, points[t][c][sidx].x); q_store(w + 4, points[t][c][sidx].y);
+                    pts.insert(pts.end(), w, w + 8);
+                    pd.where.push_back({t, c, sidx});
+                }
+            }
+            pd.out.assign(4 * pidx.size(), 0);
+            H_TRY(eval_at_points_enqueue(ctx, pp.data(), kv.first, pidx.data(), pts.data(), (uint32_t)pidx.size(), pd.out.data(), &jobs));
         }
         hs_enq.stop();
         { HostSpan hs("pc.oods collect (sync)"); H_TRY(eval_at_points_collect(ctx, &jobs)); }
         HostSpan hs_scatter("pc.oods scatter");
         for (auto& pd : pend)
-            for (size_t i = 0; i < pd.where.size(); i++) proof.sampled_values[pd.t][pd.where[i].first][pd.where[i].second] = q_load(&pd.out[4 * i]);
+            for (size_t i = 0; i < pd.where.size(); i++) proof.sampled_values[pd.where[i].t][pd.where[i].c][pd.where[i].s] = q_load(&pd.out[4 * i]);
         if (D.on()) {
             std::vector<uint32_t> mine;
             for (int t = 0; t <= T; t++) for (auto& col : proof.sampled_values[t]) for (auto& v : col) { uint32_t w[4]; q_store(w, v); mine.insert(mine.end(), w, w + 4); }

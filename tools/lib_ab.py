@@ -10,10 +10,12 @@ if sys.argv[1] == "--child":
     be = nz.HipBackend(0)
     what = os.environ.get("NX_AB_WHAT", "headline")
     comps, cfg = [(22, 27, 347, 64)], nz.default_config(pow_bits=10)
+    if what.startswith("log"):            # the headline machine at 2^N rows: NX_AB_WHAT=log16
+        comps = [(int(what[3:]), 27, 347, 64)]
     if what == "v1":
         comps, cfg = [(22, 27, 347, 1000, 2)] + [(8 + k, 2, 6 + k, 4, 1) for k in range(8)], nz.default_config(pow_bits=10, log_constraint_degree=2)
     w = be.prove_machine(comps, cfg, seed=5); be.sync()
-    n = 10 if what == "headline" else 3
+    n = 10 if what == "headline" else 3 if what == "v1" else 100
     t0 = time.perf_counter()
     for s in range(n):
         be.prove_machine(comps, cfg, seed=100 + s)
