@@ -69,9 +69,11 @@ int nx_ctx_set_hash_mode(nx_ctx* ctx, int mode);
  * IsPadding, prover/src/column.rs:13-20 — evaluated on the first HALF of that domain, which holds the neighbours of its first quarter;
  * one GPU, blowup 2, component bound 2).  Kernel-shape switches kept for A/B measurement (defaults are the
  * measured best): "fft.kmax" (most layers of a non-first FFT pass, 1..11), "fft.fused" (fused middle launch of the LDE), "merkle.subtree"
- * (highest level built by the fused sub-tree launch; 0 = one launch per level), "merkle.pair_levels" (two node-only levels per launch
+ * (highest level built by the fused sub-tree launch; 0 = one launch per level), "merkle.top" (the level, 1..10, from which ONE block
+ * builds the rest of a tree), "merkle.pair_levels" (two node-only levels per launch
  * above it), "commit.pipe_cols" (leaf hashing beside the LDE in
- * groups of this many columns; 0 = off), "fri.device_channel", "fri.tail", "logup.scan_tiled", "logup.per_column", "logup.staged" (nx_logup_cols requests
+ * groups of this many columns; 0 = off), "fri.device_channel", "fri.tail" (0 = off, 1 = the FRI layers of <= 2^11 points in one launch,
+ * 2..11 = from 2^that many points), "logup.scan_tiled", "logup.per_column", "logup.staged" (nx_logup_cols requests
  * every read of a group of 8 fractions before it uses the first value; 0 = reads where they are used).
  * Unknown names and out-of-range values are NX_ERR_ARG.
  * None of them changes a result: proofs, roots and transforms are bit-identical under every setting. */
