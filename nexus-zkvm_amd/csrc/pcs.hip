@@ -192,19 +192,23 @@ __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, u32
 // coefficients are Σ_k c_k coef_k: combining the coefficient columns (half as long as their extensions at blowup 2), extending the
 // 4 coordinate columns per batch and finishing row by row reads half the bytes of the row-wise sum over the extensions — and gives the
 // same field elements, the arithmetic being exact.  Lane = 4 consecutive coefficients; out: [batch][coordinate] columns of n words.
+// blockIdx.y = slice: a short column (few lanes) is combined by n_slices blocks per lane group, each over its share of every batch's entries, into
+// its own copy of the output (slice_stride words apart); quotient_combine_reduce_kernel adds the copies.  n_slices = 1: the whole sum, as before.
 __global__ __launch_bounds__(256) void quotient_combine_kernel(ColSet polys, u32 n4, const QBatchDev* __restrict__ batches, u32 n_batches,
                                                                const u32* __restrict__ col_idx, const u32* __restrict__ cks /*4 per entry*/,
-                                                               u32* __restrict__ out, size_t col_stride) {
+                                                               u32* __restrict__ out, size_t col_stride, u32 n_slices, size_t slice_stride) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n4) return;
     const u32 r = 4 * j;
+    const u32 sl = blockIdx.y;
+    out += (size_t)sl * slice_stride;
     for (u32 b = 0; b < n_batches; b++) {
         const QBatchDev& B = batches[b];
         u64 n[4][4];
 #pragma unroll
         for (int i = 0; i < 4; i++) for (int q = 0; q < 4; q++) n[i][q] = 0;
-        const u32 end = B.first + B.count;
-        u32 k = B.first;
+        const u32 end = B.first + (u32)(((u64)B.count * (sl + 1)) / n_slices);
+        u32 k = B.first + (u32)(((u64)B.count * sl) / n_slices);
 #ifndef NX_QC_NO_PIPELINE
         // the next four columns are requested before the current four are consumed (a wave no longer sits without a load in flight while it
         // multiplies; quotient stage 2.50 -> 2.47 ms in a same-box A/B of 4 alternating rounds, profiles/r06_quotient_pipeline_ab.jsonl: the kernel is at ~0.8 of its HBM floor either way)
@@ -254,6 +258,18 @@ __global__ __launch_bounds__(256) void quotient_combine_kernel(ColSet polys, u32
         for (int q = 0; q < 4; q++)
             *reinterpret_cast<uint4*>(out + (size_t)(4 * b + q) * col_stride + r) = make_uint4(acc_final(n[0][q]), acc_final(n[1][q]), acc_final(n[2][q]), acc_final(n[3][q]));
     }
+}
+
+// out[0] += out[1] + ... + out[n_slices - 1] (canonical M31 words, 4 per lane)
+__global__ __launch_bounds__(256) void quotient_combine_reduce_kernel(u32* __restrict__ out, size_t n4_total, u32 n_slices, size_t slice_stride) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n4_total) return;
+    uint4 a = *reinterpret_cast<const uint4*>(out + 4 * j);
+    for (u32 sl = 1; sl < n_slices; sl++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(out + (size_t)sl * slice_stride + 4 * j);
+        a.x = m_add(a.x, v.x); a.y = m_add(a.y, v.y); a.z = m_add(a.z, v.z); a.w = m_add(a.w, v.w);
+    }
+    *reinterpret_cast<uint4*>(out + 4 * j) = a;
 }
 
 // rows 4j .. 4j+3 from the extended combinations: num_b = G_b(d) - (d.y Σ a + Σ b), acc = acc * alpha^count_b + num_b / den_b(d).  The
@@ -659,13 +675,19 @@ int accumulate_quotients_coeffs(nx_ctx* ctx, const nx_twiddles* tw, uint32_t log
     const uint32_t nq = 4 * n_batches;
     const size_t nc = (size_t)1 << log_coef, ne = (size_t)1 << log_size;
     uint32_t* comb = nullptr; uint32_t* ext = nullptr;
-    NX_TRY(dev_alloc(ctx, (size_t)nq * nc * 4, (void**)&comb));
+    // short columns: nc / 4 lanes do not fill the chip and each walks every column — the entries are split over up to 16 slices (same sums: M31
+    // addition does not care how they are grouped; profiles/r06_quotient_slices_ab.jsonl)
+    const uint32_t n_slices = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, ((size_t)1 << 18) / (nc / 4)));
+    const size_t slice_stride = (size_t)nq * nc;
+    NX_TRY(dev_alloc(ctx, slice_stride * n_slices * 4, (void**)&comb));
     { int rc = dev_alloc(ctx, (size_t)nq * ne * 4, (void**)&ext); if (rc != NX_OK) { dev_free(ctx, comb); return rc; } }
     int rc = NX_OK;
     {
         KTimer timer(ctx, NX_T_QUOT, ((uint64_t)n_cols * 4 + 16) * ne);     // the same algorithmic bytes as the row-wise path: what the stage computes
-        hipLaunchKernelGGL(quotient_combine_kernel, dim3((unsigned)((nc / 4 + 255) / 256)), dim3(256), 0, ctx->stream, cs, (u32)(nc / 4), (const QBatchDev*)blob, n_batches,
-                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), comb, nc);
+        hipLaunchKernelGGL(quotient_combine_kernel, dim3((unsigned)((nc / 4 + 255) / 256), n_slices), dim3(256), 0, ctx->stream, cs, (u32)(nc / 4), (const QBatchDev*)blob, n_batches,
+                           (const u32*)(blob + off_i), (const u32*)(blob + off_c), comb, nc, n_slices, slice_stride);
+        if (n_slices > 1)
+            hipLaunchKernelGGL(quotient_combine_reduce_kernel, dim3((unsigned)((slice_stride / 4 + 255) / 256)), dim3(256), 0, ctx->stream, comb, slice_stride / 4, n_slices, slice_stride);
         if (hipGetLastError() != hipSuccess) rc = set_err(ctx, NX_ERR_HIP, "quotient_combine_kernel launch failed");
     }
     if (rc == NX_OK) {
