@@ -770,7 +770,7 @@ static int build_inner_layers(nx_ctx* ctx, nx_tree* t, uint32_t max_log, const s
             NX_TRY(launch_merkle_top(ctx, buf, log));
             break;
         }
-        if (top_fused >= 1 && log <= SUBTREE_TOP && log - top_fused >= 2 && log - top_fused <= 7 && smallest_col_log > log) {
+        if (top_fused >= 1 && log <= SUBTREE_TOP && log >= 6 && log - top_fused >= 2 && log - top_fused <= 7 && smallest_col_log > log) {      // log >= 6: level log + 1 holds at least one block's 128 nodes ("merkle.top" below 5)
             NX_TRY(launch_merkle_subtree(ctx, buf, log + 1, log - top_fused));       // levels log .. top_fused + 1
             log = top_fused + 1;
             continue;

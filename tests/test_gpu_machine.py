@@ -124,6 +124,19 @@ def test_secure_column_trees_with_the_fused_leaf_launch(nz, oracle):
             b.close()
 
 
+def test_tree_top_and_fri_tail_splits_give_the_same_bytes(nz, oracle):
+    """"merkle.top" / "merkle.subtree" (round 6: the one-block top of a tree starts at 128 nodes, the multi-block sub-tree launch covers the
+    7 levels above) and "fri.tail" (the size from which the last FRI layers are one launch; 0 = off): where the launches are cut never
+    changes a node — the same proof as the oracle's under the extremes of every switch, both node-hash rules."""
+    for comps, kw in (MACHINE_CASES[5], ([(15, 3, 20, 8), (12, 2, 6, 4)], dict(pow_bits=4, hash_mode=1, fri_alpha_mode=1))):
+        ref = M.prove_machine(comps, O.default_cfg(**kw), seed=13, ad=b"tt", threads=THREADS)
+        for top, sub, tail in ((10, 17, 1), (1, 8, 1), (3, 6, 0), (7, 0, 6), (5, 30, 11), (7, 14, 2)):
+            b = nz.HipBackend()
+            b.set_option("merkle.top", top); b.set_option("merkle.subtree", sub); b.set_option("fri.tail", tail)
+            _same(ref, b.prove_machine(comps, nz.default_config(**kw), seed=13, ad=b"tt"))
+            b.close()
+
+
 def test_machine_quotients_from_coefficients_or_rows(nz, oracle):
     """"quotients.coeffs": the DEEP quotients of the wide size group accumulated from the coefficient columns (combine per sample point,
     extend, finish row by row) or row-wise over the extensions like Stwo — the same proof, == the oracle's; also at blowup 4."""
