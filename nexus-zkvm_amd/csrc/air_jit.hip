@@ -61,7 +61,21 @@ FI Q q_add(Q x, Q y) { Q r = {m_add(x.a, y.a), m_add(x.b, y.b), m_add(x.c, y.c),
 FI Q q_sub(Q x, Q y) { Q r = {m_sub(x.a, y.a), m_sub(x.b, y.b), m_sub(x.c, y.c), m_sub(x.d, y.d)}; return r; }
 // (xa + xb u)(ya + yb u), u^2 = 2 + i, CM31 = M31[i]/(i^2+1)
 FI void c_mul(u32 xa, u32 xb, u32 ya, u32 yb, u32& ra, u32& rb) { ra = m_sub(m_mul(xa, ya), m_mul(xb, yb)); rb = m_add(m_mul(xa, yb), m_mul(xb, ya)); }
+)SRC"
+#ifndef NX_Q_MUL_NAIVE
+R"SRC(// every coordinate of the product is four raw 64-bit multiply-adds and ONE reduction once y.b (2 + i) = (e, f) is formed (field.cuh q_mul)
 FI Q q_mul(Q x, Q y) {
+    const u32 e = m_sub(m_add(y.c, y.c), y.d), f = m_add(m_add(y.d, y.d), y.c);
+    const u32 nyb = P - y.b, nyd = P - y.d, nf = P - f;
+    Q r = {acc_final(acc_mad(acc_mad(acc_mad((u64)x.a * y.a, x.b, nyb), x.c, e), x.d, nf)),
+           acc_final(acc_mad(acc_mad(acc_mad((u64)x.a * y.b, x.b, y.a), x.c, f), x.d, e)),
+           acc_final(acc_mad(acc_mad(acc_mad((u64)x.a * y.c, x.b, nyd), x.c, y.a), x.d, nyb)),
+           acc_final(acc_mad(acc_mad(acc_mad((u64)x.a * y.d, x.b, y.c), x.c, y.b), x.d, y.a))};
+    return r;
+}
+)SRC"
+#else          // A/B build (tools/build_variant_lib.sh): the four reduced CM31 products of rounds 1 - 5
+R"SRC(FI Q q_mul(Q x, Q y) {
     u32 aa0, aa1, bb0, bb1, ab0, ab1, ba0, ba1;
     c_mul(x.a, x.b, y.a, y.b, aa0, aa1); c_mul(x.c, x.d, y.c, y.d, bb0, bb1);
     c_mul(x.a, x.b, y.c, y.d, ab0, ab1); c_mul(x.c, x.d, y.a, y.b, ba0, ba1);
@@ -69,7 +83,9 @@ FI Q q_mul(Q x, Q y) {
     Q r = {m_add(aa0, r0), m_add(aa1, r1), m_add(ab0, ba0), m_add(ab1, ba1)};
     return r;
 }
-FI u32 bitrev(u32 i, int log) { return log ? (__builtin_bitreverse32(i) >> (32 - log)) : i; }
+)SRC"
+#endif
+R"SRC(FI u32 bitrev(u32 i, int log) { return log ? (__builtin_bitreverse32(i) >> (32 - log)) : i; }
 FI u32 row_offset(u32 r, int log_size, int e, int offset) {
     if (offset == 0) return r;
     u32 idx = bitrev(r, e);

@@ -90,12 +90,30 @@ NX_HD QM31 q_one() { return qm(1, 0, 0, 0); }
 NX_HD QM31 q_add(QM31 x, QM31 y) { QM31 r; r.a = c_add(x.a, y.a); r.b = c_add(x.b, y.b); return r; }
 NX_HD QM31 q_sub(QM31 x, QM31 y) { QM31 r; r.a = c_sub(x.a, y.a); r.b = c_sub(x.b, y.b); return r; }
 NX_HD QM31 q_neg(QM31 x) { QM31 r; r.a = c_neg(x.a); r.b = c_neg(x.b); return r; }
+// (x.a + x.b u)(y.a + y.b u) with u^2 = 2 + i: every coordinate of the product is a sum of FOUR M31 products once y.b (2 + i) = (e, f) is formed —
+//   r.a.a = xa ya - xb yb + xc e - xd f      r.a.b = xa yb + xb ya + xc f + xd e      r.b.a = xa yc - xb yd + xc ya - xd yb      r.b.b = xa yd + xb yc + xc yb + xd ya
+// — so each is four raw 64-bit multiply-adds (a subtracted term enters as x (P - y): P - y <= P is a fine factor, the sum is reduced at the end)
+// and ONE reduction, instead of four reduced products and three reduced additions: 16 v_mad_u64_u32 + 4 reductions against 16 + 16 + 20
+// (round 6; the same values: tests/native/field_selftest.cpp — boundary values in every coordinate and random operands against the tower formula).
+#ifndef NX_Q_MUL_NAIVE
+NX_HD QM31 q_mul(QM31 x, QM31 y) {
+    const CM31 r = c_mul_R(y.b);                                        // (e, f) = y.b (2 + i)
+    const u32 nyb = P - y.a.b, nyd = P - y.b.b, nf = P - r.b;
+    QM31 o;
+    o.a.a = acc_final(acc_mad(acc_mad(acc_mad((u64)x.a.a * y.a.a, x.a.b, nyb), x.b.a, r.a), x.b.b, nf));
+    o.a.b = acc_final(acc_mad(acc_mad(acc_mad((u64)x.a.a * y.a.b, x.a.b, y.a.a), x.b.a, r.b), x.b.b, r.a));
+    o.b.a = acc_final(acc_mad(acc_mad(acc_mad((u64)x.a.a * y.b.a, x.a.b, nyd), x.b.a, y.a.a), x.b.b, nyb));
+    o.b.b = acc_final(acc_mad(acc_mad(acc_mad((u64)x.a.a * y.b.b, x.a.b, y.b.a), x.b.a, y.a.b), x.b.b, y.a.a));
+    return o;
+}
+#else
 NX_HD QM31 q_mul(QM31 x, QM31 y) {
     QM31 r;
     r.a = c_add(c_mul(x.a, y.a), c_mul_R(c_mul(x.b, y.b)));
     r.b = c_add(c_mul(x.a, y.b), c_mul(x.b, y.a));
     return r;
 }
+#endif
 NX_HD QM31 q_sqr(QM31 x) { return q_mul(x, x); }
 NX_HD QM31 q_mul_m(QM31 x, u32 s) { QM31 r; r.a = c_mul_m(x.a, s); r.b = c_mul_m(x.b, s); return r; }
 NX_HD QM31 q_mul_c(QM31 x, CM31 s) { QM31 r; r.a = c_mul(x.a, s); r.b = c_mul(x.b, s); return r; }

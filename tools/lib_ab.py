@@ -12,15 +12,19 @@ if sys.argv[1] == "--child":
     comps, cfg = [(22, 27, 347, 64)], nz.default_config(pow_bits=10)
     if what.startswith("log"):            # the headline machine at 2^N rows: NX_AB_WHAT=log16
         comps = [(int(what[3:]), 27, 347, 64)]
+    if what in ("keccak", "keccakw"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from keccak_shaped import keccak_shaped_components
+        comps = keccak_shaped_components(0, 1000, 500, pairs=True, tuples=what == "keccakw")
     if what == "v1":
         comps, cfg = [(22, 27, 347, 1000, 2)] + [(8 + k, 2, 6 + k, 4, 1) for k in range(8)], nz.default_config(pow_bits=10, log_constraint_degree=2)
     w = be.prove_machine(comps, cfg, seed=5); be.sync()
-    n = 10 if what == "headline" else 3 if what == "v1" else 100
+    n = 10 if what == "headline" else 3 if what == "v1" else 6 if what.startswith("keccak") else 100
     t0 = time.perf_counter()
     for s in range(n):
         be.prove_machine(comps, cfg, seed=100 + s)
     be.sync(); ms = 1e3 * (time.perf_counter() - t0) / n
-    st = [be.prove_machine(comps, cfg, seed=200 + s, want_stats=True)[1] for s in range(5 if what == "headline" else 2)]
+    st = [be.prove_machine(comps, cfg, seed=200 + s, want_stats=True)[1] for s in range(2 if what == "v1" else 5)]
     keys = ("commit", "interaction", "composition", "oods", "quotients", "fri", "lde_kernel_ms", "merkle_kernel_ms")
     print(json.dumps({"ms": ms, "digest": hashlib.sha256(w.tobytes()).hexdigest(), "stages": {k: sorted(x[k] for x in st)[len(st) // 2] for k in keys}}))
     sys.exit(0)
