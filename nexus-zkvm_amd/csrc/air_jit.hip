@@ -896,7 +896,23 @@ FI u32 pos_of_coset_row(u32 c, int log) { const u32 N = 1u << log; const u32 d =
 FI u32 coset_row_of_pos(u32 p, int log) { const u32 N = 1u << log, d = bitrev(p, log); return d < N / 2 ? 2 * d : 2 * (N - 1 - d) + 1; }
 FI u32 trace_row_offset(u32 r, int log, int off) { if (off == 0) return r; return pos_of_coset_row((coset_row_of_pos(r, log) + (u32)off) & ((1u << log) - 1), log); }
 // the norm part of a QM31 inverse: x^-1 = (a, -b) D^-1, D = a^2 - (2 + i) b^2 in CM31, D^-1 = conj(D) / (D.a^2 + D.b^2)
+)SRC"
+#ifndef NX_Q_MUL_NAIVE
+R"SRC(// D = x.a^2 - (2 + i) x.b^2 and x^-1 = (x.a, -x.b) conj(D) / |D|^2: every coordinate one lazy sum of at most four products (field.cuh q_norm_cm / q_conj_times)
 FI void q_norm(Q x, u32& da, u32& db, u32& nrm) {
+    const u32 a0d = m_add(x.a, x.a), b0d = m_add(x.c, x.c), b1d = m_add(x.d, x.d), sd = m_add(b0d, b1d), nb0 = P - x.c;
+    da = acc_final(acc_mad(acc_mad(acc_mad((u64)x.a * x.a, x.b, P - x.b), b0d, nb0), sd, x.d));
+    db = acc_final(acc_mad(acc_mad(acc_mad((u64)a0d * x.b, b0d, P - b1d), x.c, nb0), x.d, x.d));
+    nrm = acc_final(acc_mad((u64)da * da, db, db));
+}
+FI Q q_inv_from(Q x, u32 da, u32 db, u32 ninv) {       // ninv = 1 / nrm
+    const u32 ia = m_mul(da, ninv), ib = m_mul(m_neg(db), ninv), na = P - ia, nb = P - ib;
+    Q r = {acc_final(acc_mad((u64)x.a * ia, x.b, nb)), acc_final(acc_mad((u64)x.a * ib, x.b, ia)), acc_final(acc_mad((u64)x.c * na, x.d, ib)), acc_final(acc_mad((u64)x.c * nb, x.d, na))};
+    return r;
+}
+)SRC"
+#else
+R"SRC(FI void q_norm(Q x, u32& da, u32& db, u32& nrm) {
     u32 a0, a1, b0, b1; c_mul(x.a, x.b, x.a, x.b, a0, a1); c_mul(x.c, x.d, x.c, x.d, b0, b1);
     da = m_sub(a0, m_sub(m_add(b0, b0), b1)); db = m_sub(a1, m_add(m_add(b1, b1), b0));
     nrm = m_add(m_sqr(da), m_sqr(db));
@@ -906,7 +922,9 @@ FI Q q_inv_from(Q x, u32 da, u32 db, u32 ninv) {       // ninv = 1 / nrm
     Q r; c_mul(x.a, x.b, ia, ib, r.a, r.b); c_mul(m_neg(x.c), m_neg(x.d), ia, ib, r.c, r.d);
     return r;
 }
-)SRC";
+)SRC"
+#endif
+;
 
 constexpr uint32_t LOGUP_PROG_GROUP = 8;
 

@@ -115,16 +115,32 @@ NX_HD QM31 q_mul(QM31 x, QM31 y) {
 }
 #endif
 NX_HD QM31 q_sqr(QM31 x) { return q_mul(x, x); }
+// The two CM31 steps of a QM31 inverse, each coordinate one lazy sum of at most four products and one reduction (round 6, like q_mul):
+//   q_norm_cm(x) = x.a^2 - (2 + i) x.b^2:   .a = a0^2 - a1^2 - 2 b0^2 + 2 b1^2 + 2 b0 b1 = a0 a0 + a1 (P - a1) + 2b0 (P - b0) + 2(b0 + b1) b1
+//                                           .b = 2 a0 a1 - 4 b0 b1 - b0^2 + b1^2          = 2a0 a1 + 2b0 (P - 2b1) + b0 (P - b0) + b1 b1
+//   q_conj_times(x, d) = (x.a d, -x.b d):   the inverse is q_conj_times(x, conj(D) / |D|^2) with D = q_norm_cm(x)
+#ifndef NX_Q_MUL_NAIVE
+NX_HD CM31 q_norm_cm(QM31 x) {
+    const u32 a0 = x.a.a, a1 = x.a.b, b0 = x.b.a, b1 = x.b.b;
+    const u32 a0d = m_add(a0, a0), b0d = m_add(b0, b0), b1d = m_add(b1, b1), sd = m_add(b0d, b1d), nb0 = P - b0;
+    return cm(acc_final(acc_mad(acc_mad(acc_mad((u64)a0 * a0, a1, P - a1), b0d, nb0), sd, b1)),
+              acc_final(acc_mad(acc_mad(acc_mad((u64)a0d * a1, b0d, P - b1d), b0, nb0), b1, b1)));
+}
+NX_HD QM31 q_conj_times(QM31 x, CM31 d) {
+    const u32 nd0 = P - d.a, nd1 = P - d.b;
+    QM31 r;
+    r.a.a = acc_final(acc_mad((u64)x.a.a * d.a, x.a.b, nd1)); r.a.b = acc_final(acc_mad((u64)x.a.a * d.b, x.a.b, d.a));
+    r.b.a = acc_final(acc_mad((u64)x.b.a * nd0, x.b.b, d.b)); r.b.b = acc_final(acc_mad((u64)x.b.a * nd1, x.b.b, nd0));
+    return r;
+}
+#else
+NX_HD CM31 q_norm_cm(QM31 x) { return c_sub(c_mul(x.a, x.a), c_mul_R(c_mul(x.b, x.b))); }
+NX_HD QM31 q_conj_times(QM31 x, CM31 d) { QM31 r; r.a = c_mul(x.a, d); r.b = c_mul(c_neg(x.b), d); return r; }
+#endif
 NX_HD QM31 q_mul_m(QM31 x, u32 s) { QM31 r; r.a = c_mul_m(x.a, s); r.b = c_mul_m(x.b, s); return r; }
 NX_HD QM31 q_mul_c(QM31 x, CM31 s) { QM31 r; r.a = c_mul(x.a, s); r.b = c_mul(x.b, s); return r; }
 NX_HD QM31 q_conj(QM31 x) { QM31 r; r.a = x.a; r.b = c_neg(x.b); return r; }
-NX_HD QM31 q_inv(QM31 x) {
-    CM31 b2 = c_mul(x.b, x.b);
-    CM31 denom = c_sub(c_mul(x.a, x.a), c_mul_R(b2));
-    CM31 di = c_inv(denom);
-    QM31 r; r.a = c_mul(x.a, di); r.b = c_mul(c_neg(x.b), di);
-    return r;
-}
+NX_HD QM31 q_inv(QM31 x) { return q_conj_times(x, c_inv(q_norm_cm(x))); }
 NX_HD bool q_eq(QM31 x, QM31 y) { return x.a.a == y.a.a && x.a.b == y.a.b && x.b.a == y.b.a && x.b.b == y.b.b; }
 NX_HD bool q_is_zero(QM31 x) { return !(x.a.a | x.a.b | x.b.a | x.b.b); }
 NX_HD QM31 q_double_x(QM31 x) { QM31 s = q_sqr(x); return q_sub(q_add(s, s), q_one()); }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* _
                         if ((k & 3) == 3) { s0 = acc_fold(s0); s1 = acc_fold(s1); s2 = acc_fold(s2); s3 = acc_fold(s3); }
                     }
                     den[g] = q_sub(qm(acc_final(s0), acc_final(s1), acc_final(s2), acc_final(s3)), f.z);
-                    dd[g] = c_sub(c_mul(den[g].a, den[g].a), c_mul_R(c_mul(den[g].b, den[g].b)));
+                    dd[g] = q_norm_cm(den[g]);
                     nrm[g] = m_add(m_sqr(dd[g].a), m_sqr(dd[g].b));
                 } else { den[g] = q_zero(); dd[g] = cm(0, 0); nrm[g] = 1; }
                 const u32 nz = nrm[g] ? nrm[g] : 1u;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* _
                 const u32 j = j0 + g;
                 const LogupBatchFrac f = fr[j];
                 const CM31 di = cm(m_mul(dd[g].a, pre[g]), m_mul(m_neg(dd[g].b), pre[g]));
-                QM31 qi; qi.a = c_mul(den[g].a, di); qi.b = c_mul(c_neg(den[g].b), di);
+                const QM31 qi = q_conj_times(den[g], di);
                 const u32 mval = f.mult ? (STAGED ? mv[g] : gld(f.mult + r)) : 0u;
                 if ((f.scale.a.b | f.scale.b.a | f.scale.b.b) == 0) {          // uniform: a base-field numerator (+-1, a multiplicity): 4 products, not 16
                     const u32 nm = f.mult ? m_mul(f.scale.a.a, mval) : f.scale.a.a;
