@@ -106,8 +106,8 @@ FI u32 row_offset(u32 r, int log_size, int e, int offset) {
 static uint32_t instr_cost(uint32_t op) {   // rough gfx950 instruction counts of the emitted statements
     switch (op) {
     case NX_C_LOAD: return 6; case NX_C_CONST: return 1; case NX_C_ADD: case NX_C_SUB: return 4; case NX_C_MUL: return 7; case NX_C_NEG: return 3;
-    case NX_C_CONSTE: return 4; case NX_C_ADDE: case NX_C_SUBE: return 16; case NX_C_MULE: return 160; case NX_C_MULEB: return 30; case NX_C_ADDEB: return 4;
-    case NX_C_LOADE: return 24; case NX_C_CONSTRAINT_B: return 14; case NX_C_CONSTRAINT_E: return 170; default: return 1;
+    case NX_C_CONSTE: return 4; case NX_C_ADDE: case NX_C_SUBE: return 16; case NX_C_MULE: return 85; case NX_C_MULEB: return 30; case NX_C_ADDEB: return 4;      // MULE / CONSTRAINT_E: the lazy q_mul of round 6 (160 / 170 before)
+    case NX_C_LOADE: return 24; case NX_C_CONSTRAINT_B: return 14; case NX_C_CONSTRAINT_E: return 100; default: return 1;
     }
 }
 // estimated-instruction budget of one generated kernel: ~70 KB of code per kernel at the default 9000; measured sweep 1500..60000

@@ -33,7 +33,10 @@ res = {n: [] for n, _ in builds}
 for r in range(rounds):
     for name, path in builds:
         env = dict(os.environ)
-        if name != "default":
+        if path.startswith("env:"):           # name=env:VAR=VALUE[,VAR=VALUE]: the default library under other environment defaults (context options)
+            for kv in path[4:].split(","):
+                k, v = kv.split("=", 1); env[k] = v
+        elif name != "default":
             env["NX_LIB"] = os.path.join(ROOT, "nexus-zkvm_amd", path)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
         res[name].append(json.loads(out))
