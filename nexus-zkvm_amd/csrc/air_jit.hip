@@ -905,6 +905,12 @@ FI void q_norm(Q x, u32& da, u32& db, u32& nrm) {
     db = acc_final(acc_mad(acc_mad(acc_mad((u64)a0d * x.b, b0d, P - b1d), x.c, nb0), x.d, x.d));
     nrm = acc_final(acc_mad((u64)da * da, db, db));
 }
+FI Q q_frac_add(Q run, Q x, u32 da, u32 db, u32 s) {    // run + num / x with s = num / nrm (a base-field numerator rides on the norm's inverse; the sum's words ride in the accumulators)
+    const u32 ia = m_mul(da, s), ib = m_mul(m_neg(db), s), na = P - ia, nb = P - ib;
+    Q r = {acc_final(acc_mad(acc_mad((u64)run.a, x.a, ia), x.b, nb)), acc_final(acc_mad(acc_mad((u64)run.b, x.a, ib), x.b, ia)),
+           acc_final(acc_mad(acc_mad((u64)run.c, x.c, na), x.d, ib)), acc_final(acc_mad(acc_mad((u64)run.d, x.c, nb), x.d, na))};
+    return r;
+}
 FI Q q_inv_from(Q x, u32 da, u32 db, u32 ninv) {       // ninv = 1 / nrm
     const u32 ia = m_mul(da, ninv), ib = m_mul(m_neg(db), ninv), na = P - ia, nb = P - ib;
     Q r = {acc_final(acc_mad((u64)x.a * ia, x.b, nb)), acc_final(acc_mad((u64)x.a * ib, x.b, ia)), acc_final(acc_mad((u64)x.c * na, x.d, ib)), acc_final(acc_mad((u64)x.c * nb, x.d, na))};
@@ -922,6 +928,7 @@ FI Q q_inv_from(Q x, u32 da, u32 db, u32 ninv) {       // ninv = 1 / nrm
     Q r; c_mul(x.a, x.b, ia, ib, r.a, r.b); c_mul(m_neg(x.c), m_neg(x.d), ia, ib, r.c, r.d);
     return r;
 }
+FI Q q_frac_add(Q run, Q x, u32 da, u32 db, u32 s) { return q_add(run, q_inv_from(x, da, db, s)); }
 )SRC"
 #endif
 ;
@@ -967,9 +974,8 @@ static std::string generate_logup_kernel(const nx_cinstr* prog, const std::vecto
         }
         for (size_t k = 0; k < G; k++) {
             const nx_cinstr& in = prog[group[k].instr];
-            s += "    { const Q qi = q_inv_from(" + v("fd", k) + ", " + v("da", k) + ", " + v("db", k) + ", " + v("ni", k) + "); ";
-            if (group[k].base) s += "run = q_add(run, Q{m_mul(qi.a, " + v("fn", k) + "), m_mul(qi.b, " + v("fn", k) + "), m_mul(qi.c, " + v("fn", k) + "), m_mul(qi.d, " + v("fn", k) + ")}); }\n";
-            else s += "run = q_add(run, q_mul(" + v("fn", k) + ", qi)); }\n";
+            if (group[k].base) s += "    run = q_frac_add(run, " + v("fd", k) + ", " + v("da", k) + ", " + v("db", k) + ", m_mul(" + v("ni", k) + ", " + v("fn", k) + "));\n";
+            else s += "    { const Q qi = q_inv_from(" + v("fd", k) + ", " + v("da", k) + ", " + v("db", k) + ", " + v("ni", k) + "); run = q_add(run, q_mul(" + v("fn", k) + ", qi)); }\n";
             if (batch_end[group[k].instr]) {
                 const std::string b = std::to_string(4 * in.dst);
                 s += "    out[" + b + "][r] = run.a; out[" + b + " + 1][r] = run.b; out[" + b + " + 2][r] = run.c; out[" + b + " + 3][r] = run.d;\n";

@@ -133,7 +133,16 @@ NX_HD QM31 q_conj_times(QM31 x, CM31 d) {
     r.b.a = acc_final(acc_mad((u64)x.b.a * nd0, x.b.b, d.b)); r.b.b = acc_final(acc_mad((u64)x.b.a * nd1, x.b.b, nd0));
     return r;
 }
+// acc + (x.a d, -x.b d): a fraction num / x added to a running sum when d already carries num / |D|^2 — the sum's word rides in the accumulator
+NX_HD QM31 q_conj_times_add(QM31 acc, QM31 x, CM31 d) {
+    const u32 nd0 = P - d.a, nd1 = P - d.b;
+    QM31 r;
+    r.a.a = acc_final(acc_mad(acc_mad((u64)acc.a.a, x.a.a, d.a), x.a.b, nd1)); r.a.b = acc_final(acc_mad(acc_mad((u64)acc.a.b, x.a.a, d.b), x.a.b, d.a));
+    r.b.a = acc_final(acc_mad(acc_mad((u64)acc.b.a, x.b.a, nd0), x.b.b, d.b)); r.b.b = acc_final(acc_mad(acc_mad((u64)acc.b.b, x.b.a, nd1), x.b.b, nd0));
+    return r;
+}
 #else
+NX_HD QM31 q_conj_times_add(QM31 acc, QM31 x, CM31 d) { QM31 r; r.a = c_mul(x.a, d); r.b = c_mul(c_neg(x.b), d); return q_add(acc, r); }
 NX_HD CM31 q_norm_cm(QM31 x) { return c_sub(c_mul(x.a, x.a), c_mul_R(c_mul(x.b, x.b))); }
 NX_HD QM31 q_conj_times(QM31 x, CM31 d) { QM31 r; r.a = c_mul(x.a, d); r.b = c_mul(c_neg(x.b), d); return r; }
 #endif

@@ -171,13 +171,14 @@ __global__ __launch_bounds__(256) void logup_cols_kernel(const LogupBatchFrac* _
             if (j0 + g < n_fracs) {
                 const u32 j = j0 + g;
                 const LogupBatchFrac f = fr[j];
-                const CM31 di = cm(m_mul(dd[g].a, pre[g]), m_mul(m_neg(dd[g].b), pre[g]));
-                const QM31 qi = q_conj_times(den[g], di);
                 const u32 mval = f.mult ? (STAGED ? mv[g] : gld(f.mult + r)) : 0u;
-                if ((f.scale.a.b | f.scale.b.a | f.scale.b.b) == 0) {          // uniform: a base-field numerator (+-1, a multiplicity): 4 products, not 16
-                    const u32 nm = f.mult ? m_mul(f.scale.a.a, mval) : f.scale.a.a;
-                    run = q_add(run, q_mul_m(qi, nm));
+                if ((f.scale.a.b | f.scale.b.a | f.scale.b.b) == 0) {          // uniform: a base-field numerator (+-1, a multiplicity): it rides on 1 / |D|^2,
+                    const u32 nm = f.mult ? m_mul(f.scale.a.a, mval) : f.scale.a.a;     // and the fraction goes straight into the running sum's accumulators
+                    const u32 sc = m_mul(pre[g], nm);
+                    run = q_conj_times_add(run, den[g], cm(m_mul(dd[g].a, sc), m_mul(m_neg(dd[g].b), sc)));
                 } else {
+                    const CM31 di = cm(m_mul(dd[g].a, pre[g]), m_mul(m_neg(dd[g].b), pre[g]));
+                    const QM31 qi = q_conj_times(den[g], di);
                     const QM31 num = f.mult ? q_mul_m(f.scale, mval) : f.scale;
                     run = q_add(run, q_mul(num, qi));
                 }

@@ -29,6 +29,8 @@ int main() {
             if (d1.a != d2.a || d1.b != d2.b || d1.a >= P || d1.b >= P) bad++;
             const QM31 c1 = q_conj_times(x, y.a), c2 = ref_conj_times(x, y.a);
             if (!q_eq(c1, c2) || !canonical(c1)) bad++;
+            const QM31 e1 = q_conj_times_add(y, x, y.b), e2 = q_add(y, ref_conj_times(x, y.b));
+            if (!q_eq(e1, e2) || !canonical(e1)) bad++;
         }
     u64 s = 0x9E3779B97F4A7C15ull;
     auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (u32)((s >> 16) % P); };
