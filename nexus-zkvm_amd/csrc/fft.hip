@@ -25,17 +25,7 @@
 namespace nx {
 
 // ------------------------------------------------------------------ twiddles (K2) -----------
-// G * 2^i for the circle group's generator: pt_from_index as a sum of table entries (no doubling chain per element)
-struct GenTable { u32 x[31], y[31]; };
-__device__ __forceinline__ Pt pt_from_index_tbl(const GenTable& g, u32 idx) {
-    Pt res; res.x = 1; res.y = 0;
-    idx &= 0x7fffffffu;
-#pragma unroll 1
-    for (int i = 0; idx; i++, idx >>= 1)
-        if (idx & 1) { Pt c; c.x = g.x[i]; c.y = g.y[i]; res = pt_add(res, c); }
-    return res;
-}
-
+// pt_from_index as a sum of table entries (field.cuh GenTable: no doubling chain per element)
 __global__ void twiddle_kernel(u32* tw, u32* itw, int h, GenTable gen) {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     u32 total = 1u << h;
@@ -482,8 +472,7 @@ int nx_twiddles_create(nx_ctx* ctx, uint32_t log_half_coset, nx_twiddles** out) 
     if (rc0 != NX_OK) { dev_free(ctx, t->d_tw); dev_free(ctx, t->d_itw); dev_free(ctx, t->d_tw2); dev_free(ctx, t->d_itw2); delete t; return rc0; }
     hipError_t e;
     u32 total = 1u << log_half_coset;
-    GenTable gen;
-    { Pt cur; cur.x = 2; cur.y = 1268011823u; for (int i = 0; i < 31; i++) { gen.x[i] = cur.x; gen.y[i] = cur.y; cur = pt_add(cur, cur); } }
+    const GenTable gen = gen_table();
     hipLaunchKernelGGL(twiddle_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, t->d_tw, t->d_itw, (int)log_half_coset, gen);
     hipLaunchKernelGGL(twiddle_double_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, t->d_tw, t->d_itw, t->d_tw2, t->d_itw2, total);
     e = hipGetLastError();

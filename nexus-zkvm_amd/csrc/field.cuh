@@ -176,6 +176,17 @@ NX_HD Pt pt_from_index(u32 idx) {
     while (idx) { if (idx & 1) res = pt_add(res, cur); cur = pt_add(cur, cur); idx >>= 1; }
     return res;
 }
+// G * 2^i for i = 0 .. 30: a point from its index as a sum over the SET bits only (pt_from_index doubles its way through all 31): what a kernel uses
+// when every lane needs its own domain point (a by-value kernel argument of 248 bytes, built on the host by gen_table()).
+struct GenTable { u32 x[31], y[31]; };
+inline GenTable gen_table() { GenTable g; Pt cur; cur.x = 2; cur.y = 1268011823u; for (int i = 0; i < 31; i++) { g.x[i] = cur.x; g.y[i] = cur.y; cur = pt_add(cur, cur); } return g; }
+NX_HD Pt pt_from_index_tbl(const GenTable& g, u32 idx) {
+    Pt res; res.x = 1; res.y = 0;
+    idx &= 0x7fffffffu;
+    for (int i = 0; idx; i++, idx >>= 1)
+        if (idx & 1) { Pt c; c.x = g.x[i]; c.y = g.y[i]; res = pt_add(res, c); }
+    return res;
+}
 struct QPt { QM31 x, y; };
 NX_HD QPt qpt_add(QPt p, QPt q) {
     QPt r;

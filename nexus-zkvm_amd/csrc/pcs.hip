@@ -125,12 +125,12 @@ __device__ __forceinline__ void quot_den_inv4(const QBatchDev& B, const Pt dp[4]
 // output pointers are biased by the caller so that indexing with the GLOBAL row works (single GPU: j0 = 0, j1 = 2^(log-2)).
 __global__ __launch_bounds__(256) void quotient_kernel(ColSet cols, int log, u32 j0, u32 j1, const QBatchDev* __restrict__ batches, u32 n_batches,
                                                        const u32* __restrict__ col_idx, const u32* __restrict__ cks /*4 per entry*/,
-                                                       u32* o0, u32* o1, u32* o2, u32* o3) {
+                                                       u32* o0, u32* o1, u32* o2, u32* o3, GenTable gen) {
     const u32 j = j0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= j1) return;
     const u32 r = 4 * j;
     Pt dp[4];
-    dp[0] = pt_from_index(circle_domain_index(log, bitrev(r, log)));
+    dp[0] = pt_from_index_tbl(gen, circle_domain_index(log, bitrev(r, log)));      // a sum over the index's set bits (~log / 2 additions), not 31 doublings
     // bitrev(4j + i) = bitrev2(i) * 2^(log-2) + bitrev(j): i = 1 lands in the conjugate half of the domain, i = 2 is
     // 2^(log-2) steps of 2^(32-log) = half a turn further, i = 3 both
     dp[1].x = dp[0].x; dp[1].y = m_neg(dp[0].y);
@@ -275,12 +275,12 @@ __global__ __launch_bounds__(256) void quotient_combine_reduce_kernel(u32* __res
 // rows 4j .. 4j+3 from the extended combinations: num_b = G_b(d) - (d.y Σ a + Σ b), acc = acc * alpha^count_b + num_b / den_b(d).  The
 // CM31 denominators of the 4 rows of a batch are inverted together (one m_inv for their 4 norms).
 __global__ __launch_bounds__(256) void quotient_finish_kernel(const u32* __restrict__ ext, size_t col_stride, int log, u32 n4, const QBatchDev* __restrict__ batches, u32 n_batches,
-                                                              u32* o0, u32* o1, u32* o2, u32* o3) {
+                                                              u32* o0, u32* o1, u32* o2, u32* o3, GenTable gen) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n4) return;
     const u32 r = 4 * j;
     Pt dp[4];
-    dp[0] = pt_from_index(circle_domain_index(log, bitrev(r, log)));
+    dp[0] = pt_from_index_tbl(gen, circle_domain_index(log, bitrev(r, log)));
     dp[1].x = dp[0].x; dp[1].y = m_neg(dp[0].y);
     dp[2].x = m_neg(dp[0].x); dp[2].y = dp[1].y;
     dp[3].x = dp[2].x; dp[3].y = dp[0].y;
@@ -636,7 +636,7 @@ static int accumulate_quotients_impl(nx_ctx* ctx, uint32_t log_size, const uint3
     u32* o[4]; for (int q = 0; q < 4; q++) o[q] = bias_rows(d_out4[q], row_begin);
     if (log_size >= 2)
         hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((n_rows / 4 + 255) / 256)), dim3(256), 0, ctx->stream, cs, (int)log_size, (u32)(row_begin / 4), (u32)((row_begin + n_rows) / 4),
-                           (const QBatchDev*)blob, n_batches, (const u32*)(blob + off_i), (const u32*)(blob + off_c), o[0], o[1], o[2], o[3]);
+                           (const QBatchDev*)blob, n_batches, (const u32*)(blob + off_i), (const u32*)(blob + off_c), o[0], o[1], o[2], o[3], gen_table());
     else
         hipLaunchKernelGGL(quotient_small_kernel, dim3(1), dim3(64), 0, ctx->stream, cs, (int)log_size, (u32)row_begin, (u32)(row_begin + n_rows), (const QBatchDev*)blob, n_batches,
                            (const u32*)(blob + off_i), (const u32*)(blob + off_c), o[0], o[1], o[2], o[3]);
@@ -700,7 +700,7 @@ int accumulate_quotients_coeffs(nx_ctx* ctx, const nx_twiddles* tw, uint32_t log
         // The extension in between is Circle-FFT work and is booked as such, bytes and time alike (fft_evaluate's own span).
         KTimer timer(ctx, NX_T_QUOT, 0);
         hipLaunchKernelGGL(quotient_finish_kernel, dim3((unsigned)((ne / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const u32*)ext, ne, (int)log_size, (u32)(ne / 4),
-                           (const QBatchDev*)blob, n_batches, d_out4[0], d_out4[1], d_out4[2], d_out4[3]);
+                           (const QBatchDev*)blob, n_batches, d_out4[0], d_out4[1], d_out4[2], d_out4[3], gen_table());
         if (hipGetLastError() != hipSuccess) rc = set_err(ctx, NX_ERR_HIP, "quotient_finish_kernel launch failed");
     }
     dev_free(ctx, comb); dev_free(ctx, ext);      // stream-ordered: reused only by later work on this stream
